@@ -1,0 +1,384 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by IMPORTING the reference.
+
+Runs ONLY in the build container (needs /root/reference, read-only).  Nothing of the reference
+travels: this script writes *data* (inputs + the reference's outputs) as .npz fixtures.  The GPU
+box, the tests, bench.py and smoke() only ever read the .npz files.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Reference entry points exercised (file:line under /root/reference):
+  lib/groomed_nms.py:10   differentiable_nms      lib/groomed_nms.py:208  get_groups
+  lib/groomed_nms.py:167  pruning_function        lib/groomed_nms.py:131  soft_sort
+  lib/groomed_nms.py:272  indices_copy
+  lib/core.py:480         iou                     lib/core.py:305         iou3d_approximate
+  lib/math_3d.py:364      get_corners_of_cuboid
+  lib/nms/py_cpu_nms.py:10 py_cpu_nms             lib/nms_others.py:6,119 navneeth_soft_nms, girshick_nms
+Known-answer vectors KAT-1/KAT-2 come from test/test_differentiable_nms_forward.py:127-140.
+
+Inputs are stored next to outputs: RNG streams differ across library versions, so nothing is ever
+re-drawn from a seed on the GPU box.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+
+
+# ----------------------------------------------------------------------------------------------
+# harness: import the reference without touching it
+# ----------------------------------------------------------------------------------------------
+def load_reference():
+    # torch>=2 rejects uint8 masks; the reference builds one at lib/groomed_nms.py:56 and uses it
+    # at :73.  Out-of-tree shim, applied before any call.
+    orig = torch.Tensor.masked_fill_
+
+    def masked_fill_compat(self, mask, value):
+        return orig(self, mask.bool() if mask.dtype == torch.uint8 else mask, value)
+
+    torch.Tensor.masked_fill_ = masked_fill_compat
+
+    spec = importlib.util.spec_from_file_location("ref_groomed_nms", REF + "/lib/groomed_nms.py")
+    gn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gn)
+
+    # lib/core.py, lib/math_3d.py import cv2/easydict/shapely/visdom at module top
+    class _Stub(types.ModuleType):          # any attribute (cv2.FONT_*, EasyDict, Polygon ...) resolves
+        def __getattr__(self, key):
+            if key.startswith("__"):
+                raise AttributeError(key)
+            return object
+
+    for name in ("cv2", "easydict", "shapely", "shapely.geometry", "visdom"):
+        if name not in sys.modules:
+            sys.modules[name] = _Stub(name)
+    sys.path.insert(0, REF)
+    import lib.core as core          # noqa: E402
+    import lib.math_3d as math_3d    # noqa: E402
+    import lib.nms_others as nms_others  # noqa: E402
+    spec = importlib.util.spec_from_file_location("ref_py_cpu_nms", REF + "/lib/nms/py_cpu_nms.py")
+    pcn = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pcn)
+    return gn, core, math_3d, nms_others, pcn
+
+
+gn, core, math_3d, nms_others, pcn = load_reference()
+
+
+def tie_free_scores(rng, n, lo=0.0, hi=1.0):
+    """fp32 scores distinct by construction (the reference's tie order is implementation-defined)."""
+    while True:
+        s = rng.uniform(lo, hi, size=n).astype(np.float32)
+        if len(np.unique(s)) == n:
+            return s
+
+
+# ----------------------------------------------------------------------------------------------
+# input generators
+# ----------------------------------------------------------------------------------------------
+def uniform_boxes_2d(rng, n):
+    c = np.stack([rng.uniform(0, 1760, n), rng.uniform(0, 512, n)], 1)
+    wh = rng.uniform(16, 136, size=(n, 2))
+    return np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+
+
+def clustered_boxes_2d(rng, n, per=16):
+    k = max(1, n // per)
+    base = uniform_boxes_2d(rng, k).astype(np.float64)
+    bc = (base[:, :2] + base[:, 2:]) / 2
+    bs = base[:, 2:] - base[:, :2]
+    which = np.arange(n) % k
+    c = bc[which] + rng.normal(0, 0.1, size=(n, 2)) * bs[which]
+    s = bs[which] * np.exp(rng.normal(0, 0.1, size=(n, 2)))
+    out = np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+    return out[rng.permutation(n)]
+
+
+def boxes_3d(rng, n, clustered=False, per=8):
+    def draw(m):
+        return np.stack([rng.uniform(-30, 30, m), rng.uniform(0.5, 2.5, m), rng.uniform(5, 60, m),
+                         rng.uniform(1.4, 2.0, m), rng.uniform(1.3, 2.0, m), rng.uniform(3, 5, m),
+                         rng.uniform(-np.pi, np.pi, m)], 1)   # x y z w h l ry
+    if not clustered:
+        return draw(n).astype(np.float32)
+    k = max(1, n // per)
+    base = draw(k)
+    which = np.arange(n) % k
+    p = base[which].copy()
+    p[:, :3] += rng.normal(0, 0.15, size=(n, 3))
+    p[:, 3:6] *= np.exp(rng.normal(0, 0.05, size=(n, 3)))
+    p[:, 6] += rng.normal(0, 0.05, size=n)
+    return p[rng.permutation(n)].astype(np.float32)
+
+
+def random_iou_like_reference_test(rng, n, symmetric=False):
+    """test/test_differentiable_nms_forward.py:16-27: iou ~ U(0,1), unit diagonal."""
+    m = rng.uniform(0, 1, size=(n, n)).astype(np.float32)
+    if symmetric:
+        m = (0.5 * (m + m.T)).astype(np.float32)
+    np.fill_diagonal(m, 1.0)
+    return m
+
+
+def block_iou(rng, n, cuts):
+    """test/test_differentiable_nms_backprop_on_subset.py:262-331: U(0.8,1) inside objects, 0 across."""
+    d = rng.uniform(0.8, 1.0, size=(n, n))
+    edges = [0] + list(cuts) + [n]
+    blk = np.zeros((n, n), bool)
+    for a, b in zip(edges[:-1], edges[1:]):
+        blk[a:b, a:b] = True
+    d[~blk] = 0
+    np.fill_diagonal(d, 1)
+    d = 0.5 * (d.T + d)
+    return d.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# running the reference
+# ----------------------------------------------------------------------------------------------
+def run_nms(scores, iou, w=None, want_iou_grad=False, **kw):
+    """Reference forward (+ backward of L = sum_k w_k * prob_k).  Returns dict of numpy arrays."""
+    s = torch.from_numpy(scores).clone().requires_grad_(True)
+    m = torch.from_numpy(iou).clone().requires_grad_(bool(want_iou_grad))
+    valid, invalid, prob = gn.differentiable_nms(s, m, **kw)
+    out = {"valid": valid.numpy().astype(np.int64), "invalid": invalid.numpy().astype(np.int64),
+           "prob": prob.detach().numpy().astype(np.float32)}
+    if w is not None and prob.requires_grad and prob.numel() > 0:
+        (prob * torch.from_numpy(w)).sum().backward()
+        out["grad_scores"] = s.grad.numpy().astype(np.float32)
+        if want_iou_grad:
+            out["grad_iou"] = (m.grad if m.grad is not None else torch.zeros_like(m)).numpy().astype(np.float32)
+    return out
+
+
+MODES = [
+    # tag, kwargs
+    ("gm_lin",      dict(group_boxes=True,  mask_group_boxes=True,  pruning_method="linear")),
+    ("gm_lin_gs2",  dict(group_boxes=True,  mask_group_boxes=True,  pruning_method="linear", group_size=2)),
+    ("gm_lin_sorted", dict(group_boxes=True, mask_group_boxes=True, pruning_method="linear", return_sorted_prob=True)),
+    ("gm_sig",      dict(group_boxes=True,  mask_group_boxes=True,  pruning_method="sigmoidal", temperature=0.1)),
+    ("gm_soft",     dict(group_boxes=True,  mask_group_boxes=True,  pruning_method="soft_nms", temperature=0.5)),
+    ("gu_lin",      dict(group_boxes=True,  mask_group_boxes=False, pruning_method="linear")),
+    ("gu_lin_gs2",  dict(group_boxes=True,  mask_group_boxes=False, pruning_method="linear", group_size=2)),
+    ("gu_sig",      dict(group_boxes=True,  mask_group_boxes=False, pruning_method="sigmoidal", temperature=0.1)),
+    ("gu_soft",     dict(group_boxes=True,  mask_group_boxes=False, pruning_method="soft_nms", temperature=0.1)),
+    ("un_lin",      dict(group_boxes=False, pruning_method="linear")),
+    ("un_lin_sorted", dict(group_boxes=False, pruning_method="linear", return_sorted_prob=True)),
+    ("un_sig",      dict(group_boxes=False, pruning_method="sigmoidal", temperature=0.1)),
+    ("un_soft",     dict(group_boxes=False, pruning_method="soft_nms", temperature=0.5)),
+    ("gm_lin_thr",  dict(group_boxes=True,  mask_group_boxes=True,  pruning_method="linear", nms_threshold=0.6,
+                         valid_box_prob_threshold=0.5)),
+]
+
+
+def pack_case(store, name, scores, iou, modes=MODES, grad_iou=False, rng=None, extra=None):
+    """Adds one input (scores, iou) and the reference's outputs under every mode."""
+    n = len(scores)
+    store[f"{name}/scores"] = scores
+    store[f"{name}/iou"] = iou
+    w = (rng.uniform(-1, 2, size=n).astype(np.float32) if rng is not None else np.ones(n, np.float32))
+    store[f"{name}/w"] = w
+    if extra:
+        for k, v in extra.items():
+            store[f"{name}/{k}"] = v
+    for tag, kw in modes:
+        res = run_nms(scores, iou, w=w, want_iou_grad=grad_iou, **kw)
+        for k, v in res.items():
+            store[f"{name}/{tag}/{k}"] = v
+    # groups (lib/groomed_nms.py:208) on the score-sorted matrix, as differentiable_nms calls it (:85)
+    if n > 0:
+        order = torch.sort(torch.from_numpy(scores), descending=True)[1]
+        ss = torch.from_numpy(scores)[order]
+        mm = torch.from_numpy(iou)[order][:, order]
+        for gs in (100, 2):
+            groups = gn.get_groups(mm, 0.4, ss, group_size=gs)
+            flat = np.concatenate([g.numpy() for g in groups]) if groups else np.zeros(0, np.int64)
+            lens = np.array([len(g) for g in groups], np.int64)
+            store[f"{name}/groups_gs{gs}/flat"] = flat.astype(np.int64)
+            store[f"{name}/groups_gs{gs}/lens"] = lens
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+
+    # ------------------------------------------------------------------ NMS layer goldens
+    nms = {}
+    # KAT-1 / KAT-2: test/test_differentiable_nms_forward.py:127-140 (temperature=0.1 there; unused by linear)
+    kat1_iou = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [.9, .9, 1, 0], [0, 0, 0, 1]], np.float32)
+    kat1_s = np.array([.99, .98, .8, .7], np.float32)
+    kat2_iou = np.array([[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [.9, .9, 1, 0, 0], [.9, .9, 0, 1, 0], [0, 0, .9, .9, 1]],
+                        np.float32)
+    kat2_s = np.array([.99, .98, .8, .7, .6], np.float32)
+    rng = np.random.default_rng(1234)
+    pack_case(nms, "kat1", kat1_s, kat1_iou, grad_iou=True, rng=rng)
+    pack_case(nms, "kat2", kat2_s, kat2_iou, grad_iou=True, rng=rng)
+    perm = np.array([3, 0, 4, 2, 1])           # permuted KAT-2: unsorted input
+    pack_case(nms, "kat2_perm", kat2_s[perm], kat2_iou[perm][:, perm], grad_iou=True, rng=rng)
+    store_expected = {"kat1/expected_prob": np.array([0.990, 0.980, 0.000, 0.700], np.float32),
+                      "kat2/expected_prob": np.array([0.990, 0.980, 0.000, 0.000, 0.600], np.float32)}
+    nms.update(store_expected)
+
+    # edge sizes
+    pack_case(nms, "n0", np.zeros(0, np.float32), np.zeros((0, 0), np.float32), modes=MODES[:1] + MODES[9:10])
+    pack_case(nms, "n1", np.array([0.7], np.float32), np.ones((1, 1), np.float32), rng=rng)
+    pack_case(nms, "n1_low", np.array([0.2], np.float32), np.ones((1, 1), np.float32), rng=rng)
+
+    # random U(0,1) IoU with unit diagonal (reference test generator), asymmetric and symmetric.
+    # Ungrouped / unmasked inverses of such dense matrices are ill-conditioned beyond a few boxes,
+    # so the dense-random cases keep only the default (masked) modes at larger n.
+    for n, sym in ((5, False), (12, True), (33, False)):
+        pack_case(nms, f"rand{n}", tie_free_scores(rng, n, 0.4, 1.0), random_iou_like_reference_test(rng, n, sym),
+                  grad_iou=(n <= 12), rng=rng)
+    masked_only = [m for m in MODES if m[0].startswith("gm_")]
+    for n, sym in ((64, True), (130, False)):
+        pack_case(nms, f"rand{n}", tie_free_scores(rng, n, 0.0, 1.0), random_iou_like_reference_test(rng, n, sym),
+                  modes=masked_only, rng=rng)
+
+    # NaN off-diagonal: the box falls out of every group (lib/groomed_nms.py:249-262)
+    s = np.array([0.9, 0.8, 0.7, 0.6], np.float32)
+    m = np.array([[1, .5, 0, 0], [np.nan, 1, 0, 0], [0, .9, 1, 0], [0, 0, 0, 1.]], np.float32)
+    pack_case(nms, "nan_offdiag", s, m, modes=MODES[:2] + MODES[5:6], rng=rng)
+
+    # block-structured IoU (backprop test generator), 1/2/3 objects, n=25 and a cap-exceeding n=120 single object
+    for tag, n, cuts in (("block1", 25, []), ("block2", 25, [5]), ("block3", 25, [5, 9]), ("block_cap", 120, [110])):
+        pack_case(nms, tag, tie_free_scores(rng, n), block_iou(rng, n, cuts), grad_iou=(n <= 25), rng=rng,
+                  modes=(MODES if n <= 25 else masked_only + MODES[5:7]))
+    np.savez_compressed(os.path.join(OUT, "nms_small.npz"), **nms)
+
+    # ------------------------------------------------------------------ box-derived goldens (2D)
+    box = {}
+    for tag, gen, n in (("uni64", uniform_boxes_2d, 64), ("clu64", clustered_boxes_2d, 64),
+                        ("uni256", uniform_boxes_2d, 256), ("clu256", clustered_boxes_2d, 256),
+                        ("clu250", clustered_boxes_2d, 250)):
+        b = gen(rng, n)
+        s = tie_free_scores(rng, n)
+        m = core.iou(torch.from_numpy(b), torch.from_numpy(b), mode="combinations").numpy()
+        m_np = core.iou(b, b, mode="combinations")          # numpy branch (lib/core.py:512-513), fp32 in -> fp32
+        assert m_np.dtype == np.float32
+        box[f"{tag}/iou_numpy_branch_maxdiff"] = np.array(np.nanmax(np.abs(m_np - m)), np.float32)
+        modes = MODES if n <= 64 else [m_ for m_ in MODES if not m_[0].endswith("_sorted")]
+        pack_case(box, tag, s, m, modes=modes, rng=rng, extra={"boxes": b})
+    # rectangular overlap (M != N) as used for best-target assignment (lib/loss/rpn_3d.py:801-825)
+    a = uniform_boxes_2d(rng, 37)
+    g = np.concatenate([a[:5] + rng.normal(0, 3, size=(5, 4)).astype(np.float32), uniform_boxes_2d(rng, 6)])
+    box["rect/a"] = a
+    box["rect/b"] = g
+    box["rect/iou"] = core.iou(torch.from_numpy(a), torch.from_numpy(g), mode="combinations").numpy()
+    # zero-area box: 0/0 -> NaN on its own diagonal (lib/core.py:507-508)
+    z = uniform_boxes_2d(rng, 6)
+    z[2, 2:] = z[2, :2]
+    box["zero_area/boxes"] = z
+    box["zero_area/iou"] = core.iou(torch.from_numpy(z), torch.from_numpy(z), mode="combinations").numpy()
+    np.savez_compressed(os.path.join(OUT, "boxes_2d.npz"), **box)
+
+    # ------------------------------------------------------------------ 3D goldens
+    d3 = {}
+    # test/test_get_corners_of_cuboid_numpy.py:9-17 generator (np seed 0, m=5)
+    np.random.seed(0)
+    m5 = 5
+    p5 = dict(x=30 * np.random.uniform(size=m5), y=10 * np.random.uniform(size=m5), z=15 * np.random.uniform(size=m5),
+              l=4 * np.random.uniform(size=m5), w=5 * np.random.uniform(size=m5), h=6 * np.random.uniform(size=m5),
+              r=np.random.uniform(low=-1.57, high=1.57, size=m5))
+    params5 = np.stack([p5["x"], p5["y"], p5["z"], p5["w"], p5["h"], p5["l"], p5["r"]], 1).astype(np.float32)
+    cases = [("m5", params5), ("uni64", boxes_3d(rng, 64)), ("clu64", boxes_3d(rng, 64, clustered=True)),
+             ("clu200", boxes_3d(rng, 200, clustered=True))]
+    for tag, p in cases:
+        t = [torch.from_numpy(np.ascontiguousarray(p[:, i])) for i in range(7)]
+        corners = math_3d.get_corners_of_cuboid(t[0], t[1], t[2], t[3], t[4], t[5], t[6])   # N x 3 x 8
+        d3[f"{tag}/params"] = p                      # x y z w h l ry
+        d3[f"{tag}/corners"] = corners.numpy().astype(np.float32)
+        # iou3d_approximate mutates its inputs (lib/core.py:379-380): pass clones
+        for method in ("normal", "generalized"):
+            bev, i3 = core.iou3d_approximate(corners.clone(), corners.clone(), mode="combinations", method=method)
+            d3[f"{tag}/{method}/iou_bev"] = bev.numpy().astype(np.float32)
+            d3[f"{tag}/{method}/iou_3d"] = i3.numpy().astype(np.float32)
+        # what the callers feed the NMS: 0.5*(1+giou) (lib/loss/rpn_3d.py:781, lib/rpn_util.py:1312)
+        _, gi = core.iou3d_approximate(corners.clone(), corners.clone(), mode="combinations", method="generalized")
+        d3[f"{tag}/nms_overlap"] = (0.5 * (1 + gi)).numpy().astype(np.float32)
+    # rectangular 3D
+    pa, pb = boxes_3d(rng, 19), boxes_3d(rng, 7, clustered=True)
+    ca = math_3d.get_corners_of_cuboid(*[torch.from_numpy(np.ascontiguousarray(pa[:, i])) for i in range(7)])
+    cb = math_3d.get_corners_of_cuboid(*[torch.from_numpy(np.ascontiguousarray(pb[:, i])) for i in range(7)])
+    d3["rect/corners_a"] = ca.numpy()
+    d3["rect/corners_b"] = cb.numpy()
+    bev, i3 = core.iou3d_approximate(ca.clone(), cb.clone(), mode="combinations", method="generalized")
+    d3["rect/iou_bev"] = bev.numpy()
+    d3["rect/iou_3d"] = i3.numpy()
+    # NMS on a 3D overlap matrix
+    s = tie_free_scores(rng, 200)
+    pack_case(d3, "clu200_nms", s, d3["clu200/nms_overlap"], modes=[m_ for m_ in MODES if not m_[0].endswith("_sorted")],
+              rng=rng)
+    np.savez_compressed(os.path.join(OUT, "boxes_3d.npz"), **d3)
+
+    # ------------------------------------------------------------------ soft sort, helpers, classical NMS
+    misc = {}
+    # soft sort only terminates in the reference when the input is already score-sorted and the
+    # temperature is small against the score gaps: iou' = C @ iou mixes rows but leaves columns in
+    # input order (lib/groomed_nms.py:164), so get_groups' "leader column" (:249) is column k of the
+    # input, and a diagonal <= threshold makes its while-loop spin forever (:247-262).
+    for n, temp in ((16, 0.01), (16, 0.003), (40, 0.002)):
+        s = np.sort(tie_free_scores(rng, n))[::-1].copy()
+        b = clustered_boxes_2d(rng, n, per=4)
+        m = core.iou(torch.from_numpy(b), torch.from_numpy(b), mode="combinations").numpy()
+        ss, C, sm = gn.soft_sort(torch.from_numpy(s), full_matrix=torch.from_numpy(m), temperature=temp)
+        tag = f"softsort_n{n}_t{temp}"
+        misc[f"{tag}/scores"] = s
+        misc[f"{tag}/iou"] = m
+        misc[f"{tag}/temperature"] = np.array(temp, np.float32)
+        misc[f"{tag}/soft_scores"] = ss.numpy()
+        misc[f"{tag}/C"] = C.numpy()
+        misc[f"{tag}/soft_matrix"] = sm.numpy()
+        w = rng.uniform(-1, 2, size=n).astype(np.float32)
+        misc[f"{tag}/w"] = w
+        for mt, kw in (("gm", dict(group_boxes=True, mask_group_boxes=True)),
+                       ("gu", dict(group_boxes=True, mask_group_boxes=False)),
+                       ("un", dict(group_boxes=False))):
+            res = run_nms(s, m, w=w, want_iou_grad=True, sorting_method="soft", sorting_temperature=temp,
+                          temperature=0.1, **kw)
+            for k, v in res.items():
+                misc[f"{tag}/{mt}/{k}"] = v
+    # pruning_function torch + numpy branches (lib/groomed_nms.py:167-189)
+    x = rng.uniform(0, 1, size=(7, 7)).astype(np.float32)
+    misc["prune/x"] = x
+    for method, temp in (("linear", 0.01), ("sigmoidal", 0.1), ("sigmoidal", 0.01), ("soft_nms", 0.5), ("soft_nms", 0.1)):
+        misc[f"prune/{method}_{temp}/torch"] = gn.pruning_function(torch.from_numpy(x), 0.4, temp, method).numpy()
+        misc[f"prune/{method}_{temp}/numpy_row0"] = np.asarray(
+            gn.pruning_function(x[0].astype(np.float64), 0.4, temp, method), np.float64)
+    # indices_copy (lib/groomed_nms.py:272) in the mode differentiable_nms uses (1-D indA -> g x g block)
+    A = np.zeros((6, 6), np.float32)
+    Bm = rng.uniform(1, 2, size=(3, 3)).astype(np.float32)
+    ind = np.array([4, 0, 3], np.int64)
+    misc["indices_copy/A"] = A
+    misc["indices_copy/B"] = Bm
+    misc["indices_copy/ind"] = ind
+    misc["indices_copy/out"] = gn.indices_copy(torch.from_numpy(A.copy()), torch.from_numpy(Bm), torch.from_numpy(ind)).numpy()
+    # classical NMS family on seeded dets (integer-ish pixel boxes, +1 convention)
+    for tag, n, gen in (("dets40", 40, clustered_boxes_2d), ("dets300", 300, clustered_boxes_2d),
+                        ("dets_uni200", 200, uniform_boxes_2d)):
+        b = gen(rng, n) if gen is uniform_boxes_2d else gen(rng, n, per=8)
+        dets = np.concatenate([b, tie_free_scores(rng, n)[:, None]], 1).astype(np.float32)
+        misc[f"{tag}/dets"] = dets
+        for thr in (0.4, 0.7):
+            misc[f"{tag}/py_cpu_nms_{thr}"] = np.asarray(pcn.py_cpu_nms(dets.copy(), thr), np.int64)
+            misc[f"{tag}/girshick_nms_{thr}"] = np.asarray(nms_others.girshick_nms(dets.copy(), thr, shift=1), np.int64)
+            misc[f"{tag}/girshick_nms_shift0_{thr}"] = np.asarray(nms_others.girshick_nms(dets.copy(), thr, shift=0), np.int64)
+        for method in (0, 1, 2):
+            misc[f"{tag}/soft_nms_m{method}"] = np.asarray(
+                nms_others.navneeth_soft_nms(dets.astype(np.float64).copy(), sigma=0.5, Nt=0.4, threshold=0.001,
+                                             method=method, shift=1), np.int64)
+    np.savez_compressed(os.path.join(OUT, "misc.npz"), **misc)
+
+    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz"):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
