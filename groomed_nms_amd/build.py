@@ -1,0 +1,62 @@
+"""Builds libgroomed_nms_hip.so (gfx950) in-tree with hipcc.  `python -m groomed_nms_amd.build`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libgroomed_nms_hip.so")
+SOURCES = ["iou_kernels.hip", "nms_layer.hip", "soft_sort.hip", "classic_nms.hip"]
+HEADERS = ["gnms_common.h", "nms_kernels.h", "nms_backward_kernels.h", "nms_solve_kernels.h",
+           os.path.join("..", "..", "include", "groomed_nms_hip.h")]
+# -ffp-contract=off: products and sums round separately, like the reference's torch CPU kernels
+# (lib/core.py:499-508) -- this is what makes the overlap matrices bit-identical.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + deps):
+            jobs.append([hipcc()] + FLAGS + ["-c", s, "-o", o])
+    if jobs:
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-6000:]))
+            if verbose and r.stderr.strip():
+                print(r.stderr[-3000:])
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(OUT, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s" % r.stderr[-6000:])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,140 @@
+// classic_nms.hip -- classical hard NMS for gfx950 behind the reference's C symbol `_nms`.
+//
+// Reference: lib/nms/nms_kernel.cu:24-32 devIoU (+1 pixel), :34-78 nms_kernel (64x64 tiles, one
+// thread per row looping 64 columns, strict '>'), :91-144 `_nms` (H2D, kernel, D2H of the whole
+// bit matrix, sequential HOST scan), lib/nms/gpu_nms.hpp:1-2.
+//
+// Here: the bit matrix is built column-major in rank blocks by the same wave64 scheme as the GrooMeD
+// bit-matrix kernel (a lane owns 4 candidate-suppressor columns and accumulates a 64-bit word over
+// the 64 rows of a rank block; no per-thread 64-iteration loop, no shared memory), only tiles that a
+// suppressor can reach are computed (suppressor index < end of the rank block), and the scan runs ON
+// the device (leaders_kernel), so only keep[] and the count cross PCIe.
+#include "nms_kernels.h"
+
+namespace {
+
+using namespace gnms;
+
+__device__ __forceinline__ float bcastf(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// boxes [n][dim] sorted by score; W[kb][c] bit r = devIoU(box[64 kb + r], box[c]) > thresh
+__global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restrict__ boxes, int n, int dim, float thresh, char* ws,
+                                                           gnms_ws_layout L) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kb = blockIdx.y;
+    const int k0 = kb * 64;
+    const int c0 = (blockIdx.x * 4 + wave) * 256;
+    if (k0 >= n || c0 >= n || c0 >= k0 + 64) return;      // suppressors come from ranks < k0 + 64
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    float bx1[4], by1[4], bx2[4], by2[4], bs[4];
+    int col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        col[j] = c0 + 4 * lane + j;
+        const float* p = boxes + (size_t)(col[j] < n ? col[j] : n - 1) * dim;
+        bx1[j] = p[0]; by1[j] = p[1]; bx2[j] = p[2]; by2[j] = p[3];
+        bs[j] = (bx2[j] - bx1[j] + 1) * (by2[j] - by1[j] + 1);                 // nms_kernel.cu:30
+    }
+    const int myr = min(k0 + lane, n - 1);
+    const float* q = boxes + (size_t)myr * dim;
+    const float rx1 = q[0], ry1 = q[1], rx2 = q[2], ry2 = q[3];
+    const float rs = (rx2 - rx1 + 1) * (ry2 - ry1 + 1);                        // :29
+    const int nrows = min(64, n - k0);
+    unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) {
+        const float ax1 = bcastf(rx1, r), ay1 = bcastf(ry1, r), ax2 = bcastf(rx2, r), ay2 = bcastf(ry2, r), as = bcastf(rs, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float left = fmaxf(ax1, bx1[j]), right = fminf(ax2, bx2[j]);   // :25
+            const float top = fmaxf(ay1, by1[j]), bottom = fminf(ay2, by2[j]);   // :26
+            const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);   // :27
+            const float inter = width * height;                                  // :28
+            const bool sup = (inter / (as + bs[j] - inter)) > thresh;            // :31, :71
+            if (r < 32) lo[j] |= sup ? (1u << r) : 0u; else hi[j] |= sup ? (1u << (r - 32)) : 0u;
+        }
+    }
+    const unsigned long long rowmask = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
+    u64* Wk = I.W + (size_t)kb * L.NC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (col[j] < L.NC) Wk[col[j]] = ((((u64)hi[j]) << 32) | lo[j]) & rowmask;
+}
+
+__global__ void classic_init_kernel(int n, char* ws, gnms_ws_layout L) {
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) I.order[k] = k;
+    if (k < 8) I.misc[k] = 0;
+}
+
+__global__ void classic_export_kernel(int n, char* ws, gnms_ws_layout L, int* __restrict__ keep, int* __restrict__ num_out) {
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    const int nl = I.misc[0];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *num_out = nl;
+    if (t < nl) keep[t] = I.leadr[t];                      // :131 keep_out[num_to_keep++] = i
+}
+
+}  // namespace
+
+extern "C" size_t gnms_nms_workspace_bytes(int n) { return n > 0 ? gnms_make_layout(n).per_image : 0; }
+
+extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int32_t* keep, int32_t* num_out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    GNMS_CHECK_ARG(n >= 0 && boxes_dim >= 4, "gnms_nms_sorted: bad shape (n=%d dim=%d)", n, boxes_dim);
+    GNMS_CHECK_ARG(num_out != nullptr, "gnms_nms_sorted: num_out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { GNMS_CHECK_HIP(hipMemsetAsync(num_out, 0, sizeof(int32_t), st)); return GNMS_OK; }
+    if (n > GNMS_MAX_BOXES) { gnms_set_error("gnms_nms_sorted: n=%d exceeds GNMS_MAX_BOXES=%d", n, GNMS_MAX_BOXES); return GNMS_ERR_UNSUPPORTED; }
+    GNMS_CHECK_ARG(boxes && keep && workspace, "gnms_nms_sorted: null pointer");
+    const gnms_ws_layout L = gnms_make_layout(n);
+    if (workspace_bytes < L.per_image) { gnms_set_error("gnms_nms_sorted: workspace too small"); return GNMS_ERR_WORKSPACE; }
+    char* ws = (char*)workspace;
+    classic_init_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L);
+    GNMS_CHECK_LAUNCH();
+    classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, ws, L);
+    GNMS_CHECK_LAUNCH();
+    const size_t lds = (size_t)n * 4;
+    if (lds > 64 * 1024)
+        GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    leaders_kernel<<<1, 256, lds, st>>>(n, nullptr, ws, L);
+    GNMS_CHECK_LAUNCH();
+    classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+// The reference's exact symbol (lib/nms/gpu_nms.hpp:1-2): host pointers, blocking, allocates per call
+// (nms_kernel.cu:100-108,142-143).  Errors cannot be returned through this signature; unlike the
+// reference (which prints and carries on, :12-19) a failure yields *num_out = 0 and the message is
+// kept for gnms_last_error().
+extern "C" void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+                     float nms_overlap_thresh, int device_id) {
+    if (num_out) *num_out = 0;
+    if (!keep_out || !num_out || boxes_num <= 0 || !boxes_host) return;
+    if (boxes_dim < 4) { gnms_set_error("_nms: boxes_dim=%d < 4", boxes_dim); return; }   // the kernel reads 5 fields, stride boxes_dim
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { gnms_set_error("_nms: hipGetDevice failed"); return; }
+    if (cur != device_id && hipSetDevice(device_id) != hipSuccess) { gnms_set_error("_nms: hipSetDevice(%d) failed", device_id); return; }   // :80-89
+    const size_t bbytes = (size_t)boxes_num * boxes_dim * sizeof(float);
+    const size_t wbytes = gnms_nms_workspace_bytes(boxes_num);
+    char* dev = nullptr;
+    const size_t off_keep = (bbytes + 255) / 256 * 256;
+    const size_t off_ws = off_keep + ((size_t)(boxes_num + 1) * 4 + 255) / 256 * 256;
+    if (hipMalloc((void**)&dev, off_ws + wbytes) != hipSuccess) { gnms_set_error("_nms: hipMalloc failed"); return; }
+    int32_t* keep_d = (int32_t*)(dev + off_keep);
+    int32_t* num_d = keep_d + boxes_num;                      // staged right behind keep[] on the device
+    int rc = GNMS_OK;
+    hipError_t e = hipMemcpy(dev, boxes_host, bbytes, hipMemcpyHostToDevice);                        // :103-106
+    if (e == hipSuccess)
+        rc = gnms_nms_sorted((const float*)dev, boxes_num, boxes_dim, nms_overlap_thresh, keep_d, num_d, dev + off_ws, wbytes, nullptr);
+    int num = 0;
+    if (e == hipSuccess && rc == GNMS_OK) e = hipMemcpy(&num, num_d, sizeof(int), hipMemcpyDeviceToHost);   // blocking: orders after the kernels
+    if (e == hipSuccess && rc == GNMS_OK && num > 0) e = hipMemcpy(keep_out, keep_d, (size_t)num * sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc == GNMS_OK) *num_out = num;
+    (void)hipFree(dev);
+    if (e != hipSuccess) gnms_set_error("_nms: HIP copy failed");
+}

@@ -1,0 +1,132 @@
+// gnms_common.h -- shared device/host helpers of libgroomed_nms_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/groomed_nms_hip.h"
+
+#define GNMS_WAVE 64
+
+// thread-local last-error message (gnms_last_error)
+void gnms_set_error(const char* fmt, ...);
+
+#define GNMS_CHECK_ARG(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            gnms_set_error(__VA_ARGS__);          \
+            return GNMS_ERR_INVALID_ARGUMENT;     \
+        }                                         \
+    } while (0)
+
+#define GNMS_CHECK_HIP(expr)                                                                  \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            gnms_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return GNMS_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+#define GNMS_CHECK_LAUNCH()                                                                   \
+    do {                                                                                      \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess) {                                                              \
+            gnms_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return GNMS_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+static inline int gnms_div_up(int a, int b) { return (a + b - 1) / b; }
+static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout of the NMS layer (per call; all offsets 256-byte aligned)
+//
+//   per image b (N = padded box count of the batch, NB = ceil(N/64) rank blocks, NC = round_up(N,4)):
+//     order      int32 [N]      rank -> input index (stable descending argsort of the scores)
+//     sscore     float [N]      scores in rank order
+//     rem        int32 [N]      rank of the leader that removed rank k from `remaining` (k itself for leaders)
+//     head       int32 [N]      rank of the first member of k's group (lib/groomed_nms.py:99 groups[j][0]),
+//                               -1 when k is in no group
+//     gpos       int32 [N]      position of k inside its group
+//     gsorted    int32 [N]      ranks sorted by (leader, rank), members only: the groups as contiguous runs
+//     gstart     int32 [N]      for rank k: index into gsorted where k's group starts (valid when head>=0)
+//     glen       int32 [N]      for rank k: number of members of k's group kept under the cap
+//     plead      float [N]      masked mode: prune(iou[k][head]) after tril (0 for heads / non-members)
+//     pre        float [N]      (M s)_k before the clamp (lib/groomed_nms.py:111); NMS order
+//     r2         float [N]      clamp(pre, 0, 1)
+//     sidx       int32 [N]      argsort (descending, stable) of the thresholded probabilities (:116-121)
+//     xsol       float [N]      unmasked/ungrouped: workspace for the triangular solves
+//     gx         float [N]      backward: dL/d(M s) after the clamp / threshold masks, by NMS position
+//     leadc      int32 [N]      input index of the i-th leader (in rank order)
+//     leadr      int32 [N]      rank of the i-th leader
+//     leadw      u64   [NB]     bit k%64 of word k/64 set iff rank k is a leader
+//     leadpfx    int32 [NB+1]   number of leaders in rank blocks < kb
+//     misc       int32 [8]      [0]=number of leaders, [1]=number of groups
+//     W          u64   [NB][NC] W[kb][c] bit r set iff !(iou[order[64*kb+r]][c] <= thr): the set of ranks that
+//                               input-box c, were it a leader, takes out of `remaining` (:249-262), in rank space
+// ------------------------------------------------------------------------------------------------
+struct gnms_ws_layout {
+    int N, NB, NC;
+    size_t off_order, off_sscore, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_plead, off_pre,
+        off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_W;
+    size_t per_image;  // bytes
+};
+
+static inline gnms_ws_layout gnms_make_layout(int N) {
+    gnms_ws_layout L;
+    L.N = N;
+    L.NB = (N + 63) / 64;
+    L.NC = (N + 3) / 4 * 4;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = gnms_align_up(o + bytes, 256); return r; };
+    size_t n4 = (size_t)(N > 0 ? N : 1) * 4;
+    L.off_order = take(n4); L.off_sscore = take(n4); L.off_rem = take(n4); L.off_head = take(n4);
+    L.off_gpos = take(n4); L.off_gsorted = take(n4); L.off_gstart = take(n4); L.off_glen = take(n4);
+    L.off_plead = take(n4); L.off_pre = take(n4); L.off_r2 = take(n4); L.off_sidx = take(n4);
+    L.off_xsol = take(n4); L.off_gx = take(n4); L.off_leadc = take(n4); L.off_leadr = take(n4);
+    L.off_leadw = take((size_t)(L.NB > 0 ? L.NB : 1) * 8);
+    L.off_leadpfx = take((size_t)(L.NB + 1) * 4);
+    L.off_misc = take(32);
+    L.off_W = take((size_t)(L.NB > 0 ? L.NB : 1) * (size_t)(L.NC > 0 ? L.NC : 4) * 8);
+    L.per_image = o;
+    return L;
+}
+
+#ifdef __HIPCC__
+// pruning_function (lib/groomed_nms.py:167-189) and its derivative, fp32, same expression order as the oracle
+__device__ __forceinline__ float gnms_prune(float x, float thr, float temp, int method) {
+    if (method == GNMS_PRUNE_LINEAR) return x;
+    if (method == GNMS_PRUNE_SIGMOIDAL) {
+        float z = (x - thr) / temp;
+        return 1.0f / (1.0f + expf(-z));
+    }
+    return 1.0f - expf(-(x * x) / temp);
+}
+__device__ __forceinline__ float gnms_prune_grad(float x, float thr, float temp, int method) {
+    if (method == GNMS_PRUNE_LINEAR) return 1.0f;
+    if (method == GNMS_PRUNE_SIGMOIDAL) {
+        float z = (x - thr) / temp;
+        float sg = 1.0f / (1.0f + expf(-z));
+        return sg * (1.0f - sg) / temp;
+    }
+    return expf(-(x * x) / temp) * (2.0f * x / temp);
+}
+
+// order-preserving map float -> uint32 for a DESCENDING sort done as an ascending sort of the key:
+// larger floats get smaller keys; NaN is the greatest value (torch.sort semantics) -> key 0; -0.0 == +0.0.
+__device__ __forceinline__ uint32_t gnms_desc_key(float v) {
+    if (v != v) return 0u;                                     // every non-NaN key below is >= 0x007fffff
+    uint32_t u = __float_as_uint(v + 0.0f);                    // -0.0 + 0.0 = +0.0
+    uint32_t asc = (u >> 31) ? ~u : (u | 0x80000000u);         // ascending-sortable image of the float
+    return ~asc;
+}
+
+// wave-wide OR of a 64-bit value (all 64 lanes get the result)
+__device__ __forceinline__ unsigned long long gnms_wave_or(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off, 64);
+    return v;
+}
+#endif

@@ -1,0 +1,321 @@
+// iou_kernels.hip -- pairwise overlap matrices for gfx950 (MI355X).
+//
+// Reference semantics: lib/core.py:178-218 intersect, :480-508 iou (mode='combinations'),
+// :305-421 iou3d_approximate (+ get_hull :423, get_volume :434, remove_rotation_in_boxes :463),
+// lib/math_3d.py:364-435 get_corners_of_cuboid.
+//
+// Roofline class: HBM write stream (4*M*N bytes out, 16..32 bytes per box in).  One wave owns a
+// 64-row x 256-column tile: the 4 column boxes of a lane live in registers for the whole tile,
+// the row box is wave-uniform (v_readlane from the lane that loaded it), and every row of the tile
+// leaves the wave as one 1-KiB coalesced global_store_dwordx4 (the 4 waves of a workgroup cover
+// 4 KiB of one row).  Arithmetic follows the oracle/reference operation order exactly and the file
+// is compiled with -ffp-contract=off, so the 2D matrix is bit-identical to torch's CPU result.
+#include "gnms_common.h"
+
+namespace {
+
+constexpr int kTileRows = 64;
+constexpr int kWaveCols = 256;   // 64 lanes x 4 columns
+constexpr int kWavesPerWG = 4;
+constexpr int kWGCols = kWaveCols * kWavesPerWG;
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float relu0(float v) { return fmaxf(v, 0.0f); }
+
+// ------------------------------------------------------------------------------------------------
+// 2D IoU.  a [B][M][4], b [B][N][4], out [B][M][ld].
+// VEC: ld % 4 == 0 and out 16-byte aligned -> lane owns columns c0+4*lane+{0..3}, one 16-B store per row;
+// otherwise lane owns columns c0+lane+64*{0..3} and stores dwords (still coalesced).
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void iou2d_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
+                                                    int M, int N, float* __restrict__ out, long ld) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int img = blockIdx.z;
+    const int i0 = blockIdx.y * kTileRows;
+    const int c0 = blockIdx.x * kWGCols + wave * kWaveCols;
+    if (c0 >= N) return;
+    const float* a = A + (size_t)img * M * 4;
+    const float* b = Bx + (size_t)img * N * 4;
+    float* o = out + (size_t)img * M * ld;
+
+    // column boxes -> registers
+    float bx1[4], by1[4], bx2[4], by2[4], barea[4];
+    int col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
+        int cc = col[j] < N ? col[j] : (N - 1);
+        float4 v = *reinterpret_cast<const float4*>(b + (size_t)cc * 4);
+        bx1[j] = v.x; by1[j] = v.y; bx2[j] = v.z; by2[j] = v.w;
+        barea[j] = (v.z - v.x) * (v.w - v.y);                        // lib/core.py:502-503
+    }
+    // row boxes: lane r holds row i0+r
+    const int myrow = i0 + lane;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (myrow < M) ra = *reinterpret_cast<const float4*>(a + (size_t)myrow * 4);
+    const float rarea = (ra.z - ra.x) * (ra.w - ra.y);               // lib/core.py:500-501
+    const int rows = min(kTileRows, M - i0);
+
+    for (int r = 0; r < rows; ++r) {
+        const float ax1 = bcast(ra.x, r), ay1 = bcast(ra.y, r), ax2 = bcast(ra.z, r), ay2 = bcast(ra.w, r);
+        const float aarea = bcast(rarea, r);
+        float res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float w = relu0(fminf(ax2, bx2[j]) - fmaxf(ax1, bx1[j]));   // lib/core.py:210-212
+            float h = relu0(fminf(ay2, by2[j]) - fmaxf(ay1, by1[j]));
+            float inter = w * h;                                        // :218
+            float uni = (aarea + barea[j]) - inter;                     // :507
+            res[j] = inter / uni;                                       // :508
+        }
+        float* orow = o + (size_t)(i0 + r) * ld;
+        if (VEC) {
+            if (col[3] < N) {
+                *reinterpret_cast<float4*>(orow + col[0]) = make_float4(res[0], res[1], res[2], res[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3D: per-box axis-aligned record.  rec[8] = {vol, y0, y1, x0, x1, z0, z1, area_bev}
+//   vol: product of the per-axis extents over all 8 corners (get_volume, lib/core.py:434-451)
+//   y0,y1: min/max corner y (:365-368); x/z extents from corners {2,3,6,7} (:383-388, :463-476)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void aabb_record(const float (&cx)[8], const float (&cy)[8], const float (&cz)[8], float* rec) {
+    float mnx = cx[0], mxx = cx[0], mny = cy[0], mxy = cy[0], mnz = cz[0], mxz = cz[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        mnx = fminf(mnx, cx[k]); mxx = fmaxf(mxx, cx[k]);
+        mny = fminf(mny, cy[k]); mxy = fmaxf(mxy, cy[k]);
+        mnz = fminf(mnz, cz[k]); mxz = fmaxf(mxz, cz[k]);
+    }
+    float vol = ((mxx - mnx) * (mxy - mny)) * (mxz - mnz);
+    float x0 = fminf(fminf(cx[2], cx[3]), fminf(cx[6], cx[7])), x1 = fmaxf(fmaxf(cx[2], cx[3]), fmaxf(cx[6], cx[7]));
+    float z0 = fminf(fminf(cz[2], cz[3]), fminf(cz[6], cz[7])), z1 = fmaxf(fmaxf(cz[2], cz[3]), fmaxf(cz[6], cz[7]));
+    rec[0] = vol; rec[1] = mny; rec[2] = mxy; rec[3] = x0; rec[4] = x1; rec[5] = z0; rec[6] = z1;
+    rec[7] = (x1 - x0) * (z1 - z0);
+}
+
+__global__ void aabb_from_corners_kernel(const float* __restrict__ corners, long count, float* __restrict__ rec) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float* c = corners + i * 24;
+    float cx[8], cy[8], cz[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { cx[k] = c[k]; cy[k] = c[8 + k]; cz[k] = c[16 + k]; }
+    float r[8];
+    aabb_record(cx, cy, cz, r);
+    float4* o = reinterpret_cast<float4*>(rec + i * 8);
+    o[0] = make_float4(r[0], r[1], r[2], r[3]);
+    o[1] = make_float4(r[4], r[5], r[6], r[7]);
+}
+
+// get_corners_of_cuboid, lib/math_3d.py:364-435 (same operation order as oracle/gnms_oracle.c)
+__device__ __forceinline__ void corners_of(const float* p, float (&cx)[8], float (&cy)[8], float (&cz)[8]) {
+    const float x = p[0], y = p[1], z = p[2], w = p[3], h = p[4], l = p[5], ry = p[6];
+    const float c = cosf(ry), s = sinf(ry);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool xh = (k == 1) | (k == 3) | (k == 5) | (k == 6);   // :401
+        const bool yh = (k == 2) | (k == 3) | (k == 6) | (k == 7);   // :402
+        const bool zh = k >= 4;                                      // :403
+        float bx = (xh ? l : 0.0f) - l / 2;
+        float by = (yh ? h : 0.0f) - h / 2;
+        float bz = (zh ? w : 0.0f) - w / 2;
+        float rx = c * bx + 0.0f * by + s * bz;                      // bmm(R, corners) :430
+        float ryy = 0.0f * bx + 1.0f * by + 0.0f * bz;
+        float rz = (-s) * bx + 0.0f * by + c * bz;
+        cx[k] = rx + x; cy[k] = ryy + y; cz[k] = rz + z;             // :433-435
+    }
+}
+
+__global__ void corners_kernel(const float* __restrict__ params, long count, float* __restrict__ corners) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float cx[8], cy[8], cz[8];
+    corners_of(params + i * 7, cx, cy, cz);
+    float* c = corners + i * 24;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { c[k] = cx[k]; c[8 + k] = cy[k]; c[16 + k] = cz[k]; }
+}
+
+__global__ void aabb_from_params_kernel(const float* __restrict__ params, long count, float* __restrict__ rec) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float cx[8], cy[8], cz[8];
+    corners_of(params + i * 7, cx, cy, cz);
+    float r[8];
+    aabb_record(cx, cy, cz, r);
+    float4* o = reinterpret_cast<float4*>(rec + i * 8);
+    o[0] = make_float4(r[0], r[1], r[2], r[3]);
+    o[1] = make_float4(r[4], r[5], r[6], r[7]);
+}
+
+// pairwise 3D overlap from the records.  METHOD 0 normal, 1 generalized, 2 0.5*(1+generalized).
+template <bool VEC, int METHOD, bool BEV>
+__global__ __launch_bounds__(256) void iou3d_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M, int N,
+                                                    float* __restrict__ out_bev, float* __restrict__ out3d, long ld) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int img = blockIdx.z;
+    const int i0 = blockIdx.y * kTileRows;
+    const int c0 = blockIdx.x * kWGCols + wave * kWaveCols;
+    if (c0 >= N) return;
+    const float* ra = RA + (size_t)img * M * 8;
+    const float* rb = RB + (size_t)img * N * 8;
+    float* o3 = out3d + (size_t)img * M * ld;
+    float* ob = BEV ? out_bev + (size_t)img * M * ld : nullptr;
+
+    float bvol[4], by0[4], by1[4], bx0[4], bx1[4], bz0[4], bz1[4], bar[4];
+    int col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
+        int cc = col[j] < N ? col[j] : (N - 1);
+        const float4* p = reinterpret_cast<const float4*>(rb + (size_t)cc * 8);
+        float4 u = p[0], v = p[1];
+        bvol[j] = u.x; by0[j] = u.y; by1[j] = u.z; bx0[j] = u.w; bx1[j] = v.x; bz0[j] = v.y; bz1[j] = v.z; bar[j] = v.w;
+    }
+    const int myrow = i0 + lane;
+    float4 ru = make_float4(0.f, 0.f, 0.f, 0.f), rv = ru;
+    if (myrow < M) {
+        const float4* p = reinterpret_cast<const float4*>(ra + (size_t)myrow * 8);
+        ru = p[0]; rv = p[1];
+    }
+    const int rows = min(kTileRows, M - i0);
+
+    for (int r = 0; r < rows; ++r) {
+        const float avol = bcast(ru.x, r), ay0 = bcast(ru.y, r), ay1 = bcast(ru.z, r), ax0 = bcast(ru.w, r);
+        const float ax1 = bcast(rv.x, r), az0 = bcast(rv.y, r), az1 = bcast(rv.z, r), aar = bcast(rv.w, r);
+        float res3[4], resb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float vol = avol + bvol[j];                                       // lib/core.py:357
+            float yi = relu0(fminf(ay1, by1[j]) - fmaxf(ay0, by0[j]));        // :371-376
+            float w = relu0(fminf(ax1, bx1[j]) - fmaxf(ax0, bx0[j]));         // intersect(bev) :410
+            float h = relu0(fminf(az1, bz1[j]) - fmaxf(az0, bz0[j]));
+            float inter = w * h;
+            if (BEV) resb[j] = inter / ((aar + bar[j]) - inter);              // iou(bev) :408
+            float i3 = inter * yi;                                            // :415
+            float u3 = vol - i3;                                              // :416
+            float q = i3 / u3;                                                // :417
+            if (METHOD >= 1) {                                                // :390-406, :418-419
+                float xh = relu0(fmaxf(ax1, bx1[j]) - fminf(ax0, bx0[j]));
+                float yh = relu0(fmaxf(ay1, by1[j]) - fminf(ay0, by0[j]));
+                float zh = relu0(fmaxf(az1, bz1[j]) - fminf(az0, bz0[j]));
+                float vh = (xh * yh) * zh;
+                q = q - ((vh - u3) / vh);
+            }
+            if (METHOD == 2) q = 0.5f * (1.0f + q);                           // lib/loss/rpn_3d.py:781
+            res3[j] = q;
+        }
+        const size_t roff = (size_t)(i0 + r) * ld;
+        if (VEC && col[3] < N) {
+            *reinterpret_cast<float4*>(o3 + roff + col[0]) = make_float4(res3[0], res3[1], res3[2], res3[3]);
+            if (BEV) *reinterpret_cast<float4*>(ob + roff + col[0]) = make_float4(resb[0], resb[1], resb[2], resb[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (col[j] < N) { o3[roff + col[j]] = res3[j]; if (BEV) ob[roff + col[j]] = resb[j]; }
+        }
+    }
+}
+
+template <bool VEC, int METHOD>
+void launch_iou3d(const float* ra, const float* rb, int B, int M, int N, float* bev, float* o3, long ld, hipStream_t st) {
+    dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, kTileRows), B);
+    if (bev) iou3d_kernel<VEC, METHOD, true><<<grid, 256, 0, st>>>(ra, rb, M, N, bev, o3, ld);
+    else iou3d_kernel<VEC, METHOD, false><<<grid, 256, 0, st>>>(ra, rb, M, N, nullptr, o3, ld);
+}
+
+int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, int method, float* bev, float* o3, int64_t ld,
+                       hipStream_t st) {
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)o3 % 16 == 0) && (!bev || (uintptr_t)bev % 16 == 0);
+    if (vec) {
+        if (method == 0) launch_iou3d<true, 0>(ra, rb, B, M, N, bev, o3, ld, st);
+        else if (method == 1) launch_iou3d<true, 1>(ra, rb, B, M, N, bev, o3, ld, st);
+        else launch_iou3d<true, 2>(ra, rb, B, M, N, bev, o3, ld, st);
+    } else {
+        if (method == 0) launch_iou3d<false, 0>(ra, rb, B, M, N, bev, o3, ld, st);
+        else if (method == 1) launch_iou3d<false, 1>(ra, rb, B, M, N, bev, o3, ld, st);
+        else launch_iou3d<false, 2>(ra, rb, B, M, N, bev, o3, ld, st);
+    }
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+}  // namespace
+
+extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int M, int N, float* out, int64_t ld,
+                          void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && M >= 0 && N >= 0, "gnms_iou2d: negative size (B=%d M=%d N=%d)", B, M, N);
+    if (B == 0 || M == 0 || N == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(boxes_a && boxes_b && out, "gnms_iou2d: null pointer");
+    GNMS_CHECK_ARG(ld >= N, "gnms_iou2d: ld (%lld) < N (%d)", (long long)ld, N);
+    GNMS_CHECK_ARG(((uintptr_t)boxes_a % 16 == 0) && ((uintptr_t)boxes_b % 16 == 0), "gnms_iou2d: boxes must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, kTileRows), B);
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    if (vec) iou2d_kernel<true><<<grid, 256, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld);
+    else iou2d_kernel<false><<<grid, 256, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+extern "C" int gnms_corners_of_cuboid(const float* params, int64_t count, float* corners, void* stream) {
+    GNMS_CHECK_ARG(count >= 0, "gnms_corners_of_cuboid: negative count");
+    if (count == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(params && corners, "gnms_corners_of_cuboid: null pointer");
+    corners_kernel<<<(unsigned)((count + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, (long)count, corners);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+// The per-box records are tiny (32 B/box); they live in a stream-ordered allocation so the public
+// entry points stay allocation-free for the caller.  hipMallocAsync/hipFreeAsync are stream ordered.
+static int iou3d_common(const float* in_a, const float* in_b, bool from_params, int B, int M, int N, int method, float* iou_bev,
+                        float* iou_3d, int64_t ld, void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && M >= 0 && N >= 0, "gnms_iou3d: negative size");
+    GNMS_CHECK_ARG(method >= 0 && method <= 2, "gnms_iou3d: method %d not in {0,1,2}", method);
+    if (B == 0 || M == 0 || N == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(in_a && in_b && iou_3d, "gnms_iou3d: null pointer");
+    GNMS_CHECK_ARG(ld >= N, "gnms_iou3d: ld < N");
+    hipStream_t st = (hipStream_t)stream;
+    float* rec = nullptr;
+    const size_t na = (size_t)B * M, nb = (size_t)B * N;
+    GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (na + nb) * 8 * sizeof(float), st));
+    float* ra = rec;
+    float* rb = rec + na * 8;
+    if (from_params) {
+        aabb_from_params_kernel<<<(unsigned)((na + 255) / 256), 256, 0, st>>>(in_a, (long)na, ra);
+        aabb_from_params_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(in_b, (long)nb, rb);
+    } else {
+        aabb_from_corners_kernel<<<(unsigned)((na + 255) / 256), 256, 0, st>>>(in_a, (long)na, ra);
+        aabb_from_corners_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(in_b, (long)nb, rb);
+    }
+    int rc = iou3d_from_records(ra, rb, B, M, N, method, iou_bev, iou_3d, ld, st);
+    hipError_t fe = hipFreeAsync(rec, st);
+    if (rc != GNMS_OK) return rc;
+    if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }
+    return GNMS_OK;
+}
+
+extern "C" int gnms_iou3d_approximate(const float* corners_a, const float* corners_b, int B, int M, int N, int method,
+                                      float* iou_bev, float* iou_3d, int64_t ld, void* stream) {
+    return iou3d_common(corners_a, corners_b, false, B, M, N, method, iou_bev, iou_3d, ld, stream);
+}
+
+extern "C" int gnms_iou3d_from_params(const float* params_a, const float* params_b, int B, int M, int N, int method,
+                                      float* iou_bev, float* iou_3d, int64_t ld, void* stream) {
+    return iou3d_common(params_a, params_b, true, B, M, N, method, iou_bev, iou_3d, ld, stream);
+}

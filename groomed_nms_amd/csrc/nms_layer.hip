@@ -1,0 +1,289 @@
+// nms_layer.hip -- host side of the GrooMeD-NMS C ABI: argument checks, workspace carving, launches.
+// Kernels: nms_kernels.h (forward), nms_backward_kernels.h, nms_solve_kernels.h.
+#include <stdarg.h>
+#include <string.h>
+
+#include "nms_solve_kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void gnms_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* gnms_last_error(void) { return g_err; }
+extern "C" int gnms_abi_version(void) { return GNMS_ABI_VERSION; }
+
+extern "C" void gnms_default_params(gnms_params* p) {
+    if (!p) return;
+    p->nms_threshold = 0.4f;             // lib/groomed_nms.py:10 defaults
+    p->temperature = 0.01f;
+    p->valid_box_prob_threshold = 0.3f;
+    p->pruning_method = GNMS_PRUNE_LINEAR;
+    p->return_sorted_prob = 0;
+    p->group_boxes = 1;
+    p->mask_group_boxes = 1;
+    p->group_size = 100;
+    p->presorted = 0;
+}
+
+namespace {
+
+using namespace gnms;
+
+int next_pow2(int n) {
+    int p = 2;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return GNMS_OK;
+    GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return GNMS_OK;
+}
+
+int check_common(const char* fn, int B, int N, int64_t ld, const gnms_params* P, const void* ws, size_t ws_bytes) {
+    GNMS_CHECK_ARG(P != nullptr, "%s: params is NULL", fn);
+    GNMS_CHECK_ARG(B >= 0 && N >= 0, "%s: negative size (B=%d N=%d)", fn, B, N);
+    GNMS_CHECK_ARG(ld >= N, "%s: ld (%lld) < N (%d)", fn, (long long)ld, N);
+    if (N > GNMS_MAX_BOXES) {
+        gnms_set_error("%s: N=%d exceeds GNMS_MAX_BOXES=%d", fn, N, GNMS_MAX_BOXES);
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    if (P->pruning_method < 0 || P->pruning_method > 2) {
+        gnms_set_error("%s: Pruning method not implemented! (pruning_method=%d)", fn, P->pruning_method);   // lib/groomed_nms.py:178
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    GNMS_CHECK_ARG(P->group_size >= 0, "%s: group_size < 0", fn);
+    if (P->group_boxes && !P->mask_group_boxes && (long long)P->group_size + 1 > kGroupMaxMembers && N > kGroupMaxMembers) {
+        gnms_set_error("%s: unmasked groups support group_size+1 <= %d", fn, kGroupMaxMembers);
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    if (B > 0 && N > 0) {
+        GNMS_CHECK_ARG(ws != nullptr, "%s: workspace is NULL", fn);
+        if (ws_bytes < gnms_workspace_bytes(B, N, P)) {
+            gnms_set_error("%s: workspace too small (%zu < %zu)", fn, ws_bytes, gnms_workspace_bytes(B, N, P));
+            return GNMS_ERR_WORKSPACE;
+        }
+        GNMS_CHECK_ARG((uintptr_t)ws % 256 == 0, "%s: workspace must be 256-byte aligned", fn);
+    }
+    return GNMS_OK;
+}
+
+// grouping pipeline K2..K4 (shared by gnms_forward and gnms_get_groups)
+int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L,
+                 hipStream_t st) {
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
+    dim3 gm(gnms_div_up(N, 1024), L.NB, B);
+    if (vec) bitmask_kernel<true><<<gm, 256, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
+    else bitmask_kernel<false><<<gm, 256, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
+    GNMS_CHECK_LAUNCH();
+    const size_t lds = (size_t)N * 4;
+    int rc = allow_lds(leaders_kernel, lds);
+    if (rc) return rc;
+    leaders_kernel<<<B, 256, lds, st>>>(N, counts, ws, L);
+    GNMS_CHECK_LAUNCH();
+    attribute_kernel<<<dim3(L.NB, B), 64, 0, st>>>(N, counts, ws, L);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gnms_workspace_bytes(int B, int N, const gnms_params* /*params*/) {
+    if (B <= 0 || N <= 0) return 0;
+    return gnms_make_layout(N).per_image * (size_t)B;
+}
+
+extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
+                            const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
+                            int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common("gnms_forward", B, N, ld, params, workspace, workspace_bytes);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return GNMS_OK;
+    if (N == 0) {
+        if (nvalid) GNMS_CHECK_HIP(hipMemsetAsync(nvalid, 0, sizeof(int32_t) * B, st));
+        if (ninvalid) GNMS_CHECK_HIP(hipMemsetAsync(ninvalid, 0, sizeof(int32_t) * B, st));
+        return GNMS_OK;
+    }
+    GNMS_CHECK_ARG(scores && iou && prob, "gnms_forward: null scores/iou/prob");
+    const gnms_params P = *params;
+    const gnms_ws_layout L = gnms_make_layout(N);
+    char* ws = (char*)workspace;
+    const int P2 = next_pow2(N);
+    const size_t sort_lds = (size_t)P2 * 8;
+    const int sort_threads = P2 / 2 < 1024 ? (P2 / 2 < 64 ? 64 : P2 / 2) : 1024;
+
+    if ((rc = allow_lds(sort_scores_kernel, sort_lds))) return rc;
+    sort_scores_kernel<<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
+    GNMS_CHECK_LAUNCH();
+
+    if (P.group_boxes) {
+        if ((rc = run_grouping(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;
+        if ((rc = allow_lds(groups_kernel, sort_lds))) return rc;
+        groups_kernel<<<B, sort_threads, sort_lds, st>>>(iou, N, (long)ld, counts, P, ws, L, P2);
+        GNMS_CHECK_LAUNCH();
+        if (!P.mask_group_boxes) {
+            const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+            if ((rc = allow_lds(solve_groups_kernel<false>, lds))) return rc;
+            solve_groups_kernel<false><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, nullptr, nullptr);
+            GNMS_CHECK_LAUNCH();
+        }
+    } else {
+        const size_t lds = (size_t)((N + 3) & ~3) * 4 + 64 * 65 * 4 + 64 * 4;
+        if ((rc = allow_lds(ungrouped_forward_kernel, lds))) return rc;
+        ungrouped_prepare_kernel<<<dim3(gnms_div_up(N, 1024), B), 1024, 0, st>>>(N, counts, P, ws, L);
+        GNMS_CHECK_LAUNCH();
+        ungrouped_forward_kernel<<<B, 1024, lds, st>>>(iou, scores, N, (long)ld, counts, P, ws, L);
+        GNMS_CHECK_LAUNCH();
+    }
+    if ((rc = allow_lds(finalize_kernel, sort_lds))) return rc;
+    finalize_kernel<<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
+                                                        ninvalid);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+extern "C" int gnms_backward(const float* grad_prob, const float* scores, const float* iou, int B, int N, int64_t ld,
+                             const int32_t* counts, const gnms_params* params, float* grad_scores, float* grad_iou,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common("gnms_backward", B, N, ld, params, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(grad_prob && scores && iou && grad_scores, "gnms_backward: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const gnms_params P = *params;
+    const gnms_ws_layout L = gnms_make_layout(N);
+    char* ws = (char*)workspace;
+    dim3 ge(gnms_div_up(N, 256), B);
+    bwd_gx_kernel<<<ge, 256, 0, st>>>(grad_prob, N, counts, P, ws, L);
+    GNMS_CHECK_LAUNCH();
+    if (grad_iou) GNMS_CHECK_HIP(hipMemsetAsync(grad_iou, 0, sizeof(float) * (size_t)B * N * ld, st));
+    if (P.group_boxes && P.mask_group_boxes) {
+        bwd_masked_kernel<<<ge, 256, 0, st>>>(N, counts, P, ws, L, grad_scores);
+        GNMS_CHECK_LAUNCH();
+        if (grad_iou) {
+            bwd_masked_iou_kernel<<<ge, 256, 0, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_iou);
+            GNMS_CHECK_LAUNCH();
+        }
+    } else if (P.group_boxes) {
+        const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+        if ((rc = allow_lds(solve_groups_kernel<true>, lds))) return rc;
+        solve_groups_kernel<true><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
+        GNMS_CHECK_LAUNCH();
+    } else {
+        const size_t lds = (size_t)((N + 3) & ~3) * 4 + 64 * 65 * 4 + 64 * 4;
+        if ((rc = allow_lds(ungrouped_backward_kernel, lds))) return rc;
+        ungrouped_backward_kernel<<<B, 1024, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
+        GNMS_CHECK_LAUNCH();
+    }
+    return GNMS_OK;
+}
+
+// Profiling hook: re-runs ONLY the threshold bit-matrix kernel (K2, the one full read of the matrix) on a
+// workspace that a previous gnms_forward filled (it needs `order`).  bench.py times it for the roofline line.
+extern "C" int gnms_profile_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float nms_threshold,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    gnms_params P;
+    gnms_default_params(&P);
+    int rc = check_common("gnms_profile_bitmask", B, N, ld, &P, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GNMS_OK;
+    const gnms_ws_layout L = gnms_make_layout(N);
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
+    dim3 gm(gnms_div_up(N, 1024), L.NB, B);
+    if (vec) bitmask_kernel<true><<<gm, 256, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
+    else bitmask_kernel<false><<<gm, 256, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// get_groups as a stand-alone entry (lib/groomed_nms.py:208-270)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void export_groups_kernel(int N, char* ws, gnms_ws_layout L, int* __restrict__ group_of, int* __restrict__ pos_in_group,
+                                     int* __restrict__ ngroups) {
+    // group id = index of the group's leader among the leaders in creation order, minus the empty groups before it
+    using namespace gnms;
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) *ngroups = I.misc[0];
+    if (k >= N) return;
+    const int c = I.order[k];
+    const int h = I.head[k];
+    int gid = -1;
+    if (h >= 0) {
+        const int lr = I.rem[k];                              // the group's leader
+        gid = I.leadpfx[lr >> 6] + __builtin_popcountll(I.leadw[lr >> 6] & ((1ull << (lr & 63)) - 1ull));
+    }
+    group_of[c] = gid;
+    pos_in_group[c] = I.gpos[k];
+}
+}  // namespace
+
+extern "C" int gnms_get_groups(const float* scores, const float* iou, int N, int64_t ld, float group_threshold, int group_size,
+                               int32_t* group_of, int32_t* pos_in_group, int32_t* ngroups_out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    gnms_params P;
+    gnms_default_params(&P);
+    P.nms_threshold = group_threshold;
+    P.group_size = group_size;
+    P.mask_group_boxes = 0;   // grouping only: skip the fused rescoring
+    int rc = check_common("gnms_get_groups", 1, N, ld, &P, workspace, workspace_bytes);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    GNMS_CHECK_ARG(ngroups_out != nullptr, "gnms_get_groups: ngroups_out is NULL");
+    if (N == 0) { GNMS_CHECK_HIP(hipMemsetAsync(ngroups_out, 0, sizeof(int32_t), st)); return GNMS_OK; }
+    GNMS_CHECK_ARG(scores && iou && group_of && pos_in_group, "gnms_get_groups: null pointer");
+    const gnms_ws_layout L = gnms_make_layout(N);
+    char* ws = (char*)workspace;
+    const int P2 = next_pow2(N);
+    const size_t sort_lds = (size_t)P2 * 8;
+    const int sort_threads = P2 / 2 < 1024 ? (P2 / 2 < 64 ? 64 : P2 / 2) : 1024;
+    if ((rc = allow_lds(sort_scores_kernel, sort_lds))) return rc;
+    sort_scores_kernel<<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr);
+    GNMS_CHECK_LAUNCH();
+    if ((rc = run_grouping(iou, 1, N, ld, nullptr, group_threshold, ws, L, st))) return rc;
+    if ((rc = allow_lds(groups_kernel, sort_lds))) return rc;
+    groups_kernel<<<1, sort_threads, sort_lds, st>>>(iou, N, (long)ld, nullptr, P, ws, L, P2);
+    GNMS_CHECK_LAUNCH();
+    export_groups_kernel<<<gnms_div_up(N, 256), 256, 0, st>>>(N, ws, L, group_of, pos_in_group, ngroups_out);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pruning_function, elementwise (lib/groomed_nms.py:167-189)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void prune_kernel(const float* __restrict__ x, long long count, float thr, float temp, int method, float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+        out[i] = gnms_prune(x[i], thr, temp, method);
+}
+}  // namespace
+
+extern "C" int gnms_pruning_function(const float* iou, int64_t count, float nms_threshold, float temperature, int pruning_method,
+                                     float* out, void* stream) {
+    if (pruning_method < 0 || pruning_method > 2) {
+        gnms_set_error("gnms_pruning_function: Pruning method not implemented! (pruning_method=%d)", pruning_method);
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    GNMS_CHECK_ARG(count >= 0, "gnms_pruning_function: negative count");
+    if (count == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(iou && out, "gnms_pruning_function: null pointer");
+    long long blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    prune_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(iou, (long long)count, nms_threshold, temperature, pruning_method, out);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}

@@ -1,0 +1,364 @@
+"""GrooMeD-NMS layer on MI355X -- host-side mirror of the reference module lib/groomed_nms.py.
+
+Same public names, argument meaning, defaults, return convention and error behaviour as the
+reference (file:line cited per function), so `from groomed_nms_amd.groomed_nms import *` can stand in
+for `from lib.groomed_nms import *` (lib/rpn_util.py:18, lib/loss/rpn_3d.py:14).  All arithmetic runs
+in hand-written HIP kernels behind the C ABI of libgroomed_nms_hip.so (include/groomed_nms_hip.h);
+there is no CPU implementation here -- without the library or without a GPU the calls raise.
+"""
+import ctypes
+import itertools
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GnmsParams, check, ptr, stream_ptr
+
+__all__ = ["differentiable_nms", "differentiable_nms_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
+           "cast_to_cpu_cuda_tensor", "get_groups", "indices_copy", "GroomedNMS"]
+
+_PRUNE = {"linear": 0, "sigmoidal": 1, "soft_nms": 2}
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _lib.GnmsError("GrooMeD-NMS needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
+            mask_group_boxes, group_size, presorted=False):
+    if pruning_method not in _PRUNE:
+        raise NotImplementedError("Pruning method not implemented!")          # lib/groomed_nms.py:177-178
+    return GnmsParams(float(nms_threshold), float(temperature), float(valid_box_prob_threshold), _PRUNE[pruning_method],
+                      int(bool(return_sorted_prob)), int(bool(group_boxes)), int(bool(mask_group_boxes)),
+                      int(min(int(group_size), 2 ** 31 - 2)), int(bool(presorted)))
+
+
+def _matrix_layout(iou):
+    """Returns (tensor, ld) with unit column stride and image stride N*ld, copying only if needed."""
+    B, N, _ = iou.shape
+    if N == 0:
+        return iou.contiguous(), max(N, 1)
+    if iou.stride(2) == 1 and iou.stride(1) >= N and (B == 1 or iou.stride(0) == N * iou.stride(1)):
+        return iou, iou.stride(1)
+    return iou.contiguous(), N
+
+
+class _GroomedNMSFunction(torch.autograd.Function):
+    """prob = GrooMeD-NMS(scores, iou); gradients w.r.t. scores and (only if it requires grad) iou.
+    The reference differentiates the same graph with autograd (lib/groomed_nms.py:111)."""
+
+    @staticmethod
+    def forward(ctx, scores, iou, counts, params):
+        lib = _lib.load()
+        B, N = scores.shape
+        dev = scores.device
+        scores_c = scores.contiguous()
+        iou_c, ld = _matrix_layout(iou)
+        prob = torch.empty((B, N), dtype=torch.float32, device=dev)
+        order = torch.empty((B, N), dtype=torch.int64, device=dev)
+        valid = torch.zeros((B, N), dtype=torch.int64, device=dev)
+        invalid = torch.zeros((B, N), dtype=torch.int64, device=dev)
+        nvalid = torch.zeros((B,), dtype=torch.int32, device=dev)
+        ninvalid = torch.zeros((B,), dtype=torch.int32, device=dev)
+        nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
+        ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gnms_forward(ptr(scores_c), ptr(iou_c), B, N, ld, ptr(counts), ctypes.byref(params), ptr(prob), ptr(order),
+                                   ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws), ws.numel(), stream_ptr(dev)),
+                  "gnms_forward")
+        ctx.params = params
+        ctx.ld = ld
+        ctx.save_for_backward(scores_c, iou_c, counts, ws)
+        ctx.mark_non_differentiable(order, valid, invalid, nvalid, ninvalid)
+        return prob, order, valid, invalid, nvalid, ninvalid
+
+    @staticmethod
+    def backward(ctx, grad_prob, *unused):
+        lib = _lib.load()
+        scores_c, iou_c, counts, ws = ctx.saved_tensors
+        B, N = scores_c.shape
+        dev = scores_c.device
+        grad_prob = grad_prob.contiguous().float()
+        grad_scores = torch.empty_like(scores_c)
+        grad_iou = None
+        if ctx.needs_input_grad[1]:
+            grad_iou = torch.empty((B, N, ctx.ld), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gnms_backward(ptr(grad_prob), ptr(scores_c), ptr(iou_c), B, N, ctx.ld, ptr(counts), ctypes.byref(ctx.params),
+                                    ptr(grad_scores), ptr(grad_iou), ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_backward")
+        if grad_iou is not None and ctx.ld != N:
+            grad_iou = grad_iou[:, :, :N]
+        return grad_scores, grad_iou, None, None
+
+
+class _SoftSortFunction(torch.autograd.Function):
+    """soft_sort (lib/groomed_nms.py:131-165) for one image: HIP forward (row kernels + fp32 MFMA GEMM);
+    backward = the hand-derived adjoint of the same expressions (including the reference's last-axis
+    broadcast of the row sums, :155), its two GEMMs on the MFMA kernel as well."""
+
+    @staticmethod
+    def forward(ctx, scores, matrix, temperature):
+        lib = _lib.load()
+        N = scores.shape[0]
+        dev = scores.device
+        scores_c = scores.contiguous()
+        C = torch.empty((N, N), dtype=torch.float32, device=dev)
+        soft_scores = torch.empty((N,), dtype=torch.float32, device=dev)
+        soft_matrix = None
+        m_c, ld = None, N
+        if matrix is not None:
+            m_c = matrix.contiguous()
+            soft_matrix = torch.empty((N, N), dtype=torch.float32, device=dev)
+        one = GnmsParams()
+        lib.gnms_default_params(ctypes.byref(one))
+        ws = torch.empty((max(lib.gnms_workspace_bytes(1, max(N, 1), ctypes.byref(one)), 256),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gnms_soft_sort(ptr(scores_c), ptr(m_c), N, ld, float(temperature), ptr(C), ptr(soft_scores), ptr(soft_matrix),
+                                     ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_soft_sort")
+        ctx.temperature = float(temperature)
+        ctx.has_matrix = matrix is not None
+        ctx.save_for_backward(scores_c, m_c if m_c is not None else scores_c, C)
+        if matrix is None:
+            return soft_scores, C
+        return soft_scores, C, soft_matrix
+
+    @staticmethod
+    def backward(ctx, g_soft, g_C, g_mat=None):
+        scores, matrix, C = ctx.saved_tensors
+        T = ctx.temperature
+        n = scores.shape[0]
+        shat, order = torch.sort(scores, descending=True, stable=True)
+        A = -(scores.unsqueeze(0) - shat.unsqueeze(1)).abs()
+        mx, amax = A.max(dim=1)
+        E = torch.exp((A - mx.unsqueeze(1)) / T)
+        Z = E.sum(dim=1) + 1e-3
+        dC = torch.zeros_like(C) if g_C is None else g_C.clone()
+        d_s = torch.zeros_like(scores)
+        d_m = None
+        if g_soft is not None:
+            dC = dC + torch.outer(g_soft, scores)
+            d_s = d_s + _sgemm(C.t().contiguous(), g_soft.unsqueeze(1).contiguous()).squeeze(1)
+        if ctx.has_matrix and g_mat is not None:
+            dC = dC + _sgemm(g_mat.contiguous(), matrix.t().contiguous())
+            d_m = _sgemm(C.t().contiguous(), g_mat.contiguous())
+        dZ = -((dC * C).sum(dim=0) / Z)                   # C[i][j] = E[i][j] / Z[j]
+        dE = dC / Z.unsqueeze(0) + dZ.unsqueeze(1)
+        dArg = dE * E / T
+        dA = dArg.clone()
+        dA[torch.arange(n, device=scores.device), amax] += -dArg.sum(dim=1)
+        sg = torch.sign(scores.unsqueeze(0) - shat.unsqueeze(1))
+        d_s = d_s + (dA * (-sg)).sum(dim=0)
+        d_s = d_s.index_add(0, order, (dA * sg).sum(dim=1))
+        return d_s, (d_m if ctx.has_matrix else None), None
+
+
+def _sgemm(a, b):
+    """fp32 GEMM on the matrix cores (gnms_sgemm, v_mfma_f32_32x32x2_f32)."""
+    lib = _lib.load()
+    M, K = a.shape
+    K2, N = b.shape
+    assert K == K2
+    d = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib.gnms_sgemm(ptr(a), ptr(b), ptr(d), M, N, K, a.stride(0), b.stride(0), N, stream_ptr(a.device)), "gnms_sgemm")
+    return d
+
+
+def differentiable_nms_batched(scores, iou, counts=None, nms_threshold=0.4, pruning_method="linear", temperature=0.01,
+                               valid_box_prob_threshold=0.3, return_sorted_prob=False, group_boxes=True,
+                               mask_group_boxes=True, group_size=100, presorted=False):
+    """Batched hard-sort GrooMeD-NMS: scores [B,N], iou [B,N,N] (CUDA fp32), counts [B] int32 or None.
+    Returns (prob [B,N], order [B,N], valid [B,N], invalid [B,N], nvalid [B], ninvalid [B]); the lists are
+    padded -- the first nvalid[b] / ninvalid[b] entries are meaningful.  No host synchronisation."""
+    params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
+                     mask_group_boxes, group_size, presorted)
+    if counts is not None:
+        counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
+    return _GroomedNMSFunction.apply(scores.float(), iou.float(), counts, params)
+
+
+def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning_method="linear", temperature=0.01,
+                       valid_box_prob_threshold=0.3, return_sorted_prob=False, sorting_method="hard", sorting_temperature=None,
+                       group_boxes=True, mask_group_boxes=True, group_size=100, debug=False):
+    """
+        GrooMeD-NMS: Grouped Mathematical Differentiable NMS -- same signature and returns as the
+        reference lib/groomed_nms.py:10-129.
+
+        :param scores_unsorted:          Unsorted scores of the boxes, Tensor or ndarray (N, )
+        :param iou_unsorted:             Overlap matrix of the boxes, Tensor or ndarray (N, N)
+        :return: valid_boxes_index   (K,)   original indices, by descending re-score
+                 invalid_boxes_index (N-K,) original indices
+                 non_suppression_prob (N,)  re-scores in descending-input-score order (the reference's order)
+        NumPy in -> CPU tensors out (lib/rpn_util.py:1319-1320 calls .numpy() on the result); tensors
+        come back on the device of `iou_unsorted` (:60-62).  Computation always runs on the GPU.
+    """
+    if type(scores_unsorted) == np.ndarray:                                   # :34-36
+        scores_unsorted = torch.from_numpy(scores_unsorted).float()
+        iou_unsorted = torch.from_numpy(np.asarray(iou_unsorted)).float()
+    out_device = iou_unsorted.device
+    dev = out_device if out_device.type == "cuda" else _device()
+    scores = scores_unsorted.to(device=dev, dtype=torch.float32)
+    iou = iou_unsorted.to(device=dev, dtype=torch.float32)
+    n = scores.shape[0]
+    if iou.dim() != 2 or iou.shape[0] != n or iou.shape[1] != n:
+        raise ValueError("iou_unsorted must be (N, N) with N = len(scores_unsorted)")
+    kw = dict(nms_threshold=nms_threshold, pruning_method=pruning_method, temperature=temperature,
+              valid_box_prob_threshold=valid_box_prob_threshold, return_sorted_prob=return_sorted_prob,
+              group_boxes=group_boxes, mask_group_boxes=mask_group_boxes, group_size=group_size)
+    if sorting_method == "soft":                                              # :42-45
+        if sorting_temperature is None:
+            sorting_temperature = temperature
+        indices = torch.sort(scores.detach(), descending=True, stable=True)[1]   # :41
+        if n == 0:
+            soft_scores, soft_iou = scores, iou
+        else:
+            soft_scores, _, soft_iou = _SoftSortFunction.apply(scores, iou, sorting_temperature)
+        prob, _, valid, invalid, nvalid, ninvalid = differentiable_nms_batched(
+            soft_scores.unsqueeze(0), soft_iou.unsqueeze(0), presorted=True, **kw)
+    else:
+        prob, order, valid, invalid, nvalid, ninvalid = differentiable_nms_batched(scores.unsqueeze(0), iou.unsqueeze(0), **kw)
+        indices = None
+    counts = torch.stack([nvalid[0], ninvalid[0]]).tolist() if n > 0 else [0, 0]   # the one host sync: K is data dependent
+    valid_boxes_index = valid[0, :counts[0]]
+    invalid_boxes_index = invalid[0, :counts[1]]
+    if indices is not None:
+        valid_boxes_index = indices[valid_boxes_index]
+        invalid_boxes_index = indices[invalid_boxes_index]
+    non_suppression_prob = prob[0]
+    if debug:
+        print("\nInside diff NMS... After sorting")
+        print(non_suppression_prob)
+    if out_device != dev:
+        valid_boxes_index = valid_boxes_index.to(out_device)
+        invalid_boxes_index = invalid_boxes_index.to(out_device)
+        non_suppression_prob = non_suppression_prob.to(out_device)
+    return valid_boxes_index, invalid_boxes_index, non_suppression_prob
+
+
+class GroomedNMS(torch.nn.Module):
+    """nn.Module wrapper of the batched layer (parameter-free)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.kwargs = kwargs
+
+    def forward(self, scores, iou, counts=None):
+        return differentiable_nms_batched(scores, iou, counts, **self.kwargs)
+
+
+def soft_sort(scores, full_matrix=None, temperature=0.01):
+    """lib/groomed_nms.py:131-165.  Returns (soft_sorted_scores, convex_comb_matrix[, soft_sorted_matrix])."""
+    out_device = scores.device
+    dev = out_device if out_device.type == "cuda" else _device()
+    s = scores.to(device=dev, dtype=torch.float32)
+    m = full_matrix.to(device=dev, dtype=torch.float32) if full_matrix is not None else None
+    res = _SoftSortFunction.apply(s, m, temperature)
+    return tuple(r.to(out_device) for r in res)
+
+
+def pruning_function(iou, nms_threshold=0.4, temperature=0.01, pruning_method="linear"):
+    """lib/groomed_nms.py:167-189.  Tensors run through the HIP kernel; an ndarray takes the reference's
+    own NumPy branch (a plotting helper, plot/plot_nms_overlap_function.py:42-91) and returns an ndarray."""
+    if pruning_method not in _PRUNE:
+        raise NotImplementedError("Pruning method not implemented!")
+    if type(iou) == np.ndarray:
+        if pruning_method == "sigmoidal":
+            return sigmoid_numpy((iou - nms_threshold) / temperature)
+        if pruning_method == "linear":
+            return iou
+        return 1 - np.exp(-np.power(iou, 2) / temperature)
+    if pruning_method == "linear":
+        return iou                                                            # :173-174 (same tensor, as the reference)
+    lib = _lib.load()
+    out_device = iou.device
+    dev = out_device if out_device.type == "cuda" else _device()
+    x = iou.detach().to(device=dev, dtype=torch.float32).contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        check(lib.gnms_pruning_function(ptr(x), x.numel(), float(nms_threshold), float(temperature), _PRUNE[pruning_method],
+                                        ptr(out), stream_ptr(dev)), "gnms_pruning_function")
+    return out.to(out_device)
+
+
+def sigmoid_numpy(x):
+    """lib/groomed_nms.py:191-199 (NumPy, 1-D input as in the reference)."""
+    y = np.zeros(x.shape)
+    index_gt = np.where(x > 0)[0]
+    y[index_gt] = 1.0 / (1 + np.exp(-x[index_gt]))
+    index_lt = np.where(x <= 0)[0]
+    y[index_lt] = np.exp(x[index_lt]) / (1 + np.exp(x[index_lt]))
+    return y
+
+
+def cast_to_cpu_cuda_tensor(input, reference_tensor):
+    """lib/groomed_nms.py:201-206."""
+    if reference_tensor.is_cuda and not input.is_cuda:
+        input = input.cuda()
+    if not reference_tensor.is_cuda and input.is_cuda:
+        input = input.cpu()
+    return input
+
+
+def get_groups(iou_unsorted, group_threshold, scores_unsorted, group_size=100, return_original_indices=True):
+    """lib/groomed_nms.py:208-270: list of LongTensors, one per group, in creation order; each holds the
+    group's boxes by descending score (original indices, or score-rank positions when
+    return_original_indices=False).  Grouping runs in the HIP kernels (bit matrix, leader scan,
+    attribution, cap); only the ragged Python list is assembled on the host."""
+    lib = _lib.load()
+    out_device = iou_unsorted.device
+    dev = out_device if out_device.type == "cuda" else _device()
+    scores = scores_unsorted.detach().to(device=dev, dtype=torch.float32).contiguous()
+    iou = iou_unsorted.detach().to(device=dev, dtype=torch.float32).contiguous()
+    n = scores.shape[0]
+    if n == 0:
+        return []
+    group_of = torch.empty((n,), dtype=torch.int32, device=dev)
+    pos = torch.empty((n,), dtype=torch.int32, device=dev)
+    ngroups = torch.zeros((1,), dtype=torch.int32, device=dev)
+    one = GnmsParams()
+    lib.gnms_default_params(ctypes.byref(one))
+    ws = torch.empty((max(lib.gnms_workspace_bytes(1, n, ctypes.byref(one)), 256),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.gnms_get_groups(ptr(scores), ptr(iou), n, n, float(group_threshold), int(min(int(group_size), 2 ** 31 - 2)),
+                                  ptr(group_of), ptr(pos), ptr(ngroups), ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_get_groups")
+    g = int(ngroups.item())
+    group_of_h = group_of.cpu().numpy()
+    pos_h = pos.cpu().numpy()
+    ids = np.arange(n)
+    if not return_original_indices:
+        rank = torch.empty(n, dtype=torch.int64)
+        rank[torch.sort(scores.cpu(), descending=True, stable=True)[1]] = torch.arange(n)
+        ids = rank.numpy()
+    groups = [[] for _ in range(g)]
+    for i in np.argsort(pos_h, kind="stable"):
+        if group_of_h[i] >= 0:
+            groups[group_of_h[i]].append(int(ids[i]))
+    return [torch.tensor(x, dtype=torch.int64, device=out_device) for x in groups]
+
+
+def indices_copy(A, B, indA, indB=None, inplace=True):
+    """lib/groomed_nms.py:272-337: copy B into A at 2-D positions; a 1-D indA expands to indA x indA (:301-307).
+    Kept for API completeness (the layer itself never builds the N x N inversion matrix)."""
+    shapeA = A.shape
+    if not A.is_contiguous():
+        A = A.contiguous()
+    if not B.is_contiguous():
+        B = B.contiguous()
+    if indA.dim() == 1:
+        idx = indA.detach().cpu().numpy()
+        indA = torch.tensor(list(itertools.product(idx, idx)), dtype=torch.int64).reshape(-1, 2).to(A.device)
+    if indB is None:
+        indB = torch.tensor(list(itertools.product(np.arange(B.shape[0]), np.arange(B.shape[1]))), dtype=torch.int64).reshape(-1, 2)
+    indB = indB.to(A.device)
+    tailA = A.shape[2:]
+    vA = A.reshape((A.shape[0] * A.shape[1],) + tuple(tailA))
+    vB = B.reshape((B.shape[0] * B.shape[1],) + tuple(B.shape[2:]))
+    if not inplace:
+        vA = vA.clone()
+    linA = indA[:, 0] * A.shape[1] + indA[:, 1]
+    linB = indB[:, 0] * B.shape[1] + indB[:, 1]
+    vA.index_copy_(0, linA, vB.index_select(0, linB))
+    return vA.view(shapeA)

@@ -1,0 +1,136 @@
+"""Pairwise overlaps on MI355X -- mirror of the overlap helpers of the reference's lib/core.py and
+lib/math_3d.py that feed the NMS.  Same names and argument meaning:
+  iou(box_a, box_b, mode, data_type)                 lib/core.py:480-532
+  intersect(box_a, box_b, mode, data_type)           lib/core.py:178-243
+  iou3d_approximate(c1, c2, mode, method)            lib/core.py:305-421
+  get_corners_of_cuboid(x, y, z, w, h, l, ry)        lib/math_3d.py:364-490
+'combinations' mode runs in the HIP kernels (csrc/iou_kernels.hip); 'list' mode is O(N) elementwise
+tensor arithmetic.  ndarray in -> ndarray out, computed in fp32 on the GPU (the reference's NumPy
+branch keeps the input dtype, e.g. float64 at lib/rpn_util.py:1295; the NMS casts to fp32 anyway,
+lib/groomed_nms.py:36).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+from .groomed_nms import _device
+
+__all__ = ["iou", "intersect", "iou3d_approximate", "get_corners_of_cuboid", "iou_batched", "iou3d_batched"]
+
+
+def _to_dev(x):
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(device=_device(), dtype=torch.float32), "numpy", None
+    dev = x.device if x.device.type == "cuda" else _device()
+    return x.detach().to(device=dev, dtype=torch.float32), "torch", x.device
+
+
+def _back(t, kind, device):
+    if kind == "numpy":
+        return t.cpu().numpy()
+    return t.to(device)
+
+
+def iou_batched(boxes_a, boxes_b=None, out=None):
+    """boxes_a [B,M,4], boxes_b [B,N,4] (CUDA fp32) -> [B,M,N].  boxes_b=None means boxes_a."""
+    lib = _lib.load()
+    boxes_a = boxes_a.contiguous()
+    boxes_b = boxes_a if boxes_b is None else boxes_b.contiguous()
+    B, M, _ = boxes_a.shape
+    N = boxes_b.shape[1]
+    if out is None:
+        out = torch.empty((B, M, N), dtype=torch.float32, device=boxes_a.device)
+    with torch.cuda.device(boxes_a.device):
+        check(lib.gnms_iou2d(ptr(boxes_a), ptr(boxes_b), B, M, N, ptr(out), N, stream_ptr(boxes_a.device)), "gnms_iou2d")
+    return out
+
+
+def iou3d_batched(a, b=None, method="generalized", from_params=False, want_bev=False, nms_overlap=False):
+    """a [B,M,3,8] corners (or [B,M,7] params when from_params) -> iou_3d [B,M,N] (and iou_bev).
+    nms_overlap=True returns 0.5*(1+giou), the matrix both reference callers hand to the NMS."""
+    lib = _lib.load()
+    a = a.contiguous()
+    b = a if b is None else b.contiguous()
+    B, M = a.shape[0], a.shape[1]
+    N = b.shape[1]
+    m = 2 if nms_overlap else {"normal": 0, "generalized": 1}[method]
+    o3 = torch.empty((B, M, N), dtype=torch.float32, device=a.device)
+    bev = torch.empty((B, M, N), dtype=torch.float32, device=a.device) if want_bev else None
+    fn = lib.gnms_iou3d_from_params if from_params else lib.gnms_iou3d_approximate
+    with torch.cuda.device(a.device):
+        check(fn(ptr(a), ptr(b), B, M, N, m, ptr(bev), ptr(o3), N, stream_ptr(a.device)), "gnms_iou3d")
+    return (bev, o3) if want_bev else o3
+
+
+def intersect(box_a, box_b, mode='combinations', data_type=None):
+    """lib/core.py:178-243.  combinations -> N x M (note: [b][a], as in the reference); list -> M."""
+    a, kind, dev = _to_dev(box_a)
+    b, _, _ = _to_dev(box_b)
+    if mode == 'combinations':
+        max_xy = torch.min(a[:, 2:4], b[:, 2:4].unsqueeze(1))
+        min_xy = torch.max(a[:, 0:2], b[:, 0:2].unsqueeze(1))
+    elif mode == 'list':
+        max_xy = torch.min(a[:, 2:4], b[:, 2:4])
+        min_xy = torch.max(a[:, 0:2], b[:, 0:2])
+    else:
+        raise ValueError('unknown mode {}'.format(mode))
+    inter = torch.clamp(max_xy - min_xy, 0)
+    return _back(inter[..., 0] * inter[..., 1], kind, dev)
+
+
+def iou(box_a, box_b, mode='combinations', data_type=None):
+    """lib/core.py:480-532.  combinations: M x N matrix from the HIP kernel; list: M values."""
+    if mode == 'combinations':
+        a, kind, dev = _to_dev(box_a)
+        b, _, _ = _to_dev(box_b)
+        out = iou_batched(a[:, :4].unsqueeze(0), b[:, :4].unsqueeze(0))[0]
+        return _back(out, kind, dev)
+    if mode == 'list':
+        a, kind, dev = _to_dev(box_a)
+        b, _, _ = _to_dev(box_b)
+        max_xy = torch.min(a[:, 2:4], b[:, 2:4])
+        min_xy = torch.max(a[:, 0:2], b[:, 0:2])
+        wh = torch.clamp(max_xy - min_xy, 0)
+        inter = wh[:, 0] * wh[:, 1]
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        return _back(inter / (area_a + area_b - inter), kind, dev)
+    raise ValueError('unknown mode {}'.format(mode))
+
+
+def get_corners_of_cuboid(x3d, y3d, z3d, w3d, h3d, l3d, ry3d, iou_3d_convention=True):
+    """lib/math_3d.py:364-490 (iou_3d_convention=True only: the one the overlap path uses).  N x 3 x 8."""
+    if not iou_3d_convention:
+        raise NotImplementedError("only iou_3d_convention=True is on the NMS path (lib/loss/rpn_3d.py:746-750)")
+    lib = _lib.load()
+    kind = "numpy" if isinstance(x3d, np.ndarray) else "torch"
+    cols = [torch.as_tensor(v) for v in (x3d, y3d, z3d, w3d, h3d, l3d, ry3d)]
+    out_device = cols[0].device
+    dev = out_device if out_device.type == "cuda" else _device()
+    params = torch.stack([c.to(device=dev, dtype=torch.float32).reshape(-1) for c in cols], dim=1).contiguous()
+    n = params.shape[0]
+    corners = torch.empty((n, 3, 8), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.gnms_corners_of_cuboid(ptr(params), n, ptr(corners), stream_ptr(dev)), "gnms_corners_of_cuboid")
+    return _back(corners, kind, out_device)
+
+
+def iou3d_approximate(corners_3d_b1, corners_3d_b2, mode="list", method="normal"):
+    """lib/core.py:305-421.  Returns (iou_bev, iou_3d).  Inputs are NOT modified (the reference overwrites
+    the y row of its inputs through a view, :379-380)."""
+    c1, kind, dev = _to_dev(corners_3d_b1)
+    c2, _, _ = _to_dev(corners_3d_b2)
+    if c1.dim() == 2:
+        c1, c2 = c1.unsqueeze(0), c2.unsqueeze(0)
+    if method not in ("normal", "generalized"):
+        raise ValueError("unknown method {}".format(method))
+    if mode == "combinations":
+        bev, i3 = iou3d_batched(c1.unsqueeze(0), c2.unsqueeze(0), method=method, want_bev=True)
+        return _back(bev[0], kind, dev), _back(i3[0], kind, dev)
+    if mode == "list":
+        # O(N): the diagonal of the pairwise problem, done box by box on the same kernel
+        n = c1.shape[0]
+        bev, i3 = iou3d_batched(c1.reshape(n, 1, 3, 8), c2.reshape(n, 1, 3, 8), method=method, want_bev=True)
+        return _back(bev.reshape(n), kind, dev), _back(i3.reshape(n), kind, dev)
+    raise ValueError('unknown mode {}'.format(mode))

@@ -1,0 +1,172 @@
+/*
+ * groomed_nms_hip.h -- C ABI of libgroomed_nms_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the GrooMeD-NMS hot path of abhi1kumar/groomed_nms.  Citations are
+ * file:line in the reference checkout.  The reference's boundary for this path is a Python call
+ * (lib/groomed_nms.py:10 differentiable_nms, imported at lib/loss/rpn_3d.py:14 and
+ * lib/rpn_util.py:18) plus ONE true C symbol, `_nms` (lib/nms/gpu_nms.hpp:1-2, bound by Cython at
+ * lib/nms/gpu_nms.pyx:13-14).  `_nms` is exported here with the identical signature; the gnms_*
+ * functions are what a ctypes/Cython/cffi binding of lib/groomed_nms.py and of the overlap helpers
+ * in lib/core.py binds (see INTEGRATION.md for the stubs).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host;
+ *   - calls are asynchronous and ordered on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream); no hidden synchronisation and no hidden allocation, except `_nms`, which keeps
+ *     the reference's blocking host-pointer contract, and the two gnms_iou3d_* calls, which take a
+ *     stream-ordered temporary (hipMallocAsync/hipFreeAsync) of 32 bytes per box;
+ *   - a batch is B images of up to N boxes; image b uses the first counts[b] boxes (counts may be
+ *     NULL: every image has N).  Scores are [B][N]; overlap matrices are [B][N][ld] row-major with
+ *     row stride ld >= N elements (image stride N*ld);
+ *   - return value: 0 on success, negative gnms_status on failure; gnms_last_error() gives the
+ *     message of the calling thread's last failure (the reference prints CUDA errors and carries
+ *     on, lib/nms/nms_kernel.cu:12-19; this library never does that).
+ *   - fp32 arithmetic without FMA contraction, IEEE division: results are bit-identical to the
+ *     CPU restatement in oracle/ wherever that one is fp32-sequential (overlaps, default rescoring).
+ */
+#ifndef GROOMED_NMS_HIP_H
+#define GROOMED_NMS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNMS_ABI_VERSION 1
+#define GNMS_MAX_BOXES 16384 /* per image; the in-LDS sort holds 16384 64-bit keys in 128 KiB of the CU's 160 KiB */
+
+typedef enum gnms_status {
+    GNMS_OK = 0,
+    GNMS_ERR_INVALID_ARGUMENT = -1,
+    GNMS_ERR_UNSUPPORTED = -2, /* e.g. N > GNMS_MAX_BOXES, unknown pruning method (reference: NotImplementedError) */
+    GNMS_ERR_HIP = -3,
+    GNMS_ERR_WORKSPACE = -4
+} gnms_status;
+
+/* lib/groomed_nms.py:167-189 pruning_function */
+typedef enum gnms_pruning { GNMS_PRUNE_LINEAR = 0, GNMS_PRUNE_SIGMOIDAL = 1, GNMS_PRUNE_SOFT_NMS = 2 } gnms_pruning;
+
+/* keyword arguments of differentiable_nms (lib/groomed_nms.py:10), same names, same defaults */
+typedef struct gnms_params {
+    float nms_threshold;            /* 0.4  */
+    float temperature;              /* 0.01 (unused by "linear") */
+    float valid_box_prob_threshold; /* 0.3  */
+    int32_t pruning_method;         /* gnms_pruning */
+    int32_t return_sorted_prob;     /* 0 */
+    int32_t group_boxes;            /* 1 */
+    int32_t mask_group_boxes;       /* 1 */
+    int32_t group_size;             /* 100 */
+    int32_t presorted;              /* 0.  1 = the soft-sort hand-off (lib/groomed_nms.py:42-45): scores/iou are
+                                       consumed in INPUT order (prune matrix, rescoring, returned probabilities), only
+                                       the grouping re-sorts by score as get_groups does (:213-214). */
+} gnms_params;
+
+void gnms_default_params(gnms_params* p);
+int gnms_abi_version(void);
+const char* gnms_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pairwise overlaps (lib/core.py)
+ * ------------------------------------------------------------------------------------------- */
+
+/* iou(box_a, box_b, mode='combinations')  lib/core.py:480-508 (+ intersect :178-218).
+ * boxes_a [B][M][4], boxes_b [B][N][4] as (x1,y1,x2,y2); out[b][i][j] = IoU(a_i, b_j), row stride ld >= N.
+ * No +1 pixel; a zero-area pair yields 0/0 = NaN exactly like the reference. */
+int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int M, int N, float* out, int64_t ld, void* stream);
+
+/* get_corners_of_cuboid  lib/math_3d.py:364-435 (torch branch, iou_3d_convention=True).
+ * params [count][7] = (x3d, y3d, z3d, w3d, h3d, l3d, ry3d) -> corners [count][3][8]. */
+int gnms_corners_of_cuboid(const float* params, int64_t count, float* corners, void* stream);
+
+/* iou3d_approximate(corners_b1, corners_b2, mode="combinations", method=...)  lib/core.py:305-421.
+ * corners_a [B][M][3][8], corners_b [B][N][3][8].  Inputs are const (the reference overwrites them, :379-380).
+ *   method 0 "normal", 1 "generalized", 2 = 0.5*(1+generalized): what both callers feed the NMS
+ *   (lib/loss/rpn_3d.py:781, lib/rpn_util.py:1312).
+ * iou_bev may be NULL.  Outputs [B][M][ld]. */
+int gnms_iou3d_approximate(const float* corners_a, const float* corners_b, int B, int M, int N, int method,
+                           float* iou_bev, float* iou_3d, int64_t ld, void* stream);
+
+/* same, with get_corners_of_cuboid fused as the prologue: params_a [B][M][7], params_b [B][N][7] */
+int gnms_iou3d_from_params(const float* params_a, const float* params_b, int B, int M, int N, int method,
+                           float* iou_bev, float* iou_3d, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GrooMeD-NMS layer (lib/groomed_nms.py:10-129), hard sort.  Soft sort = gnms_soft_sort + presorted=1.
+ * ------------------------------------------------------------------------------------------- */
+
+/* bytes of the workspace gnms_forward needs for (B, N).  The same buffer carries the state that
+ * gnms_backward reads, so keep it alive and untouched between the two calls. */
+size_t gnms_workspace_bytes(int B, int N, const gnms_params* params);
+
+/* forward.  scores [B][N], iou [B][N][ld].
+ *   prob    [B][N]  third return value (:124-129): rescored probabilities in descending-input-score
+ *                   order (grouped: un-thresholded clone; ungrouped: thresholded; return_sorted_prob:
+ *                   thresholded and sorted).  presorted=1: input order.
+ *   order   [B][N]  rank -> input index (the `indices` of :41), int64
+ *   valid   [B][N]  first return value, first nvalid[b] entries (input indices, by descending rescored prob)
+ *   invalid [B][N]  second return value, first ninvalid[b] entries
+ *   nvalid, ninvalid [B] int32 (NaN probabilities are in neither list, :118-123)
+ * order/valid/invalid/nvalid/ninvalid may each be NULL if not wanted. */
+int gnms_forward(const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
+                 const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
+                 int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream);
+
+/* backward of L through prob.  grad_prob [B][N] = dL/dprob (same order as prob).
+ *   grad_scores [B][N] (input order), overwritten.
+ *   grad_iou    [B][N][ld] or NULL.  When given it is fully overwritten (zero fill + the sparse
+ *               entries); training detaches the matrix (lib/loss/rpn_3d.py:791), so NULL is the fast path.
+ * scores/iou/counts/params/workspace must be the ones the forward call saw. */
+int gnms_backward(const float* grad_prob, const float* scores, const float* iou, int B, int N, int64_t ld,
+                  const int32_t* counts, const gnms_params* params, float* grad_scores, float* grad_iou,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* profiling hook: re-runs only the threshold bit-matrix kernel (the single full read of the overlap matrix, the
+ * dominant kernel of gnms_forward) on a workspace a previous gnms_forward call filled. */
+int gnms_profile_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float nms_threshold,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* get_groups(iou_unsorted, group_threshold, scores_unsorted, group_size)  lib/groomed_nms.py:208-270 for one
+ * image.  group_of[N]: index of the box's group (groups numbered in creation order) or -1 if the box is in
+ * no group (beyond the cap, or NaN overlap with its leader); pos_in_group[N]: position inside the group
+ * (0 = first member).  Both int32, indexed by INPUT index.  *ngroups_out is a device int32. */
+int gnms_get_groups(const float* scores, const float* iou, int N, int64_t ld, float group_threshold, int group_size,
+                    int32_t* group_of, int32_t* pos_in_group, int32_t* ngroups_out, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* pruning_function(iou, nms_threshold, temperature, pruning_method)  lib/groomed_nms.py:167-189, elementwise */
+int gnms_pruning_function(const float* iou, int64_t count, float nms_threshold, float temperature, int pruning_method,
+                          float* out, void* stream);
+
+/* soft_sort(scores, full_matrix, temperature)  lib/groomed_nms.py:131-165 for one image.
+ * C [N][N] (convex_comb_matrix, including the reference's last-axis broadcast of the row sums, :155),
+ * soft_scores [N] = C s, soft_matrix [N][N] = C iou (fp32 MFMA GEMM).  iou/soft_matrix may both be NULL. */
+int gnms_soft_sort(const float* scores, const float* iou, int N, int64_t ld, float temperature, float* C,
+                   float* soft_scores, float* soft_matrix, void* workspace, size_t workspace_bytes, void* stream);
+
+/* D[M x N] = A[M x K] B[K x N], fp32 row-major with leading dimensions lda/ldb/ldd, on the matrix cores
+ * (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf chain over k).  The GEMM behind soft_sort's C @ iou (:163). */
+int gnms_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd,
+               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Classical hard NMS (lib/nms)
+ * ------------------------------------------------------------------------------------------- */
+
+/* EXACT reference symbol and contract (lib/nms/gpu_nms.hpp:1-2, lib/nms/nms_kernel.cu:91-144):
+ * host pointers, boxes_host is boxes_num x boxes_dim fp32 pre-sorted by descending score,
+ * keep_out holds boxes_num ints, blocking.  +1-pixel IoU (:24-32), strict '>' (:71). */
+void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+          float nms_overlap_thresh, int device_id);
+
+/* device-pointer, stream-ordered variant: boxes [n][boxes_dim] sorted by score; keep [n] int32; num_out device int32.
+ * workspace: gnms_nms_workspace_bytes(n). */
+size_t gnms_nms_workspace_bytes(int n);
+int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int32_t* keep, int32_t* num_out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GROOMED_NMS_HIP_H */

@@ -87,6 +87,9 @@ int gnms_oracle_prune(const float* x, int64_t count, float thr, float temp, int 
 /* lib/core.py:178-218 intersect + :480-508 iou, mode='combinations', torch branch               */
 /*   out[i][j] = IoU(a_i, b_j); areas carry no +1; a zero-area pair gives 0/0 = NaN             */
 /* ------------------------------------------------------------------------------------------- */
+static inline float minf_(float a, float b) { return a < b ? a : b; }   /* torch.min/max on non-NaN boxes */
+static inline float maxf_(float a, float b) { return a > b ? a : b; }
+
 void gnms_oracle_iou2d(const float* a, int64_t M, const float* b, int64_t N, float* out) {
     for (int64_t i = 0; i < M; ++i) {
         const float* pa = a + 4 * i;
@@ -94,8 +97,8 @@ void gnms_oracle_iou2d(const float* a, int64_t M, const float* b, int64_t N, flo
         for (int64_t j = 0; j < N; ++j) {
             const float* pb = b + 4 * j;
             float area_b = (pb[2] - pb[0]) * (pb[3] - pb[1]);                    /* :502-503 */
-            float w = fminf(pa[2], pb[2]) - fmaxf(pa[0], pb[0]);                 /* :210-211 */
-            float h = fminf(pa[3], pb[3]) - fmaxf(pa[1], pb[1]);
+            float w = minf_(pa[2], pb[2]) - maxf_(pa[0], pb[0]);                 /* :210-211 */
+            float h = minf_(pa[3], pb[3]) - maxf_(pa[1], pb[1]);
             w = w > 0.0f ? w : (w != w ? w : 0.0f);                              /* clamp(.,0) :212 (NaN passes) */
             h = h > 0.0f ? h : (h != h ? h : 0.0f);
             float inter = w * h;                                                 /* :218 */

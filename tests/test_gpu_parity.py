@@ -1,0 +1,312 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden vectors
+captured from the reference.  Run on the MI355X box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import MODES, TOL, check_index_lists
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import groomed_nms_amd as g
+    from groomed_nms_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    return g
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def _run_gpu(G, s, m, w, want_gi, **kw):
+    st = torch.from_numpy(s).cuda().requires_grad_(True)
+    mt = torch.from_numpy(m).cuda().requires_grad_(bool(want_gi))
+    valid, invalid, prob = G.differentiable_nms(st, mt, **kw)
+    out = dict(valid=valid.cpu().numpy(), invalid=invalid.cpu().numpy(), prob=prob.detach().cpu().numpy())
+    if len(s) and prob.requires_grad:
+        (prob * torch.from_numpy(w).cuda()).sum().backward()
+        out["grad_scores"] = st.grad.cpu().numpy()
+        if want_gi:
+            out["grad_iou"] = mt.grad.cpu().numpy()
+    return out
+
+
+def _golden_cases(g):
+    out = []
+    for case in g.cases():
+        if not g.has(f"{case}/scores"):
+            continue
+        for mode in g.modes(case):
+            if mode in MODES:
+                out.append((case, mode))
+    return out
+
+
+def _check_case(G, O, g, case, mode):
+    s, m, w = g[f"{case}/scores"], g[f"{case}/iou"], g[f"{case}/w"]
+    want_gi = g.has(f"{case}/{mode}/grad_iou")
+    res = _run_gpu(G, s, m, w, want_gi, **MODES[mode])
+    # (1) against the reference's own outputs
+    np.testing.assert_allclose(res["prob"], g[f"{case}/{mode}/prob"], atol=TOL, rtol=0, equal_nan=True)
+    check_index_lists(res["valid"], res["invalid"], g[f"{case}/{mode}/valid"], g[f"{case}/{mode}/invalid"])
+    if g.has(f"{case}/{mode}/grad_scores"):
+        np.testing.assert_allclose(res["grad_scores"], g[f"{case}/{mode}/grad_scores"], atol=2e-4, rtol=1e-4)
+    if want_gi:
+        np.testing.assert_allclose(res["grad_iou"], g[f"{case}/{mode}/grad_iou"], atol=2e-4, rtol=1e-4)
+    # (2) against the oracle: default (masked) mode is bit-exact
+    ref = O.differentiable_nms(s, m, grad_prob=w if len(s) else None, want_grad_iou=want_gi, **MODES[mode])
+    if mode.startswith("gm_"):
+        assert np.array_equal(res["prob"], ref["prob"], equal_nan=True), f"{case}/{mode} prob not bit-exact"
+        assert list(res["valid"]) == list(ref["valid"]) and list(res["invalid"]) == list(ref["invalid"])
+        if len(s):
+            assert np.array_equal(res["grad_scores"], ref["grad_scores"]), f"{case}/{mode} grad not bit-exact"
+    else:
+        np.testing.assert_allclose(res["prob"], ref["prob"], atol=TOL, rtol=0, equal_nan=True)
+
+
+def test_nms_golden_small(G, O, golden_nms):
+    cases = _golden_cases(golden_nms)
+    assert len(cases) > 100
+    for case, mode in cases:
+        try:
+            _check_case(G, O, golden_nms, case, mode)
+        except AssertionError as e:
+            raise AssertionError(f"{case}/{mode}: {e}") from e
+
+
+def test_nms_golden_box_derived(G, O, golden_box2d, golden_box3d):
+    for g in (golden_box2d, golden_box3d):
+        for case, mode in _golden_cases(g):
+            try:
+                _check_case(G, O, g, case, mode)
+            except AssertionError as e:
+                raise AssertionError(f"{case}/{mode}: {e}") from e
+
+
+def test_known_answer_vectors(G, golden_nms):
+    """test/test_differentiable_nms_forward.py:127-140."""
+    for case, v, iv in (("kat1", [0, 1, 3], [2]), ("kat2", [0, 1, 4], [2, 3])):
+        valid, invalid, prob = G.differentiable_nms(torch.from_numpy(golden_nms[f"{case}/scores"]).cuda(),
+                                                    torch.from_numpy(golden_nms[f"{case}/iou"]).cuda(), temperature=0.1)
+        np.testing.assert_allclose(prob.cpu().numpy(), golden_nms[f"{case}/expected_prob"], atol=5e-4)
+        assert valid.tolist() == v and sorted(invalid.tolist()) == iv
+
+
+def test_numpy_in_cpu_out(G, golden_nms):
+    """lib/rpn_util.py:1319-1320: NumPy float64 in, `.numpy()` on the index result."""
+    s = golden_nms["kat2/scores"].astype(np.float64)
+    m = golden_nms["kat2/iou"].astype(np.float64)
+    valid, invalid, prob = G.differentiable_nms(s, m)
+    assert valid.device.type == "cpu" and prob.device.type == "cpu"
+    assert valid.numpy().tolist() == [0, 1, 4]
+
+
+def test_iou2d_bit_exact(G, O, golden_box2d):
+    from groomed_nms_amd import overlaps
+    for case in ("uni64", "clu64", "uni256", "clu256", "clu250"):
+        b = torch.from_numpy(golden_box2d[f"{case}/boxes"]).cuda()
+        got = overlaps.iou(b, b).cpu().numpy()
+        assert np.array_equal(got, golden_box2d[f"{case}/iou"], equal_nan=True), case
+    got = overlaps.iou(golden_box2d["rect/a"], golden_box2d["rect/b"])          # ndarray in -> ndarray out
+    assert isinstance(got, np.ndarray) and np.array_equal(got, golden_box2d["rect/iou"])
+    z = overlaps.iou(torch.from_numpy(golden_box2d["zero_area/boxes"]).cuda(), torch.from_numpy(golden_box2d["zero_area/boxes"]).cuda())
+    assert np.array_equal(z.cpu().numpy(), golden_box2d["zero_area/iou"], equal_nan=True)
+    # odd sizes / unaligned leading dimension against the oracle
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(5)
+    for M, N in ((1, 1), (3, 7), (65, 129), (257, 1023), (1000, 1001)):
+        a, b = synthetic.uniform_boxes_2d(rng, M), synthetic.clustered_boxes_2d(rng, N, 8)
+        got = overlaps.iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+        assert np.array_equal(got, O.iou2d(a, b), equal_nan=True), (M, N)
+
+
+def test_iou3d(G, O, golden_box3d):
+    from groomed_nms_amd import overlaps
+    g = golden_box3d
+    for case in ("m5", "uni64", "clu64", "clu200"):
+        p = g[f"{case}/params"]
+        c = overlaps.get_corners_of_cuboid(*[torch.from_numpy(np.ascontiguousarray(p[:, i])).cuda() for i in range(7)])
+        np.testing.assert_allclose(c.cpu().numpy(), g[f"{case}/corners"], atol=2e-5, rtol=1e-6)
+        ref_c = torch.from_numpy(g[f"{case}/corners"]).cuda()
+        keep = ref_c.clone()
+        for method in ("normal", "generalized"):
+            bev, i3 = overlaps.iou3d_approximate(ref_c, ref_c, mode="combinations", method=method)
+            np.testing.assert_allclose(bev.cpu().numpy(), g[f"{case}/{method}/iou_bev"], atol=1e-6, rtol=1e-6)
+            np.testing.assert_allclose(i3.cpu().numpy(), g[f"{case}/{method}/iou_3d"], atol=1e-6, rtol=1e-6)
+            ob, o3 = O.iou3d_approximate(g[f"{case}/corners"], g[f"{case}/corners"], generalized=(method == "generalized"))
+            assert np.array_equal(i3.cpu().numpy(), o3, equal_nan=True) and np.array_equal(bev.cpu().numpy(), ob, equal_nan=True)
+        assert torch.equal(ref_c, keep)                                          # inputs are const (unlike lib/core.py:379-380)
+        ov = overlaps.iou3d_batched(torch.from_numpy(p).cuda().unsqueeze(0), from_params=True, nms_overlap=True)[0]
+        np.testing.assert_allclose(ov.cpu().numpy(), g[f"{case}/nms_overlap"], atol=TOL)
+    bev, i3 = overlaps.iou3d_approximate(torch.from_numpy(g["rect/corners_a"]).cuda(), torch.from_numpy(g["rect/corners_b"]).cuda(),
+                                         mode="combinations", method="generalized")
+    np.testing.assert_allclose(i3.cpu().numpy(), g["rect/iou_3d"], atol=1e-6)
+    np.testing.assert_allclose(bev.cpu().numpy(), g["rect/iou_bev"], atol=1e-6)
+
+
+def test_get_groups(G, golden_nms, golden_box2d):
+    for g in (golden_nms, golden_box2d):
+        for case in g.cases():
+            for gs in (100, 2):
+                if not g.has(f"{case}/groups_gs{gs}/lens"):
+                    continue
+                s, m = g[f"{case}/scores"], g[f"{case}/iou"]
+                groups = G.get_groups(torch.from_numpy(m).cuda(), 0.4, torch.from_numpy(s).cuda(), group_size=gs)
+                assert [len(x) for x in groups] == list(g[f"{case}/groups_gs{gs}/lens"]), (case, gs)
+                flat = [int(v) for x in groups for v in x.tolist()]
+                assert flat == list(g[f"{case}/groups_gs{gs}/flat"]), (case, gs)
+
+
+def test_pruning_function(G, golden_misc):
+    g = golden_misc
+    x = torch.from_numpy(g["prune/x"]).cuda()
+    for method, temp in (("linear", 0.01), ("sigmoidal", 0.1), ("sigmoidal", 0.01), ("soft_nms", 0.5), ("soft_nms", 0.1)):
+        got = G.pruning_function(x, 0.4, temp, method).cpu().numpy()
+        np.testing.assert_allclose(got, g[f"prune/{method}_{temp}/torch"], atol=1e-6)
+        np.testing.assert_allclose(G.pruning_function(g["prune/x"][0].astype(np.float64), 0.4, temp, method),
+                                   g[f"prune/{method}_{temp}/numpy_row0"], atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        G.pruning_function(x, 0.4, 0.1, "bogus")
+    with pytest.raises(NotImplementedError):
+        G.differentiable_nms(torch.rand(4).cuda(), torch.eye(4).cuda(), pruning_method="bogus")
+
+
+def test_soft_sort(G, golden_misc):
+    g = golden_misc
+    tags = sorted({k.split("/")[0] for k in g.keys if k.startswith("softsort_")})
+    for tag in tags:
+        s, m, t = g[f"{tag}/scores"], g[f"{tag}/iou"], float(g[f"{tag}/temperature"])
+        ss, C, sm = G.soft_sort(torch.from_numpy(s).cuda(), torch.from_numpy(m).cuda(), t)
+        np.testing.assert_allclose(C.cpu().numpy(), g[f"{tag}/C"], atol=1e-5)
+        np.testing.assert_allclose(ss.cpu().numpy(), g[f"{tag}/soft_scores"], atol=1e-5)
+        np.testing.assert_allclose(sm.cpu().numpy(), g[f"{tag}/soft_matrix"], atol=1e-5)
+        for mt, kw in (("gm", dict(group_boxes=True, mask_group_boxes=True)),
+                       ("gu", dict(group_boxes=True, mask_group_boxes=False)), ("un", dict(group_boxes=False))):
+            res = _run_gpu(G, s, m, g[f"{tag}/w"], True, sorting_method="soft", sorting_temperature=t, temperature=0.1, **kw)
+            np.testing.assert_allclose(res["prob"], g[f"{tag}/{mt}/prob"], atol=TOL, err_msg=f"{tag}/{mt}")
+            check_index_lists(res["valid"], res["invalid"], g[f"{tag}/{mt}/valid"], g[f"{tag}/{mt}/invalid"])
+            np.testing.assert_allclose(res["grad_scores"], g[f"{tag}/{mt}/grad_scores"], atol=5e-3, rtol=2e-3, err_msg=f"{tag}/{mt}")
+            np.testing.assert_allclose(res["grad_iou"], g[f"{tag}/{mt}/grad_iou"], atol=2e-4, rtol=1e-3, err_msg=f"{tag}/{mt}")
+
+
+def test_sgemm_mfma(G):
+    from groomed_nms_amd.groomed_nms import _sgemm
+    rng = np.random.default_rng(0)
+    for M, N, K in ((1, 1, 1), (33, 65, 17), (128, 128, 128), (200, 300, 250), (512, 384, 1024)):
+        a = rng.uniform(-1, 1, size=(M, K)).astype(np.float32)
+        b = rng.uniform(-1, 1, size=(K, N)).astype(np.float32)     # asymmetric operands
+        got = _sgemm(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        np.testing.assert_allclose(got, ref, atol=1e-6 * K + 1e-5, rtol=1e-5)
+
+
+def test_classic_nms(G, O, golden_misc):
+    from groomed_nms_amd.nms import gpu_nms
+    g = golden_misc
+    for tag in ("dets40", "dets300", "dets_uni200"):
+        dets = g[f"{tag}/dets"]
+        for thr in (0.4, 0.7):
+            got = [int(i) for i in gpu_nms(dets, thr, device_id=0)]
+            assert got == list(g[f"{tag}/py_cpu_nms_{thr}"]), (tag, thr)
+            assert got == O.classic_nms(dets, thr, rule="gpu")
+    assert gpu_nms(np.zeros((0, 5), np.float32), 0.4) == []
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(3)
+    for n in (1, 63, 64, 65, 1000, 4096):
+        dets = np.concatenate([synthetic.clustered_boxes_2d(rng, n, 16), synthetic.tie_free_scores(rng, n)[:, None]], 1)
+        assert [int(i) for i in gpu_nms(dets, 0.5)] == O.classic_nms(dets, 0.5, rule="gpu"), n
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 130, 257, 1000, 1024])
+def test_random_vs_oracle(G, O, n):
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(100 + n)
+    for kind in ("uniform", "clustered"):
+        b = synthetic.uniform_boxes_2d(rng, n) if kind == "uniform" else synthetic.clustered_boxes_2d(rng, n, 32)
+        s = synthetic.tie_free_scores(rng, n)
+        m = O.iou2d(b, b)
+        w = rng.uniform(-1, 2, size=n).astype(np.float32)
+        for mode in ("gm_lin", "gm_lin_gs2", "gm_sig", "gm_lin_sorted", "gu_lin", "gu_soft", "un_lin", "un_sig"):
+            if n > 300 and mode.startswith("un"):
+                continue
+            res = _run_gpu(G, s, m, w, n <= 130, **MODES[mode])
+            ref = O.differentiable_nms(s, m, grad_prob=w, want_grad_iou=(n <= 130), **MODES[mode])
+            tag = f"n={n} {kind} {mode}"
+            if mode.startswith("gm_"):
+                assert np.array_equal(res["prob"], ref["prob"]), tag
+                assert np.array_equal(res["grad_scores"], ref["grad_scores"]), tag
+                assert list(res["valid"]) == list(ref["valid"]) and list(res["invalid"]) == list(ref["invalid"]), tag
+            else:
+                np.testing.assert_allclose(res["prob"], ref["prob"], atol=TOL, err_msg=tag)
+                np.testing.assert_allclose(res["grad_scores"], ref["grad_scores"], atol=5e-4, rtol=1e-3, err_msg=tag)
+                check_index_lists(res["valid"], res["invalid"], ref["valid"], ref["invalid"])
+            if n <= 130:
+                np.testing.assert_allclose(res["grad_iou"], ref["grad_iou"], atol=5e-4, rtol=1e-3, err_msg=tag)
+
+
+def test_batched_ragged(G, O):
+    """Padded batch with per-image counts (ragged inputs), including an empty image."""
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(7)
+    B, N = 5, 200
+    counts = np.array([200, 0, 1, 77, 130], np.int32)
+    boxes = np.stack([synthetic.clustered_boxes_2d(rng, N, 16) for _ in range(B)])
+    scores = np.stack([synthetic.tie_free_scores(rng, N) for _ in range(B)])
+    from groomed_nms_amd import overlaps
+    bt = torch.from_numpy(boxes).cuda()
+    iou = overlaps.iou_batched(bt)
+    st = torch.from_numpy(scores).cuda().requires_grad_(True)
+    prob, order, valid, invalid, nv, ni = G.differentiable_nms_batched(st, iou, counts=torch.from_numpy(counts).cuda())
+    w = torch.from_numpy(rng.uniform(-1, 2, size=(B, N)).astype(np.float32)).cuda()
+    (prob * w).sum().backward()
+    for b in range(B):
+        n = int(counts[b])
+        ref = O.differentiable_nms(scores[b, :n], O.iou2d(boxes[b, :n], boxes[b, :n]), grad_prob=w[b, :n].cpu().numpy())
+        assert np.array_equal(prob[b, :n].detach().cpu().numpy(), ref["prob"]), b
+        assert int(nv[b]) == len(ref["valid"]) and int(ni[b]) == len(ref["invalid"])
+        assert valid[b, :int(nv[b])].tolist() == list(ref["valid"])
+        assert np.array_equal(st.grad[b, :n].cpu().numpy(), ref["grad_scores"]), b
+        assert torch.all(st.grad[b, n:] == 0) and torch.all(prob[b, n:] == 0)
+
+
+def test_full_size_properties(G):
+    """BASELINE sizes (N=4096, B=8; N=16384, B=2): size-independent properties of the layer."""
+    from groomed_nms_amd import synthetic, overlaps
+    for B, N, kind in ((8, 4096, "clustered"), (2, 16384, "uniform")):
+        boxes, scores = synthetic.batch_2d(11, B, N, kind)
+        bt, st = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda().requires_grad_(True)
+        iou = overlaps.iou_batched(bt)
+        prob, order, valid, invalid, nv, ni = G.differentiable_nms_batched(st, iou)
+        prob.sum().backward()
+        p = prob.detach()
+        assert torch.all((p >= 0) & (p <= 1))
+        sorted_scores = torch.gather(st.detach(), 1, order)
+        assert torch.all(sorted_scores[:, :-1] > sorted_scores[:, 1:])               # order is the descending argsort
+        assert torch.all(p <= sorted_scores + 1e-7)                                 # rescoring never raises a score
+        assert torch.all(nv + ni == N)
+        for b in range(B):
+            v = valid[b, :int(nv[b])]
+            iv = invalid[b, :int(ni[b])]
+            assert len(set(v.tolist()) | set(iv.tolist())) == N                     # a partition of the boxes
+            rank_of = torch.empty(N, dtype=torch.long, device="cuda")
+            rank_of[order[b]] = torch.arange(N, device="cuda")
+            pv = p[b][rank_of[v]]
+            assert torch.all(pv[:-1] >= pv[1:]) and torch.all(pv >= 0.3)            # valid list sorted by re-score
+            assert torch.all(p[b][rank_of[iv]] < 0.3)
+            # kept boxes with an unchanged score are greedy-NMS leaders: mutually non-overlapping
+            lead = order[b][(p[b] == sorted_scores[b].clamp(0, 1))]
+            sub = iou[b][lead][:, lead]
+            sub.fill_diagonal_(0)
+            assert float(sub.max()) <= 0.4 + 1e-7
+        # idempotence of the sort path: feeding the already-sorted problem gives the same probabilities
+        iou_sorted = torch.stack([iou[b][order[b]][:, order[b]] for b in range(B)])
+        prob2 = G.differentiable_nms_batched(sorted_scores, iou_sorted)[0]
+        assert torch.equal(prob2, p)
+        g = st.grad
+        assert torch.isfinite(g).all()
