@@ -1,0 +1,81 @@
+"""Multi-GPU plumbing for the GrooMeD-NMS path: one process per GPU, images sharded across ranks.
+
+The reference is single-process nn.DataParallel (lib/core.py:68) and runs the NMS per image in a Python
+loop on the gathered batch (lib/loss/rpn_3d.py:375).  Images are independent units, so here every rank
+owns a contiguous slice of the batch and the NMS layer needs NO collective; the only collectives are the
+timing barrier / max-reduce below (and, in a training step, DDP's gradient all-reduce of the backbone,
+which is stock torch over RCCL).  backend "nccl" is RCCL on ROCm; the CPU tests use "gloo".
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialises torch.distributed from the launcher's env (RANK/WORLD_SIZE/MASTER_*).  Returns (world, rank, local_rank)."""
+    world, rank, local_rank = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, **kw)
+    return world, rank, local_rank
+
+
+def shard_range(total, rank, world):
+    """Contiguous [lo, hi) slice of `total` images owned by `rank`: sizes differ by at most one, every image
+    belongs to exactly one rank (B split contiguously across ranks)."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(seconds, device=None):
+    """MAX-reduce of a wall-clock measurement (the driver's timing contract)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(seconds)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(value)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def timed_steps(step, steps, warmup, sync):
+    """warmup untimed steps, then exactly `steps` timed ones bracketed by barrier + device sync on both sides.
+    Returns the MAX over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    barrier()
+    sync()
+    return max_over_ranks(time.perf_counter() - t0)
