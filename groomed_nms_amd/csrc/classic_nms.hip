@@ -97,10 +97,10 @@ extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float t
     GNMS_CHECK_LAUNCH();
     classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, ws, L);
     GNMS_CHECK_LAUNCH();
-    const size_t lds = (size_t)n * 4;
+    const size_t lds = (size_t)kSBPairs * 64 * 8 + kSB * 8 + kSB * 64 * 4 + 2 * kSBPairs * 4 + (size_t)n * 4;
     if (lds > 64 * 1024)
         GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    leaders_kernel<<<1, 256, lds, st>>>(n, nullptr, ws, L);
+    leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L);
     GNMS_CHECK_LAUNCH();
     classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);
     GNMS_CHECK_LAUNCH();

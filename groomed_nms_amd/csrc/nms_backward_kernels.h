@@ -50,10 +50,21 @@ __global__ __launch_bounds__(256) void bwd_masked_kernel(int N, const int* __res
         g = I.gx[q];
         if (h == k) {
             const int start = I.gstart[k], len = I.glen[k];
-            for (int t = 1; t < len; ++t) {                          // members in rank order: deterministic sum
+            int t = 1;
+            for (; t + 8 <= len; t += 8) {                           // 8 independent gathers in flight, summed in rank order
+                float pl[8], gv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int mk = I.gsorted[start + t + u];
+                    pl[u] = I.plead[mk];
+                    gv[u] = I.gx[P.presorted ? I.order[mk] : mk];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) g -= pl[u] * gv[u];
+            }
+            for (; t < len; ++t) {
                 const int mk = I.gsorted[start + t];
-                const int mq = P.presorted ? I.order[mk] : mk;
-                g -= I.plead[mk] * I.gx[mq];
+                g -= I.plead[mk] * I.gx[P.presorted ? I.order[mk] : mk];
             }
         }
     }

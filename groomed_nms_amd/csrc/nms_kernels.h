@@ -25,25 +25,80 @@ namespace {   // internal linkage: the header is included by several translation
 typedef unsigned long long u64;
 
 // ------------------------------------------------------------------------------------------------
-// in-LDS bitonic sort of P (power of two) 64-bit keys, ascending, by the whole workgroup
+// Workgroup sort of P = blockDim.x * E 64-bit keys (P a power of two, blockDim.x a multiple of 64),
+// ascending.  Thread t owns elements t*E .. t*E+E-1 in registers.  A bitonic network whose stages run
+//   j <  E      in registers (compile-time partner),
+//   j <  64*E   as wave shuffles (partner lane = lane ^ j/E),
+//   j >= 64*E   through LDS (transposed [e][t] layout: conflict-free), two barriers each.
+// For P = 4096 that is 10 LDS stages instead of the 78 barrier-separated stages of a plain LDS bitonic.
+// On return the sorted keys are in r[] AND in keys[0..P) (natural order), barrier included.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bitonic_sort_lds(u64* keys, int P) {
+__device__ __forceinline__ u64 shfl_xor_key(u64 v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffu), m, 64);
+    const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned shfl_xor_key(unsigned v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ u64 shfl_up_u64(u64 v, int off) {
+    const unsigned lo = __shfl_up((unsigned)(v & 0xffffffffu), off, 64);
+    const unsigned hi = __shfl_up((unsigned)(v >> 32), off, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+template <int E, typename K>
+__device__ __forceinline__ void block_sort(K (&r)[E], K* keys, int P) {
+    const int t = threadIdx.x;
     const int T = blockDim.x;
     for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += T) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const u64 a = keys[i], b = keys[l];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+        for (int j = k >> 1; j >= 64 * E; j >>= 1) {                    // cross-wave stages
+#pragma unroll
+            for (int e = 0; e < E; ++e) keys[e * T + t] = r[e];
+            __syncthreads();
+            const int pt = t ^ (j / E);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = t * E + e;
+                const K o = keys[e * T + pt];
+                const bool keepmin = ((i & k) == 0) == ((i & j) == 0);
+                r[e] = ((o < r[e]) == keepmin) ? o : r[e];              // one 64-bit compare per exchange
             }
             __syncthreads();
         }
+        {
+            int j = (k >> 1) < 64 * E ? (k >> 1) : 32 * E;              // intra-wave stages
+            for (; j >= E; j >>= 1) {
+                const int m = j / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = t * E + e;
+                    const K o = shfl_xor_key(r[e], m);
+                    const bool keepmin = ((i & k) == 0) == ((i & j) == 0);
+                    r[e] = ((o < r[e]) == keepmin) ? o : r[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = E / 2; jj >= 1; jj >>= 1) {                        // in-register stages
+            if (jj < k) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & jj) == 0) {
+                        const int i = t * E + e;
+                        const bool up = (i & k) == 0;
+                        const K a = r[e], b = r[e | jj];
+                        if ((a > b) == up) { r[e] = b; r[e | jj] = a; }
+                    }
+                }
+            }
+        }
     }
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[t * E + e] = r[e];
+    __syncthreads();
 }
 
-__device__ __forceinline__ int lower_bound_lds(const u64* keys, int n, u64 v) {
+template <typename K>
+__device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
     int lo = 0, hi = n;
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
@@ -74,6 +129,7 @@ __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_lay
 // ------------------------------------------------------------------------------------------------
 // K1: stable descending argsort of the scores (lib/groomed_nms.py:41; get_groups :213)
 // ------------------------------------------------------------------------------------------------
+template <int E>
 __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restrict__ scores, int N, const int* __restrict__ counts,
                                                            char* ws, gnms_ws_layout L, int P, long long* __restrict__ order_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -82,10 +138,13 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
     const int n = counts ? counts[b] : N;
     const float* s = scores + (size_t)b * N;
     ImgPtrs I = img_ptrs(ws, L, b);
-    for (int i = threadIdx.x; i < P; i += blockDim.x)
-        keys[i] = (i < n) ? (((u64)gnms_desc_key(s[i]) << 32) | (unsigned)i) : ~0ull;
-    __syncthreads();
-    bitonic_sort_lds(keys, P);
+    u64 r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = threadIdx.x * E + e;
+        r[e] = (i < n) ? (((u64)gnms_desc_key(s[i]) << 32) | (unsigned)i) : ~0ull;
+    }
+    block_sort<E, u64>(r, keys, P);
     for (int k = threadIdx.x; k < N; k += blockDim.x) {
         int idx = k;                  // padding ranks map to themselves
         float v = 0.0f;
@@ -164,69 +223,188 @@ __global__ __launch_bounds__(256) void bitmask_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: leaders (= the boxes classical greedy NMS keeps).  For rank block kb the word
-//   removed = OR over all earlier leaders L of W[kb][order[L]]
-// is pulled cooperatively (leaders' input indices sit in LDS), then wave 0 resolves the 64 ranks of
-// the block against each other on the diagonal words, visiting only the leaders (s_ff1 on ~removed).
+// K3: leaders (= the boxes classical greedy NMS keeps).  The scan is inherently sequential over rank
+// blocks; what must NOT be sequential is global-memory latency.  So ranks are processed in super-blocks
+// of kSB = 16 blocks (1024 ranks):
+//   phase A (all 16 waves, one memory round trip): wave b pulls, for block b of the super-block, the OR of
+//           W[block][order[L]] over every leader L found in EARLIER super-blocks; all waves stage into LDS
+//           the triangular table Xs[(b,b')][lane] = W[b'][order[rank (b,lane)]]: what each candidate of
+//           block b would remove in blocks b' >= b of the same super-block (speculative, 68 KiB).
+//   phase B (wave 0, LDS + registers only): blocks resolved in order; lane b' carries the removed-word
+//           of block b'; the 64 ranks of a block are resolved visiting only the leaders (s_ff1 on
+//           ~removed); each new leader ORs its table row into the lanes of the later blocks.
 // ------------------------------------------------------------------------------------------------
+constexpr int kSB = 16;
+constexpr int kSBPairs = kSB * (kSB + 1) / 2;
+
+#ifdef GNMS_TIMING   // developer instrumentation (tools/microbench.hip): accumulates s_memtime deltas into ws gx[] of image 0
+#define GNMS_T0() long long t__ = (long long)__builtin_amdgcn_s_memtime()
+#define GNMS_TACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) ((long long*)I.gx)[slot] += n__ - t__; t__ = n__; } while (0)
+#else
+#define GNMS_T0() do {} while (0)
+#define GNMS_TACC(slot) do {} while (0)
+#endif
+
 __device__ __forceinline__ u64 uniform64(u64 v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffu));
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((u64)hi << 32) | lo;
 }
+__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(v & 0xffffffffu), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ int tri_index(int b, int bp) { return b * kSB - (b * (b - 1)) / 2 + (bp - b); }   // b <= bp < kSB
 
-__global__ __launch_bounds__(256) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
+__global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* leadc_s = reinterpret_cast<int*>(smem);                 // [N]
-    __shared__ u64 part[4];
+    u64* Xs = reinterpret_cast<u64*>(smem);                      // [kSBPairs][64]
+    u64* accS = Xs + kSBPairs * 64;                              // [kSB]
+    int* cand_s = reinterpret_cast<int*>(accS + kSB);            // [kSB*64]
+    int* pair_b = cand_s + kSB * 64;                             // [kSBPairs] pair -> b
+    int* pair_bp = pair_b + kSBPairs;                            // [kSBPairs] pair -> b'
+    int* leadc_s = pair_bp + kSBPairs;                           // [N]
     __shared__ int nlead_s;
     const int b = blockIdx.x;
     const int n = counts ? counts[b] : N;
     ImgPtrs I = img_ptrs(ws, L, b);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = (n + 63) >> 6;
-    if (threadIdx.x == 0) { nlead_s = 0; I.leadpfx[0] = 0; }
+    if (tid == 0) { nlead_s = 0; I.leadpfx[0] = 0; }
+    if (tid < kSB) for (int bp = tid; bp < kSB; ++bp) { pair_b[tri_index(tid, bp)] = tid; pair_bp[tri_index(tid, bp)] = bp; }
     __syncthreads();
-    for (int kb = 0; kb < nb; ++kb) {
-        const u64* slab = I.W + (size_t)kb * L.NC;
-        const int nlead = nlead_s;
-        u64 acc = 0;
-        for (int t = threadIdx.x; t < nlead; t += 256) acc |= slab[leadc_s[t]];
-        acc = gnms_wave_or(acc);
-        if (lane == 0) part[wave] = acc;
+    for (int kb0 = 0; kb0 < nb; kb0 += kSB) {
+        const int nblk = min(kSB, nb - kb0);
+        GNMS_T0();
+        for (int i = tid; i < nblk * 64; i += 1024) {
+            const int k = kb0 * 64 + i;
+            cand_s[i] = (k < n) ? I.order[k] : -1;
+        }
         __syncthreads();
+        GNMS_TACC(0);
+        const int nlead = nlead_s;
+        // ---- phase A.1: wave w pulls block kb0+w from all earlier leaders ----
+        if (wave < nblk) {
+            const u64* slab = I.W + (size_t)(kb0 + wave) * L.NC;
+            u64 acc = 0;
+            int li = lane;
+            for (; li + 64 * 7 < nlead; li += 64 * 8) {                // 8 loads in flight per lane
+                u64 w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = slab[leadc_s[li + 64 * u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc |= w[u];
+            }
+            for (; li < nlead; li += 64) acc |= slab[leadc_s[li]];
+            acc = gnms_wave_or(acc);
+            if (lane == 0) accS[wave] = acc;
+        }
+        GNMS_TACC(1);
+        // ---- phase A.2: the speculative triangular table (all loads of a thread issued before the first use) ----
+        {
+            constexpr int kPer = (kSBPairs * 64 + 1023) / 1024;         // 9 entries per thread
+            u64 w[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int e = tid + u * 1024;
+                w[u] = 0;
+                if (e < kSBPairs * 64) {
+                    const int pr = e >> 6;
+                    const int bb = pair_b[pr], bp = pair_bp[pr];
+                    if (bp < nblk) {
+                        const int c = cand_s[bb * 64 + (e & 63)];
+                        if (c >= 0) w[u] = I.W[(size_t)(kb0 + bp) * L.NC + c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int e = tid + u * 1024;
+                if (e < kSBPairs * 64) Xs[e] = w[u];
+            }
+        }
+        GNMS_TACC(2);
+        __syncthreads();
+        GNMS_TACC(3);
+        // ---- phase B: sequential resolve, wave 0 only; nothing but registers and LDS on this path ----
         if (wave == 0) {
-            const int k0 = kb << 6;
-            const int nrows = min(64, n - k0);
-            const int myc = (lane < nrows) ? I.order[k0 + lane] : 0;
-            const u64 d = (lane < nrows) ? slab[myc] : 0ull;      // who rank k0+lane would remove inside this block
-            u64 cur = part[0] | part[1] | part[2] | part[3];
-            if (nrows < 64) cur |= ~((1ull << nrows) - 1ull);      // ranks >= n never lead
-            cur = uniform64(cur);                                  // wave-uniform: keep the resolve loop on the scalar unit
-            u64 leaders = 0;
-            while (~cur != 0ull) {
-                const int p = __builtin_ctzll(~cur);
-                const unsigned dl = __builtin_amdgcn_readlane((unsigned)(d & 0xffffffffu), p);
-                const unsigned dh = __builtin_amdgcn_readlane((unsigned)(d >> 32), p);
-                leaders |= 1ull << p;
-                cur |= (((u64)dh << 32) | dl) | (1ull << p);       // a leader always leaves `remaining`
+            u64 myacc = (lane < nblk) ? accS[lane] : 0ull;             // lane b' = removed-word of block kb0+b'
+            u64 mylead = 0;                                            // lane b' = leader mask of block kb0+b'
+            for (int bb = 0; bb < nblk; ++bb) {
+                const int k0 = (kb0 + bb) << 6;
+                const int nrows = min(64, n - k0);
+                u64 cur = readlane64(myacc, bb);
+                if (nrows < 64) cur |= ~((1ull << nrows) - 1ull);     // ranks >= n never lead
+                const u64 d = Xs[tri_index(bb, bb) * 64 + lane];       // what rank k0+lane removes inside its own block
+                u64 leaders = 0;
+                while (~cur != 0ull) {                                 // scalar loop: one trip per leader
+                    const int p = __builtin_ctzll(~cur);
+                    leaders |= 1ull << p;
+                    cur |= readlane64(d, p) | (1ull << p);             // a leader always leaves `remaining`
+                }
+                if (lane == bb) mylead = leaders;
+                if (leaders != 0ull && bb + 1 < nblk) {
+                    // push: lane b' (> bb) ORs the table rows of this block's leaders
+                    const bool tgt = lane > bb && lane < nblk;
+                    const u64* row = Xs + (size_t)tri_index(bb, tgt ? lane : bb) * 64;
+                    u64 lm = leaders;
+                    if (__builtin_popcountll(lm) <= 2) {
+                        while (lm) {
+                            const int p = __builtin_ctzll(lm);
+                            lm &= lm - 1ull;
+                            if (tgt) myacc |= row[p];
+                        }
+                    } else {
+                        while (lm) {                                   // 8 LDS reads in flight
+                            int p[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                p[u] = lm ? __builtin_ctzll(lm) : -1;
+                                lm &= lm - 1ull;
+                            }
+                            u64 v[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) v[u] = (tgt && p[u] >= 0) ? row[p[u]] : 0ull;
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) myacc |= v[u];
+                        }
+                    }
+                }
             }
-            const int before = __builtin_popcountll(leaders & ((1ull << lane) - 1ull));
-            if ((leaders >> lane) & 1ull) {
-                leadc_s[nlead + before] = myc;
-                I.leadc[nlead + before] = myc;
-                I.leadr[nlead + before] = k0 + lane;
+            if (lane < kSB) accS[lane] = mylead;                       // hand the masks to the bookkeeping below
+        }
+        GNMS_TACC(4);
+        __syncthreads();
+        // ---- bookkeeping, one wave per block: leader lists, per-block words, running counts ----
+        {
+            int base = nlead;
+            u64 mine = 0;
+            for (int bb = 0; bb < nblk; ++bb) {
+                const u64 lm = accS[bb];
+                if (bb < wave) base += __builtin_popcountll(lm);
+                if (bb == wave) mine = lm;
             }
-            if (lane == 0) {
-                I.leadw[kb] = leaders;
-                const int tot = nlead + __builtin_popcountll(leaders);
-                I.leadpfx[kb + 1] = tot;
-                nlead_s = tot;
+            if (wave < nblk) {
+                const int k0 = (kb0 + wave) << 6;
+                if ((mine >> lane) & 1ull) {
+                    const int slot = base + __builtin_popcountll(mine & ((1ull << lane) - 1ull));
+                    const int myc = cand_s[wave * 64 + lane];
+                    leadc_s[slot] = myc;
+                    I.leadc[slot] = myc;
+                    I.leadr[slot] = k0 + lane;
+                }
+                if (lane == 0) {
+                    I.leadw[kb0 + wave] = mine;
+                    I.leadpfx[kb0 + wave + 1] = base + __builtin_popcountll(mine);
+                    if (wave == nblk - 1) nlead_s = base + __builtin_popcountll(mine);
+                }
             }
         }
         __syncthreads();
+        GNMS_TACC(5);
     }
-    if (threadIdx.x == 0) I.misc[0] = nlead_s;
+    if (tid == 0) I.misc[0] = nlead_s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -286,45 +464,60 @@ __global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restr
 // Arrays head/gpos/gstart/glen/gsorted/plead are indexed by rank; pre is indexed by NMS position q
 // (q = rank for hard sort, q = input index when presorted).
 // ------------------------------------------------------------------------------------------------
+template <int E>
 __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                                       gnms_params P, char* ws, gnms_ws_layout L, int Ppow2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);
+    unsigned* keys = reinterpret_cast<unsigned*>(smem);          // (leader rank << 14) | rank : 28 bits (N <= 16384)
     const int b = blockIdx.x;
     const int n = counts ? counts[b] : N;
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = iou + (size_t)b * N * ld;
     const float thr = P.nms_threshold;
-    for (int k = threadIdx.x; k < Ppow2; k += blockDim.x) {
-        u64 key = ~0ull;
+    unsigned r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = threadIdx.x * E + e;
+        unsigned key = ~0u;
         if (k < n) {
             const int lr = I.rem[k];
             const float v = m[(size_t)I.order[k] * ld + I.order[lr]];
-            if (v > thr) key = ((u64)(unsigned)lr << 32) | (unsigned)k;
+            if (v > thr) key = ((unsigned)lr << 14) | (unsigned)k;
         }
-        keys[k] = key;
+        r[e] = key;
         if (k < N) { I.head[k] = -1; I.gpos[k] = -1; I.glen[k] = 0; I.gstart[k] = 0; I.plead[k] = 0.0f; }
     }
-    __syncthreads();
-    bitonic_sort_lds(keys, Ppow2);
+    block_sort<E, unsigned>(r, keys, Ppow2);
     const long long cap = (long long)P.group_size + 1;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const u64 key = keys[i];
-        if (key == ~0ull) { I.gsorted[i] = -1; continue; }
-        const unsigned lr = (unsigned)(key >> 32);
-        const int k = (int)(key & 0xffffffffu);
-        const int start = lower_bound_lds(keys, n, (u64)lr << 32);
-        const int end = lower_bound_lds(keys, n, ((u64)lr + 1ull) << 32);
-        const long long pos = i - start;
+        const unsigned key = keys[i];
+        if (key == ~0u) { I.gsorted[i] = -1; continue; }
+        const unsigned lr = key >> 14;
+        const int k = (int)(key & 0x3fffu);
+        const bool first = (i == 0) || ((keys[i - 1] >> 14) != lr);
         I.gsorted[i] = k;
+        // most boxes sit in short runs: walk back a few entries before falling back to the binary search
+        int start = i;
+        if (!first) {
+            int back = 1;
+            while (back <= 8 && i - back >= 0 && (keys[i - back] >> 14) == lr) ++back;
+            start = (back <= 8) ? (i - back + 1) : lower_bound_lds<unsigned>(keys, n, lr << 14);
+        }
+        const long long pos = i - start;
         if (pos < cap) {
-            I.head[k] = (int)(keys[start] & 0xffffffffu);
+            int end = i + 1;
+            {
+                int fwd = 0;
+                while (fwd < 8 && end < n && (keys[end] >> 14) == lr) { ++end; ++fwd; }
+                if (fwd == 8 && end < n && (keys[end] >> 14) == lr)
+                    end = (lr + 1u >= (1u << 14)) ? lower_bound_lds<unsigned>(keys, n, ~0u) : lower_bound_lds<unsigned>(keys, n, (lr + 1u) << 14);
+            }
+            I.head[k] = (int)(keys[start] & 0x3fffu);
             I.gpos[k] = (int)pos;
             I.gstart[k] = start;
             const long long len = end - start;
             I.glen[k] = (int)(len < cap ? len : cap);
         }
-        if (pos == 0) atomicAdd(&I.misc[1], 1);
     }
     __syncthreads();
     if (!P.mask_group_boxes) return;
@@ -349,56 +542,108 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // K6: finalize (lib/groomed_nms.py:111-129).  r2 = clamp(pre,0,1); r = r2 with (< valid_thr) zeroed;
-// stable descending sort of r; valid / invalid lists of INPUT indices; the prob vector in the order
-// the reference returns it.
+// the reference then sorts r descending (:116-121).  After thresholding every invalid box is an exact 0,
+// so a STABLE descending sort is: [NaN boxes by position][valid boxes by (r desc, position)][invalid boxes
+// by position].  Only the valid subset needs a sort; the other two are stream compactions (one packed
+// block scan).  valid / invalid are INPUT indices padded with -1; prob is written in the order the
+// reference returns it.
 // ------------------------------------------------------------------------------------------------
+template <int E>
 __global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                                         int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
                                                         long long* __restrict__ invalid, int* __restrict__ nvalid,
                                                         int* __restrict__ ninvalid) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u64* keys = reinterpret_cast<u64*>(smem);
+    u64* keys = reinterpret_cast<u64*>(smem);                     // [Ppow2]
+    __shared__ u64 wave_tot[16];
     const int b = blockIdx.x;
     const int n = counts ? counts[b] : N;
     ImgPtrs I = img_ptrs(ws, L, b);
     const float vthr = P.valid_box_prob_threshold;
-    for (int q = threadIdx.x; q < Ppow2; q += blockDim.x) {
-        u64 key = ~0ull;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, T = blockDim.x;
+    // classify
+    u64 key[E];
+    int cls[E];                                                    // 0 nan, 1 valid, 2 invalid, 3 padding
+    u64 packed = 0;                                                // nan | valid << 20 | invalid << 40
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int q = t * E + e;
+        cls[e] = 3;
+        key[e] = ~0ull;
         if (q < n) {
             const float pre = I.pre[q];
             const float r2 = pre < 0.0f ? 0.0f : (pre > 1.0f ? 1.0f : pre);      // torch.clamp keeps NaN
-            const float r = (r2 < vthr) ? 0.0f : r2;                            // :115
+            const float rr = (r2 < vthr) ? 0.0f : r2;                           // :115
             I.r2[q] = r2;
-            key = ((u64)gnms_desc_key(r) << 32) | (unsigned)q;
+            cls[e] = (rr != rr) ? 0 : ((rr >= vthr) ? 1 : ((rr < vthr) ? 2 : 0)); // vthr NaN: neither list (:118-123)
+            key[e] = ((u64)gnms_desc_key(rr) << 32) | (unsigned)q;
+            packed += (cls[e] == 0) ? 1ull : (cls[e] == 1 ? (1ull << 20) : (1ull << 40));
         }
-        keys[q] = key;
+    }
+    // exclusive block scan of the packed counters
+    u64 inc = packed;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 v = shfl_up_u64(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    for (int i = t; i < Ppow2; i += T) keys[i] = ~0ull;
+    __syncthreads();
+    u64 base = 0, total = 0;
+    const int nwaves = T >> 6;
+    for (int w = 0; w < nwaves; ++w) { const u64 v = wave_tot[w]; if (w < wave) base += v; total += v; }
+    u64 run = base + inc - packed;
+    const int n_nan = (int)(total & 0xfffff), nv = (int)((total >> 20) & 0xfffff), ni = (int)(total >> 40);
+    const int n_ge = n_nan + nv;
+    // sidx layout: [0,n_nan) NaN by position, [n_nan, n_ge) valid (sorted below), [n_ge, n_ge+ni) invalid by position
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int q = t * E + e;
+        if (cls[e] == 0) { I.sidx[(int)(run & 0xfffff)] = q; run += 1ull; }
+        else if (cls[e] == 1) { keys[(int)((run >> 20) & 0xfffff)] = key[e]; run += 1ull << 20; }
+        else if (cls[e] == 2) {
+            const int j = (int)(run >> 40);
+            I.sidx[n_ge + j] = q;
+            if (invalid) invalid[(size_t)b * N + j] = P.presorted ? q : I.order[q];
+            run += 1ull << 40;
+        }
     }
     __syncthreads();
-    bitonic_sort_lds(keys, Ppow2);
-    // NaN keys are 0; valid  <=> r >= vthr <=> key32 <= desc_key(vthr)
-    const int n_nan = lower_bound_lds(keys, n, 1ull << 32);
-    int n_ge = (vthr != vthr) ? n_nan : lower_bound_lds(keys, n, ((u64)gnms_desc_key(vthr) + 1ull) << 32);
-    if (n_ge < n_nan) n_ge = n_nan;
-    const int nv = n_ge - n_nan;
-    const int ni = (vthr != vthr) ? 0 : (n - n_ge);
-    float* pb = prob + (size_t)b * N;
-    for (int j = threadIdx.x; j < N; j += blockDim.x) {
-        if (j >= n) {
-            pb[j] = 0.0f;
-            I.sidx[j] = j;
-            continue;
+    // sort the valid keys: they sit in keys[0..nv), padded with ~0
+    if (nv > 1) {
+        if (nv <= T) {
+            u64 r1[1] = {keys[t]};
+            __syncthreads();
+            block_sort<1, u64>(r1, keys, T);
+        } else {
+            u64 r[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) r[e] = keys[t * E + e];
+            __syncthreads();
+            block_sort<E, u64>(r, keys, Ppow2);
         }
-        const int q = (int)(keys[j] & 0xffffffffu);
-        I.sidx[j] = q;
-        const int inp = P.presorted ? q : I.order[q];
-        if (j >= n_nan && j < n_ge) { if (valid) valid[(size_t)b * N + (j - n_nan)] = inp; }
-        else if (j >= n_ge && ni > 0) { if (invalid) invalid[(size_t)b * N + (j - n_ge)] = inp; }
-        const float r2q = I.r2[q];
-        if (P.return_sorted_prob) pb[j] = (r2q < vthr) ? 0.0f : r2q;                       // :117
-        const float r2j = I.r2[j];
-        if (!P.return_sorted_prob) pb[j] = P.group_boxes ? r2j : ((r2j < vthr) ? 0.0f : r2j);  // :124-127
     }
-    if (threadIdx.x == 0) {
+    float* pb = prob + (size_t)b * N;
+    for (int j = t; j < N; j += T) {
+        if (j < nv) {
+            const int q = (int)(keys[j] & 0xffffffffu);
+            I.sidx[n_nan + j] = q;
+            if (valid) valid[(size_t)b * N + j] = P.presorted ? q : I.order[q];
+        } else if (valid) valid[(size_t)b * N + j] = -1;
+        if (j >= ni && invalid) invalid[(size_t)b * N + j] = -1;
+        if (j >= n) I.sidx[j] = j;
+    }
+    __syncthreads();
+    for (int j = t; j < N; j += T) {
+        float out = 0.0f;
+        if (j < n) {
+            if (P.return_sorted_prob) { const float r2q = I.r2[I.sidx[j]]; out = (r2q < vthr) ? 0.0f : r2q; }   // :117
+            else { const float r2j = I.r2[j]; out = P.group_boxes ? r2j : ((r2j < vthr) ? 0.0f : r2j); }       // :124-127
+        }
+        pb[j] = out;
+    }
+    if (t == 0) {
         if (nvalid) nvalid[b] = nv;
         if (ninvalid) ninvalid[b] = ni;
     }

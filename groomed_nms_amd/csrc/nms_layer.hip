@@ -38,10 +38,23 @@ namespace {
 using namespace gnms;
 
 int next_pow2(int n) {
-    int p = 2;
+    int p = 64;               // block_sort works on >= 64 keys (one wave)
     while (p < n) p <<= 1;
     return p;
 }
+
+// block_sort<E>: P = threads * E.  P <= 1024 -> E = 1; above, 1024 threads and E = P / 1024 (N <= 16384 -> E <= 16).
+#define GNMS_DISPATCH_SORT(P2, ...)                               \
+    do {                                                          \
+        const int e__ = (P2) <= 1024 ? 1 : (P2) / 1024;           \
+        if (e__ == 1) { constexpr int E = 1; __VA_ARGS__; }              \
+        else if (e__ == 2) { constexpr int E = 2; __VA_ARGS__; }         \
+        else if (e__ == 4) { constexpr int E = 4; __VA_ARGS__; }         \
+        else if (e__ == 8) { constexpr int E = 8; __VA_ARGS__; }         \
+        else { constexpr int E = 16; __VA_ARGS__; }                      \
+    } while (0)
+
+size_t leaders_lds_bytes(int N) { return (size_t)kSBPairs * 64 * 8 + kSB * 8 + kSB * 64 * 4 + 2 * kSBPairs * 4 + (size_t)N * 4; }
 
 template <typename K>
 int allow_lds(K kernel, size_t bytes) {
@@ -86,10 +99,10 @@ int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* coun
     if (vec) bitmask_kernel<true><<<gm, 256, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
     else bitmask_kernel<false><<<gm, 256, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
     GNMS_CHECK_LAUNCH();
-    const size_t lds = (size_t)N * 4;
+    const size_t lds = leaders_lds_bytes(N);
     int rc = allow_lds(leaders_kernel, lds);
     if (rc) return rc;
-    leaders_kernel<<<B, 256, lds, st>>>(N, counts, ws, L);
+    leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
     attribute_kernel<<<dim3(L.NB, B), 64, 0, st>>>(N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
@@ -121,16 +134,20 @@ extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N,
     char* ws = (char*)workspace;
     const int P2 = next_pow2(N);
     const size_t sort_lds = (size_t)P2 * 8;
-    const int sort_threads = P2 / 2 < 1024 ? (P2 / 2 < 64 ? 64 : P2 / 2) : 1024;
+    const int sort_threads = P2 <= 1024 ? P2 : 1024;
 
-    if ((rc = allow_lds(sort_scores_kernel, sort_lds))) return rc;
-    sort_scores_kernel<<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
+        sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
+    });
     GNMS_CHECK_LAUNCH();
 
     if (P.group_boxes) {
         if ((rc = run_grouping(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;
-        if ((rc = allow_lds(groups_kernel, sort_lds))) return rc;
-        groups_kernel<<<B, sort_threads, sort_lds, st>>>(iou, N, (long)ld, counts, P, ws, L, P2);
+        GNMS_DISPATCH_SORT(P2, {
+            if ((rc = allow_lds(groups_kernel<E>, sort_lds))) return rc;
+            groups_kernel<E><<<B, sort_threads, sort_lds, st>>>(iou, N, (long)ld, counts, P, ws, L, P2);
+        });
         GNMS_CHECK_LAUNCH();
         if (!P.mask_group_boxes) {
             const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
@@ -146,9 +163,11 @@ extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N,
         ungrouped_forward_kernel<<<B, 1024, lds, st>>>(iou, scores, N, (long)ld, counts, P, ws, L);
         GNMS_CHECK_LAUNCH();
     }
-    if ((rc = allow_lds(finalize_kernel, sort_lds))) return rc;
-    finalize_kernel<<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
-                                                        ninvalid);
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
+        finalize_kernel<E><<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid,
+                                                               nvalid, ninvalid);
+    });
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -249,13 +268,17 @@ extern "C" int gnms_get_groups(const float* scores, const float* iou, int N, int
     char* ws = (char*)workspace;
     const int P2 = next_pow2(N);
     const size_t sort_lds = (size_t)P2 * 8;
-    const int sort_threads = P2 / 2 < 1024 ? (P2 / 2 < 64 ? 64 : P2 / 2) : 1024;
-    if ((rc = allow_lds(sort_scores_kernel, sort_lds))) return rc;
-    sort_scores_kernel<<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr);
+    const int sort_threads = P2 <= 1024 ? P2 : 1024;
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
+        sort_scores_kernel<E><<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr);
+    });
     GNMS_CHECK_LAUNCH();
     if ((rc = run_grouping(iou, 1, N, ld, nullptr, group_threshold, ws, L, st))) return rc;
-    if ((rc = allow_lds(groups_kernel, sort_lds))) return rc;
-    groups_kernel<<<1, sort_threads, sort_lds, st>>>(iou, N, (long)ld, nullptr, P, ws, L, P2);
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(groups_kernel<E>, sort_lds))) return rc;
+        groups_kernel<E><<<1, sort_threads, sort_lds, st>>>(iou, N, (long)ld, nullptr, P, ws, L, P2);
+    });
     GNMS_CHECK_LAUNCH();
     export_groups_kernel<<<gnms_div_up(N, 256), 256, 0, st>>>(N, ws, L, group_of, pos_in_group, ngroups_out);
     GNMS_CHECK_LAUNCH();

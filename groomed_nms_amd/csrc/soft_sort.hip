@@ -159,14 +159,25 @@ extern "C" int gnms_soft_sort(const float* scores, const float* iou, int N, int6
     if (workspace_bytes < L.per_image) { gnms_set_error("gnms_soft_sort: workspace too small"); return GNMS_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    int P2 = 2;
+    int P2 = 64;
     while (P2 < N) P2 <<= 1;
     const size_t sort_lds = (size_t)P2 * 8;
-    const int sort_threads = P2 / 2 < 1024 ? (P2 / 2 < 64 ? 64 : P2 / 2) : 1024;
-    if (sort_lds > 64 * 1024)
-        GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_scores_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)sort_lds));
-    sort_scores_kernel<<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr);
+    const int sort_threads = P2 <= 1024 ? P2 : 1024;
+#define GNMS_SS_SORT(EE)                                                                                                         \
+    do {                                                                                                                         \
+        if (sort_lds > 64 * 1024)                                                                                                \
+            GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_scores_kernel<EE>),                             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));                      \
+        sort_scores_kernel<EE><<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr);                       \
+    } while (0)
+    switch (P2 <= 1024 ? 1 : P2 / 1024) {
+        case 1: GNMS_SS_SORT(1); break;
+        case 2: GNMS_SS_SORT(2); break;
+        case 4: GNMS_SS_SORT(4); break;
+        case 8: GNMS_SS_SORT(8); break;
+        default: GNMS_SS_SORT(16); break;
+    }
+#undef GNMS_SS_SORT
     GNMS_CHECK_LAUNCH();
     float* Z = img_ptrs(ws, L, 0).xsol;
     softsort_rows_kernel<<<N, 256, 0, st>>>(scores, N, temperature, ws, L, C, Z);

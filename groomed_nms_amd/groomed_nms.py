@@ -59,10 +59,10 @@ class _GroomedNMSFunction(torch.autograd.Function):
         iou_c, ld = _matrix_layout(iou)
         prob = torch.empty((B, N), dtype=torch.float32, device=dev)
         order = torch.empty((B, N), dtype=torch.int64, device=dev)
-        valid = torch.zeros((B, N), dtype=torch.int64, device=dev)
-        invalid = torch.zeros((B, N), dtype=torch.int64, device=dev)
-        nvalid = torch.zeros((B,), dtype=torch.int32, device=dev)
-        ninvalid = torch.zeros((B,), dtype=torch.int32, device=dev)
+        valid = torch.empty((B, N), dtype=torch.int64, device=dev)       # finalize_kernel writes every entry (-1 padding)
+        invalid = torch.empty((B, N), dtype=torch.int64, device=dev)
+        nvalid = torch.empty((B,), dtype=torch.int32, device=dev)
+        ninvalid = torch.empty((B,), dtype=torch.int32, device=dev)
         nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):

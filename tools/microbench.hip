@@ -1,0 +1,108 @@
+// tools/microbench.hip -- developer microbenchmarks of the single-workgroup NMS kernels (not part of the product).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I groomed_nms_amd/csrc tools/microbench.hip -o /tmp/microbench -L groomed_nms_amd -lgroomed_nms_hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+#include "nms_kernels.h"
+using namespace gnms;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int E>
+__global__ __launch_bounds__(1024) void sort_only_kernel(const u64* in, u64* out, int P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    u64 r[E];
+    const u64* src = in + (size_t)blockIdx.x * P;
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = src[threadIdx.x * E + e];
+    block_sort<E, u64>(r, keys, P);
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[(size_t)blockIdx.x * P + threadIdx.x * E + e] = r[e];
+}
+
+__global__ void empty_kernel(int* p) { if (p && threadIdx.x == 12345) *p = 1; }
+
+template <typename F>
+float time_us(F f, int reps = 20) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms * 1000.f / reps;
+}
+
+int main(int argc, char** argv) {
+    int N = argc > 1 ? atoi(argv[1]) : 4096;
+    int B = argc > 2 ? atoi(argv[2]) : 8;
+    int per = argc > 3 ? atoi(argv[3]) : 64;     // boxes per cluster (0 = uniform)
+    srand(1);
+    auto U = []() { return (float)rand() / RAND_MAX; };
+    std::vector<float> boxes((size_t)B * N * 4), scores((size_t)B * N);
+    for (int b = 0; b < B; ++b) {
+        int K = per > 0 ? (N / per > 0 ? N / per : 1) : N;
+        std::vector<float> base(K * 4);
+        for (int k = 0; k < K; ++k) { float cx = U() * 1760, cy = U() * 512, w = 16 + U() * 120, h = 16 + U() * 120; base[k*4]=cx; base[k*4+1]=cy; base[k*4+2]=w; base[k*4+3]=h; }
+        for (int i = 0; i < N; ++i) {
+            int k = per > 0 ? i % K : i;
+            float cx = base[k*4], cy = base[k*4+1], w = base[k*4+2], h = base[k*4+3];
+            if (per > 0) { cx += (U() - 0.5f) * 0.35f * w; cy += (U() - 0.5f) * 0.35f * h; w *= 0.85f + 0.3f * U(); h *= 0.85f + 0.3f * U(); }
+            float* p = &boxes[((size_t)b * N + i) * 4];
+            p[0] = cx - w / 2; p[1] = cy - h / 2; p[2] = cx + w / 2; p[3] = cy + h / 2;
+            scores[(size_t)b * N + i] = U() + 1e-7f * i;
+        }
+    }
+    float *d_boxes, *d_scores, *d_iou, *d_prob; char* ws;
+    CK(hipMalloc(&d_boxes, boxes.size() * 4)); CK(hipMalloc(&d_scores, scores.size() * 4));
+    CK(hipMalloc(&d_iou, (size_t)B * N * N * 4)); CK(hipMalloc(&d_prob, (size_t)B * N * 4));
+    CK(hipMemcpy(d_boxes, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_scores, scores.data(), scores.size() * 4, hipMemcpyHostToDevice));
+    gnms_params P; gnms_default_params(&P);
+    size_t wsb = gnms_workspace_bytes(B, N, &P);
+    CK(hipMalloc(&ws, wsb));
+    gnms_ws_layout L = gnms_make_layout(N);
+    if (gnms_iou2d(d_boxes, d_boxes, B, N, N, d_iou, N, nullptr)) { printf("iou2d failed %s\n", gnms_last_error()); return 1; }
+    if (gnms_forward(d_scores, d_iou, B, N, N, nullptr, &P, d_prob, nullptr, nullptr, nullptr, nullptr, nullptr, ws, wsb, nullptr)) { printf("fwd failed %s\n", gnms_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    int nlead[8]; for (int b = 0; b < B && b < 8; ++b) { CK(hipMemcpy(&nlead[b], img_ptrs(ws, L, b).misc, 4, hipMemcpyDeviceToHost)); }
+    printf("N=%d B=%d per=%d leaders(img0)=%d\n", N, B, per, nlead[0]);
+
+    int P2 = 64; while (P2 < N) P2 <<= 1;
+    const size_t sort_lds = (size_t)P2 * 8;
+    const int T = P2 <= 1024 ? P2 : 1024;
+    printf("empty kernel            %8.1f us\n", time_us([&] { empty_kernel<<<B, 1024>>>(nullptr); }));
+    printf("iou2d                   %8.1f us\n", time_us([&] { gnms_iou2d(d_boxes, d_boxes, B, N, N, d_iou, N, nullptr); }));
+    printf("forward (all)           %8.1f us\n", time_us([&] { gnms_forward(d_scores, d_iou, B, N, N, nullptr, &P, d_prob, nullptr, nullptr, nullptr, nullptr, nullptr, ws, wsb, nullptr); }));
+    const size_t llds = (size_t)kSBPairs * 64 * 8 + kSB * 8 + kSB * 64 * 4 + 2 * kSBPairs * 4 + (size_t)N * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
+    printf("leaders                 %8.1f us\n", time_us([&] { leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); }));
+#ifdef GNMS_TIMING
+    {
+        long long z[8] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
+        leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
+        printf("  leaders phases (ticks @100MHz=10ns): cand %lld | pull %lld | table %lld | sync %lld | resolve(w0) %lld | sync %lld\n", z[0], z[1], z[2], z[3], z[4], z[5]);
+    }
+#endif
+    printf("attribute               %8.1f us\n", time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); }));
+    if (P2 == 4096) {
+        printf("sort_scores<4>          %8.1f us\n", time_us([&] { sort_scores_kernel<4><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr); }));
+        printf("groups<4>               %8.1f us\n", time_us([&] { groups_kernel<4><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); }));
+        printf("finalize<4>             %8.1f us\n", time_us([&] { finalize_kernel<4><<<B, T, sort_lds>>>(N, nullptr, P, ws, L, P2, d_prob, nullptr, nullptr, nullptr, nullptr); }));
+        std::vector<u64> hk((size_t)B * P2);
+        for (auto& v : hk) v = ((u64)rand() << 32) ^ (u64)rand() ^ ((u64)rand() << 17);
+        u64 *din, *dout; CK(hipMalloc(&din, hk.size() * 8)); CK(hipMalloc(&dout, hk.size() * 8));
+        CK(hipMemcpy(din, hk.data(), hk.size() * 8, hipMemcpyHostToDevice));
+        printf("block_sort<4> only      %8.1f us\n", time_us([&] { sort_only_kernel<4><<<B, 1024, sort_lds>>>(din, dout, P2); }));
+        printf("block_sort<8> only      %8.1f us\n", time_us([&] { sort_only_kernel<8><<<B, 512, sort_lds>>>(din, dout, P2); }));
+        printf("block_sort<16> only     %8.1f us\n", time_us([&] { sort_only_kernel<16><<<B, 256, sort_lds>>>(din, dout, P2); }));
+        std::vector<u64> ho(hk.size()); CK(hipMemcpy(ho.data(), dout, ho.size() * 8, hipMemcpyDeviceToHost));
+        bool ok = true; for (int b = 0; b < B; ++b) for (int i = 1; i < P2; ++i) if (ho[(size_t)b * P2 + i - 1] > ho[(size_t)b * P2 + i]) ok = false;
+        printf("sorted ok: %d\n", (int)ok);
+    }
+    return 0;
+}
