@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
 __global__ void classic_init_kernel(int n, char* ws, gnms_ws_layout L) {
     ImgPtrs I = img_ptrs(ws, L, 0);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) I.order[k] = k;
+    if (k < n) { I.order[k] = k; I.rankof[k] = k; }
     if (k < 8) I.misc[k] = 0;
 }
 
@@ -97,7 +97,7 @@ extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float t
     GNMS_CHECK_LAUNCH();
     classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, ws, L);
     GNMS_CHECK_LAUNCH();
-    const size_t lds = (size_t)kSBPairs * 64 * 8 + kSB * 8 + kSB * 64 * 4 + 2 * kSBPairs * 4 + (size_t)n * 4;
+    const size_t lds = (size_t)kSBPairs * 64 * 8 + 2 * (size_t)((L.NB + 1) & ~1) * 8 + 2 * kSBPairs * 4;
     if (lds > 64 * 1024)
         GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L);

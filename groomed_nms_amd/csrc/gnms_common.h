@@ -46,6 +46,7 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //   per image b (N = padded box count of the batch, NB = ceil(N/64) rank blocks, NC = round_up(N,4)):
 //     order      int32 [N]      rank -> input index (stable descending argsort of the scores)
 //     sscore     float [N]      scores in rank order
+//     rankof     int32 [N]      input index -> rank (inverse of order)
 //     rem        int32 [N]      rank of the leader that removed rank k from `remaining` (k itself for leaders)
 //     head       int32 [N]      rank of the first member of k's group (lib/groomed_nms.py:99 groups[j][0]),
 //                               -1 when k is in no group
@@ -64,12 +65,13 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //     leadw      u64   [NB]     bit k%64 of word k/64 set iff rank k is a leader
 //     leadpfx    int32 [NB+1]   number of leaders in rank blocks < kb
 //     misc       int32 [8]      [0]=number of leaders, [1]=number of groups
-//     W          u64   [NB][NC] W[kb][c] bit r set iff !(iou[order[64*kb+r]][c] <= thr): the set of ranks that
-//                               input-box c, were it a leader, takes out of `remaining` (:249-262), in rank space
+//     W          u64   [NB][NC] W[kb][k'] bit r set iff !(iou[order[64*kb+r]][order[k']] <= thr): the ranks of block kb that
+//                               rank k', were it a leader, takes out of `remaining` (:249-262).  Rank x rank space: the
+//                               bit-matrix kernel reads input columns and scatters each word to its rank position.
 // ------------------------------------------------------------------------------------------------
 struct gnms_ws_layout {
     int N, NB, NC;
-    size_t off_order, off_sscore, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_plead, off_pre,
+    size_t off_order, off_sscore, off_rankof, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_plead, off_pre,
         off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_W;
     size_t per_image;  // bytes
 };
@@ -82,7 +84,7 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = gnms_align_up(o + bytes, 256); return r; };
     size_t n4 = (size_t)(N > 0 ? N : 1) * 4;
-    L.off_order = take(n4); L.off_sscore = take(n4); L.off_rem = take(n4); L.off_head = take(n4);
+    L.off_order = take(n4); L.off_sscore = take(n4); L.off_rankof = take(n4); L.off_rem = take(n4); L.off_head = take(n4);
     L.off_gpos = take(n4); L.off_gsorted = take(n4); L.off_gstart = take(n4); L.off_glen = take(n4);
     L.off_plead = take(n4); L.off_pre = take(n4); L.off_r2 = take(n4); L.off_sidx = take(n4);
     L.off_xsol = take(n4); L.off_gx = take(n4); L.off_leadc = take(n4); L.off_leadr = take(n4);

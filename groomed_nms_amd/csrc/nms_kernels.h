@@ -108,7 +108,7 @@ __device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
 }
 
 struct ImgPtrs {
-    int* order; float* sscore; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen;
+    int* order; float* sscore; int* rankof; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen;
     float* plead; float* pre; float* r2; int* sidx; float* xsol; float* gx; int* leadc; int* leadr; u64* leadw; int* leadpfx;
     int* misc; u64* W;
 };
@@ -116,7 +116,7 @@ struct ImgPtrs {
 __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_layout& L, int b) {
     char* p = ws + (size_t)b * L.per_image;
     ImgPtrs I;
-    I.order = (int*)(p + L.off_order); I.sscore = (float*)(p + L.off_sscore); I.rem = (int*)(p + L.off_rem);
+    I.order = (int*)(p + L.off_order); I.sscore = (float*)(p + L.off_sscore); I.rankof = (int*)(p + L.off_rankof); I.rem = (int*)(p + L.off_rem);
     I.head = (int*)(p + L.off_head); I.gpos = (int*)(p + L.off_gpos); I.gsorted = (int*)(p + L.off_gsorted);
     I.gstart = (int*)(p + L.off_gstart); I.glen = (int*)(p + L.off_glen); I.plead = (float*)(p + L.off_plead);
     I.pre = (float*)(p + L.off_pre); I.r2 = (float*)(p + L.off_r2); I.sidx = (int*)(p + L.off_sidx);
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
         float v = 0.0f;
         if (k < n) { idx = (int)(keys[k] & 0xffffffffu); v = s[idx]; }
         I.order[k] = idx;
+        I.rankof[idx] = k;            // order is a permutation of [0,N) (identity on the padding)
         I.sscore[k] = v;
         if (order_out) order_out[(size_t)b * N + k] = idx;
     }
@@ -215,27 +216,39 @@ __global__ __launch_bounds__(256) void bitmask_kernel(const float* __restrict__ 
             }
         }
     }
+    // scatter each column word to the column's RANK: downstream kernels then read W contiguously
     u64* Wk = I.W + (size_t)kb * L.NC;
+    int rk[4];
+    if (VEC && col[3] < n) {
+        const int4 t = *reinterpret_cast<const int4*>(I.rankof + col[0]);
+        rk[0] = t.x; rk[1] = t.y; rk[2] = t.z; rk[3] = t.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rk[j] = (col[j] < n) ? I.rankof[col[j]] : -1;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (col[j] < L.NC) Wk[col[j]] = (((u64)hi[j] << 32) | lo[j]) & rowmask;
+        if (col[j] < n) Wk[rk[j]] = (((u64)hi[j] << 32) | lo[j]) & rowmask;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3: leaders (= the boxes classical greedy NMS keeps).  The scan is inherently sequential over rank
-// blocks; what must NOT be sequential is global-memory latency.  So ranks are processed in super-blocks
-// of kSB = 16 blocks (1024 ranks):
-//   phase A (all 16 waves, one memory round trip): wave b pulls, for block b of the super-block, the OR of
-//           W[block][order[L]] over every leader L found in EARLIER super-blocks; all waves stage into LDS
-//           the triangular table Xs[(b,b')][lane] = W[b'][order[rank (b,lane)]]: what each candidate of
-//           block b would remove in blocks b' >= b of the same super-block (speculative, 68 KiB).
-//   phase B (wave 0, LDS + registers only): blocks resolved in order; lane b' carries the removed-word
-//           of block b'; the 64 ranks of a block are resolved visiting only the leaders (s_ff1 on
-//           ~removed); each new leader ORs its table row into the lanes of the later blocks.
+// blocks; what must NOT be on that sequential path is global-memory latency.  Ranks are processed in
+// super-blocks of kSB = 16 blocks (1024 ranks), software-pipelined inside ONE workgroup of 16 waves:
+//   * removed-words of ALL blocks live in LDS (accAll[NB]);
+//   * while wave 0 resolves super-block sb (registers + LDS only), waves 1..15 prefetch, for super-block
+//     sb+1, the speculative triangular table  Xs[(b,b')][lane] = W[b'][rank(b,lane)]  (what each candidate
+//     of block b would remove in blocks b' >= b of its own super-block): contiguous 512-B rows of W;
+//   * after the resolve, every wave PUSHES the new leaders' words into the removed-words of all later
+//     blocks (one memory round trip per super-block, single writer per block, no atomics).
+// Resolve of one block: lane b' carries the removed-word of block b'; the 64 ranks are resolved on the
+// scalar unit visiting only the leaders (s_ff1 on ~removed); each new leader ORs its table row into the
+// lanes of the later blocks of the super-block.
 // ------------------------------------------------------------------------------------------------
 constexpr int kSB = 16;
 constexpr int kSBPairs = kSB * (kSB + 1) / 2;
+constexpr int kTabPer = (kSBPairs * 64 + 959) / 960;            // table entries per prefetching thread (waves 1..15)
 
 #ifdef GNMS_TIMING   // developer instrumentation (tools/microbench.hip): accumulates s_memtime deltas into ws gx[] of image 0
 #define GNMS_T0() long long t__ = (long long)__builtin_amdgcn_s_memtime()
@@ -257,154 +270,166 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
 }
 __device__ __forceinline__ int tri_index(int b, int bp) { return b * kSB - (b * (b - 1)) / 2 + (bp - b); }   // b <= bp < kSB
 
+__device__ __forceinline__ size_t leaders_lds_layout(int NB, size_t* off_acc, size_t* off_lm, size_t* off_cand, size_t* off_pair) {
+    size_t o = (size_t)kSBPairs * 64 * 8;                       // Xs
+    *off_acc = o; o += (size_t)((NB + 1) & ~1) * 8;             // accAll[NB]
+    *off_lm = o; o += (size_t)((NB + 1) & ~1) * 8;              // leader masks of all blocks
+    *off_cand = o;                                              // (unused)
+    *off_pair = o; o += 2 * kSBPairs * 4;                       // pair -> (b, b')
+    return o;
+}
+
 __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    size_t oa, ol, oc, op;
+    leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
     u64* Xs = reinterpret_cast<u64*>(smem);                      // [kSBPairs][64]
-    u64* accS = Xs + kSBPairs * 64;                              // [kSB]
-    int* cand_s = reinterpret_cast<int*>(accS + kSB);            // [kSB*64]
-    int* pair_b = cand_s + kSB * 64;                             // [kSBPairs] pair -> b
-    int* pair_bp = pair_b + kSBPairs;                            // [kSBPairs] pair -> b'
-    int* leadc_s = pair_bp + kSBPairs;                           // [N]
-    __shared__ int nlead_s;
+    u64* accAll = reinterpret_cast<u64*>(smem + oa);             // [NB]
+    u64* lmask = reinterpret_cast<u64*>(smem + ol);              // [NB]
+    int* pair_b = reinterpret_cast<int*>(smem + op);             // [kSBPairs]
+    int* pair_bp = pair_b + kSBPairs;
     const int b = blockIdx.x;
     const int n = counts ? counts[b] : N;
     ImgPtrs I = img_ptrs(ws, L, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = (n + 63) >> 6;
-    if (tid == 0) { nlead_s = 0; I.leadpfx[0] = 0; }
+    const int nsb = (nb + kSB - 1) / kSB;
+    GNMS_T0();
+    if (tid == 0) I.leadpfx[0] = 0;
     if (tid < kSB) for (int bp = tid; bp < kSB; ++bp) { pair_b[tri_index(tid, bp)] = tid; pair_bp[tri_index(tid, bp)] = bp; }
+    for (int i = tid; i < nb; i += 1024) { accAll[i] = 0ull; lmask[i] = 0ull; }
     __syncthreads();
-    for (int kb0 = 0; kb0 < nb; kb0 += kSB) {
+
+    // table prefetch of super-block `sb` into registers, by the threads [first, 1024)
+    u64 tw[kTabPer];
+    auto table_load = [&](int sb, int first, int nthr) {
+        const int kb0 = sb * kSB;
         const int nblk = min(kSB, nb - kb0);
-        GNMS_T0();
-        for (int i = tid; i < nblk * 64; i += 1024) {
-            const int k = kb0 * 64 + i;
-            cand_s[i] = (k < n) ? I.order[k] : -1;
-        }
-        __syncthreads();
-        GNMS_TACC(0);
-        const int nlead = nlead_s;
-        // ---- phase A.1: wave w pulls block kb0+w from all earlier leaders ----
-        if (wave < nblk) {
-            const u64* slab = I.W + (size_t)(kb0 + wave) * L.NC;
-            u64 acc = 0;
-            int li = lane;
-            for (; li + 64 * 7 < nlead; li += 64 * 8) {                // 8 loads in flight per lane
-                u64 w[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) w[u] = slab[leadc_s[li + 64 * u]];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc |= w[u];
-            }
-            for (; li < nlead; li += 64) acc |= slab[leadc_s[li]];
-            acc = gnms_wave_or(acc);
-            if (lane == 0) accS[wave] = acc;
-        }
-        GNMS_TACC(1);
-        // ---- phase A.2: the speculative triangular table (all loads of a thread issued before the first use) ----
-        {
-            constexpr int kPer = (kSBPairs * 64 + 1023) / 1024;         // 9 entries per thread
-            u64 w[kPer];
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int e = tid + u * 1024;
-                w[u] = 0;
-                if (e < kSBPairs * 64) {
-                    const int pr = e >> 6;
-                    const int bb = pair_b[pr], bp = pair_bp[pr];
-                    if (bp < nblk) {
-                        const int c = cand_s[bb * 64 + (e & 63)];
-                        if (c >= 0) w[u] = I.W[(size_t)(kb0 + bp) * L.NC + c];
-                    }
+        for (int u = 0; u < kTabPer; ++u) {
+            const int e = (tid - first) + u * nthr;
+            tw[u] = 0ull;
+            if (tid >= first && e < kSBPairs * 64) {
+                const int pr = e >> 6;
+                const int bb = pair_b[pr], bp = pair_bp[pr];
+                if (bp < nblk) {
+                    const int k = (kb0 + bb) * 64 + (e & 63);
+                    if (k < n) tw[u] = I.W[(size_t)(kb0 + bp) * L.NC + k];      // contiguous 512 B per (b,b') row
                 }
             }
-#pragma unroll
-            for (int u = 0; u < kPer; ++u) {
-                const int e = tid + u * 1024;
-                if (e < kSBPairs * 64) Xs[e] = w[u];
-            }
         }
-        GNMS_TACC(2);
-        __syncthreads();
-        GNMS_TACC(3);
-        // ---- phase B: sequential resolve, wave 0 only; nothing but registers and LDS on this path ----
-        if (wave == 0) {
-            u64 myacc = (lane < nblk) ? accS[lane] : 0ull;             // lane b' = removed-word of block kb0+b'
+    };
+    auto table_store = [&](int first, int nthr) {
+#pragma unroll
+        for (int u = 0; u < kTabPer; ++u) {
+            const int e = (tid - first) + u * nthr;
+            if (tid >= first && e < kSBPairs * 64) Xs[e] = tw[u];
+        }
+    };
+    // prologue: table of super-block 0 (waves 1..15 so the register footprint is the same as in the loop)
+    table_load(0, 64, 960);
+    table_store(64, 960);
+    __syncthreads();
+    GNMS_TACC(0);
+
+    for (int sb = 0; sb < nsb; ++sb) {
+        const int kb0 = sb * kSB;
+        const int nblk = min(kSB, nb - kb0);
+        if (wave != 0) {
+            // ---- prefetch the next super-block's table while wave 0 resolves this one ----
+            if (sb + 1 < nsb) table_load(sb + 1, 64, 960);
+        } else {
+            // ---- sequential resolve of this super-block: registers and LDS only ----
+            u64 myacc = (lane < nblk) ? accAll[kb0 + lane] : 0ull;     // lane b' = removed-word of block kb0+b'
             u64 mylead = 0;                                            // lane b' = leader mask of block kb0+b'
             for (int bb = 0; bb < nblk; ++bb) {
                 const int k0 = (kb0 + bb) << 6;
                 const int nrows = min(64, n - k0);
                 u64 cur = readlane64(myacc, bb);
                 if (nrows < 64) cur |= ~((1ull << nrows) - 1ull);     // ranks >= n never lead
+                if (~cur == 0ull) continue;                            // everything in this block is already removed
                 const u64 d = Xs[tri_index(bb, bb) * 64 + lane];       // what rank k0+lane removes inside its own block
-                u64 leaders = 0;
-                while (~cur != 0ull) {                                 // scalar loop: one trip per leader
+                // lane b' (> bb) also ORs the table row of every new leader into its removed-word; the LDS read of
+                // leader i is consumed one trip later, so its latency hides behind the scalar chain of leader i+1
+                const bool tgt = lane > bb && lane < nblk;
+                const u64* row = Xs + (size_t)tri_index(bb, tgt ? lane : bb) * 64;
+                u64 leaders = 0, pend = 0;
+                do {                                                   // scalar loop: one trip per leader
                     const int p = __builtin_ctzll(~cur);
                     leaders |= 1ull << p;
+                    const u64 nxt = row[p];
                     cur |= readlane64(d, p) | (1ull << p);             // a leader always leaves `remaining`
-                }
+                    myacc |= tgt ? pend : 0ull;
+                    pend = nxt;
+                } while (~cur != 0ull);
+                myacc |= tgt ? pend : 0ull;
                 if (lane == bb) mylead = leaders;
-                if (leaders != 0ull && bb + 1 < nblk) {
-                    // push: lane b' (> bb) ORs the table rows of this block's leaders
-                    const bool tgt = lane > bb && lane < nblk;
-                    const u64* row = Xs + (size_t)tri_index(bb, tgt ? lane : bb) * 64;
-                    u64 lm = leaders;
-                    if (__builtin_popcountll(lm) <= 2) {
-                        while (lm) {
-                            const int p = __builtin_ctzll(lm);
-                            lm &= lm - 1ull;
-                            if (tgt) myacc |= row[p];
-                        }
-                    } else {
-                        while (lm) {                                   // 8 LDS reads in flight
-                            int p[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) {
-                                p[u] = lm ? __builtin_ctzll(lm) : -1;
-                                lm &= lm - 1ull;
-                            }
-                            u64 v[8];
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) v[u] = (tgt && p[u] >= 0) ? row[p[u]] : 0ull;
-#pragma unroll
-                            for (int u = 0; u < 8; ++u) myacc |= v[u];
-                        }
-                    }
-                }
             }
-            if (lane < kSB) accS[lane] = mylead;                       // hand the masks to the bookkeeping below
+            if (lane < nblk) lmask[kb0 + lane] = mylead;
         }
-        GNMS_TACC(4);
-        __syncthreads();
-        // ---- bookkeeping, one wave per block: leader lists, per-block words, running counts ----
+        GNMS_TACC(1);
+        __syncthreads();                                               // (A) wave 0 is done with Xs and cand(sb)
+        GNMS_TACC(2);
+        // ---- push the new leaders' words into every block after this super-block (all 16 waves) ----
         {
-            int base = nlead;
-            u64 mine = 0;
-            for (int bb = 0; bb < nblk; ++bb) {
-                const u64 lm = accS[bb];
-                if (bb < wave) base += __builtin_popcountll(lm);
-                if (bb == wave) mine = lm;
-            }
-            if (wave < nblk) {
-                const int k0 = (kb0 + wave) << 6;
-                if ((mine >> lane) & 1ull) {
-                    const int slot = base + __builtin_popcountll(mine & ((1ull << lane) - 1ull));
-                    const int myc = cand_s[wave * 64 + lane];
-                    leadc_s[slot] = myc;
-                    I.leadc[slot] = myc;
-                    I.leadr[slot] = k0 + lane;
+            const int kb_end = kb0 + nblk;
+            u64 lms[kSB];
+#pragma unroll
+            for (int it = 0; it < kSB; ++it) lms[it] = (it < nblk) ? lmask[kb0 + it] : 0ull;
+            for (int kbp = kb_end + wave; kbp < nb; kbp += 16) {
+                const u64* slab = I.W + (size_t)kbp * L.NC + (size_t)kb0 * 64 + lane;
+                u64 v[kSB];
+#pragma unroll
+                for (int it = 0; it < kSB; ++it) {                     // all loads issued before the first use
+                    v[it] = 0ull;
+                    if (uniform64(lms[it]) != 0ull) v[it] = slab[it * 64];   // the leaders' words sit in one 8-KiB row segment
                 }
-                if (lane == 0) {
-                    I.leadw[kb0 + wave] = mine;
-                    I.leadpfx[kb0 + wave + 1] = base + __builtin_popcountll(mine);
-                    if (wave == nblk - 1) nlead_s = base + __builtin_popcountll(mine);
-                }
+                u64 acc = 0;
+#pragma unroll
+                for (int it = 0; it < kSB; ++it) acc |= ((lms[it] >> lane) & 1ull) ? v[it] : 0ull;
+                if (acc != 0ull) atomicOr(reinterpret_cast<unsigned long long*>(&accAll[kbp]), (unsigned long long)acc);
             }
         }
-        __syncthreads();
-        GNMS_TACC(5);
+        // ---- land the prefetched table for the next super-block ----
+        if (sb + 1 < nsb) table_store(64, 960);
+        GNMS_TACC(3);
+        __syncthreads();                                               // (B)
+        GNMS_TACC(4);
     }
-    if (tid == 0) I.misc[0] = nlead_s;
+    // ---- epilogue, off the sequential path: leader lists, per-block words, running counts ----
+    {
+        // exclusive prefix of popcounts over blocks: thread i < nb owns block i (nb <= 256)
+        int cnt = (tid < nb) ? __builtin_popcountll(lmask[tid]) : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += v;
+        }
+        int* wsum = reinterpret_cast<int*>(Xs);                      // Xs is free now
+        if (lane == 63 && wave < 4) wsum[wave] = inc;
+        __syncthreads();
+        int basew = 0;
+        for (int w = 0; w < 4; ++w) if (w < wave) basew += wsum[w];
+        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        int* pfx = wsum + 8;                                          // [nb] exclusive prefix
+        if (tid < nb) {
+            pfx[tid] = basew + inc - cnt;
+            I.leadw[tid] = lmask[tid];
+            I.leadpfx[tid + 1] = basew + inc;
+        }
+        __syncthreads();
+        for (int kb = wave; kb < nb; kb += 16) {
+            const u64 mine = lmask[kb];
+            if ((mine >> lane) & 1ull) {
+                const int slot = pfx[kb] + __builtin_popcountll(mine & ((1ull << lane) - 1ull));
+                const int k = (kb << 6) + lane;
+                I.leadc[slot] = I.order[k];
+                I.leadr[slot] = k;
+            }
+        }
+        if (tid == 0) I.misc[0] = total;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,7 +466,7 @@ __global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restr
         int lr = -1;
         if (t < nl) {
             lr = I.leadr[t];
-            w = slab[I.leadc[t]];
+            w = slab[lr];
             if (lr >= k0) w |= 1ull << (lr - k0);     // the leader's own slot
             w &= want;
         }

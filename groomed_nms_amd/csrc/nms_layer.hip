@@ -54,7 +54,7 @@ int next_pow2(int n) {
         else { constexpr int E = 16; __VA_ARGS__; }                      \
     } while (0)
 
-size_t leaders_lds_bytes(int N) { return (size_t)kSBPairs * 64 * 8 + kSB * 8 + kSB * 64 * 4 + 2 * kSBPairs * 4 + (size_t)N * 4; }
+size_t leaders_lds_bytes(int N) { const int NB = (N + 63) / 64; return (size_t)kSBPairs * 64 * 8 + 2 * (size_t)((NB + 1) & ~1) * 8 + 2 * kSBPairs * 4; }
 
 template <typename K>
 int allow_lds(K kernel, size_t bytes) {

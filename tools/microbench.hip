@@ -69,7 +69,7 @@ int main(int argc, char** argv) {
     if (gnms_forward(d_scores, d_iou, B, N, N, nullptr, &P, d_prob, nullptr, nullptr, nullptr, nullptr, nullptr, ws, wsb, nullptr)) { printf("fwd failed %s\n", gnms_last_error()); return 1; }
     CK(hipDeviceSynchronize());
     int nlead[8]; for (int b = 0; b < B && b < 8; ++b) { CK(hipMemcpy(&nlead[b], img_ptrs(ws, L, b).misc, 4, hipMemcpyDeviceToHost)); }
-    printf("N=%d B=%d per=%d leaders(img0)=%d\n", N, B, per, nlead[0]);
+    printf("N=%d B=%d per=%d leaders(img0)=%d\n", N, B, per, nlead[0]); setvbuf(stdout, NULL, _IONBF, 0);
 
     int P2 = 64; while (P2 < N) P2 <<= 1;
     const size_t sort_lds = (size_t)P2 * 8;
@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     printf("empty kernel            %8.1f us\n", time_us([&] { empty_kernel<<<B, 1024>>>(nullptr); }));
     printf("iou2d                   %8.1f us\n", time_us([&] { gnms_iou2d(d_boxes, d_boxes, B, N, N, d_iou, N, nullptr); }));
     printf("forward (all)           %8.1f us\n", time_us([&] { gnms_forward(d_scores, d_iou, B, N, N, nullptr, &P, d_prob, nullptr, nullptr, nullptr, nullptr, nullptr, ws, wsb, nullptr); }));
-    const size_t llds = (size_t)kSBPairs * 64 * 8 + kSB * 8 + kSB * 64 * 4 + 2 * kSBPairs * 4 + (size_t)N * 4;
+    const size_t llds = (size_t)kSBPairs * 64 * 8 + 2 * (size_t)((L.NB + 1) & ~1) * 8 + 2 * kSBPairs * 4;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
     printf("leaders                 %8.1f us\n", time_us([&] { leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); }));
 #ifdef GNMS_TIMING
@@ -85,9 +85,24 @@ int main(int argc, char** argv) {
         long long z[8] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
         leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); CK(hipDeviceSynchronize());
         CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
-        printf("  leaders phases (ticks @100MHz=10ns): cand %lld | pull %lld | table %lld | sync %lld | resolve(w0) %lld | sync %lld\n", z[0], z[1], z[2], z[3], z[4], z[5]);
+        printf("  leaders phases (cycles, wave0): prologue %lld | resolve %lld | barrierA %lld | push+book %lld | barrierB %lld\n", z[0], z[1], z[2], z[3], z[4]);
     }
 #endif
+    {
+        const bool vec = true;
+        dim3 gm((N + 1023) / 1024, L.NB, B);
+        float tb = time_us([&] { bitmask_kernel<true><<<gm, 256>>>(d_iou, N, N, nullptr, 0.4f, ws, L); });
+        float tbl = time_us([&] { bitmask_kernel<true><<<gm, 256>>>(d_iou, N, N, nullptr, 0.4f, ws, L); leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); });
+        printf("bitmask                 %8.1f us ; bitmask+leaders %8.1f us -> leaders cold %8.1f us\n", tb, tbl, tbl - tb);
+        (void)vec;
+#ifdef GNMS_TIMING
+        long long z[8] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
+        bitmask_kernel<true><<<gm, 256>>>(d_iou, N, N, nullptr, 0.4f, ws, L);
+        leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); CK(hipDeviceSynchronize());
+        CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
+        printf("  COLD leaders phases (cycles, wave0): prologue %lld | resolve %lld | barrierA %lld | push+book %lld | barrierB %lld\n", z[0], z[1], z[2], z[3], z[4]);
+#endif
+    }
     printf("attribute               %8.1f us\n", time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); }));
     if (P2 == 4096) {
         printf("sort_scores<4>          %8.1f us\n", time_us([&] { sort_scores_kernel<4><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr); }));
