@@ -16,13 +16,20 @@ namespace {
 
 constexpr int kTileRows = 64;
 constexpr int kWaveCols = 256;   // 64 lanes x 4 columns
-constexpr int kWavesPerWG = 4;
+constexpr int kWavesPerWG = 8;   // tools/bw_variants.hip: 8 waves + non-temporal stores = 5.6 TB/s (4 waves, plain stores: 5.3)
 constexpr int kWGCols = kWaveCols * kWavesPerWG;
 
 __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 __device__ __forceinline__ float relu0(float v) { return fmaxf(v, 0.0f); }
+// streaming 16-byte store: the matrix is written once and read once by another kernel much later
+__device__ __forceinline__ void store_nt_f4(float* p, float a, float b, float c, float d) {
+    __builtin_nontemporal_store(a, p);
+    __builtin_nontemporal_store(b, p + 1);
+    __builtin_nontemporal_store(c, p + 2);
+    __builtin_nontemporal_store(d, p + 3);
+}
 
 // ------------------------------------------------------------------------------------------------
 // 2D IoU.  a [B][M][4], b [B][N][4], out [B][M][ld].
@@ -30,7 +37,7 @@ __device__ __forceinline__ float relu0(float v) { return fmaxf(v, 0.0f); }
 // otherwise lane owns columns c0+lane+64*{0..3} and stores dwords (still coalesced).
 // ------------------------------------------------------------------------------------------------
 template <bool VEC>
-__global__ __launch_bounds__(256) void iou2d_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
+__global__ __launch_bounds__(kWavesPerWG * 64) void iou2d_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
                                                     int M, int N, float* __restrict__ out, long ld) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -75,7 +82,7 @@ __global__ __launch_bounds__(256) void iou2d_kernel(const float* __restrict__ A,
         float* orow = o + (size_t)(i0 + r) * ld;
         if (VEC) {
             if (col[3] < N) {
-                *reinterpret_cast<float4*>(orow + col[0]) = make_float4(res[0], res[1], res[2], res[3]);
+                store_nt_f4(orow + col[0], res[0], res[1], res[2], res[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
@@ -164,7 +171,7 @@ __global__ void aabb_from_params_kernel(const float* __restrict__ params, long c
 
 // pairwise 3D overlap from the records.  METHOD 0 normal, 1 generalized, 2 0.5*(1+generalized).
 template <bool VEC, int METHOD, bool BEV>
-__global__ __launch_bounds__(256) void iou3d_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M, int N,
+__global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M, int N,
                                                     float* __restrict__ out_bev, float* __restrict__ out3d, long ld) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -222,8 +229,8 @@ __global__ __launch_bounds__(256) void iou3d_kernel(const float* __restrict__ RA
         }
         const size_t roff = (size_t)(i0 + r) * ld;
         if (VEC && col[3] < N) {
-            *reinterpret_cast<float4*>(o3 + roff + col[0]) = make_float4(res3[0], res3[1], res3[2], res3[3]);
-            if (BEV) *reinterpret_cast<float4*>(ob + roff + col[0]) = make_float4(resb[0], resb[1], resb[2], resb[3]);
+            store_nt_f4(o3 + roff + col[0], res3[0], res3[1], res3[2], res3[3]);
+            if (BEV) store_nt_f4(ob + roff + col[0], resb[0], resb[1], resb[2], resb[3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (col[j] < N) { o3[roff + col[j]] = res3[j]; if (BEV) ob[roff + col[j]] = resb[j]; }
@@ -234,8 +241,8 @@ __global__ __launch_bounds__(256) void iou3d_kernel(const float* __restrict__ RA
 template <bool VEC, int METHOD>
 void launch_iou3d(const float* ra, const float* rb, int B, int M, int N, float* bev, float* o3, long ld, hipStream_t st) {
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, kTileRows), B);
-    if (bev) iou3d_kernel<VEC, METHOD, true><<<grid, 256, 0, st>>>(ra, rb, M, N, bev, o3, ld);
-    else iou3d_kernel<VEC, METHOD, false><<<grid, 256, 0, st>>>(ra, rb, M, N, nullptr, o3, ld);
+    if (bev) iou3d_kernel<VEC, METHOD, true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, bev, o3, ld);
+    else iou3d_kernel<VEC, METHOD, false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, nullptr, o3, ld);
 }
 
 int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, int method, float* bev, float* o3, int64_t ld,
@@ -266,8 +273,8 @@ extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, kTileRows), B);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
-    if (vec) iou2d_kernel<true><<<grid, 256, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld);
-    else iou2d_kernel<false><<<grid, 256, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld);
+    if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld);
+    else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

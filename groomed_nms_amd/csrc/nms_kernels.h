@@ -158,23 +158,38 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: threshold bit matrix.  One wave = 64 rank-rows x 256 input columns.  Rows order[64*kb + r] are
-// contiguous 4N-byte streams whatever the permutation, so the row gather is free; the column side
-// is never permuted: lane t accumulates, for each of its 4 columns c, the 64-bit word
-//     W[kb][c] = sum_r  !(iou[order[64 kb + r]][c] <= thr) << r
-// i.e. column c of the thresholded matrix with its bits already in RANK space.  16 x 1-KiB loads are
-// kept in flight per wave.
+// K2: threshold bit matrix -- the ONE full read of the N x N fp32 matrix (HBM-read bound).
+// One wave = 64 rank-rows x 256 input columns.  Rows order[64*kb + r] are contiguous 4N-byte streams
+// whatever the permutation, so the row gather is free; lane t accumulates, for each of its 4 columns c,
+//     word(c) = sum_r  !(iou[order[64 kb + r]][c] <= thr) << r
+// i.e. column c of the thresholded matrix with its bits already in RANK order, and scatters it to
+// W[kb][rankof[c]] so that every later kernel reads W contiguously (rank x rank space).
+// Tuning (tools/bw_variants.hip, MI355X): ROLLED row loops with 8 x 1-KiB non-temporal loads in flight per
+// wave keep the kernel at 63 VGPRs = 8 waves/SIMD; that beats the fully unrolled 64-load version
+// (256 VGPRs, 1 wave/SIMD) by 18 % and reaches 5.6 TB/s with the scatter (6.0 TB/s without).
 // ------------------------------------------------------------------------------------------------
+constexpr int kMaskWaves = 8;       // waves per workgroup: 8 x 256 = 2048 columns
+constexpr int kMaskRB = 8;          // rows (1-KiB loads) in flight per wave
+
+__device__ __forceinline__ float4 load_nt_f4(const float* p) {
+    float4 v;
+    v.x = __builtin_nontemporal_load(p);
+    v.y = __builtin_nontemporal_load(p + 1);
+    v.z = __builtin_nontemporal_load(p + 2);
+    v.w = __builtin_nontemporal_load(p + 3);
+    return v;
+}
+
 template <bool VEC>
-__global__ __launch_bounds__(256) void bitmask_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
-                                                      float thr, char* ws, gnms_ws_layout L) {
+__global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                                                  float thr, char* ws, gnms_ws_layout L) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
     const int kb = blockIdx.y;
     const int n = counts ? counts[b] : N;
     const int k0 = kb * 64;
-    const int c0 = (blockIdx.x * 4 + wave) * 256;
+    const int c0 = (blockIdx.x * kMaskWaves + wave) * 256;
     if (k0 >= n || c0 >= n) return;
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = iou + (size_t)b * N * ld;
@@ -187,32 +202,33 @@ __global__ __launch_bounds__(256) void bitmask_kernel(const float* __restrict__ 
     int col[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
-    // VEC reads 16 B at col[0]; legal while col[0] < ld (ld % 4 == 0).  Columns >= n produce words nobody reads.
-    const bool active = VEC ? (col[0] < L.NC && col[0] + 3 < ld) : true;
+    // VEC reads 16 B at col[0]; legal while col[0]+3 < ld (ld % 4 == 0).  Columns >= n produce words nobody stores.
+    const bool active = VEC ? (col[0] + 3 < ld) : true;
 
-    unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
+    unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
-    for (int rb = 0; rb < 64; rb += 16) {
-        float v[16][4];
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+        for (int rb = 0; rb < 32; rb += kMaskRB) {
+            float v[kMaskRB][4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int row = __builtin_amdgcn_readlane(myrow, rb + u);
-            const float* p = m + (size_t)row * ld;
-            if (VEC) {
-                float4 t = active ? *reinterpret_cast<const float4*>(p + col[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
-            } else {
+            for (int u = 0; u < kMaskRB; ++u) {
+                const int row = __builtin_amdgcn_readlane(myrow, half * 32 + rb + u);
+                const float* p = m + (size_t)row * ld;
+                if (VEC) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (active) t = load_nt_f4(p + col[0]);
+                    v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[u][j] = (col[j] < n) ? p[col[j]] : 0.0f;
+                    for (int j = 0; j < 4; ++j) v[u][j] = (col[j] < n) ? __builtin_nontemporal_load(p + col[j]) : 0.0f;
+                }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int r = rb + u;
+            for (int u = 0; u < kMaskRB; ++u) {
+                const unsigned bit = 1u << (rb + u);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool notlow = !(v[u][j] <= thr);                       // lib/groomed_nms.py:250 (NaN -> removed)
-                if (r < 32) lo[j] |= notlow ? (1u << r) : 0u; else hi[j] |= notlow ? (1u << (r - 32)) : 0u;
+                for (int j = 0; j < 4; ++j) wd[half][j] |= !(v[u][j] <= thr) ? bit : 0u;   // lib/groomed_nms.py:250 (NaN -> removed)
             }
         }
     }
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(256) void bitmask_kernel(const float* __restrict__ 
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (col[j] < n) Wk[rk[j]] = (((u64)hi[j] << 32) | lo[j]) & rowmask;
+        if (col[j] < n) Wk[rk[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
     }
 }
 

@@ -95,9 +95,9 @@ int check_common(const char* fn, int B, int N, int64_t ld, const gnms_params* P,
 int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L,
                  hipStream_t st) {
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
-    dim3 gm(gnms_div_up(N, 1024), L.NB, B);
-    if (vec) bitmask_kernel<true><<<gm, 256, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
-    else bitmask_kernel<false><<<gm, 256, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
+    dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
+    if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
+    else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
     GNMS_CHECK_LAUNCH();
     const size_t lds = leaders_lds_bytes(N);
     int rc = allow_lds(leaders_kernel, lds);
@@ -219,9 +219,9 @@ extern "C" int gnms_profile_bitmask(const float* iou, int B, int N, int64_t ld, 
     if (B == 0 || N == 0) return GNMS_OK;
     const gnms_ws_layout L = gnms_make_layout(N);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
-    dim3 gm(gnms_div_up(N, 1024), L.NB, B);
-    if (vec) bitmask_kernel<true><<<gm, 256, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
-    else bitmask_kernel<false><<<gm, 256, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
+    dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
+    if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
+    else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

@@ -90,14 +90,14 @@ int main(int argc, char** argv) {
 #endif
     {
         const bool vec = true;
-        dim3 gm((N + 1023) / 1024, L.NB, B);
-        float tb = time_us([&] { bitmask_kernel<true><<<gm, 256>>>(d_iou, N, N, nullptr, 0.4f, ws, L); });
-        float tbl = time_us([&] { bitmask_kernel<true><<<gm, 256>>>(d_iou, N, N, nullptr, 0.4f, ws, L); leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); });
+        dim3 gm((N + kMaskWaves * 256 - 1) / (kMaskWaves * 256), L.NB, B);
+        float tb = time_us([&] { bitmask_kernel<true><<<gm, kMaskWaves * 64>>>(d_iou, N, N, nullptr, 0.4f, ws, L); });
+        float tbl = time_us([&] { bitmask_kernel<true><<<gm, kMaskWaves * 64>>>(d_iou, N, N, nullptr, 0.4f, ws, L); leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); });
         printf("bitmask                 %8.1f us ; bitmask+leaders %8.1f us -> leaders cold %8.1f us\n", tb, tbl, tbl - tb);
         (void)vec;
 #ifdef GNMS_TIMING
         long long z[8] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
-        bitmask_kernel<true><<<gm, 256>>>(d_iou, N, N, nullptr, 0.4f, ws, L);
+        bitmask_kernel<true><<<gm, kMaskWaves * 64>>>(d_iou, N, N, nullptr, 0.4f, ws, L);
         leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); CK(hipDeviceSynchronize());
         CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
         printf("  COLD leaders phases (cycles, wave0): prologue %lld | resolve %lld | barrierA %lld | push+book %lld | barrierB %lld\n", z[0], z[1], z[2], z[3], z[4]);
