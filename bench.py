@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--boxes", type=int, default=4096, help="boxes per image (BASELINE metric: N=4096/img)")
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--kind", default="clustered", choices=["uniform", "clustered"])
+    ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="2: lib/core.py iou; 3: 0.5*(1+GIoU3D) of the corner AABBs from (x,y,z,w,h,l,ry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=4, help="images the CPU baseline processes")
     return ap.parse_args()
@@ -60,55 +61,38 @@ def event_time_ms(fn, iters, stream):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    import groomed_nms_amd as G
+    from groomed_nms_amd import overlaps, synthetic, _lib, dist as gdist
+    world, rank, local_rank = gdist.env_world()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    import groomed_nms_amd as G
-    from groomed_nms_amd import overlaps, synthetic, _lib
+    gdist.init(backend="nccl")                     # RCCL; no-op at world size 1
     lib = _lib.load()
     B, N = args.batch, args.boxes
 
-    boxes_np, scores_np = synthetic.batch_2d(1000 + rank, B, N, args.kind)
+    # every rank owns its own `B` images (weak scaling): rank r draws the images [r*B, (r+1)*B) of the global batch
+    if args.dim == 2:
+        boxes_np, scores_np = synthetic.batch_2d(1000 + rank, B, N, args.kind)
+    else:
+        boxes_np, scores_np = synthetic.batch_3d(1000 + rank, B, N, clustered=(args.kind == "clustered"))
     boxes = torch.from_numpy(boxes_np).to(dev)
     scores = torch.from_numpy(scores_np).to(dev).requires_grad_(True)
     w = torch.linspace(-1.0, 2.0, N, device=dev).repeat(B, 1).contiguous()
     iou_buf = torch.empty((B, N, N), dtype=torch.float32, device=dev)
 
+    def build_overlaps():
+        if args.dim == 2:
+            return overlaps.iou_batched(boxes, out=iou_buf)
+        return overlaps.iou3d_batched(boxes, from_params=True, nms_overlap=True, out=iou_buf)
+
     def step():
-        iou = overlaps.iou_batched(boxes, out=iou_buf)
+        iou = build_overlaps()
         prob, order, valid, invalid, nv, ni = G.differentiable_nms_batched(scores, iou)
         scores.grad = None
         torch.autograd.backward(prob, w)          # dL/dprob = w
         return prob
 
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = gdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
 
     # ---------------- per-kernel roofline (rank 0), HIP events on the launch stream -----------------
     out = None
@@ -116,8 +100,10 @@ def main():
         import ctypes
         from groomed_nms_amd._lib import GnmsParams, ptr, stream_ptr, check
         stream = torch.cuda.current_stream(dev)
-        alg_bytes = B * (4.0 * N * N + 16.0 * N)          # 4N^2 + 16N per image, for either kernel
-        t_iou = event_time_ms(lambda: overlaps.iou_batched(boxes, out=iou_buf), 20, stream)
+        per_box = 16.0 if args.dim == 2 else 28.0
+        alg_bytes = B * (4.0 * N * N + 16.0 * N)          # NMS forward 4N^2 + 16N per image
+        alg_bytes_iou = B * (4.0 * N * N + per_box * N)   # IoU-2D 4N^2 + 16N, IoU-3D (params) 4N^2 + 28N
+        t_iou = event_time_ms(build_overlaps, 20, stream)
         P = GnmsParams()
         lib.gnms_default_params(ctypes.byref(P))
         ws = torch.empty((lib.gnms_workspace_bytes(B, N, ctypes.byref(P)),), dtype=torch.uint8, device=dev)
@@ -133,10 +119,21 @@ def main():
         t_bwd = event_time_ms(lambda: check(lib.gnms_backward(ptr(w), ptr(s_det), ptr(iou_buf), B, N, N, None, ctypes.byref(P), ptr(gs),
                                                               None, ptr(ws), ws.numel(), stream_ptr(dev)), "bwd"), 20, stream)
 
-        def roof(t_ms):
-            ach = alg_bytes / (t_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the committed PMC passes (profiles/), valid only for the configuration they were taken on
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                ps = json.load(f)
+            c = ps["config"]
+            if (c["images_per_gpu"], c["boxes_per_image"], c["kind"]) == (B, N, args.kind) and args.dim == 2:
+                pmc = {k: v["traffic_bytes_per_launch"] for k, v in ps["kernels"].items()}
+        except (OSError, KeyError, ValueError):
+            pmc = {}
+
+        def roof(t_ms, nbytes, kname):
+            ach = nbytes / (t_ms * 1e-3) / 1e9
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "kernel_ms": round(t_ms, 4)}
+                    "traffic": (round(pmc[kname]) if kname in pmc else None), "algorithmic_bytes": round(nbytes), "kernel_ms": round(t_ms, 4)}
 
         total_boxes = world * B * N * args.steps
         out = {
@@ -152,10 +149,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%d images/GPU x %d %s 2D boxes/image, nms_threshold 0.4, linear pruning, grouped+masked, group_size 100"
-                                   % (B, N, args.kind), "boxes_per_image": N, "images_per_gpu": B, "parallelism": "images sharded, dp%d" % world},
-            "roofline": dict(roof(t_mask), kernel="bitmask_kernel (gnms_forward: one full read of the NxN fp32 matrix)"),
-            "roofline_iou": dict(roof(t_iou), kernel="iou2d_kernel (gnms_iou2d: one full write of the NxN fp32 matrix)"),
+            "config": {"workload": "%d images/GPU x %d %s %dD boxes/image, nms_threshold 0.4, linear pruning, grouped+masked, group_size 100"
+                                   % (B, N, args.kind, args.dim), "boxes_per_image": N, "images_per_gpu": B,
+                       "parallelism": "images sharded, dp%d" % world},
+            "roofline": dict(roof(t_mask, alg_bytes, "bitmask_kernel"), kernel="bitmask_kernel (gnms_forward: one full read of the NxN fp32 matrix)"),
+            "roofline_iou": dict(roof(t_iou, alg_bytes_iou, "iou2d_kernel" if args.dim == 2 else "iou3d_kernel"),
+                                 kernel=("iou2d_kernel" if args.dim == 2 else "iou3d_kernel") + " (one full write of the NxN fp32 matrix)"),
             "phase_ms": {"iou2d": round(t_iou, 4), "nms_forward": round(t_fwd, 4), "nms_backward": round(t_bwd, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -163,11 +162,15 @@ def main():
             k = min(args.cpu_images, B)
             t0 = time.perf_counter()
             for b in range(k):
-                m = O.iou2d(boxes_np[b], boxes_np[b])
+                if args.dim == 2:
+                    m = O.iou2d(boxes_np[b], boxes_np[b])
+                else:
+                    c = O.corners_of_cuboid(boxes_np[b])
+                    m = 0.5 * (1.0 + O.iou3d_approximate(c, c, generalized=True)[1])
                 O.differentiable_nms(scores_np[b], m, grad_prob=np.linspace(-1, 2, N).astype(np.float32))
             tc = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": round(k * N / tc, 1), "unit": "boxes/s", "cores": 1, "kind": "port",
-                                   "sample": "%d of the %d images of rank 0's batch (N=%d), oracle/gnms_oracle.c: iou2d + nms fwd+bwd" % (k, B, N)}
+                                   "sample": "%d of the %d images of rank 0's batch (N=%d), oracle/gnms_oracle.c: overlap matrix + nms fwd+bwd" % (k, B, N)}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -46,7 +46,7 @@ def iou_batched(boxes_a, boxes_b=None, out=None):
     return out
 
 
-def iou3d_batched(a, b=None, method="generalized", from_params=False, want_bev=False, nms_overlap=False):
+def iou3d_batched(a, b=None, method="generalized", from_params=False, want_bev=False, nms_overlap=False, out=None):
     """a [B,M,3,8] corners (or [B,M,7] params when from_params) -> iou_3d [B,M,N] (and iou_bev).
     nms_overlap=True returns 0.5*(1+giou), the matrix both reference callers hand to the NMS."""
     lib = _lib.load()
@@ -55,7 +55,7 @@ def iou3d_batched(a, b=None, method="generalized", from_params=False, want_bev=F
     B, M = a.shape[0], a.shape[1]
     N = b.shape[1]
     m = 2 if nms_overlap else {"normal": 0, "generalized": 1}[method]
-    o3 = torch.empty((B, M, N), dtype=torch.float32, device=a.device)
+    o3 = out if out is not None else torch.empty((B, M, N), dtype=torch.float32, device=a.device)
     bev = torch.empty((B, M, N), dtype=torch.float32, device=a.device) if want_bev else None
     fn = lib.gnms_iou3d_from_params if from_params else lib.gnms_iou3d_approximate
     with torch.cuda.device(a.device):
