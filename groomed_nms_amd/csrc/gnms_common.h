@@ -54,6 +54,7 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //     gsorted    int32 [N]      ranks sorted by (leader, rank), members only: the groups as contiguous runs
 //     gstart     int32 [N]      for rank k: index into gsorted where k's group starts (valid when head>=0)
 //     glen       int32 [N]      for rank k: number of members of k's group kept under the cap
+//     hlist      int32 [N]      ranks of the heads of groups with more than one member (misc[1] of them, any order)
 //     plead      float [N]      masked mode: prune(iou[k][head]) after tril (0 for heads / non-members)
 //     pre        float [N]      (M s)_k before the clamp (lib/groomed_nms.py:111); NMS order
 //     r2         float [N]      clamp(pre, 0, 1)
@@ -64,14 +65,14 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //     leadr      int32 [N]      rank of the i-th leader
 //     leadw      u64   [NB]     bit k%64 of word k/64 set iff rank k is a leader
 //     leadpfx    int32 [NB+1]   number of leaders in rank blocks < kb
-//     misc       int32 [8]      [0]=number of leaders, [1]=number of groups
+//     misc       int32 [8]      [0]=number of leaders, [1]=length of hlist
 //     W          u64   [NB][NC] W[kb][k'] bit r set iff !(iou[order[64*kb+r]][order[k']] <= thr): the ranks of block kb that
 //                               rank k', were it a leader, takes out of `remaining` (:249-262).  Rank x rank space: the
 //                               bit-matrix kernel reads input columns and scatters each word to its rank position.
 // ------------------------------------------------------------------------------------------------
 struct gnms_ws_layout {
     int N, NB, NC;
-    size_t off_order, off_sscore, off_rankof, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_plead, off_pre,
+    size_t off_order, off_sscore, off_rankof, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_hlist, off_plead, off_pre,
         off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_W;
     size_t per_image;  // bytes
 };
@@ -85,7 +86,7 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     auto take = [&](size_t bytes) { size_t r = o; o = gnms_align_up(o + bytes, 256); return r; };
     size_t n4 = (size_t)(N > 0 ? N : 1) * 4;
     L.off_order = take(n4); L.off_sscore = take(n4); L.off_rankof = take(n4); L.off_rem = take(n4); L.off_head = take(n4);
-    L.off_gpos = take(n4); L.off_gsorted = take(n4); L.off_gstart = take(n4); L.off_glen = take(n4);
+    L.off_gpos = take(n4); L.off_gsorted = take(n4); L.off_gstart = take(n4); L.off_glen = take(n4); L.off_hlist = take(n4);
     L.off_plead = take(n4); L.off_pre = take(n4); L.off_r2 = take(n4); L.off_sidx = take(n4);
     L.off_xsol = take(n4); L.off_gx = take(n4); L.off_leadc = take(n4); L.off_leadr = take(n4);
     L.off_leadw = take((size_t)(L.NB > 0 ? L.NB : 1) * 8);

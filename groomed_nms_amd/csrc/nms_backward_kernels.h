@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void bwd_gx_kernel(const float* __restrict__ g
     I.gx[q] = g;
 }
 
-// masked groups: one thread per rank.
+// masked groups, part 1: one thread per rank.  dL/ds = gx for every box that is in a group (heads included: part 2
+// subtracts their members' terms), 0 for boxes in no group.
 __global__ __launch_bounds__(256) void bwd_masked_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                                          float* __restrict__ grad_scores) {
     const int b = blockIdx.y;
@@ -43,32 +44,37 @@ __global__ __launch_bounds__(256) void bwd_masked_kernel(int N, const int* __res
     ImgPtrs I = img_ptrs(ws, L, b);
     float* gs = grad_scores + (size_t)b * N;
     if (k >= n) { gs[k] = 0.0f; return; }
-    const int h = I.head[k];
-    float g = 0.0f;
-    if (h >= 0) {
-        const int q = P.presorted ? I.order[k] : k;
-        g = I.gx[q];
-        if (h == k) {
-            const int start = I.gstart[k], len = I.glen[k];
-            int t = 1;
-            for (; t + 8 <= len; t += 8) {                           // 8 independent gathers in flight, summed in rank order
-                float pl[8], gv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int mk = I.gsorted[start + t + u];
-                    pl[u] = I.plead[mk];
-                    gv[u] = I.gx[P.presorted ? I.order[mk] : mk];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) g -= pl[u] * gv[u];
+    const int c = I.order[k];
+    gs[c] = (I.head[k] >= 0) ? I.gx[P.presorted ? c : k] : 0.0f;
+}
+
+// masked groups, part 2: one WAVE per multi-member group (hlist).  All lanes fetch the members' products P_i*gx_i in
+// parallel (two memory round trips per 64 members); the head's value is then reduced SEQUENTIALLY in member order
+// (v_readlane + v_sub, no memory on that path): deterministic, and bit-identical to the left-to-right accumulation of
+// the reference's matmul row as restated by the oracle.
+__global__ __launch_bounds__(256) void bwd_masked_heads_kernel(int N, gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores) {
+    const int b = blockIdx.y;
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nheads = I.misc[1];
+    float* gs = grad_scores + (size_t)b * N;
+    for (int hi = blockIdx.x * 4 + wave; hi < nheads; hi += gridDim.x * 4) {
+        const int k = I.hlist[hi];
+        const int hstart = I.gstart[k], hlen = I.glen[k];
+        const int c = I.order[k];
+        float acc = I.gx[P.presorted ? c : k];
+        for (int base = 1; base < hlen; base += 64) {
+            const int t = base + lane;
+            float prod = 0.0f;
+            if (t < hlen) {
+                const int mk = I.gsorted[hstart + t];
+                prod = I.plead[mk] * I.gx[P.presorted ? I.order[mk] : mk];
             }
-            for (; t < len; ++t) {
-                const int mk = I.gsorted[start + t];
-                g -= I.plead[mk] * I.gx[P.presorted ? I.order[mk] : mk];
-            }
+            const int cnt = min(64, hlen - base);
+            for (int u = 0; u < cnt; ++u) acc -= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prod), u));
         }
+        if (lane == 0) gs[c] = acc;
     }
-    gs[I.order[k]] = g;
 }
 
 // sparse part of dL/diou for masked groups (the dense zero fill is a hipMemsetAsync before this kernel)

@@ -108,7 +108,7 @@ __device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
 }
 
 struct ImgPtrs {
-    int* order; float* sscore; int* rankof; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen;
+    int* order; float* sscore; int* rankof; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen; int* hlist;
     float* plead; float* pre; float* r2; int* sidx; float* xsol; float* gx; int* leadc; int* leadr; u64* leadw; int* leadpfx;
     int* misc; u64* W;
 };
@@ -118,7 +118,7 @@ __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_lay
     ImgPtrs I;
     I.order = (int*)(p + L.off_order); I.sscore = (float*)(p + L.off_sscore); I.rankof = (int*)(p + L.off_rankof); I.rem = (int*)(p + L.off_rem);
     I.head = (int*)(p + L.off_head); I.gpos = (int*)(p + L.off_gpos); I.gsorted = (int*)(p + L.off_gsorted);
-    I.gstart = (int*)(p + L.off_gstart); I.glen = (int*)(p + L.off_glen); I.plead = (float*)(p + L.off_plead);
+    I.gstart = (int*)(p + L.off_gstart); I.glen = (int*)(p + L.off_glen); I.hlist = (int*)(p + L.off_hlist); I.plead = (float*)(p + L.off_plead);
     I.pre = (float*)(p + L.off_pre); I.r2 = (float*)(p + L.off_r2); I.sidx = (int*)(p + L.off_sidx);
     I.xsol = (float*)(p + L.off_xsol); I.gx = (float*)(p + L.off_gx); I.leadc = (int*)(p + L.off_leadc); I.leadr = (int*)(p + L.off_leadr);
     I.leadw = (u64*)(p + L.off_leadw); I.leadpfx = (int*)(p + L.off_leadpfx); I.misc = (int*)(p + L.off_misc);
@@ -530,11 +530,14 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
     }
     block_sort<E, unsigned>(r, keys, Ppow2);
     const long long cap = (long long)P.group_size + 1;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const unsigned key = keys[i];
-        if (key == ~0u) { I.gsorted[i] = -1; continue; }
+    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+        const int i = i0 + threadIdx.x;                               // whole waves stay in the loop (ballot below)
+        const unsigned key = (i < n) ? keys[i] : ~0u;
+        bool big_head = false;
         const unsigned lr = key >> 14;
         const int k = (int)(key & 0x3fffu);
+        if (key == ~0u) { if (i < n) I.gsorted[i] = -1; }
+        else {
         const bool first = (i == 0) || ((keys[i - 1] >> 14) != lr);
         I.gsorted[i] = k;
         // most boxes sit in short runs: walk back a few entries before falling back to the binary search
@@ -558,6 +561,17 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
             I.gstart[k] = start;
             const long long len = end - start;
             I.glen[k] = (int)(len < cap ? len : cap);
+            big_head = first && len > 1;
+        }
+        }
+        // heads of multi-member groups go to hlist (one atomic per wave)
+        const unsigned long long bm = __ballot(big_head);
+        if (bm) {
+            int base = 0;
+            const int ln = threadIdx.x & 63;
+            if (ln == __builtin_ctzll(bm)) base = atomicAdd(&I.misc[1], __builtin_popcountll(bm));
+            base = __builtin_amdgcn_readlane(base, __builtin_ctzll(bm));
+            if (big_head) I.hlist[base + __builtin_popcountll(bm & ((1ull << ln) - 1ull))] = k;
         }
     }
     __syncthreads();

@@ -190,6 +190,8 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
     if (P.group_boxes && P.mask_group_boxes) {
         bwd_masked_kernel<<<ge, 256, 0, st>>>(N, counts, P, ws, L, grad_scores);
         GNMS_CHECK_LAUNCH();
+        bwd_masked_heads_kernel<<<dim3(N >= 2048 ? 128 : gnms_div_up(N, 16), B), 256, 0, st>>>(N, P, ws, L, grad_scores);
+        GNMS_CHECK_LAUNCH();
         if (grad_iou) {
             bwd_masked_iou_kernel<<<ge, 256, 0, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_iou);
             GNMS_CHECK_LAUNCH();

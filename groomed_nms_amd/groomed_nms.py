@@ -71,6 +71,7 @@ class _GroomedNMSFunction(torch.autograd.Function):
                   "gnms_forward")
         ctx.params = params
         ctx.ld = ld
+        ctx.set_materialize_grads(False)      # no zero-filled "gradients" for the five index outputs
         ctx.save_for_backward(scores_c, iou_c, counts, ws)
         ctx.mark_non_differentiable(order, valid, invalid, nvalid, ninvalid)
         return prob, order, valid, invalid, nvalid, ninvalid
@@ -81,6 +82,8 @@ class _GroomedNMSFunction(torch.autograd.Function):
         scores_c, iou_c, counts, ws = ctx.saved_tensors
         B, N = scores_c.shape
         dev = scores_c.device
+        if grad_prob is None:
+            return None, None, None, None
         grad_prob = grad_prob.contiguous().float()
         grad_scores = torch.empty_like(scores_c)
         grad_iou = None
@@ -119,6 +122,7 @@ class _SoftSortFunction(torch.autograd.Function):
             check(lib.gnms_soft_sort(ptr(scores_c), ptr(m_c), N, ld, float(temperature), ptr(C), ptr(soft_scores), ptr(soft_matrix),
                                      ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_soft_sort")
         ctx.temperature = float(temperature)
+        ctx.set_materialize_grads(False)
         ctx.has_matrix = matrix is not None
         ctx.save_for_backward(scores_c, m_c if m_c is not None else scores_c, C)
         if matrix is None:
