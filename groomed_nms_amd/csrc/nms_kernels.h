@@ -510,89 +510,147 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
                                                       gnms_params P, char* ws, gnms_ws_layout L, int Ppow2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* keys = reinterpret_cast<unsigned*>(smem);          // (leader rank << 14) | rank : 28 bits (N <= 16384)
+    unsigned* info = keys + Ppow2;                               // per rank: head | pos << 14, or ~0 (in no group)
     const int b = blockIdx.x;
     const int n = counts ? counts[b] : N;
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = iou + (size_t)b * N * ld;
     const float thr = P.nms_threshold;
+    // ---- phase 1: membership key of every rank (thread t owns ranks t*E .. t*E+E-1 throughout) ----
+    GNMS_T0();
     unsigned r[E];
+    float v_lead[E], s_lead[E], s_own[E];
+    int c_own[E], lr_own[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = threadIdx.x * E + e;
-        unsigned key = ~0u;
-        if (k < n) {
-            const int lr = I.rem[k];
-            const float v = m[(size_t)I.order[k] * ld + I.order[lr]];
-            if (v > thr) key = ((unsigned)lr << 14) | (unsigned)k;
-        }
-        r[e] = key;
-        if (k < N) { I.head[k] = -1; I.gpos[k] = -1; I.glen[k] = 0; I.gstart[k] = 0; I.plead[k] = 0.0f; }
+        lr_own[e] = (k < n) ? I.rem[k] : 0;
+        c_own[e] = (k < n) ? I.order[k] : 0;
+        s_own[e] = (k < n) ? I.sscore[k] : 0.0f;
     }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = threadIdx.x * E + e;
+        v_lead[e] = 0.0f; s_lead[e] = 0.0f;
+        if (k < n) {
+            v_lead[e] = m[(size_t)c_own[e] * ld + I.order[lr_own[e]]];     // iou of the box against the leader that removed it
+            s_lead[e] = I.sscore[lr_own[e]];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = threadIdx.x * E + e;
+        r[e] = (k < n && v_lead[e] > thr) ? (((unsigned)lr_own[e] << 14) | (unsigned)k) : ~0u;   // strict > (:249)
+        info[k] = ~0u;
+    }
+    GNMS_TACC(8);
     block_sort<E, unsigned>(r, keys, Ppow2);
+    GNMS_TACC(9);
+    // ---- phase 2: runs of equal leader are the groups; cap, head, position.  Thread t owns sorted positions
+    //      t*E .. t*E+E-1; the start of each position's run comes from a max-scan of the run-start flags
+    //      (registers -> wave shuffles -> 16 per-wave totals in LDS): no per-element search. ----
     const long long cap = (long long)P.group_size + 1;
-    for (int i0 = 0; i0 < n; i0 += blockDim.x) {
-        const int i = i0 + threadIdx.x;                               // whole waves stay in the loop (ballot below)
-        const unsigned key = (i < n) ? keys[i] : ~0u;
-        bool big_head = false;
-        const unsigned lr = key >> 14;
-        const int k = (int)(key & 0x3fffu);
-        if (key == ~0u) { if (i < n) I.gsorted[i] = -1; }
-        else {
-        const bool first = (i == 0) || ((keys[i - 1] >> 14) != lr);
-        I.gsorted[i] = k;
-        // most boxes sit in short runs: walk back a few entries before falling back to the binary search
-        int start = i;
-        if (!first) {
-            int back = 1;
-            while (back <= 8 && i - back >= 0 && (keys[i - back] >> 14) == lr) ++back;
-            start = (back <= 8) ? (i - back + 1) : lower_bound_lds<unsigned>(keys, n, lr << 14);
+    __shared__ int wave_last_start[16];
+    {
+        const int t = threadIdx.x, ln = t & 63, wv = t >> 6;
+        unsigned ky[E];
+        int st[E];                                                     // run start of position i, or -1 if it lies in an earlier thread
+        int last = -1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = t * E + e;
+            ky[e] = keys[i];
+            const bool valid = ky[e] != ~0u;
+            const bool first = valid && (i == 0 || (keys[i - 1] >> 14) != (ky[e] >> 14));
+            if (first) last = i;
+            st[e] = last;
         }
-        const long long pos = i - start;
-        if (pos < cap) {
-            int end = i + 1;
-            {
-                int fwd = 0;
-                while (fwd < 8 && end < n && (keys[end] >> 14) == lr) { ++end; ++fwd; }
-                if (fwd == 8 && end < n && (keys[end] >> 14) == lr)
-                    end = (lr + 1u >= (1u << 14)) ? lower_bound_lds<unsigned>(keys, n, ~0u) : lower_bound_lds<unsigned>(keys, n, (lr + 1u) << 14);
+        // inclusive max-scan of `last` over the wave, then exclusive value for this thread
+        int inc = last;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off, 64);
+            if (ln >= off) inc = max(inc, v);
+        }
+        int excl = __shfl_up(inc, 1, 64);
+        if (ln == 0) excl = -1;
+        if (ln == 63) wave_last_start[wv] = inc;
+        __syncthreads();
+        int carry = -1;
+        for (int w = 0; w < wv; ++w) carry = max(carry, wave_last_start[w]);
+        const int before = max(excl, carry);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = t * E + e;
+            bool big_head = false;
+            int hk = 0;
+            if (i < n) {
+                if (ky[e] == ~0u) {
+                    I.gsorted[i] = -1;
+                } else {
+                    const int k = (int)(ky[e] & 0x3fffu);
+                    I.gsorted[i] = k;
+                    const int start = st[e] >= 0 ? st[e] : before;
+                    const long long pos = i - start;
+                    const unsigned hd = keys[start] & 0x3fffu;
+                    if (pos < cap) info[k] = hd | ((unsigned)pos << 14);
+                    const bool lastofrun = (i + 1 >= n) || (keys[i + 1] == ~0u) || ((keys[i + 1] >> 14) != (ky[e] >> 14));
+                    if (lastofrun) {                                  // the run's last element publishes the extent for the head
+                        const long long len = pos + 1;
+                        I.gstart[hd] = start;
+                        I.glen[hd] = (int)(len < cap ? len : cap);
+                        big_head = len > 1;
+                        hk = (int)hd;
+                    }
+                }
             }
-            I.head[k] = (int)(keys[start] & 0x3fffu);
-            I.gpos[k] = (int)pos;
-            I.gstart[k] = start;
-            const long long len = end - start;
-            I.glen[k] = (int)(len < cap ? len : cap);
-            big_head = first && len > 1;
-        }
-        }
-        // heads of multi-member groups go to hlist (one atomic per wave)
-        const unsigned long long bm = __ballot(big_head);
-        if (bm) {
-            int base = 0;
-            const int ln = threadIdx.x & 63;
-            if (ln == __builtin_ctzll(bm)) base = atomicAdd(&I.misc[1], __builtin_popcountll(bm));
-            base = __builtin_amdgcn_readlane(base, __builtin_ctzll(bm));
-            if (big_head) I.hlist[base + __builtin_popcountll(bm & ((1ull << ln) - 1ull))] = k;
+            // heads of multi-member groups go to hlist (one atomic per wave)
+            const unsigned long long bm = __ballot(big_head);
+            if (bm) {
+                int base = 0;
+                if (ln == __builtin_ctzll(bm)) base = atomicAdd(&I.misc[1], __builtin_popcountll(bm));
+                base = __builtin_amdgcn_readlane(base, __builtin_ctzll(bm));
+                if (big_head) I.hlist[base + __builtin_popcountll(bm & ((1ull << ln) - 1ull))] = hk;
+            }
         }
     }
     __syncthreads();
-    if (!P.mask_group_boxes) return;
-    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+    GNMS_TACC(10);
+    // ---- phase 3 (owner threads again, coalesced stores): group fields and, for MASKED groups, the default
+    //      rescoring  pre_k = s_k - prune(iou[k][head]) * s_head  (I - P restricted to the head column, :95-105,:111) ----
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = threadIdx.x * E + e;
+        if (k >= N) continue;
+        const unsigned inf = info[k];
+        const int h = (k < n && inf != ~0u) ? (int)(inf & 0x3fffu) : -1;
+        I.head[k] = h;
+        I.gpos[k] = (h >= 0) ? (int)(inf >> 14) : -1;
+        if (h != k) I.glen[k] = 0;                                   // only heads carry an extent
+        if (!P.mask_group_boxes) continue;
         float pre = 0.0f, pl = 0.0f;
-        const int q = P.presorted ? I.order[k] : k;
-        if (k < n) {
-            const int h = I.head[k];
-            if (h == k) {
-                pre = I.sscore[k];
-            } else if (h >= 0) {
-                const int ck = I.order[k], ch = I.order[h];
-                const bool tril = P.presorted ? (ch < ck) : true;       // torch.tril in NMS order (:72)
-                if (tril) pl = gnms_prune(m[(size_t)ck * ld + ch], thr, P.temperature, P.pruning_method);
-                pre = I.sscore[k] - pl * I.sscore[h];
+        const int q = P.presorted ? c_own[e] : k;
+        if (h == k) {
+            pre = s_own[e];
+        } else if (h >= 0) {
+            float v = v_lead[e], sh = s_lead[e];
+            int ch;
+            if (h != lr_own[e]) {                                    // the leader itself is not a member (NaN / <= thr diagonal)
+                ch = I.order[h];
+                v = m[(size_t)c_own[e] * ld + ch];
+                sh = I.sscore[h];
+            } else {
+                ch = -1;
             }
+            bool tril = true;                                        // torch.tril in NMS order (:72): always true for hard sort
+            if (P.presorted) { if (ch < 0) ch = I.order[h]; tril = ch < c_own[e]; }
+            if (tril) pl = gnms_prune(v, thr, P.temperature, P.pruning_method);
+            pre = s_own[e] - pl * sh;
         }
         I.plead[k] = pl;
-        I.pre[q] = pre;
+        I.pre[(k < n) ? q : k] = pre;
     }
+    GNMS_TACC(11);
 }
 
 // ------------------------------------------------------------------------------------------------

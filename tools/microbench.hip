@@ -107,6 +107,14 @@ int main(int argc, char** argv) {
     if (P2 == 4096) {
         printf("sort_scores<4>          %8.1f us\n", time_us([&] { sort_scores_kernel<4><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr); }));
         printf("groups<4>               %8.1f us\n", time_us([&] { groups_kernel<4><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); }));
+#ifdef GNMS_TIMING
+        {
+            long long z[16] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
+            groups_kernel<4><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
+            printf("  groups phases (cycles, thread0): keys %lld | sort %lld | runs %lld | rescoring %lld\n", z[8], z[9], z[10], z[11]);
+        }
+#endif
         printf("finalize<4>             %8.1f us\n", time_us([&] { finalize_kernel<4><<<B, T, sort_lds>>>(N, nullptr, P, ws, L, P2, d_prob, nullptr, nullptr, nullptr, nullptr); }));
         std::vector<u64> hk((size_t)B * P2);
         for (auto& v : hk) v = ((u64)rand() << 32) ^ (u64)rand() ^ ((u64)rand() << 17);
