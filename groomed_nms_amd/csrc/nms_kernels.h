@@ -45,38 +45,48 @@ __device__ __forceinline__ u64 shfl_up_u64(u64 v, int off) {
     return ((u64)hi << 32) | lo;
 }
 
+#ifdef GNMS_TIMING
+__device__ long long g_sort_ticks[4];
+#define GNMS_ST0() long long st__ = (long long)__builtin_amdgcn_s_memtime()
+#define GNMS_STACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) g_sort_ticks[slot] += n__ - st__; st__ = n__; } while (0)
+#else
+#define GNMS_ST0() do {} while (0)
+#define GNMS_STACC(slot) do {} while (0)
+#endif
+
 template <int E, typename K>
 __device__ __forceinline__ void block_sort(K (&r)[E], K* keys, int P) {
     const int t = threadIdx.x;
     const int T = blockDim.x;
+    GNMS_ST0();
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j >= 64 * E; j >>= 1) {                    // cross-wave stages
 #pragma unroll
             for (int e = 0; e < E; ++e) keys[e * T + t] = r[e];
             __syncthreads();
             const int pt = t ^ (j / E);
+            const bool keepmin = (((t * E) & k) == 0) == (((t * E) & j) == 0);   // j >= E: the same for all E elements
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int i = t * E + e;
                 const K o = keys[e * T + pt];
-                const bool keepmin = ((i & k) == 0) == ((i & j) == 0);
-                r[e] = ((o < r[e]) == keepmin) ? o : r[e];              // one 64-bit compare per exchange
+                r[e] = ((o < r[e]) == keepmin) ? o : r[e];              // one compare per exchange
             }
             __syncthreads();
         }
+        GNMS_STACC(0);
         {
             int j = (k >> 1) < 64 * E ? (k >> 1) : 32 * E;              // intra-wave stages
             for (; j >= E; j >>= 1) {
                 const int m = j / E;
+                const bool keepmin = (((t * E) & k) == 0) == (((t * E) & j) == 0);   // j >= E: the same for all E elements
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const int i = t * E + e;
                     const K o = shfl_xor_key(r[e], m);
-                    const bool keepmin = ((i & k) == 0) == ((i & j) == 0);
                     r[e] = ((o < r[e]) == keepmin) ? o : r[e];
                 }
             }
         }
+        GNMS_STACC(1);
 #pragma unroll
         for (int jj = E / 2; jj >= 1; jj >>= 1) {                        // in-register stages
             if (jj < k) {
@@ -91,10 +101,12 @@ __device__ __forceinline__ void block_sort(K (&r)[E], K* keys, int P) {
                 }
             }
         }
+        GNMS_STACC(2);
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) keys[t * E + e] = r[e];
     __syncthreads();
+    GNMS_STACC(3);
 }
 
 template <typename K>

@@ -317,3 +317,164 @@ def test_full_size_properties(G):
         assert torch.equal(prob2, p)
         g = st.grad
         assert torch.isfinite(g).all()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# edge cases and larger sizes against the oracle
+# --------------------------------------------------------------------------------------------------------------
+def _cmp_exact(res, ref, tag):
+    assert np.array_equal(res["prob"], ref["prob"], equal_nan=True), tag + " prob"
+    assert list(res["valid"]) == list(ref["valid"]), tag + " valid"
+    assert sorted(res["invalid"]) == sorted(ref["invalid"]), tag + " invalid"
+    if "grad_scores" in res:
+        assert np.array_equal(res["grad_scores"], ref["grad_scores"]), tag + " grad"
+
+
+@pytest.mark.parametrize("kind", ["clustered", "uniform"])
+def test_n4096_single_image_bit_exact(G, O, kind):
+    """BASELINE size N=4096 against the oracle, default mode: probabilities, lists and gradient bit for bit."""
+    from groomed_nms_amd import synthetic
+    boxes, scores = synthetic.batch_2d(77, 1, 4096, kind)
+    m = O.iou2d(boxes[0], boxes[0])
+    w = np.linspace(-1, 2, 4096).astype(np.float32)
+    res = _run_gpu(G, scores[0], m, w, False)
+    ref = O.differentiable_nms(scores[0], m, grad_prob=w)
+    _cmp_exact(res, ref, kind)
+
+
+def test_odd_sizes_and_strided_matrix(G, O):
+    """N not a multiple of 4/64 (scalar load path) and a matrix whose row stride is larger than N."""
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(21)
+    for n in (3, 61, 67, 255, 1001):
+        b = synthetic.clustered_boxes_2d(rng, n, 8)
+        s = synthetic.tie_free_scores(rng, n)
+        m = O.iou2d(b, b)
+        w = rng.uniform(-1, 2, size=n).astype(np.float32)
+        ref = O.differentiable_nms(s, m, grad_prob=w)
+        _cmp_exact(_run_gpu(G, s, m, w, False), ref, f"n={n}")
+        # strided view: the layer must honour ld = stride(0) without copying
+        big = torch.zeros((n, n + 7), device="cuda")
+        big[:, :n] = torch.from_numpy(m).cuda()
+        view = big[:, :n]
+        assert not view.is_contiguous()
+        st = torch.from_numpy(s).cuda()
+        valid, invalid, prob = G.differentiable_nms(st, view)
+        assert np.array_equal(prob.cpu().numpy(), ref["prob"]) and valid.tolist() == list(ref["valid"]), f"strided n={n}"
+
+
+def test_ties_are_broken_stably(G, O):
+    """Duplicate scores: the build defines the order as stable (lower index first), like the oracle."""
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(5)
+    n = 200
+    b = synthetic.clustered_boxes_2d(rng, n, 8)
+    s = np.round(synthetic.tie_free_scores(rng, n), 1)          # 11 distinct values -> many ties
+    m = O.iou2d(b, b)
+    w = rng.uniform(-1, 2, size=n).astype(np.float32)
+    for mode in ("gm_lin", "gm_lin_gs2", "gm_lin_sorted"):
+        ref = O.differentiable_nms(s, m, grad_prob=w, **MODES[mode])
+        _cmp_exact(_run_gpu(G, s, m, w, False, **MODES[mode]), ref, mode)
+    order = torch.sort(torch.from_numpy(s), descending=True, stable=True)[1].numpy()
+    assert list(order) == list(O.argsort_desc(s))
+
+
+def test_degenerate_overlaps(G, O):
+    """NaN entries: a zero-area box (NaN self-overlap, lib/core.py:507) whose group is non-empty, NaN against the leader,
+    a diagonal below the threshold.  The reference raises / loops on some of these; the build and the oracle
+    share one definition."""
+    s = np.array([0.95, 0.9, 0.8, 0.7, 0.6, 0.5], np.float32)
+    m = np.eye(6, dtype=np.float32)
+    m[0, 0] = np.nan            # leader 0 does not belong to its own group ...
+    m[2, 0] = 0.9               # ... but box 2 does: group [2], head = 2
+    m[3, 0] = 0.8
+    m[4, 1] = np.nan            # box 4 vanishes (NaN against leader 1)
+    m[5, 5] = 0.2               # diagonal <= threshold: leader 5 leaves, in no group
+    w = np.arange(1, 7, dtype=np.float32)
+    for mode in ("gm_lin", "gu_lin"):
+        ref = O.differentiable_nms(s, m, grad_prob=w, want_grad_iou=True, **MODES[mode])
+        res = _run_gpu(G, s, m, w, True, **MODES[mode])
+        np.testing.assert_allclose(res["prob"], ref["prob"], atol=1e-6, equal_nan=True, err_msg=mode)
+        assert sorted(res["valid"]) == sorted(ref["valid"]) and sorted(res["invalid"]) == sorted(ref["invalid"]), mode
+        np.testing.assert_allclose(res["grad_scores"], ref["grad_scores"], atol=1e-6, err_msg=mode)
+        np.testing.assert_allclose(res["grad_iou"], ref["grad_iou"], atol=1e-6, err_msg=mode)
+    assert ref["prob"][0] == 0 and ref["prob"][4] == 0 and ref["prob"][5] == 0      # the three boxes that fall out of every group
+
+
+def test_parameter_extremes(G, O):
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(8)
+    n = 300
+    b = synthetic.clustered_boxes_2d(rng, n, 150)                # two huge clusters: groups beyond every cap
+    s = synthetic.tie_free_scores(rng, n)
+    m = O.iou2d(b, b)
+    w = rng.uniform(-1, 2, size=n).astype(np.float32)
+    cases = [dict(group_size=0), dict(group_size=1), dict(group_size=500), dict(nms_threshold=0.0), dict(nms_threshold=0.999),
+             dict(valid_box_prob_threshold=0.0), dict(valid_box_prob_threshold=1.0),
+             dict(mask_group_boxes=False, group_size=500), dict(mask_group_boxes=False, group_size=120),
+             dict(mask_group_boxes=False, group_size=3), dict(group_boxes=False)]
+    for kw in cases:
+        ref = O.differentiable_nms(s, m, grad_prob=w, **kw)
+        res = _run_gpu(G, s, m, w, False, **kw)
+        np.testing.assert_allclose(res["prob"], ref["prob"], atol=TOL, err_msg=str(kw))
+        check_index_lists(res["valid"], res["invalid"], ref["valid"], ref["invalid"])
+        np.testing.assert_allclose(res["grad_scores"], ref["grad_scores"], atol=5e-4, rtol=1e-3, err_msg=str(kw))
+
+
+def test_batched_equals_per_image(G):
+    from groomed_nms_amd import synthetic, overlaps
+    boxes, scores = synthetic.batch_2d(3, 4, 700, "clustered", per=20)
+    bt, st = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+    iou = overlaps.iou_batched(bt)
+    prob, order, valid, invalid, nv, ni = G.differentiable_nms_batched(st, iou)
+    for b in range(4):
+        v1, i1, p1 = G.differentiable_nms(st[b], iou[b])
+        assert torch.equal(p1, prob[b]) and torch.equal(v1, valid[b, :int(nv[b])]) and torch.equal(i1, invalid[b, :int(ni[b])])
+        assert torch.all(valid[b, int(nv[b]):] == -1) and torch.all(invalid[b, int(ni[b]):] == -1)
+    empty = G.differentiable_nms_batched(torch.zeros((2, 0), device="cuda"), torch.zeros((2, 0, 0), device="cuda"))
+    assert empty[0].shape == (2, 0) and int(empty[4].sum()) == 0
+    v, i, p = G.differentiable_nms(torch.zeros(0, device="cuda"), torch.zeros((0, 0), device="cuda"))
+    assert v.numel() == 0 and i.numel() == 0 and p.numel() == 0
+
+
+def test_soft_sort_larger(G, O):
+    """soft sort at a size that spans several MFMA tiles, sorted input (the only regime where the reference terminates)."""
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(31)
+    n = 300
+    b = synthetic.clustered_boxes_2d(rng, n, 6)
+    s = np.sort(synthetic.tie_free_scores(rng, n))[::-1].copy()
+    m = O.iou2d(b, b)
+    w = rng.uniform(-1, 2, size=n).astype(np.float32)
+    ss, C, sm = G.soft_sort(torch.from_numpy(s).cuda(), torch.from_numpy(m).cuda(), 2e-4)
+    oss, oC, osm = O.soft_sort(s, m, 2e-4)
+    np.testing.assert_allclose(C.cpu().numpy(), oC, atol=2e-5)
+    np.testing.assert_allclose(sm.cpu().numpy(), osm, atol=2e-4)
+    ref = O.differentiable_nms(s, m, sorting_method="soft", sorting_temperature=2e-4, grad_prob=w)
+    res = _run_gpu(G, s, m, w, False, sorting_method="soft", sorting_temperature=2e-4)
+    np.testing.assert_allclose(res["prob"], ref["prob"], atol=TOL)
+    check_index_lists(res["valid"], res["invalid"], ref["valid"], ref["invalid"])
+    np.testing.assert_allclose(res["grad_scores"], ref["grad_scores"], atol=5e-3, rtol=5e-3)
+
+
+def test_classic_nms_wide_rows_and_device_entry(G, O):
+    """`_nms` with boxes_dim > 5 (stride honoured, nms_kernel.cu reads the first five fields) and the device-pointer entry."""
+    import ctypes
+    from groomed_nms_amd import synthetic, _lib
+    from groomed_nms_amd.nms import gpu_nms
+    from groomed_nms_amd._lib import ptr, check
+    rng = np.random.default_rng(2)
+    n = 500
+    dets5 = np.concatenate([synthetic.clustered_boxes_2d(rng, n, 10), synthetic.tie_free_scores(rng, n)[:, None]], 1).astype(np.float32)
+    dets7 = np.concatenate([dets5, rng.uniform(size=(n, 2)).astype(np.float32)], 1)
+    want = O.classic_nms(dets5, 0.45, rule="gpu")
+    assert [int(i) for i in gpu_nms(dets7, 0.45)] == want
+    lib = _lib.load()
+    order = dets5[:, 4].argsort()[::-1]
+    sd = torch.from_numpy(np.ascontiguousarray(dets5[order])).cuda()
+    keep = torch.empty(n, dtype=torch.int32, device="cuda")
+    num = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.gnms_nms_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    check(lib.gnms_nms_sorted(ptr(sd), n, 5, 0.45, ptr(keep), ptr(num), ptr(ws), ws.numel(), None), "gnms_nms_sorted")
+    torch.cuda.synchronize()
+    assert [int(order[i]) for i in keep[:int(num)].tolist()] == want

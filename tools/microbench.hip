@@ -121,6 +121,12 @@ int main(int argc, char** argv) {
         u64 *din, *dout; CK(hipMalloc(&din, hk.size() * 8)); CK(hipMalloc(&dout, hk.size() * 8));
         CK(hipMemcpy(din, hk.data(), hk.size() * 8, hipMemcpyHostToDevice));
         printf("block_sort<4> only      %8.1f us\n", time_us([&] { sort_only_kernel<4><<<B, 1024, sort_lds>>>(din, dout, P2); }));
+#ifdef GNMS_TIMING
+        { long long z[4] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_sort_ticks), z, sizeof(z)));
+          sort_only_kernel<4><<<B, 1024, sort_lds>>>(din, dout, P2); CK(hipDeviceSynchronize());
+          CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_sort_ticks), sizeof(z)));
+          printf("  block_sort<4,u64> cycles: LDS stages %lld | shuffle stages %lld | register stages %lld | final %lld\n", z[0], z[1], z[2], z[3]); }
+#endif
         printf("block_sort<8> only      %8.1f us\n", time_us([&] { sort_only_kernel<8><<<B, 512, sort_lds>>>(din, dout, P2); }));
         printf("block_sort<16> only     %8.1f us\n", time_us([&] { sort_only_kernel<16><<<B, 256, sort_lds>>>(din, dout, P2); }));
         std::vector<u64> ho(hk.size()); CK(hipMemcpy(ho.data(), dout, ho.size() * 8, hipMemcpyDeviceToHost));
