@@ -33,8 +33,26 @@ __global__ __launch_bounds__(256) void bwd_gx_kernel(const float* __restrict__ g
     I.gx[q] = g;
 }
 
-// masked groups, part 1: one thread per rank.  dL/ds = gx for every box that is in a group (heads included: part 2
-// subtracts their members' terms), 0 for boxes in no group.
+// masked groups, part 1: one thread per rank (gx fused: position q = rank for hard sort, so the thread that routes
+// dL/dprob to position k is the one that needs it).  dL/ds = gx for every box in a group (heads included: part 2
+// subtracts their members' terms), 0 for boxes in no group.  Not used with return_sorted_prob / presorted (the routing is
+// a permutation there: bwd_gx_kernel runs first).
+__global__ __launch_bounds__(256) void bwd_masked_fused_kernel(const float* __restrict__ grad_prob, int N, const int* __restrict__ counts,
+                                                               gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores) {
+    const int b = blockIdx.y;
+    const int n = counts ? counts[b] : N;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    ImgPtrs I = img_ptrs(ws, L, b);
+    float* gs = grad_scores + (size_t)b * N;
+    if (k >= n) { gs[k] = 0.0f; I.gx[k] = 0.0f; return; }
+    float g = grad_prob[(size_t)b * N + k];
+    const float pre = I.pre[k];
+    if (!(pre >= 0.0f && pre <= 1.0f)) g = 0.0f;                     // clamp passes the gradient at the bounds only
+    I.gx[k] = g;
+    gs[I.order[k]] = (I.head[k] >= 0) ? g : 0.0f;
+}
+
 __global__ __launch_bounds__(256) void bwd_masked_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                                          float* __restrict__ grad_scores) {
     const int b = blockIdx.y;

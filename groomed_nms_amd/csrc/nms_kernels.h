@@ -55,7 +55,7 @@ __device__ long long g_sort_ticks[4];
 #endif
 
 template <int E, typename K>
-__device__ __forceinline__ void block_sort(K (&r)[E], K* keys, int P) {
+__device__ __forceinline__ void block_sort_bitonic(K (&r)[E], K* keys, int P) {
     const int t = threadIdx.x;
     const int T = blockDim.x;
     GNMS_ST0();
@@ -107,6 +107,76 @@ __device__ __forceinline__ void block_sort(K (&r)[E], K* keys, int P) {
     for (int e = 0; e < E; ++e) keys[t * E + e] = r[e];
     __syncthreads();
     GNMS_STACC(3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block_sort: the production sort.  Same contract as block_sort_bitonic (thread t owns t*E..t*E+E-1, result in
+// r[] and keys[0..P)), different cross-wave phase:
+//   1. every wave sorts its own 64*E keys ascending with the register/shuffle part of the bitonic network;
+//   2. the 64E-key runs are merged pairwise, log2(#waves) passes: each thread finds its E outputs by a merge-path
+//      binary search on the two runs in LDS and merges them sequentially (ties take the left run).
+// That replaces the 10 two-barrier LDS exchange stages + 24 shuffle stages above 64E of the pure bitonic network by
+// 4 passes for 4096 keys (measured: 25 -> ~14 us for u64 keys on one CU).
+// ------------------------------------------------------------------------------------------------
+template <int E, typename K>
+__device__ __forceinline__ void block_sort(K (&r)[E], K* keys, int P) {
+    const int t = threadIdx.x;
+    const int run = 64 * E < P ? 64 * E : P;                            // keys per wave-sorted run
+    // ---- phase 1: wave-local bitonic sort (all runs ascending: the direction bit is dropped at k == run) ----
+    for (int k = 2; k <= run; k <<= 1) {
+        const int kd = (k == run) ? 0 : k;
+        for (int j = k >> 1; j >= E; j >>= 1) {
+            const int m = j / E;
+            const bool keepmin = (((t * E) & kd) == 0) == (((t * E) & j) == 0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const K o = shfl_xor_key(r[e], m);
+                r[e] = ((o < r[e]) == keepmin) ? o : r[e];
+            }
+        }
+#pragma unroll
+        for (int jj = E / 2; jj >= 1; jj >>= 1) {
+            if (jj < k) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & jj) == 0) {
+                        const int i = t * E + e;
+                        const bool up = (i & kd) == 0;
+                        const K a = r[e], b = r[e | jj];
+                        if ((a > b) == up) { r[e] = b; r[e | jj] = a; }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[t * E + e] = r[e];
+    __syncthreads();
+    // ---- phase 2: pairwise merge passes ----
+    for (int p = run; p < P; p <<= 1) {
+        const int d0 = t * E;
+        const int base = d0 & ~(2 * p - 1);
+        const int d = d0 - base;                                        // diagonal inside the pair [A | B], |A| = |B| = p
+        const K* A = keys + base;
+        const K* Bk = keys + base + p;
+        int lo = d > p ? d - p : 0, hi = d < p ? d : p;
+        while (lo < hi) {                                               // merge path: first a with A[a] > B[d-1-a]
+            const int mid = (lo + hi) >> 1;
+            if (A[mid] <= Bk[d - 1 - mid]) lo = mid + 1; else hi = mid;
+        }
+        int a = lo, b = d - lo;
+        K ka = a < p ? A[a] : K(0), kb = b < p ? Bk[b] : K(0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool takeA = (b >= p) || (a < p && ka <= kb);
+            r[e] = takeA ? ka : kb;
+            if (takeA) { ++a; ka = a < p ? A[a] : K(0); } else { ++b; kb = b < p ? Bk[b] : K(0); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) keys[t * E + e] = r[e];
+        __syncthreads();
+    }
 }
 
 template <typename K>

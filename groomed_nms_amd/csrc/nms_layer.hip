@@ -184,11 +184,15 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
     const gnms_ws_layout L = gnms_make_layout(N);
     char* ws = (char*)workspace;
     dim3 ge(gnms_div_up(N, 256), B);
-    bwd_gx_kernel<<<ge, 256, 0, st>>>(grad_prob, N, counts, P, ws, L);
-    GNMS_CHECK_LAUNCH();
+    const bool fused_gx = P.group_boxes && P.mask_group_boxes && !P.return_sorted_prob && !P.presorted;   // the default path
+    if (!fused_gx) {
+        bwd_gx_kernel<<<ge, 256, 0, st>>>(grad_prob, N, counts, P, ws, L);
+        GNMS_CHECK_LAUNCH();
+    }
     if (grad_iou) GNMS_CHECK_HIP(hipMemsetAsync(grad_iou, 0, sizeof(float) * (size_t)B * N * ld, st));
     if (P.group_boxes && P.mask_group_boxes) {
-        bwd_masked_kernel<<<ge, 256, 0, st>>>(N, counts, P, ws, L, grad_scores);
+        if (fused_gx) bwd_masked_fused_kernel<<<ge, 256, 0, st>>>(grad_prob, N, counts, P, ws, L, grad_scores);
+        else bwd_masked_kernel<<<ge, 256, 0, st>>>(N, counts, P, ws, L, grad_scores);
         GNMS_CHECK_LAUNCH();
         bwd_masked_heads_kernel<<<dim3(N >= 2048 ? 128 : gnms_div_up(N, 16), B), 256, 0, st>>>(N, P, ws, L, grad_scores);
         GNMS_CHECK_LAUNCH();

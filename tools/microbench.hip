@@ -11,6 +11,19 @@ using namespace gnms;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 template <int E>
+__global__ __launch_bounds__(1024) void sort_only_bitonic_kernel(const u64* in, u64* out, int P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    u64 r[E];
+    const u64* src = in + (size_t)blockIdx.x * P;
+#pragma unroll
+    for (int e = 0; e < E; ++e) r[e] = src[threadIdx.x * E + e];
+    block_sort_bitonic<E, u64>(r, keys, P);
+#pragma unroll
+    for (int e = 0; e < E; ++e) out[(size_t)blockIdx.x * P + threadIdx.x * E + e] = r[e];
+}
+
+template <int E>
 __global__ __launch_bounds__(1024) void sort_only_kernel(const u64* in, u64* out, int P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
@@ -127,6 +140,7 @@ int main(int argc, char** argv) {
           CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_sort_ticks), sizeof(z)));
           printf("  block_sort<4,u64> cycles: LDS stages %lld | shuffle stages %lld | register stages %lld | final %lld\n", z[0], z[1], z[2], z[3]); }
 #endif
+        printf("bitonic<4> only         %8.1f us\n", time_us([&] { sort_only_bitonic_kernel<4><<<B, 1024, sort_lds>>>(din, dout, P2); }));
         printf("block_sort<8> only      %8.1f us\n", time_us([&] { sort_only_kernel<8><<<B, 512, sort_lds>>>(din, dout, P2); }));
         printf("block_sort<16> only     %8.1f us\n", time_us([&] { sort_only_kernel<16><<<B, 256, sort_lds>>>(din, dout, P2); }));
         std::vector<u64> ho(hk.size()); CK(hipMemcpy(ho.data(), dout, ho.size() * 8, hipMemcpyDeviceToHost));
