@@ -157,6 +157,34 @@ def main():
                                  kernel=("iou2d_kernel" if args.dim == 2 else "iou3d_kernel") + " (one full write of the NxN fp32 matrix)"),
             "phase_ms": {"iou2d": round(t_iou, 4), "nms_forward": round(t_fwd, 4), "nms_backward": round(t_bwd, 4)},
         }
+        if args.dim == 2:
+            # ---- reported SEPARATELY (never part of `value`): the from-boxes path, same outputs bit for bit, no N x N matrix ----
+            def fused_step():
+                p = G.differentiable_nms_from_boxes_batched(scores, boxes)[0]
+                scores.grad = None
+                torch.autograd.backward(p, w)
+            k_f = max(5, args.steps // 4)
+            for _ in range(3):
+                fused_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k_f):
+                fused_step()
+            torch.cuda.synchronize()
+            t_fused = (time.perf_counter() - t0) / k_f
+            t_mb = event_time_ms(lambda: check(lib.gnms_profile_bitmask_boxes(ptr(boxes), B, N, None, P.nms_threshold, ptr(ws), ws.numel(),
+                                                                             stream_ptr(dev)), "bitmask_boxes"), 20, stream)
+            # pairs actually evaluated: tiles of 64 rank-rows x 256 rank-columns with first column < end of the row block
+            nbk = (N + 63) // 64
+            pairs = B * sum(64 * 256 * min((N + 255) // 256, (64 * (kb + 1) + 255) // 256) for kb in range(nbk))
+            flop = 12.0 * pairs          # 4 min/max, 2 sub, 2 relu, mul, add, sub, div per pair
+            out["fused_from_boxes"] = {
+                "value": round(B * N / t_fused, 1), "unit": "boxes/s (1 GPU, this rank)", "ms_per_step": round(t_fused * 1e3, 4), "steps": k_f,
+                "note": "gnms_forward_from_boxes + gnms_backward_from_boxes: identical outputs (tests/test_gpu_parity.py::"
+                        "test_from_boxes_path_is_bit_identical), the NxN matrix is never materialised; not comparable with `value`",
+                "roofline": {"bound": "fp32-vector", "kernel": "bitmask_boxes_kernel", "kernel_ms": round(t_mb, 4),
+                             "achieved": round(flop / (t_mb * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                             "frac": round(flop / (t_mb * 1e-3) / 1e12 / 157.3, 4), "pairs": pairs, "flop_per_pair": 12}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             k = min(args.cpu_images, B)

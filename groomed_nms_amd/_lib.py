@@ -43,8 +43,13 @@ _SIGNATURES = {
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_vp,
                                      ctypes.POINTER(GnmsParams), c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "gnms_forward_from_boxes": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.POINTER(GnmsParams), c_vp, c_vp, c_vp,
+                                               c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "gnms_backward_from_boxes": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.POINTER(GnmsParams), c_vp,
+                                                c_vp, ctypes.c_size_t, c_vp]),
     "gnms_profile_bitmask": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_vp, ctypes.c_float, c_vp,
                                             ctypes.c_size_t, c_vp]),
+    "gnms_profile_bitmask_boxes": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_float, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_get_groups": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_int, c_vp, c_vp, c_vp,
                                        c_vp, ctypes.c_size_t, c_vp]),
     "gnms_pruning_function": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_vp, c_vp]),

@@ -208,6 +208,28 @@ __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_lay
     return I;
 }
 
+// IoU of box a (row) against box b (column): the arithmetic of iou2d_kernel / lib/core.py:210-218,499-508, operation
+// for operation, so that the from-boxes path takes exactly the decisions the matrix path takes.
+__device__ __forceinline__ float pair_iou(const float4 a, const float4 b) {
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    const float area_b = (b.z - b.x) * (b.w - b.y);
+    const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.0f);
+    const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.0f);
+    const float inter = w * h;
+    return inter / ((area_a + area_b) - inter);
+}
+
+// overlap accessor of the kernels that need single matrix entries: element [ca][cb] (input indices) either from the
+// N x N matrix or recomputed from the boxes
+template <bool BOXES>
+__device__ __forceinline__ float overlap_at(const float* __restrict__ src, long ld, int ca, int cb) {
+    if (BOXES) {
+        const float4* bx = reinterpret_cast<const float4*>(src);
+        return pair_iou(bx[ca], bx[cb]);
+    }
+    return src[(size_t)ca * ld + cb];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: stable descending argsort of the scores (lib/groomed_nms.py:41; get_groups :213)
 // ------------------------------------------------------------------------------------------------
@@ -328,6 +350,87 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
     for (int j = 0; j < 4; ++j) {
         if (col[j] < n) Wk[rk[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2b: threshold bit matrix straight from the boxes (the from-boxes path: the N x N fp32 matrix never exists).
+// Same wave tile (64 rank-rows x 256 RANK columns; boxes are gathered through `order`, 16 B each), the overlap
+// of each pair is recomputed with pair_iou and thresholded in registers.  Only tiles a leader can reach are
+// computed (leader rank < end of the row block): half the pairs.  Bound: fp32 VALU (about 24 ops per pair,
+// 10 of them the IEEE division that keeps the decision bit-identical to the matrix path); HBM traffic is
+// 16 N bytes in and N^2/8 bytes out per image.
+// ------------------------------------------------------------------------------------------------
+// Tile enumeration: only the tiles a leader can reach exist (column chunk c < ceil(64(kb+1)/256) = (kb>>2)+1), and they
+// are numbered in ONE dimension so that every wave of every workgroup has equal work.  (A (chunk, kb) grid with early
+// exits put all the work on the workgroups with blockIdx.x == 0, i.e. -- blocks are dealt round-robin to the 8 XCDs -- on
+// XCDs 0 and 4: measured 99 us instead of 40.)  Tiles before row block kb = 4q + r:  2q(q+1) + r(q+1).
+__device__ __forceinline__ void tri_tile(int id, int* kb, int* chunk) {
+    int q = (int)((sqrtf(1.0f + 2.0f * (float)id) - 1.0f) * 0.5f);
+    while (2 * q * (q + 1) > id) --q;
+    while (2 * (q + 1) * (q + 2) <= id) ++q;
+    const int rem = id - 2 * q * (q + 1);
+    const int r = rem / (q + 1);
+    *kb = 4 * q + r;
+    *chunk = rem - r * (q + 1);
+}
+__host__ __device__ inline int tri_tile_count(int NB) {                // number of reachable tiles for NB row blocks
+    const int q = NB >> 2, r = NB & 3;
+    return 2 * q * (q + 1) + r * (q + 1);
+}
+
+__global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
+                                                            float thr, char* ws, gnms_ws_layout L) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int n = counts ? counts[b] : N;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tri_tile_count(L.NB)) return;
+    int kb, chunk;
+    tri_tile(tile, &kb, &chunk);
+    const int k0 = kb * 64;
+    const int c0 = chunk * 256;
+    if (k0 >= n || c0 >= n) return;                                  // (ragged images)
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * N;
+    float4 cb[4];
+    float carea[4];
+    int col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        col[j] = c0 + 4 * lane + j;
+        cb[j] = bx[I.order[col[j] < n ? col[j] : n - 1]];
+        carea[j] = (cb[j].z - cb[j].x) * (cb[j].w - cb[j].y);
+    }
+    const float4 rb = bx[I.order[min(k0 + lane, n - 1)]];
+    const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
+    const int nrows = min(64, n - k0);
+    unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll 4
+        for (int rr = 0; rr < 32; ++rr) {
+            const int r = half * 32 + rr;
+            const float ax1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.x), r));
+            const float ay1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.y), r));
+            const float ax2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.z), r));
+            const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), r));
+            const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), r));
+            const unsigned bit = 1u << rr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = fmaxf(fminf(ax2, cb[j].z) - fmaxf(ax1, cb[j].x), 0.0f);
+                const float h = fmaxf(fminf(ay2, cb[j].w) - fmaxf(ay1, cb[j].y), 0.0f);
+                const float inter = w * h;
+                const float v = inter / ((aa + carea[j]) - inter);       // row box is `a`, column (leader) box is `b`
+                wd[half][j] |= !(v <= thr) ? bit : 0u;
+            }
+        }
+    }
+    const u64 rowmask = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
+    u64* Wk = I.W + (size_t)kb * L.NC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (col[j] < n) Wk[col[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -587,7 +690,7 @@ __global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restr
 // Arrays head/gpos/gstart/glen/gsorted/plead are indexed by rank; pre is indexed by NMS position q
 // (q = rank for hard sort, q = input index when presorted).
 // ------------------------------------------------------------------------------------------------
-template <int E>
+template <int E, bool BOXES>
 __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                                       gnms_params P, char* ws, gnms_ws_layout L, int Ppow2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -596,7 +699,7 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
     const int b = blockIdx.x;
     const int n = counts ? counts[b] : N;
     ImgPtrs I = img_ptrs(ws, L, b);
-    const float* m = iou + (size_t)b * N * ld;
+    const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
     const float thr = P.nms_threshold;
     // ---- phase 1: membership key of every rank (thread t owns ranks t*E .. t*E+E-1 throughout) ----
     GNMS_T0();
@@ -615,7 +718,7 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
         const int k = threadIdx.x * E + e;
         v_lead[e] = 0.0f; s_lead[e] = 0.0f;
         if (k < n) {
-            v_lead[e] = m[(size_t)c_own[e] * ld + I.order[lr_own[e]]];     // iou of the box against the leader that removed it
+            v_lead[e] = overlap_at<BOXES>(m, ld, c_own[e], I.order[lr_own[e]]);   // iou of the box against the leader that removed it
             s_lead[e] = I.sscore[lr_own[e]];
         }
     }
@@ -719,7 +822,7 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
             int ch;
             if (h != lr_own[e]) {                                    // the leader itself is not a member (NaN / <= thr diagonal)
                 ch = I.order[h];
-                v = m[(size_t)c_own[e] * ld + ch];
+                v = overlap_at<BOXES>(m, ld, c_own[e], ch);
                 sh = I.sscore[h];
             } else {
                 ch = -1;

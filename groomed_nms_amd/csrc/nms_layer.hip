@@ -145,14 +145,14 @@ extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N,
     if (P.group_boxes) {
         if ((rc = run_grouping(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;
         GNMS_DISPATCH_SORT(P2, {
-            if ((rc = allow_lds(groups_kernel<E>, sort_lds))) return rc;
-            groups_kernel<E><<<B, sort_threads, sort_lds, st>>>(iou, N, (long)ld, counts, P, ws, L, P2);
+            if ((rc = allow_lds(groups_kernel<E, false>, sort_lds))) return rc;
+            groups_kernel<E, false><<<B, sort_threads, sort_lds, st>>>(iou, N, (long)ld, counts, P, ws, L, P2);
         });
         GNMS_CHECK_LAUNCH();
         if (!P.mask_group_boxes) {
             const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
-            if ((rc = allow_lds(solve_groups_kernel<false>, lds))) return rc;
-            solve_groups_kernel<false><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, nullptr, nullptr);
+            if ((rc = allow_lds(solve_groups_kernel<false, false>, lds))) return rc;
+            solve_groups_kernel<false, false><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, nullptr, nullptr);
             GNMS_CHECK_LAUNCH();
         }
     } else {
@@ -202,8 +202,8 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
         }
     } else if (P.group_boxes) {
         const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
-        if ((rc = allow_lds(solve_groups_kernel<true>, lds))) return rc;
-        solve_groups_kernel<true><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
+        if ((rc = allow_lds(solve_groups_kernel<true, false>, lds))) return rc;
+        solve_groups_kernel<true, false><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
         GNMS_CHECK_LAUNCH();
     } else {
         const size_t lds = (size_t)((N + 3) & ~3) * 4 + 64 * 65 * 4 + 64 * 4;
@@ -211,6 +211,92 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
         ungrouped_backward_kernel<<<B, 1024, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
         GNMS_CHECK_LAUNCH();
     }
+    return GNMS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// from-boxes path: same layer, the N x N matrix never materialised (grouped modes)
+// ------------------------------------------------------------------------------------------------
+extern "C" int gnms_forward_from_boxes(const float* boxes, const float* scores, int B, int N, const int32_t* counts,
+                                       const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
+                                       int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_common("gnms_forward_from_boxes", B, N, N, params, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!params->group_boxes || params->presorted) {
+        gnms_set_error("gnms_forward_from_boxes: only the grouped, hard-sorted modes run without the matrix");
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) return GNMS_OK;
+    if (N == 0) {
+        if (nvalid) GNMS_CHECK_HIP(hipMemsetAsync(nvalid, 0, sizeof(int32_t) * B, st));
+        if (ninvalid) GNMS_CHECK_HIP(hipMemsetAsync(ninvalid, 0, sizeof(int32_t) * B, st));
+        return GNMS_OK;
+    }
+    GNMS_CHECK_ARG(boxes && scores && prob, "gnms_forward_from_boxes: null boxes/scores/prob");
+    GNMS_CHECK_ARG((uintptr_t)boxes % 16 == 0, "gnms_forward_from_boxes: boxes must be 16-byte aligned");
+    const gnms_params P = *params;
+    const gnms_ws_layout L = gnms_make_layout(N);
+    char* ws = (char*)workspace;
+    const int P2 = next_pow2(N);
+    const size_t sort_lds = (size_t)P2 * 8;
+    const int sort_threads = P2 <= 1024 ? P2 : 1024;
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
+        sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
+    });
+    GNMS_CHECK_LAUNCH();
+    bitmask_boxes_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(boxes, N, counts, P.nms_threshold, ws, L);
+    GNMS_CHECK_LAUNCH();
+    const size_t llds = leaders_lds_bytes(N);
+    if ((rc = allow_lds(leaders_kernel, llds))) return rc;
+    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
+    GNMS_CHECK_LAUNCH();
+    attribute_kernel<<<dim3(L.NB, B), 64, 0, st>>>(N, counts, ws, L);
+    GNMS_CHECK_LAUNCH();
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(groups_kernel<E, true>, sort_lds))) return rc;
+        groups_kernel<E, true><<<B, sort_threads, sort_lds, st>>>(boxes, N, (long)N, counts, P, ws, L, P2);
+    });
+    GNMS_CHECK_LAUNCH();
+    if (!P.mask_group_boxes) {
+        const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+        if ((rc = allow_lds(solve_groups_kernel<false, true>, lds))) return rc;
+        solve_groups_kernel<false, true><<<dim3(N, B), 64, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, nullptr, nullptr);
+        GNMS_CHECK_LAUNCH();
+    }
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
+        finalize_kernel<E><<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid,
+                                                               nvalid, ninvalid);
+    });
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+extern "C" int gnms_backward_from_boxes(const float* grad_prob, const float* boxes, const float* scores, int B, int N,
+                                        const int32_t* counts, const gnms_params* params, float* grad_scores, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    int rc = check_common("gnms_backward_from_boxes", B, N, N, params, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (!params->group_boxes || params->presorted) {
+        gnms_set_error("gnms_backward_from_boxes: only the grouped, hard-sorted modes run without the matrix");
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    if (B == 0 || N == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(grad_prob && boxes && scores && grad_scores, "gnms_backward_from_boxes: null pointer");
+    if (params->mask_group_boxes)      // the masked backward never touches the overlaps
+        return gnms_backward(grad_prob, scores, boxes, B, N, N, counts, params, grad_scores, nullptr, workspace, workspace_bytes, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const gnms_params P = *params;
+    const gnms_ws_layout L = gnms_make_layout(N);
+    char* ws = (char*)workspace;
+    bwd_gx_kernel<<<dim3(gnms_div_up(N, 256), B), 256, 0, st>>>(grad_prob, N, counts, P, ws, L);
+    GNMS_CHECK_LAUNCH();
+    const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+    if ((rc = allow_lds(solve_groups_kernel<true, true>, lds))) return rc;
+    solve_groups_kernel<true, true><<<dim3(N, B), 64, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, grad_scores, nullptr);
+    GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
 
@@ -228,6 +314,20 @@ extern "C" int gnms_profile_bitmask(const float* iou, int B, int N, int64_t ld, 
     dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
     if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
     else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+extern "C" int gnms_profile_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float nms_threshold, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    gnms_params P;
+    gnms_default_params(&P);
+    int rc = check_common("gnms_profile_bitmask_boxes", B, N, N, &P, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (B == 0 || N == 0) return GNMS_OK;
+    const gnms_ws_layout L = gnms_make_layout(N);
+    bitmask_boxes_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, (hipStream_t)stream>>>(boxes, N, counts, nms_threshold,
+                                                                                                            (char*)workspace, L);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -282,8 +382,8 @@ extern "C" int gnms_get_groups(const float* scores, const float* iou, int N, int
     GNMS_CHECK_LAUNCH();
     if ((rc = run_grouping(iou, 1, N, ld, nullptr, group_threshold, ws, L, st))) return rc;
     GNMS_DISPATCH_SORT(P2, {
-        if ((rc = allow_lds(groups_kernel<E>, sort_lds))) return rc;
-        groups_kernel<E><<<1, sort_threads, sort_lds, st>>>(iou, N, (long)ld, nullptr, P, ws, L, P2);
+        if ((rc = allow_lds(groups_kernel<E, false>, sort_lds))) return rc;
+        groups_kernel<E, false><<<1, sort_threads, sort_lds, st>>>(iou, N, (long)ld, nullptr, P, ws, L, P2);
     });
     GNMS_CHECK_LAUNCH();
     export_groups_kernel<<<gnms_div_up(N, 256), 256, 0, st>>>(N, ws, L, group_of, pos_in_group, ngroups_out);

@@ -19,7 +19,7 @@ constexpr int kGroupMaxMembers = 2048;
 // unmasked groups: one wave per group (launched per rank; only heads work).
 // dynamic LDS: int sc[G], int sq[G], float acc[G], float Pl[tile*(tile+1)]   with G = kGroupMaxMembers
 // ------------------------------------------------------------------------------------------------
-template <bool BWD>
+template <bool BWD, bool BOXES>
 __global__ __launch_bounds__(64) void solve_groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                                           gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores,
                                                           float* __restrict__ grad_iou) {
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(64) void solve_groups_kernel(const float* __restric
         return;
     }
     if (h != k) return;
-    const float* m = iou + (size_t)b * N * ld;
-    float* gi = (BWD && grad_iou) ? grad_iou + (size_t)b * N * ld : nullptr;
+    const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
+    float* gi = (BWD && grad_iou && !BOXES) ? grad_iou + (size_t)b * N * ld : nullptr;
     const int g = I.glen[k], start = I.gstart[k];
     const bool tiled = g <= kGroupTileCap;
     const int ts = g + 1;   // padded tile stride
@@ -67,12 +67,12 @@ __global__ __launch_bounds__(64) void solve_groups_kernel(const float* __restric
     if (tiled) {
         for (int e = lane; e < g * g; e += 64) {
             const int a = e / g, bb = e - a * g;
-            Pl[a * ts + bb] = (bb < a) ? gnms_prune(m[(size_t)sc[a] * ld + sc[bb]], P.nms_threshold, P.temperature, P.pruning_method) : 0.0f;
+            Pl[a * ts + bb] = (bb < a) ? gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb]), P.nms_threshold, P.temperature, P.pruning_method) : 0.0f;
         }
         __syncthreads();
     }
     auto Pab = [&](int a, int bb) -> float {
-        return tiled ? Pl[a * ts + bb] : gnms_prune(m[(size_t)sc[a] * ld + sc[bb]], P.nms_threshold, P.temperature, P.pruning_method);
+        return tiled ? Pl[a * ts + bb] : gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb]), P.nms_threshold, P.temperature, P.pruning_method);
     };
     if (!BWD) {
         for (int bb = 0; bb < g - 1; ++bb) {

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import GnmsParams, check, ptr, stream_ptr
 
-__all__ = ["differentiable_nms", "differentiable_nms_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
+__all__ = ["differentiable_nms", "differentiable_nms_batched", "differentiable_nms_from_boxes_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
            "cast_to_cpu_cuda_tensor", "get_groups", "indices_copy", "GroomedNMS"]
 
 _PRUNE = {"linear": 0, "sigmoidal": 1, "soft_nms": 2}
@@ -95,6 +95,52 @@ class _GroomedNMSFunction(torch.autograd.Function):
         if grad_iou is not None and ctx.ld != N:
             grad_iou = grad_iou[:, :, :N]
         return grad_scores, grad_iou, None, None
+
+
+class _GroomedNMSFromBoxesFunction(torch.autograd.Function):
+    """prob = GrooMeD-NMS(scores, boxes) without ever building the N x N overlap matrix (gnms_forward_from_boxes):
+    bit-identical to overlaps.iou_batched + _GroomedNMSFunction, gradient w.r.t. scores (the reference's loss detaches the
+    overlaps, lib/loss/rpn_3d.py:791)."""
+
+    @staticmethod
+    def forward(ctx, scores, boxes, counts, params):
+        lib = _lib.load()
+        B, N = scores.shape
+        dev = scores.device
+        scores_c = scores.contiguous()
+        boxes_c = boxes.contiguous()
+        prob = torch.empty((B, N), dtype=torch.float32, device=dev)
+        order = torch.empty((B, N), dtype=torch.int64, device=dev)
+        valid = torch.empty((B, N), dtype=torch.int64, device=dev)
+        invalid = torch.empty((B, N), dtype=torch.int64, device=dev)
+        nvalid = torch.empty((B,), dtype=torch.int32, device=dev)
+        ninvalid = torch.empty((B,), dtype=torch.int32, device=dev)
+        nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
+        ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gnms_forward_from_boxes(ptr(boxes_c), ptr(scores_c), B, N, ptr(counts), ctypes.byref(params), ptr(prob), ptr(order),
+                                              ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws), ws.numel(), stream_ptr(dev)),
+                  "gnms_forward_from_boxes")
+        ctx.params = params
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(scores_c, boxes_c, counts, ws)
+        ctx.mark_non_differentiable(order, valid, invalid, nvalid, ninvalid)
+        return prob, order, valid, invalid, nvalid, ninvalid
+
+    @staticmethod
+    def backward(ctx, grad_prob, *unused):
+        if grad_prob is None:
+            return None, None, None, None
+        lib = _lib.load()
+        scores_c, boxes_c, counts, ws = ctx.saved_tensors
+        B, N = scores_c.shape
+        dev = scores_c.device
+        grad_prob = grad_prob.contiguous().float()
+        grad_scores = torch.empty_like(scores_c)
+        with torch.cuda.device(dev):
+            check(lib.gnms_backward_from_boxes(ptr(grad_prob), ptr(boxes_c), ptr(scores_c), B, N, ptr(counts), ctypes.byref(ctx.params),
+                                               ptr(grad_scores), ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_backward_from_boxes")
+        return grad_scores, None, None, None
 
 
 class _SoftSortFunction(torch.autograd.Function):
@@ -182,6 +228,19 @@ def differentiable_nms_batched(scores, iou, counts=None, nms_threshold=0.4, prun
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSFunction.apply(scores.float(), iou.float(), counts, params)
+
+
+def differentiable_nms_from_boxes_batched(scores, boxes, counts=None, nms_threshold=0.4, pruning_method="linear", temperature=0.01,
+                                          valid_box_prob_threshold=0.3, return_sorted_prob=False, mask_group_boxes=True,
+                                          group_size=100):
+    """From-boxes path: scores [B,N], boxes [B,N,4] = (x1,y1,x2,y2) -> the same six outputs as differentiable_nms_batched,
+    bit-identical to building the 2D IoU matrix (overlaps.iou_batched) and running the layer on it, but the N x N matrix is
+    never written to or read from HBM.  Grouped modes only (the defaults of scripts/config/groumd_nms.py)."""
+    params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, True,
+                     mask_group_boxes, group_size, False)
+    if counts is not None:
+        counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
+    return _GroomedNMSFromBoxesFunction.apply(scores.float(), boxes.float(), counts, params)
 
 
 def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning_method="linear", temperature=0.01,

@@ -122,10 +122,27 @@ int gnms_backward(const float* grad_prob, const float* scores, const float* iou,
                   const int32_t* counts, const gnms_params* params, float* grad_scores, float* grad_iou,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* From-boxes path (2D): the same layer computed straight from boxes [B][N][4] = (x1,y1,x2,y2); the N x N overlap
+ * matrix is never materialised -- the bit-matrix kernel recomputes every pair's IoU in registers with the arithmetic of
+ * gnms_iou2d (lib/core.py:499-508), so all outputs and gradients are bit-identical to gnms_iou2d + gnms_forward /
+ * gnms_backward.  Grouped, hard-sorted modes only (masked or unmasked groups); ungrouped / presorted return
+ * GNMS_ERR_UNSUPPORTED (they need the matrix).  HBM traffic drops from 8 N^2 to N^2/8 + O(N) bytes per image; the
+ * bound becomes fp32 VALU.  Workspace: gnms_workspace_bytes. */
+int gnms_forward_from_boxes(const float* boxes, const float* scores, int B, int N, const int32_t* counts,
+                            const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
+                            int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream);
+int gnms_backward_from_boxes(const float* grad_prob, const float* boxes, const float* scores, int B, int N,
+                             const int32_t* counts, const gnms_params* params, float* grad_scores, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* profiling hook: re-runs only the threshold bit-matrix kernel (the single full read of the overlap matrix, the
  * dominant kernel of gnms_forward) on a workspace a previous gnms_forward call filled. */
 int gnms_profile_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float nms_threshold,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* same hook for the from-boxes bit-matrix kernel (VALU bound) */
+int gnms_profile_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float nms_threshold, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* get_groups(iou_unsorted, group_threshold, scores_unsorted, group_size)  lib/groomed_nms.py:208-270 for one
  * image.  group_of[N]: index of the box's group (groups numbered in creation order) or -1 if the box is in

@@ -478,3 +478,32 @@ def test_classic_nms_wide_rows_and_device_entry(G, O):
     check(lib.gnms_nms_sorted(ptr(sd), n, 5, 0.45, ptr(keep), ptr(num), ptr(ws), ws.numel(), None), "gnms_nms_sorted")
     torch.cuda.synchronize()
     assert [int(order[i]) for i in keep[:int(num)].tolist()] == want
+
+
+def test_from_boxes_path_is_bit_identical(G):
+    """gnms_forward_from_boxes / gnms_backward_from_boxes (no N x N matrix) == iou_batched + the matrix path, bit for bit,
+    including ragged counts, the group-size cap, unmasked groups and sorted output."""
+    from groomed_nms_amd import synthetic, overlaps
+    from groomed_nms_amd._lib import GnmsError
+    for B, N, per in ((3, 500, 20), (2, 4096, 64), (1, 64, 8), (2, 1001, 250), (2, 300, 150)):
+        boxes, scores = synthetic.batch_2d(13, B, N, "clustered", per=per)
+        boxes[0, 3 % N, 2:] = boxes[0, 3 % N, :2]                 # a zero-area box: NaN self-overlap
+        bt = torch.from_numpy(boxes).cuda()
+        counts = torch.tensor([N] + [max(1, N // 3)] * (B - 1), dtype=torch.int32).cuda()
+        w = torch.rand((B, N), device="cuda")
+        for kw in (dict(), dict(group_size=2), dict(mask_group_boxes=False, group_size=40), dict(return_sorted_prob=True),
+                   dict(pruning_method="sigmoidal", temperature=0.1), dict(nms_threshold=0.7, valid_box_prob_threshold=0.5)):
+            s1 = torch.from_numpy(scores).cuda().requires_grad_(True)
+            s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
+            out1 = G.differentiable_nms_from_boxes_batched(s1, bt, counts=counts, **kw)
+            out2 = G.differentiable_nms_batched(s2, overlaps.iou_batched(bt), counts=counts, **kw)
+            for a, b in zip(out1, out2):
+                assert torch.equal(a, b) or (a.dtype.is_floating_point and torch.allclose(a, b, atol=0, rtol=0, equal_nan=True)), (B, N, kw)
+            (out1[0] * w).sum().backward()
+            (out2[0] * w).sum().backward()
+            assert torch.equal(s1.grad, s2.grad), (B, N, kw)
+    with pytest.raises(GnmsError):
+        import ctypes
+        from groomed_nms_amd.groomed_nms import _params, _GroomedNMSFromBoxesFunction
+        _GroomedNMSFromBoxesFunction.apply(torch.rand((1, 8), device="cuda"), torch.rand((1, 8, 4), device="cuda"), None,
+                                           _params(0.4, "linear", 0.01, 0.3, False, False, True, 100))     # ungrouped needs the matrix

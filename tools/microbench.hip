@@ -36,6 +36,53 @@ __global__ __launch_bounds__(1024) void sort_only_kernel(const u64* in, u64* out
     for (int e = 0; e < E; ++e) out[(size_t)blockIdx.x * P + threadIdx.x * E + e] = r[e];
 }
 
+// experiment: the from-boxes bit-matrix kernel with the division replaced (0 exact, 1 rcp-multiply, 2 cross-multiply)
+template <int DIVMODE, int UNR>
+__global__ __launch_bounds__(256) void bitmask_boxes_exp(const float* __restrict__ boxes, int N, float thr, char* ws, gnms_ws_layout L) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z, kb = blockIdx.y;
+    const int n = N;
+    const int k0 = kb * 64;
+    const int c0 = (blockIdx.x * 4 + wave) * 256;
+    if (k0 >= n || c0 >= n || c0 >= k0 + 64) return;
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * N;
+    float4 cb[4]; float carea[4]; int col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { col[j] = c0 + 4 * lane + j; cb[j] = bx[I.order[col[j] < n ? col[j] : n - 1]]; carea[j] = (cb[j].z - cb[j].x) * (cb[j].w - cb[j].y); }
+    const float4 rb = bx[I.order[min(k0 + lane, n - 1)]];
+    const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
+    unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll UNR
+        for (int rr = 0; rr < 32; ++rr) {
+            const int r = half * 32 + rr;
+            const float ax1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.x), r));
+            const float ay1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.y), r));
+            const float ax2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.z), r));
+            const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), r));
+            const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), r));
+            const unsigned bit = 1u << rr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = fmaxf(fminf(ax2, cb[j].z) - fmaxf(ax1, cb[j].x), 0.0f);
+                const float h = fmaxf(fminf(ay2, cb[j].w) - fmaxf(ay1, cb[j].y), 0.0f);
+                const float inter = w * h;
+                const float uni = (aa + carea[j]) - inter;
+                bool nl;
+                if (DIVMODE == 0) nl = !(inter / uni <= thr);
+                else if (DIVMODE == 1) nl = !(inter * __builtin_amdgcn_rcpf(uni) <= thr);
+                else nl = !(inter <= thr * uni);
+                wd[half][j] |= nl ? bit : 0u;
+            }
+        }
+    }
+    u64* Wk = I.W + (size_t)kb * L.NC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (col[j] < n) Wk[col[j]] = (((u64)wd[1][j] << 32) | wd[0][j]);
+}
+
 __global__ void empty_kernel(int* p) { if (p && threadIdx.x == 12345) *p = 1; }
 
 template <typename F>
@@ -116,14 +163,24 @@ int main(int argc, char** argv) {
         printf("  COLD leaders phases (cycles, wave0): prologue %lld | resolve %lld | barrierA %lld | push+book %lld | barrierB %lld\n", z[0], z[1], z[2], z[3], z[4]);
 #endif
     }
+    {
+        dim3 gb((N + 1023) / 1024, L.NB, B);
+        printf("bitmask_boxes exact  u4 %8.1f us\n", time_us([&] { bitmask_boxes_exp<0, 4><<<gb, 256>>>(d_boxes, N, 0.4f, ws, L); }));
+        printf("bitmask_boxes exact  u1 %8.1f us\n", time_us([&] { bitmask_boxes_exp<0, 1><<<gb, 256>>>(d_boxes, N, 0.4f, ws, L); }));
+        printf("bitmask_boxes exact u32 %8.1f us\n", time_us([&] { bitmask_boxes_exp<0, 32><<<gb, 256>>>(d_boxes, N, 0.4f, ws, L); }));
+        printf("bitmask_boxes rcp    u4 %8.1f us\n", time_us([&] { bitmask_boxes_exp<1, 4><<<gb, 256>>>(d_boxes, N, 0.4f, ws, L); }));
+        printf("bitmask_boxes xmul   u4 %8.1f us\n", time_us([&] { bitmask_boxes_exp<2, 4><<<gb, 256>>>(d_boxes, N, 0.4f, ws, L); }));
+        // restore W for the kernels below
+        bitmask_kernel<true><<<dim3((N + kMaskWaves * 256 - 1) / (kMaskWaves * 256), L.NB, B), kMaskWaves * 64>>>(d_iou, N, N, nullptr, 0.4f, ws, L);
+    }
     printf("attribute               %8.1f us\n", time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); }));
     if (P2 == 4096) {
         printf("sort_scores<4>          %8.1f us\n", time_us([&] { sort_scores_kernel<4><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr); }));
-        printf("groups<4>               %8.1f us\n", time_us([&] { groups_kernel<4><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); }));
+        printf("groups<4>               %8.1f us\n", time_us([&] { groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); }));
 #ifdef GNMS_TIMING
         {
             long long z[16] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
-            groups_kernel<4><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); CK(hipDeviceSynchronize());
+            groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); CK(hipDeviceSynchronize());
             CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
             printf("  groups phases (cycles, thread0): keys %lld | sort %lld | runs %lld | rescoring %lld\n", z[8], z[9], z[10], z[11]);
         }
