@@ -126,10 +126,26 @@ __device__ __forceinline__ uint32_t gnms_desc_key(float v) {
     return ~asc;
 }
 
-// wave-wide OR of a 64-bit value (all 64 lanes get the result)
+// wave-wide OR on the VALU: DPP row_shr 1,2,4,8 + row_bcast:15 + row_bcast:31 leave the total in lane 63 (an inclusive
+// OR-scan on the way); 6 dependent DPP ops instead of 6 ds_bpermute round trips (checked on gfx950: tools/scratch/t_dpp2.hip)
+__device__ __forceinline__ unsigned gnms_or_scan32(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);   // row_bcast:15 -> rows 1,3
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);   // row_bcast:31 -> rows 2,3
+    return v;                                                                       // inclusive OR-scan over the 64 lanes
+}
+__device__ __forceinline__ unsigned long long gnms_or_scan64(unsigned long long v) {
+    const unsigned lo = gnms_or_scan32((unsigned)(v & 0xffffffffu));
+    const unsigned hi = gnms_or_scan32((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// wave-wide OR of a 64-bit value; the result is wave-uniform (read from lane 63)
 __device__ __forceinline__ unsigned long long gnms_wave_or(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off, 64);
-    return v;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)gnms_or_scan32((unsigned)(v & 0xffffffffu)), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)gnms_or_scan32((unsigned)(v >> 32)), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 #endif

@@ -639,14 +639,9 @@ __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restr
 //   rem[k] = rank of the leader that removed rank k (k itself for a leader).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
-    u64 inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        u64 t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc |= t;
-    }
-    u64 ex = __shfl_up(inc, 1, 64);
-    return lane == 0 ? 0ull : ex;
+    u64 up = shfl_up_u64(v, 1);                                     // lane i <- lane i-1
+    if (lane == 0) up = 0ull;
+    return gnms_or_scan64(up);                                      // DPP inclusive OR-scan (gnms_common.h)
 }
 
 __global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
