@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--kind", default="clustered", choices=["uniform", "clustered"])
     ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="2: lib/core.py iou; 3: 0.5*(1+GIoU3D) of the corner AABBs from (x,y,z,w,h,l,ry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=4, help="images the CPU baseline processes")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: keep processing images of the batch for about this long")
     return ap.parse_args()
 
 
@@ -187,21 +187,26 @@ def main():
                              "frac": round(flop / (t_mb * 1e-3) / 1e12 / 157.3, 4), "pairs": pairs, "flop_per_pair": 12}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
-            k = min(args.cpu_images, B)
             t0 = time.perf_counter()
-            for b in range(k):
+            k = 0
+            while k < 4 or (time.perf_counter() - t0) < args.cpu_seconds:      # bounded sample: whole images, >= 4 of them
+                b = k % B
                 if args.dim == 2:
                     m = O.iou2d(boxes_np[b], boxes_np[b])
                 else:
                     c = O.corners_of_cuboid(boxes_np[b])
                     m = 0.5 * (1.0 + O.iou3d_approximate(c, c, generalized=True)[1])
                 O.differentiable_nms(scores_np[b], m, grad_prob=np.linspace(-1, 2, N).astype(np.float32))
+                k += 1
+                if k >= 4096:
+                    break
             tc = time.perf_counter() - t0
             out["cpu_baseline"] = {"value": round(k * N / tc, 1), "unit": "boxes/s", "cores": 1, "kind": "port",
-                                   "sample": "%d of the %d images of rank 0's batch (N=%d), oracle/gnms_oracle.c: overlap matrix + nms fwd+bwd" % (k, B, N)}
+                                   "sample": "%d image passes over rank 0's batch of %d images (N=%d) in %.1f s: oracle/gnms_oracle.c overlap matrix + "
+                                             "nms fwd+bwd, single thread" % (k, B, N, tc)}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

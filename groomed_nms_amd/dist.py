@@ -20,7 +20,8 @@ def env_world():
 def init(backend=None):
     """Initialises torch.distributed from the launcher's env (RANK/WORLD_SIZE/MASTER_*).  Returns (world, rank, local_rank)."""
     world, rank, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("GNMS_FORCE_DIST", "0") == "1"      # exercise the collective path on a single rank (CI on 1-GPU boxes)
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
