@@ -1,19 +1,7 @@
-"""py_cpu_nms(dets, thresh) -- the reference's NumPy baseline lib/nms/py_cpu_nms.py:10-38 (keeps '<= thresh')."""
-import numpy as np
+"""py_cpu_nms(dets, thresh): stand-in for the reference's NumPy baseline (lib/nms/py_cpu_nms.py:10-38): +1-pixel areas,
+boxes whose IoU with a kept box is <= thresh survive."""
+from ._host import greedy_nms
 
 
 def py_cpu_nms(dets, thresh):
-    x1, y1, x2, y2, scores = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3], dets[:, 4]
-    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
-    order = scores.argsort()[::-1]
-    keep = []
-    while order.size > 0:
-        i = order[0]
-        keep.append(i)
-        rest = order[1:]
-        w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + 1)
-        h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + 1)
-        inter = w * h
-        ovr = inter / (areas[i] + areas[rest] - inter)
-        order = rest[np.where(ovr <= thresh)[0]]
-    return keep
+    return greedy_nms(dets, thresh, shift=1, rule="le_keep")

@@ -8,62 +8,52 @@ __all__ = ["navneeth_soft_nms", "girshick_nms"]
 
 
 def navneeth_soft_nms(boxes, sigma=0.5, Nt=0.4, threshold=0.001, method=0, shift=1):
-    """lib/nms_others.py:6-116.  Like the reference it reorders/rescoring `boxes` IN PLACE and returns the kept
-    original indices.  method 0 hard, 1 linear, 2 gaussian."""
-    n = boxes.shape[0]
-    tracker = np.arange(n)
+    """Soft-NMS (Bodla et al.) with the index tracking of lib/nms_others.py:6-116; returns the kept original indices in
+    the reference's slot order.  method 0 hard, 1 linear, 2 gaussian.  Formulated on a slot permutation: rows never move,
+    `slots[p]` names the box sitting in slot p (the reference swaps rows and its keep_orig array in lockstep, :45-60,
+    :98-110), and -- unlike the reference -- the caller's array is left untouched."""
+    geom = np.asarray(boxes, dtype=np.float64)[:, :4]
+    score = np.array(np.asarray(boxes)[:, 4], dtype=np.float64)
+    n = geom.shape[0]
+    slots = list(range(n))
     live = n
     for i in range(n):
-        if i >= live:                      # the reference keeps looping over dead slots; nothing happens there
-            break
-        best = i + int(np.argmax(boxes[i:live, 4])) if live > i else i
-        if boxes[best, 4] <= boxes[i, 4]:
-            best = i                       # strict '<' in the reference's scan (:32): first maximum wins
-        boxes[[i, best]] = boxes[[best, i]]
-        tracker[[i, best]] = tracker[[best, i]]
-        tx1, ty1, tx2, ty2 = boxes[i, 0], boxes[i, 1], boxes[i, 2], boxes[i, 3]
-        pos = i + 1
-        while pos < live:
-            x1, y1, x2, y2 = boxes[pos, 0], boxes[pos, 1], boxes[pos, 2], boxes[pos, 3]
-            area = (x2 - x1 + shift) * (y2 - y1 + shift)
-            iw = min(tx2, x2) - max(tx1, x1) + shift
-            if iw > 0:
-                ih = min(ty2, y2) - max(ty1, y1) + shift
-                if ih > 0:
-                    ua = float((tx2 - tx1 + shift) * (ty2 - ty1 + shift) + area - iw * ih)
-                    ov = iw * ih / ua
-                    if method == 1:
-                        weight = 1 - ov if ov > Nt else 1
-                    elif method == 2:
-                        weight = math.exp(-(ov * ov) / sigma)
-                    else:
-                        weight = 0 if ov > Nt else 1
-                    boxes[pos, 4] = weight * boxes[pos, 4]
-                    if boxes[pos, 4] < threshold:
-                        boxes[pos] = boxes[live - 1]
-                        tracker[[live - 1, pos]] = tracker[[pos, live - 1]]
-                        live -= 1
-                        pos -= 1
-            pos += 1
-    return tracker[:live]
+        if i >= live:
+            break                                   # the reference keeps iterating over dead slots, a no-op (:18)
+        # slot of the best remaining score; the first maximum wins (strict '<' at :32)
+        best = i
+        for p in range(i + 1, live):
+            if score[slots[best]] < score[slots[p]]:
+                best = p
+        slots[i], slots[best] = slots[best], slots[i]
+        ax1, ay1, ax2, ay2 = geom[slots[i]]
+        area_a = (ax2 - ax1 + shift) * (ay2 - ay1 + shift)
+        p = i + 1
+        while p < live:
+            j = slots[p]
+            bx1, by1, bx2, by2 = geom[j]
+            iw = min(ax2, bx2) - max(ax1, bx1) + shift
+            ih = min(ay2, by2) - max(ay1, by1) + shift
+            if iw > 0 and ih > 0:
+                ov = iw * ih / float(area_a + (bx2 - bx1 + shift) * (by2 - by1 + shift) - iw * ih)
+                if method == 1:
+                    weight = 1 - ov if ov > Nt else 1
+                elif method == 2:
+                    weight = math.exp(-(ov * ov) / sigma)
+                else:
+                    weight = 0 if ov > Nt else 1
+                score[j] = weight * score[j]
+                if score[j] < threshold:            # discard: the last live slot takes this place and is examined next
+                    slots[p], slots[live - 1] = slots[live - 1], slots[p]
+                    live -= 1
+                    continue
+            p += 1
+    return np.asarray(slots[:live], dtype=np.int64)
 
 
 def girshick_nms(dets, thresh, shift=1):
-    """lib/nms_others.py:119-150 (returns its keep_orig list, computed as in the reference: i + N_dropped)."""
-    x1, y1, x2, y2, scores = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3], dets[:, 4]
-    areas = (x2 - x1 + shift) * (y2 - y1 + shift)
-    order = scores.argsort()[::-1]
-    keep_orig = []
-    n_dropped = 0
-    while order.size > 0:
-        i = order[0]
-        keep_orig.append(i + n_dropped)
-        rest = order[1:]
-        w = np.maximum(0.0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + shift)
-        h = np.maximum(0.0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + shift)
-        inter = w * h
-        ovr = inter / (areas[i] + areas[rest] - inter)
-        inds = np.where(ovr <= thresh)[0]
-        order = order[inds + 1]
-        n_dropped = order.shape[0] - inds.shape[0]
-    return keep_orig
+    """lib/nms_others.py:119-150: greedy NMS with a configurable pixel `shift`.  The reference returns `keep_orig`, built
+    as kept index + N_dropped where N_dropped is recomputed after every round as len(order) - len(inds) on the ALREADY
+    filtered order (:148) -- which is always 0 -- so the list equals the kept indices; reproduced as such."""
+    from .nms._host import greedy_nms
+    return [np.int64(i) for i in greedy_nms(np.asarray(dets), thresh, shift=shift, rule="le_keep")]

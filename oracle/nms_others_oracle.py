@@ -7,47 +7,43 @@ import numpy as np
 
 
 def soft_nms(boxes, sigma=0.5, Nt=0.4, threshold=0.001, method=0, shift=1):
-    """lib/nms_others.py:6-116 navneeth_soft_nms.  Works on a float64 copy; returns kept original indices."""
+    """lib/nms_others.py:6-116 navneeth_soft_nms, restated with the overlaps of the selected box against all live boxes
+    computed at once (they do not depend on the slot shuffling) and the slot bookkeeping done on index arrays.
+    Returns the kept original indices in the reference's slot order."""
     b = np.array(boxes, dtype=np.float64, copy=True)
-    n = b.shape[0]
-    idx = list(range(n))
-    i = 0
-    while i < n:      # `for i in range(N)` (:18) keeps the initial N, but iterations past the live N are no-ops
-        # select the max-score box among [i, n) and swap it into slot i (:19-60)
-        maxpos = i
-        maxscore = b[i, 4]
-        for pos in range(i + 1, n):
-            if maxscore < b[pos, 4]:
-                maxscore = b[pos, 4]
-                maxpos = pos
-        b[[i, maxpos]] = b[[maxpos, i]]
-        idx[i], idx[maxpos] = idx[maxpos], idx[i]
-        tx1, ty1, tx2, ty2 = b[i, 0], b[i, 1], b[i, 2], b[i, 3]
-        pos = i + 1
-        while pos < n:                                     # :64-112
-            x1, y1, x2, y2 = b[pos, 0], b[pos, 1], b[pos, 2], b[pos, 3]
-            area = (x2 - x1 + shift) * (y2 - y1 + shift)
-            iw = min(tx2, x2) - max(tx1, x1) + shift
-            if iw > 0:
-                ih = min(ty2, y2) - max(ty1, y1) + shift
-                if ih > 0:
-                    ua = float((tx2 - tx1 + shift) * (ty2 - ty1 + shift) + area - iw * ih)
-                    ov = iw * ih / ua
-                    if method == 1:
-                        weight = 1 - ov if ov > Nt else 1
-                    elif method == 2:
-                        weight = math.exp(-(ov * ov) / sigma)
-                    else:
-                        weight = 0 if ov > Nt else 1
-                    b[pos, 4] = weight * b[pos, 4]
-                    if b[pos, 4] < threshold:              # discard: swap with the last live box (:98-110)
-                        b[pos] = b[n - 1]
-                        idx[n - 1], idx[pos] = idx[pos], idx[n - 1]
-                        n -= 1
-                        pos -= 1
-            pos += 1
-        i += 1
-    return np.asarray(idx[:n], dtype=np.int64)
+    geom, score = b[:, :4], b[:, 4].copy()
+    n = len(b)
+    where = np.arange(n)                       # where[p] = original index of the box in slot p   (keep_orig, :15)
+    live = n
+    for i in range(n):                         # :18 (iterations with i >= live do nothing)
+        if i >= live:
+            continue
+        seg = score[where[i:live]]
+        best = i + int(np.argmax(seg))         # np.argmax returns the FIRST maximum == the strict '<' scan of :29-34
+        where[[i, best]] = where[[best, i]]    # :45-60
+        a = geom[where[i]]
+        w_all = np.minimum(a[2], geom[:, 2]) - np.maximum(a[0], geom[:, 0]) + shift        # against every box, by original index
+        h_all = np.minimum(a[3], geom[:, 3]) - np.maximum(a[1], geom[:, 1]) + shift
+        area_all = (geom[:, 2] - geom[:, 0] + shift) * (geom[:, 3] - geom[:, 1] + shift)
+        area_a = (a[2] - a[0] + shift) * (a[3] - a[1] + shift)
+        p = i + 1
+        while p < live:                        # :64-112
+            j = where[p]
+            if w_all[j] > 0 and h_all[j] > 0:
+                ov = w_all[j] * h_all[j] / float(area_a + area_all[j] - w_all[j] * h_all[j])
+                if method == 1:
+                    wgt = 1 - ov if ov > Nt else 1
+                elif method == 2:
+                    wgt = math.exp(-(ov * ov) / sigma)
+                else:
+                    wgt = 0 if ov > Nt else 1
+                score[j] = wgt * score[j]
+                if score[j] < threshold:       # :98-110
+                    where[[p, live - 1]] = where[[live - 1, p]]
+                    live -= 1
+                    continue
+            p += 1
+    return where[:live].astype(np.int64)
 
 
 def girshick_nms(dets, thresh, shift=1):
