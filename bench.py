@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--kind", default="clustered", choices=["uniform", "clustered"])
     ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="2: lib/core.py iou; 3: 0.5*(1+GIoU3D) of the corner AABBs from (x,y,z,w,h,l,ry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sorted-scores", action="store_true",
+                    help="feed scores already sorted by descending value, as both reference call sites do (lib/loss/rpn_3d.py:731-737, "
+                         "lib/rpn_util.py:1258-1266): the bit-matrix kernel then reads only the reachable half of the matrix")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: keep processing images of the batch for about this long")
     return ap.parse_args()
 
@@ -75,8 +78,12 @@ def main():
         boxes_np, scores_np = synthetic.batch_2d(1000 + rank, B, N, args.kind)
     else:
         boxes_np, scores_np = synthetic.batch_3d(1000 + rank, B, N, clustered=(args.kind == "clustered"))
-    boxes = torch.from_numpy(boxes_np).to(dev)
-    scores = torch.from_numpy(scores_np).to(dev).requires_grad_(True)
+    if args.sorted_scores:
+        o = np.argsort(-scores_np, axis=1, kind="stable")
+        scores_np = np.take_along_axis(scores_np, o, axis=1)
+        boxes_np = np.take_along_axis(boxes_np, o[:, :, None], axis=1)
+    boxes = torch.from_numpy(np.ascontiguousarray(boxes_np)).to(dev)
+    scores = torch.from_numpy(np.ascontiguousarray(scores_np)).to(dev).requires_grad_(True)
     w = torch.linspace(-1.0, 2.0, N, device=dev).repeat(B, 1).contiguous()
     iou_buf = torch.empty((B, N, N), dtype=torch.float32, device=dev)
 
@@ -102,6 +109,8 @@ def main():
         stream = torch.cuda.current_stream(dev)
         per_box = 16.0 if args.dim == 2 else 28.0
         alg_bytes = B * (4.0 * N * N + 16.0 * N)          # NMS forward 4N^2 + 16N per image
+        if args.sorted_scores:                            # only the columns a leader of the row block can sit in are needed
+            alg_bytes = B * (sum(64 * min(N, 64 * (kb + 1)) for kb in range((N + 63) // 64)) * 4.0 + 16.0 * N)
         alg_bytes_iou = B * (4.0 * N * N + per_box * N)   # IoU-2D 4N^2 + 16N, IoU-3D (params) 4N^2 + 28N
         t_iou = event_time_ms(build_overlaps, 20, stream)
         P = GnmsParams()
@@ -151,7 +160,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%d images/GPU x %d %s %dD boxes/image, nms_threshold 0.4, linear pruning, grouped+masked, group_size 100"
                                    % (B, N, args.kind, args.dim), "boxes_per_image": N, "images_per_gpu": B,
-                       "parallelism": "images sharded, dp%d" % world},
+                       "scores_presorted": bool(args.sorted_scores), "parallelism": "images sharded, dp%d" % world},
             "roofline": dict(roof(t_mask, alg_bytes, "bitmask_kernel"), kernel="bitmask_kernel (gnms_forward: one full read of the NxN fp32 matrix)"),
             "roofline_iou": dict(roof(t_iou, alg_bytes_iou, "iou2d_kernel" if args.dim == 2 else "iou3d_kernel"),
                                  kernel=("iou2d_kernel" if args.dim == 2 else "iou3d_kernel") + " (one full write of the NxN fp32 matrix)"),

@@ -249,16 +249,22 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
         r[e] = (i < n) ? (((u64)gnms_desc_key(s[i]) << 32) | (unsigned)i) : ~0ull;
     }
     block_sort<E, u64>(r, keys, P);
+    int same = 1;
     for (int k = threadIdx.x; k < N; k += blockDim.x) {
         int idx = k;                  // padding ranks map to themselves
         float v = 0.0f;
         if (k < n) { idx = (int)(keys[k] & 0xffffffffu); v = s[idx]; }
+        same &= (idx == k);
         I.order[k] = idx;
         I.rankof[idx] = k;            // order is a permutation of [0,N) (identity on the padding)
         I.sscore[k] = v;
         if (order_out) order_out[(size_t)b * N + k] = idx;
     }
-    if (threadIdx.x < 8) I.misc[threadIdx.x] = 0;
+    // misc[2] = 1 when the scores came in already sorted (both reference call sites do that: lib/loss/rpn_3d.py:731-737,
+    // lib/rpn_util.py:1258-1266): rank == input index, so the bit-matrix kernel can skip the half of the matrix that no
+    // leader can reach and needs no scatter.
+    const int all_same = __syncthreads_and(same);
+    if (threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,9 +299,14 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
     const int kb = blockIdx.y;
     const int n = counts ? counts[b] : N;
     const int k0 = kb * 64;
-    const int c0 = (blockIdx.x * kMaskWaves + wave) * 256;
+    // column chunk rotated by the row block: with pre-sorted scores half the tiles exit below, and an un-rotated grid
+    // would leave that work on every other XCD (blocks are dealt round-robin to the 8 XCDs)
+    const int bx = (blockIdx.x + kb) % gridDim.x;
+    const int c0 = (bx * kMaskWaves + wave) * 256;
     if (k0 >= n || c0 >= n) return;
     ImgPtrs I = img_ptrs(ws, L, b);
+    const bool ident = I.misc[2] != 0;                                   // scores were already sorted: rank == input index
+    if (ident && c0 >= k0 + 64) return;                                  // no leader of this row block lives in these columns
     const float* m = iou + (size_t)b * N * ld;
 
     const int myrank = k0 + lane;
@@ -339,7 +350,10 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
     // scatter each column word to the column's RANK: downstream kernels then read W contiguously
     u64* Wk = I.W + (size_t)kb * L.NC;
     int rk[4];
-    if (VEC && col[3] < n) {
+    if (ident) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rk[j] = col[j];
+    } else if (VEC && col[3] < n) {
         const int4 t = *reinterpret_cast<const int4*>(I.rankof + col[0]);
         rk[0] = t.x; rk[1] = t.y; rk[2] = t.z; rk[3] = t.w;
     } else {
