@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
     const float4 rb = bx[I.order[min(k0 + lane, n - 1)]];
     const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
     const int nrows = min(64, n - k0);
+    const float guard = fmaxf(fabsf(thr), 1.0f) * 9.6e-7f;            // 8 ulp at the threshold's magnitude (>= 1 for tiny thresholds)
     unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -430,14 +431,27 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
             const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), r));
             const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), r));
             const unsigned bit = 1u << rr;
+            // Decision !(inter/uni <= thr).  q = inter * rcp(uni) is within 2.5 ulp of the correctly rounded quotient
+            // (v_rcp_f32: 1 ulp, the product: 0.5 ulp, the quotient's own rounding: 0.5 ulp), so it decides every pair
+            // whose q is further than `guard` (8 ulp) from the threshold; the few pairs inside the guard band -- and
+            // those where q is not finite -- take the exact IEEE division.  Same bits as the matrix path, 1/3 fewer VALU ops.
+            float inter4[4], uni4[4], q4[4];
+            bool unsure = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float w = fmaxf(fminf(ax2, cb[j].z) - fmaxf(ax1, cb[j].x), 0.0f);
                 const float h = fmaxf(fminf(ay2, cb[j].w) - fmaxf(ay1, cb[j].y), 0.0f);
-                const float inter = w * h;
-                const float v = inter / ((aa + carea[j]) - inter);       // row box is `a`, column (leader) box is `b`
-                wd[half][j] |= !(v <= thr) ? bit : 0u;
+                inter4[j] = w * h;
+                uni4[j] = (aa + carea[j]) - inter4[j];                    // row box is `a`, column (leader) box is `b`
+                q4[j] = inter4[j] * __builtin_amdgcn_rcpf(uni4[j]);
+                unsure |= !(fabsf(q4[j] - thr) > guard);                  // also true for NaN / inf
             }
+            if (__any(unsure)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q4[j] = inter4[j] / uni4[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wd[half][j] |= !(q4[j] <= thr) ? bit : 0u;
         }
     }
     const u64 rowmask = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
