@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--kind", default="clustered", choices=["uniform", "clustered"])
     ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="2: lib/core.py iou; 3: 0.5*(1+GIoU3D) of the corner AABBs from (x,y,z,w,h,l,ry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step (IoU + forward + backward through the C ABI, preallocated buffers) in a HIP graph and replay "
+                         "it: removes the per-launch host cost that bounds small problems (N <= 1024)")
     ap.add_argument("--sorted-scores", action="store_true",
                     help="feed scores already sorted by descending value, as both reference call sites do (lib/loss/rpn_3d.py:731-737, "
                          "lib/rpn_util.py:1258-1266): the bit-matrix kernel then reads only the reachable half of the matrix")
@@ -99,6 +102,33 @@ def main():
         torch.autograd.backward(prob, w)          # dL/dprob = w
         return prob
 
+    if args.graph:
+        import ctypes
+        from groomed_nms_amd._lib import GnmsParams, ptr, stream_ptr, check
+        Pg = GnmsParams()
+        lib.gnms_default_params(ctypes.byref(Pg))
+        ws_g = torch.empty((lib.gnms_workspace_bytes(B, N, ctypes.byref(Pg)),), dtype=torch.uint8, device=dev)
+        prob_g = torch.empty((B, N), dtype=torch.float32, device=dev)
+        grad_g = torch.empty((B, N), dtype=torch.float32, device=dev)
+        s_det = scores.detach()
+
+        def raw_step():
+            sp = stream_ptr(dev)
+            if args.dim == 2:
+                check(lib.gnms_iou2d(ptr(boxes), ptr(boxes), B, N, N, ptr(iou_buf), N, sp), "iou2d")
+            else:
+                check(lib.gnms_iou3d_from_params(ptr(boxes), ptr(boxes), B, N, N, 2, None, ptr(iou_buf), N, sp), "iou3d")
+            check(lib.gnms_forward(ptr(s_det), ptr(iou_buf), B, N, N, None, ctypes.byref(Pg), ptr(prob_g), None, None, None, None, None,
+                                   ptr(ws_g), ws_g.numel(), sp), "fwd")
+            check(lib.gnms_backward(ptr(w), ptr(s_det), ptr(iou_buf), B, N, N, None, ctypes.byref(Pg), ptr(grad_g), None, ptr(ws_g),
+                                    ws_g.numel(), sp), "bwd")
+
+        raw_step()
+        torch.cuda.synchronize()
+        hip_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hip_graph):
+            raw_step()
+        step = hip_graph.replay       # noqa: F811  one replay = one full step
     dt = gdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
 
     # ---------------- per-kernel roofline (rank 0), HIP events on the launch stream -----------------
@@ -160,7 +190,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%d images/GPU x %d %s %dD boxes/image, nms_threshold 0.4, linear pruning, grouped+masked, group_size 100"
                                    % (B, N, args.kind, args.dim), "boxes_per_image": N, "images_per_gpu": B,
-                       "scores_presorted": bool(args.sorted_scores), "parallelism": "images sharded, dp%d" % world},
+                       "scores_presorted": bool(args.sorted_scores), "hip_graph_replay": bool(args.graph), "parallelism": "images sharded, dp%d" % world},
             "roofline": dict(roof(t_mask, alg_bytes, "bitmask_kernel"), kernel="bitmask_kernel (gnms_forward: one full read of the NxN fp32 matrix)"),
             "roofline_iou": dict(roof(t_iou, alg_bytes_iou, "iou2d_kernel" if args.dim == 2 else "iou3d_kernel"),
                                  kernel=("iou2d_kernel" if args.dim == 2 else "iou3d_kernel") + " (one full write of the NxN fp32 matrix)"),
