@@ -65,8 +65,13 @@ __global__ __launch_bounds__(256) void softsort_normalize_kernel(const float* __
 }
 
 // D[M x Nn] = A[M x K] * B[K x Nn], fp32, row-major, leading dims lda/ldb/ldd.
-constexpr int BM = 128, BN = 128, BK = 16, LDP = 132;   // LDS row pitch (floats): 128 + 4 keeps 16-B alignment, spreads banks
+// 128x128 block tile, K step 32, 4 waves each owning a 64x64 quadrant = 2x2 MFMA 32x32 tiles (64 accumulator registers).
+// The next K tile is fetched from HBM/L2 into registers (16-byte loads) while the current one is multiplied out of LDS
+// (register-staged double buffering): v_mfma_f32_32x32x2_f32 is 64 cycles per issue, 16 per K tile and wave pair, which
+// covers the ~1 us global latency with two workgroups per CU.
+constexpr int BM = 128, BN = 128, BK = 32, LDP = 132;   // LDS row pitch (floats): 128 + 4 keeps 16-B alignment and spreads banks
 
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D,
                                                          int M, int Nn, int K, long lda, long ldb, long ldd) {
     __shared__ __attribute__((aligned(16))) float As[BK][LDP];   // As[k][m]
@@ -82,28 +87,44 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
+    // staging registers: A tile 128 rows x 32 k = 1024 float4 -> 4 per thread (row = tid/2 + 0/.., k chunk);  B tile 32 k x 128 n -> 4 per thread
+    float4 ra[4], rb[4];
+    const int a_row = tid >> 3, a_k4 = (tid & 7) * 4;            // 32 rows x 8 float4 per pass, 4 passes of 32 rows
+    const int b_k = tid >> 5, b_n4 = (tid & 31) * 4;             // 8 k rows x 32 float4 per pass, 4 passes of 8 k
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int gm = m0 + a_row + 32 * p, gk = k0 + a_k4;
+            if (ALIGNED && gm < M && gk + 3 < K) ra[p] = *reinterpret_cast<const float4*>(A + (size_t)gm * lda + gk);
+            else {
+                float t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = (gm < M && gk + u < K) ? A[(size_t)gm * lda + gk + u] : 0.0f;
+                ra[p] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+            const int gkb = k0 + b_k + 8 * p, gn = n0 + b_n4;
+            if (ALIGNED && gkb < K && gn + 3 < Nn) rb[p] = *reinterpret_cast<const float4*>(Bm + (size_t)gkb * ldb + gn);
+            else {
+                float t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = (gkb < K && gn + u < Nn) ? Bm[(size_t)gkb * ldb + gn + u] : 0.0f;
+                rb[p] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = a_row + 32 * p;
+            As[a_k4 + 0][row] = ra[p].x; As[a_k4 + 1][row] = ra[p].y; As[a_k4 + 2][row] = ra[p].z; As[a_k4 + 3][row] = ra[p].w;
+            *reinterpret_cast<float4*>(&Bs[b_k + 8 * p][b_n4]) = rb[p];
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < K; k0 += BK) {
-        // A tile: 128 rows x 16 k  -> As[k][m]; thread t loads row t/2.., 8 consecutive k
-        {
-            const int row = tid >> 1, kk = (tid & 1) * 8;
-            const int gm = m0 + row;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int gk = k0 + kk + u;
-                As[kk + u][row] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.0f;
-            }
-        }
-        // B tile: 16 k x 128 n -> Bs[k][n]; thread t loads k = t/16, 8 consecutive n
-        {
-            const int kk = tid >> 4, nn = (tid & 15) * 8;
-            const int gk = k0 + kk;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int gn = n0 + nn + u;
-                Bs[kk][nn + u] = (gk < K && gn < Nn) ? Bm[(size_t)gk * ldb + gn] : 0.0f;
-            }
-        }
+        stage();
         __syncthreads();
+        if (k0 + BK < K) fetch(k0 + BK);                          // in flight while the MFMAs below run
 #pragma unroll
         for (int ks = 0; ks < BK; ks += 2) {
             const int kr = ks + (lane >> 5);
@@ -142,7 +163,9 @@ extern "C" int gnms_sgemm(const float* A, const float* B, float* D, int M, int N
     if (M == 0 || N == 0) return GNMS_OK;
     GNMS_CHECK_ARG(A && B && D, "gnms_sgemm: null pointer");
     dim3 grid(gnms_div_up(N, BN), gnms_div_up(M, BM));
-    sgemm_mfma_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd);
+    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
+    if (aligned) sgemm_mfma_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd);
+    else sgemm_mfma_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
