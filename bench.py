@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--kind", default="clustered", choices=["uniform", "clustered"])
     ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="2: lib/core.py iou; 3: 0.5*(1+GIoU3D) of the corner AABBs from (x,y,z,w,h,l,ry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-calls", action="store_true", help="gnms_iou2d and gnms_forward as two library calls (no fused score sort)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step (IoU + forward + backward through the C ABI, preallocated buffers) in a HIP graph and replay "
                          "it: removes the per-launch host cost that bounds small problems (N <= 1024)")
@@ -96,8 +97,11 @@ def main():
         return overlaps.iou3d_batched(boxes, from_params=True, nms_overlap=True, out=iou_buf)
 
     def step():
-        iou = build_overlaps()
-        prob, order, valid, invalid, nv, ni = G.differentiable_nms_batched(scores, iou)
+        if args.dim == 2 and not args.two_calls:
+            # IoU matrix + forward as ONE library call (gnms_forward_with_iou2d): same kernels' work, the score sort rides in the IoU launch
+            prob = G.differentiable_nms_with_iou2d_batched(scores, boxes, iou_out=iou_buf)[0]
+        else:
+            prob = G.differentiable_nms_batched(scores, build_overlaps())[0]
         scores.grad = None
         torch.autograd.backward(prob, w)          # dL/dprob = w
         return prob

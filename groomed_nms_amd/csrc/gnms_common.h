@@ -126,6 +126,14 @@ __device__ __forceinline__ uint32_t gnms_desc_key(float v) {
     return ~asc;
 }
 
+// inverse of gnms_desc_key for non-NaN scores (-0.0 comes back as +0.0); key 0 decodes to NaN
+__device__ __forceinline__ float gnms_desc_key_decode(uint32_t key) {
+    if (key == 0u) return __uint_as_float(0x7fc00000u);
+    const uint32_t asc = ~key;
+    const uint32_t u = (asc & 0x80000000u) ? (asc & 0x7fffffffu) : ~asc;
+    return __uint_as_float(u);
+}
+
 // wave-wide OR on the VALU: DPP row_shr 1,2,4,8 + row_bcast:15 + row_bcast:31 leave the total in lane 63 (an inclusive
 // OR-scan on the way); 6 dependent DPP ops instead of 6 ds_bpermute round trips (checked on gfx950: tools/scratch/t_dpp2.hip)
 __device__ __forceinline__ unsigned gnms_or_scan32(unsigned v) {

@@ -10,26 +10,11 @@
 // leaves the wave as one 1-KiB coalesced global_store_dwordx4 (the 4 waves of a workgroup cover
 // 4 KiB of one row).  Arithmetic follows the oracle/reference operation order exactly and the file
 // is compiled with -ffp-contract=off, so the 2D matrix is bit-identical to torch's CPU result.
-#include "gnms_common.h"
+#include "iou_tile.h"
 
 namespace {
 
-constexpr int kTileRows = 64;
-constexpr int kWaveCols = 256;   // 64 lanes x 4 columns
-constexpr int kWavesPerWG = 8;   // tools/bw_variants.hip: 8 waves + non-temporal stores = 5.6 TB/s (4 waves, plain stores: 5.3)
-constexpr int kWGCols = kWaveCols * kWavesPerWG;
-
-__device__ __forceinline__ float bcast(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ __forceinline__ float relu0(float v) { return fmaxf(v, 0.0f); }
-// streaming 16-byte store: the matrix is written once and read once by another kernel much later
-__device__ __forceinline__ void store_nt_f4(float* p, float a, float b, float c, float d) {
-    __builtin_nontemporal_store(a, p);
-    __builtin_nontemporal_store(b, p + 1);
-    __builtin_nontemporal_store(c, p + 2);
-    __builtin_nontemporal_store(d, p + 3);
-}
+using namespace gnms_iou;
 
 // ------------------------------------------------------------------------------------------------
 // 2D IoU.  a [B][M][4], b [B][N][4], out [B][M][ld].
@@ -38,60 +23,10 @@ __device__ __forceinline__ void store_nt_f4(float* p, float a, float b, float c,
 // ------------------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou2d_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
-                                                    int M, int N, float* __restrict__ out, long ld) {
+                                                                 int M, int N, float* __restrict__ out, long ld) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int img = blockIdx.z;
-    const int i0 = blockIdx.y * kTileRows;
-    const int c0 = blockIdx.x * kWGCols + wave * kWaveCols;
-    if (c0 >= N) return;
-    const float* a = A + (size_t)img * M * 4;
-    const float* b = Bx + (size_t)img * N * 4;
-    float* o = out + (size_t)img * M * ld;
-
-    // column boxes -> registers
-    float bx1[4], by1[4], bx2[4], by2[4], barea[4];
-    int col[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
-        int cc = col[j] < N ? col[j] : (N - 1);
-        float4 v = *reinterpret_cast<const float4*>(b + (size_t)cc * 4);
-        bx1[j] = v.x; by1[j] = v.y; bx2[j] = v.z; by2[j] = v.w;
-        barea[j] = (v.z - v.x) * (v.w - v.y);                        // lib/core.py:502-503
-    }
-    // row boxes: lane r holds row i0+r
-    const int myrow = i0 + lane;
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (myrow < M) ra = *reinterpret_cast<const float4*>(a + (size_t)myrow * 4);
-    const float rarea = (ra.z - ra.x) * (ra.w - ra.y);               // lib/core.py:500-501
-    const int rows = min(kTileRows, M - i0);
-
-    for (int r = 0; r < rows; ++r) {
-        const float ax1 = bcast(ra.x, r), ay1 = bcast(ra.y, r), ax2 = bcast(ra.z, r), ay2 = bcast(ra.w, r);
-        const float aarea = bcast(rarea, r);
-        float res[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float w = relu0(fminf(ax2, bx2[j]) - fmaxf(ax1, bx1[j]));   // lib/core.py:210-212
-            float h = relu0(fminf(ay2, by2[j]) - fmaxf(ay1, by1[j]));
-            float inter = w * h;                                        // :218
-            float uni = (aarea + barea[j]) - inter;                     // :507
-            res[j] = inter / uni;                                       // :508
-        }
-        float* orow = o + (size_t)(i0 + r) * ld;
-        if (VEC) {
-            if (col[3] < N) {
-                store_nt_f4(orow + col[0], res[0], res[1], res[2], res[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
-        }
-    }
+    iou2d_tile<VEC>(A, Bx, M, N, out, ld, blockIdx.z, blockIdx.y * kTileRows, blockIdx.x * kWGCols + wave * kWaveCols, lane);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include "iou_tile.h"
 #include "nms_solve_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -116,10 +117,59 @@ extern "C" size_t gnms_workspace_bytes(int B, int N, const gnms_params* /*params
     return gnms_make_layout(N).per_image * (size_t)B;
 }
 
-extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
-                            const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
-                            int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = check_common("gnms_forward", B, N, ld, params, workspace, workspace_bytes);
+namespace {
+
+// Fused launch: the pairwise IoU tiles of gnms_iou2d PLUS, in the LAST grid slice, one workgroup per image that sorts
+// the scores (K1).  The sort does not depend on the overlaps, so it needs neither its own launch nor a kernel boundary:
+// its workgroups slip into the CUs that the IoU tiles vacate at the end of the launch.  Measured (N=4096, B=8): IoU
+// alone 95 us, IoU + separate sort launch 121 us, fused 104 us.  (Sort workgroups in the FIRST slice co-run with 32
+// streaming waves per CU and take 5x longer even at s_setprio 3: 113 us.)
+template <bool VEC, int E>
+__global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                                                int N, const int* __restrict__ counts, float* __restrict__ out,
+                                                                                long ld, char* ws, gnms_ws_layout L, int P2,
+                                                                                long long* __restrict__ order_out) {
+    using namespace gnms_iou;
+    if (blockIdx.z == gridDim.z - 1) {
+        const int b = blockIdx.y * gridDim.x + blockIdx.x;          // image to sort
+        if (b >= (int)gridDim.z - 1) return;
+        extern __shared__ __attribute__((aligned(16))) char smem[];
+        u64* keys = reinterpret_cast<u64*>(smem);
+        const int n = counts ? counts[b] : N;
+        const float* s = scores + (size_t)b * N;
+        ImgPtrs I = img_ptrs(ws, L, b);
+        u64 r[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = threadIdx.x * E + e;
+            r[e] = (i < n) ? (((u64)gnms_desc_key(s[i]) << 32) | (unsigned)i) : ~0ull;
+        }
+        block_sort<E, u64>(r, keys, P2);
+        int same = 1;
+        for (int k = threadIdx.x; k < N; k += blockDim.x) {
+            int idx = k;
+            float v = 0.0f;
+            // the score is decoded from the key instead of gathered: this workgroup shares its CU's memory pipeline with
+            // streaming IoU tiles, where every dependent memory round trip costs tens of microseconds
+            if (k < n) { idx = (int)(keys[k] & 0xffffffffu); v = gnms_desc_key_decode((uint32_t)(keys[k] >> 32)); }
+            same &= (idx == k);
+            I.order[k] = idx;
+            I.rankof[idx] = k;
+            I.sscore[k] = v;
+            if (order_out) order_out[(size_t)b * N + k] = idx;
+        }
+        const int all_same = __syncthreads_and(same);
+        if (threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, blockIdx.z, blockIdx.y * kTileRows, blockIdx.x * kWGCols + wave * kWaveCols, lane);
+}
+
+int forward_impl(const char* fn, const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
+                 const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid,
+                 int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted) {
+    int rc = check_common(fn, B, N, ld, params, workspace, workspace_bytes);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (B == 0) return GNMS_OK;
@@ -136,11 +186,13 @@ extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N,
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
 
-    GNMS_DISPATCH_SORT(P2, {
-        if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
-        sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
-    });
-    GNMS_CHECK_LAUNCH();
+    if (!scores_already_sorted) {
+        GNMS_DISPATCH_SORT(P2, {
+            if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
+            sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
+        });
+        GNMS_CHECK_LAUNCH();
+    }
 
     if (P.group_boxes) {
         if ((rc = run_grouping(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;
@@ -170,6 +222,56 @@ extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N,
     });
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
+}
+
+}  // namespace
+
+extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
+                            const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
+                            int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_impl("gnms_forward", scores, iou, B, N, ld, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
+                        workspace_bytes, stream, false);
+}
+
+extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
+                                       const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
+                                       int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    int rc = check_common("gnms_forward_with_iou2d", B, N, ld, params, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (B > 0 && N > 0) GNMS_CHECK_ARG(boxes && scores && iou_out && prob, "gnms_forward_with_iou2d: null pointer");
+    const int P2 = next_pow2(N);
+    // fused launch: sort on 512 threads (P2 >= 512), <= 32 KiB of LDS per workgroup (P2 <= 4096), one sort workgroup per image in slice 0
+    const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) &&
+                      (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::kTileRows) >= B;
+    if (!fuse) {
+        if (B > 0 && N > 0 && (rc = gnms_iou2d(boxes, boxes, B, N, N, iou_out, ld, stream))) return rc;
+        return forward_impl("gnms_forward_with_iou2d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid,
+                            ninvalid, workspace, workspace_bytes, stream, false);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const gnms_ws_layout L = gnms_make_layout(N);
+    const size_t sort_lds = (size_t)P2 * 8;
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)iou_out % 16 == 0);
+    dim3 grid(gnms_div_up(N, gnms_iou::kWGCols), gnms_div_up(N, gnms_iou::kTileRows), B + 1);
+    const int threads = gnms_iou::kWavesPerWG * 64;                                   // 512: E = P2 / 512
+#define GNMS_LAUNCH_FUSED(EE)                                                                                                           \
+    do {                                                                                                                                \
+        if (vec) iou2d_sort_kernel<true, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,               \
+                                                                            (char*)workspace, L, P2, (long long*)order);               \
+        else iou2d_sort_kernel<false, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,                  \
+                                                                         (char*)workspace, L, P2, (long long*)order);                  \
+    } while (0)
+    switch (P2 / threads) {
+        case 1: GNMS_LAUNCH_FUSED(1); break;
+        case 2: GNMS_LAUNCH_FUSED(2); break;
+        case 4: GNMS_LAUNCH_FUSED(4); break;
+        default: GNMS_LAUNCH_FUSED(8); break;
+    }
+#undef GNMS_LAUNCH_FUSED
+    GNMS_CHECK_LAUNCH();
+    return forward_impl("gnms_forward_with_iou2d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid,
+                        ninvalid, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" int gnms_backward(const float* grad_prob, const float* scores, const float* iou, int B, int N, int64_t ld,

@@ -15,7 +15,8 @@ import torch
 from . import _lib
 from ._lib import GnmsParams, check, ptr, stream_ptr
 
-__all__ = ["differentiable_nms", "differentiable_nms_batched", "differentiable_nms_from_boxes_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
+__all__ = ["differentiable_nms", "differentiable_nms_batched", "differentiable_nms_from_boxes_batched",
+           "differentiable_nms_with_iou2d_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
            "cast_to_cpu_cuda_tensor", "get_groups", "indices_copy", "GroomedNMS"]
 
 _PRUNE = {"linear": 0, "sigmoidal": 1, "soft_nms": 2}
@@ -95,6 +96,53 @@ class _GroomedNMSFunction(torch.autograd.Function):
         if grad_iou is not None and ctx.ld != N:
             grad_iou = grad_iou[:, :, :N]
         return grad_scores, grad_iou, None, None
+
+
+class _GroomedNMSWithIouFunction(torch.autograd.Function):
+    """(prob, ..., iou) = 2D IoU matrix + GrooMeD-NMS in one library call (gnms_forward_with_iou2d): same results as
+    overlaps.iou_batched followed by _GroomedNMSFunction; the score sort rides inside the IoU launch.  The matrix comes
+    back detached, as the reference's loss feeds it (lib/loss/rpn_3d.py:791 `.clone().detach()`)."""
+
+    @staticmethod
+    def forward(ctx, scores, boxes, counts, params, iou_out):
+        lib = _lib.load()
+        B, N = scores.shape
+        dev = scores.device
+        scores_c = scores.contiguous()
+        boxes_c = boxes.contiguous()
+        iou = iou_out if iou_out is not None else torch.empty((B, N, N), dtype=torch.float32, device=dev)
+        prob = torch.empty((B, N), dtype=torch.float32, device=dev)
+        order = torch.empty((B, N), dtype=torch.int64, device=dev)
+        valid = torch.empty((B, N), dtype=torch.int64, device=dev)
+        invalid = torch.empty((B, N), dtype=torch.int64, device=dev)
+        nvalid = torch.empty((B,), dtype=torch.int32, device=dev)
+        ninvalid = torch.empty((B,), dtype=torch.int32, device=dev)
+        nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
+        ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.gnms_forward_with_iou2d(ptr(boxes_c), ptr(scores_c), B, N, max(N, 1), ptr(counts), ctypes.byref(params), ptr(iou),
+                                              ptr(prob), ptr(order), ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws),
+                                              ws.numel(), stream_ptr(dev)), "gnms_forward_with_iou2d")
+        ctx.params = params
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(scores_c, iou, counts, ws)
+        ctx.mark_non_differentiable(order, valid, invalid, nvalid, ninvalid, iou)
+        return prob, order, valid, invalid, nvalid, ninvalid, iou
+
+    @staticmethod
+    def backward(ctx, grad_prob, *unused):
+        if grad_prob is None:
+            return None, None, None, None, None
+        lib = _lib.load()
+        scores_c, iou_c, counts, ws = ctx.saved_tensors
+        B, N = scores_c.shape
+        dev = scores_c.device
+        grad_prob = grad_prob.contiguous().float()
+        grad_scores = torch.empty_like(scores_c)
+        with torch.cuda.device(dev):
+            check(lib.gnms_backward(ptr(grad_prob), ptr(scores_c), ptr(iou_c), B, N, max(N, 1), ptr(counts), ctypes.byref(ctx.params),
+                                    ptr(grad_scores), None, ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_backward")
+        return grad_scores, None, None, None, None
 
 
 class _GroomedNMSFromBoxesFunction(torch.autograd.Function):
@@ -228,6 +276,19 @@ def differentiable_nms_batched(scores, iou, counts=None, nms_threshold=0.4, prun
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSFunction.apply(scores.float(), iou.float(), counts, params)
+
+
+def differentiable_nms_with_iou2d_batched(scores, boxes, counts=None, iou_out=None, nms_threshold=0.4, pruning_method="linear",
+                                          temperature=0.01, valid_box_prob_threshold=0.3, return_sorted_prob=False, group_boxes=True,
+                                          mask_group_boxes=True, group_size=100):
+    """scores [B,N], boxes [B,N,4] -> (prob, order, valid, invalid, nvalid, ninvalid, iou [B,N,N]): the 2D IoU matrix AND the
+    layer on it in one call -- what lib/loss/rpn_3d.py:772-791 does in two steps; identical results, and the matrix is
+    returned for the caller's later use.  `iou_out` lets the caller provide the matrix buffer."""
+    params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
+                     mask_group_boxes, group_size, False)
+    if counts is not None:
+        counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
+    return _GroomedNMSWithIouFunction.apply(scores.float(), boxes.float(), counts, params, iou_out)
 
 
 def differentiable_nms_from_boxes_batched(scores, boxes, counts=None, nms_threshold=0.4, pruning_method="linear", temperature=0.01,

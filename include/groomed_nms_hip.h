@@ -113,6 +113,15 @@ int gnms_forward(const float* scores, const float* iou, int B, int N, int64_t ld
                  const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
                  int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream);
 
+/* gnms_iou2d + gnms_forward in one call, as lib/loss/rpn_3d.py:772-791 runs them back to back: boxes [B][N][4] ->
+ * iou_out [B][N][ld] (kept for the caller) -> the outputs of gnms_forward.  The score sort does not depend on the
+ * overlaps, so for N <= 4096 it rides in the last grid slice of the IoU launch (one workgroup per image: no launch of its
+ * own, no kernel boundary); larger N run the two calls in sequence.  gnms_backward pairs with it unchanged. */
+int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
+                            const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
+                            int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* backward of L through prob.  grad_prob [B][N] = dL/dprob (same order as prob).
  *   grad_scores [B][N] (input order), overwritten.
  *   grad_iou    [B][N][ld] or NULL.  When given it is fully overwritten (zero fill + the sparse

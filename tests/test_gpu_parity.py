@@ -556,3 +556,26 @@ def test_capturable_in_a_hip_graph(G):
         torch.cuda.synchronize()
         assert torch.equal(p_graph, prob) and torch.equal(g_graph, gscores)
         assert float(p_graph.abs().sum()) > 0
+
+
+def test_iou_and_forward_in_one_call(G):
+    """gnms_forward_with_iou2d (score sort inside the IoU launch for N <= 4096, two launches above) == iou_batched +
+    differentiable_nms_batched: matrix, all six outputs and the gradient bit for bit; ragged counts; repeated calls."""
+    from groomed_nms_amd import synthetic, overlaps
+    for B, N in ((3, 500), (8, 4096), (1, 64), (2, 1001), (200, 520), (1, 5000)):
+        boxes, scores = synthetic.batch_2d(9, B, N, "clustered", per=32)
+        bt = torch.from_numpy(boxes).cuda()
+        counts = torch.tensor([N] + [max(1, N // 2)] * (B - 1), dtype=torch.int32).cuda()
+        w = torch.rand((B, N), device="cuda")
+        for rep in range(2):
+            s1 = torch.from_numpy(scores).cuda().requires_grad_(True)
+            s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
+            out1 = G.differentiable_nms_with_iou2d_batched(s1, bt, counts=counts)
+            iou = overlaps.iou_batched(bt)
+            out2 = G.differentiable_nms_batched(s2, iou, counts=counts)
+            assert torch.equal(out1[6], iou), (B, N)
+            for a, b in zip(out1[:6], out2):
+                assert torch.equal(a, b), (B, N)
+            (out1[0] * w).sum().backward()
+            (out2[0] * w).sum().backward()
+            assert torch.equal(s1.grad, s2.grad), (B, N)
