@@ -98,6 +98,13 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
 }
 
 #ifdef __HIPCC__
+// number of boxes of image b: counts[b] clamped to [0, N] (a bad count must not turn into an out-of-bounds access)
+__device__ __forceinline__ int gnms_count(const int* __restrict__ counts, int b, int N) {
+    if (!counts) return N;
+    const int c = counts[b];
+    return c < 0 ? 0 : (c > N ? N : c);
+}
+
 // pruning_function (lib/groomed_nms.py:167-189) and its derivative, fp32, same expression order as the oracle
 __device__ __forceinline__ float gnms_prune(float x, float thr, float temp, int method) {
     if (method == GNMS_PRUNE_LINEAR) return x;

@@ -18,7 +18,7 @@ namespace gnms {
 __global__ __launch_bounds__(256) void bwd_gx_kernel(const float* __restrict__ grad_prob, int N, const int* __restrict__ counts,
                                                      gnms_params P, char* ws, gnms_ws_layout L) {
     const int b = blockIdx.y;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N) return;
     ImgPtrs I = img_ptrs(ws, L, b);
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void bwd_gx_kernel(const float* __restrict__ g
 __global__ __launch_bounds__(256) void bwd_masked_fused_kernel(const float* __restrict__ grad_prob, int N, const int* __restrict__ counts,
                                                                gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores) {
     const int b = blockIdx.y;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     ImgPtrs I = img_ptrs(ws, L, b);
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void bwd_masked_fused_kernel(const float* __re
 __global__ __launch_bounds__(256) void bwd_masked_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                                          float* __restrict__ grad_scores) {
     const int b = blockIdx.y;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     ImgPtrs I = img_ptrs(ws, L, b);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void bwd_masked_heads_kernel(int N, gnms_param
 __global__ __launch_bounds__(256) void bwd_masked_iou_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                                              gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_iou) {
     const int b = blockIdx.y;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     ImgPtrs I = img_ptrs(ws, L, b);

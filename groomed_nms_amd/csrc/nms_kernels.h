@@ -239,7 +239,7 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
     const int b = blockIdx.x;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     const float* s = scores + (size_t)b * N;
     ImgPtrs I = img_ptrs(ws, L, b);
     u64 r[E];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
     const int kb = blockIdx.y;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     const int k0 = kb * 64;
     // column chunk rotated by the row block: with pre-sorted scores half the tiles exit below, and an un-rotated grid
     // would leave that work on every other XCD (blocks are dealt round-robin to the 8 XCDs)
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
                                                             float thr, char* ws, gnms_ws_layout L) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= tri_tile_count(L.NB)) return;
     int kb, chunk;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restr
     int* pair_b = reinterpret_cast<int*>(smem + op);             // [kSBPairs]
     int* pair_bp = pair_b + kSBPairs;
     const int b = blockIdx.x;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = (n + 63) >> 6;
@@ -674,7 +674,7 @@ __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
 
 __global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
     const int b = blockIdx.y, kb = blockIdx.x;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     const int k0 = kb << 6;
     if (k0 >= n) return;
     ImgPtrs I = img_ptrs(ws, L, b);
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
     unsigned* keys = reinterpret_cast<unsigned*>(smem);          // (leader rank << 14) | rank : 28 bits (N <= 16384)
     unsigned* info = keys + Ppow2;                               // per rank: head | pos << 14, or ~0 (in no group)
     const int b = blockIdx.x;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
     const float thr = P.nms_threshold;
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __rest
     u64* keys = reinterpret_cast<u64*>(smem);                     // [Ppow2]
     __shared__ u64 wave_tot[16];
     const int b = blockIdx.x;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const float vthr = P.valid_box_prob_threshold;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, T = blockDim.x;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
         if (b >= (int)gridDim.z - 1) return;
         extern __shared__ __attribute__((aligned(16))) char smem[];
         u64* keys = reinterpret_cast<u64*>(smem);
-        const int n = counts ? counts[b] : N;
+        const int n = gnms_count(counts, b, N);
         const float* s = scores + (size_t)b * N;
         ImgPtrs I = img_ptrs(ws, L, b);
         u64 r[E];

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64) void solve_groups_kernel(const float* __restric
     float* acc = reinterpret_cast<float*>(sq + kGroupMaxMembers);
     float* Pl = acc + kGroupMaxMembers;
     const int b = blockIdx.y, k = blockIdx.x;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int lane = threadIdx.x;
     if (k >= n) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024) void ungrouped_forward_kernel(const float* __
     float* T = xin + ((N + 3) & ~3);
     float* xb = T + 64 * 65;
     const int b = blockIdx.x;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = iou + (size_t)b * N * ld;
     const float* s = scores + (size_t)b * N;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(1024) void ungrouped_backward_kernel(const float* _
     float* T = ain + ((N + 3) & ~3);
     float* yb = T + 64 * 65;
     const int b = blockIdx.x;
-    const int n = counts ? counts[b] : N;
+    const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = iou + (size_t)b * N * ld;
     float* gi = grad_iou ? grad_iou + (size_t)b * N * ld : nullptr;
