@@ -192,6 +192,19 @@ size_t gnms_nms_workspace_bytes(int n);
 int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int32_t* keep, int32_t* num_out,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * After-NMS AP loss (lib/loss/aploss.py:14-87 backpropAPLoss.forward, called per image on the rescored
+ * scores at lib/loss/rpn_3d.py:1117-1131): the immediate consumer of gnms_forward's `prob`.
+ *   logits, targets: [B][N] fp32 (image b uses its first counts[b] entries, all N when counts is NULL).
+ *   loss: [B] = 1 - mean precision of the positives; grad: [B][N] = d loss / d logits, both produced by the
+ *   forward pass as in the reference (:69-78; its backward only scales grad by the incoming gradient, :80-85).
+ *   An image without a positive (max(targets) <= 0, :26-28) gets loss 0 and a zero gradient.
+ *   delta is 1.0 whatever the caller of the reference passes (:16).  N <= 4096 (GNMS_ERR_UNSUPPORTED above).
+ * ------------------------------------------------------------------------------------------------ */
+#define GNMS_APLOSS_MAX_BOXES 4096
+int gnms_aploss(const float* logits, const float* targets, int B, int N, const int32_t* counts, float positive_label,
+                float negative_label, float* loss, float* grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

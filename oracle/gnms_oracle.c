@@ -494,3 +494,74 @@ void gnms_oracle_classic_nms(const float* boxes, int64_t n, int64_t boxes_dim, f
     *num_out = k;
     free(removed);
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* lib/loss/aploss.py:14-78 backpropAPLoss.forward (AP-loss, Chen et al. CVPR 2019): the consumer  */
+/* of the rescored scores (lib/loss/rpn_3d.py:1117-1131), SURVEY 8-f1.                             */
+/*   loss_out[0] = 1 - mean interpolated precision (:76-78); grad[n] = d loss / d logits (:69-74), */
+/*   which the reference computes in forward and multiplies by grad_output in backward (:80-85).   */
+/* delta is forced to 1.0 by the reference (:16) whatever the caller passes.  Row sums are taken   */
+/* in double (torch.sum's vectorised fp32 order is not reproducible; compared at 1e-5).            */
+/* ------------------------------------------------------------------------------------------- */
+void gnms_oracle_aploss(const float* logits, const float* targets, int64_t n, float positive_label, float negative_label,
+                        float* loss_out, float* grad) {
+    const float delta = 1.0f;                                                    /* :16 */
+    for (int64_t i = 0; i < n; ++i) grad[i] = 0.0f;                              /* :18 */
+    loss_out[0] = 0.0f;                                                          /* :19 metric = zeros(1) */
+    float tmax = -INFINITY;
+    for (int64_t i = 0; i < n; ++i) if (targets[i] > tmax) tmax = targets[i];
+    if (n == 0 || tmax <= 0.0f) return;                                          /* :26-28 */
+    int64_t* fg = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+    int64_t* bg = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
+    int64_t F = 0, G = 0;
+    float fmin = INFINITY;
+    for (int64_t i = 0; i < n; ++i) if (targets[i] == positive_label) { fg[F++] = i; if (logits[i] < fmin) fmin = logits[i]; }   /* :30-31 */
+    if (F == 0) { free(fg); free(bg); return; }   /* max(targets) > 0 without any positive_label entry: torch.min of an empty tensor raises */
+    const float threshold_logit = fmin - delta;                                  /* :32 */
+    for (int64_t i = 0; i < n; ++i) if (targets[i] == negative_label && logits[i] >= threshold_logit) bg[G++] = i;           /* :35 */
+    float* bg_grad = (float*)calloc((size_t)(G > 0 ? G : 1), sizeof(float));     /* :37 */
+    float* prec = (float*)calloc((size_t)F, sizeof(float));                      /* :44 */
+    float* fgv = (float*)malloc(sizeof(float) * (size_t)F);
+    int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)F);
+    for (int64_t k = 0; k < F; ++k) fgv[k] = -logits[fg[k]];
+    gnms_oracle_argsort_desc(fgv, F, order);                                     /* ascending sort of fg_logits (:47), stable */
+    float max_prec = 0.0f;                                                       /* :48 */
+    float* tmp2 = (float*)malloc(sizeof(float) * (size_t)(G > 0 ? G : 1));
+    for (int64_t oi = 0; oi < F; ++oi) {                                         /* :50 */
+        const int64_t ii = order[oi];
+        const float x = logits[fg[ii]];
+        double sa = 0.0, sb = 0.0;
+        for (int64_t k = 0; k < F; ++k) {                                        /* :52-53 */
+            float t = (logits[fg[k]] - x) / (2 * delta) + 0.5f;
+            t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+            sa += t;
+        }
+        for (int64_t j = 0; j < G; ++j) {                                        /* :55-56 */
+            float t = (logits[bg[j]] - x) / (2 * delta) + 0.5f;
+            t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+            tmp2[j] = t;
+            sb += t;
+        }
+        const float a = (float)sa + 0.5f;                                        /* :58 */
+        const float b = (float)sb;                                               /* :60 */
+        const float denom = a + b;
+        const float current_prec = a / denom;                                    /* :62 */
+        float scale = 1.0f;
+        int rescale = 0;
+        if (max_prec <= current_prec) max_prec = current_prec;                   /* :63-64 */
+        else { scale = (1 - max_prec) / (1 - current_prec); rescale = 1; }       /* :65-66 */
+        for (int64_t j = 0; j < G; ++j) {
+            float t = tmp2[j] / denom;                                           /* :61 */
+            if (rescale) t *= scale;                                             /* :66 */
+            bg_grad[j] += t;                                                     /* :67 */
+        }
+        prec[ii] = max_prec;                                                     /* :68 */
+    }
+    const float fnum = (float)(F > 1 ? F : 1);                                   /* :73 */
+    for (int64_t j = 0; j < G; ++j) grad[bg[j]] = bg_grad[j];                    /* :70 */
+    double sp = 0.0;
+    for (int64_t k = 0; k < F; ++k) { grad[fg[k]] = -(1 - prec[k]); sp += prec[k]; }   /* :71 */
+    for (int64_t i = 0; i < n; ++i) grad[i] /= fnum;                             /* :75 */
+    loss_out[0] = 1.0f - (float)sp / fnum;                                       /* :77-78 */
+    free(fg); free(bg); free(bg_grad); free(prec); free(fgv); free(order); free(tmp2);
+}

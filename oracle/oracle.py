@@ -227,3 +227,14 @@ def classic_nms(dets, thresh, rule="gpu"):
     order = dets[:, 4].argsort()[::-1]
     keep = classic_nms_sorted(dets[order], thresh, rule)
     return [int(i) for i in order[keep]]
+
+
+def aploss(logits, targets, positive_label=1, negative_label=0):
+    """lib/loss/aploss.py:14-78: returns (loss, grad) with grad = d loss / d logits (the reference stores it in forward)."""
+    logits, targets = _f32(logits), _f32(targets)
+    n = len(logits)
+    loss = np.zeros(1, np.float32)
+    grad = np.zeros(n, np.float32)
+    lib().gnms_oracle_aploss(_p(logits), _p(targets), ctypes.c_int64(n), ctypes.c_float(positive_label), ctypes.c_float(negative_label),
+                             _p(loss), _p(grad))
+    return float(loss[0]), grad

@@ -14,6 +14,7 @@ Reference entry points exercised (file:line under /root/reference):
   lib/core.py:480         iou                     lib/core.py:305         iou3d_approximate
   lib/math_3d.py:364      get_corners_of_cuboid
   lib/nms/py_cpu_nms.py:10 py_cpu_nms             lib/nms_others.py:6,119 navneeth_soft_nms, girshick_nms
+  lib/loss/aploss.py:14   backpropAPLoss / APLoss (the consumer of the rescored scores)
 Known-answer vectors KAT-1/KAT-2 come from test/test_differentiable_nms_forward.py:127-140.
 
 Inputs are stored next to outputs: RNG streams differ across library versions, so nothing is ever
@@ -376,7 +377,45 @@ def main():
                                              method=method, shift=1), np.int64)
     np.savez_compressed(os.path.join(OUT, "misc.npz"), **misc)
 
-    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz"):
+    # ------------------------------------------------------------------ after-NMS AP loss (lib/loss/aploss.py)
+    spec = importlib.util.spec_from_file_location("ref_aploss", REF + "/lib/loss/aploss.py")
+    apm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(apm)
+    apg = {}
+
+    def ap_case(tag, logits, targets, upstream=1.0):
+        x = torch.from_numpy(logits).clone().requires_grad_(True)
+        t = torch.from_numpy(targets)
+        loss = apm.APLoss()(x, t)
+        (loss.sum() * upstream).backward()
+        apg[f"{tag}/logits"] = logits
+        apg[f"{tag}/targets"] = targets
+        apg[f"{tag}/loss"] = loss.detach().numpy().reshape(-1).astype(np.float32)
+        apg[f"{tag}/grad"] = x.grad.numpy().astype(np.float32)
+        apg[f"{tag}/upstream"] = np.array(upstream, np.float32)
+
+    for n, npos in ((12, 3), (50, 1), (50, 10), (257, 20), (500, 37), (500, 499), (1000, 120)):
+        lg = rng.uniform(0, 1, size=n).astype(np.float32)          # rescored probabilities live in [0, 1]
+        tg = np.zeros(n, np.float32)
+        tg[rng.choice(n, size=npos, replace=False)] = 1
+        ap_case(f"u{n}_{npos}", lg, tg)
+    lg = rng.normal(0, 3, size=300).astype(np.float32)             # raw logits: the clamp saturates
+    tg = (rng.uniform(size=300) < 0.1).astype(np.float32)
+    ap_case("wide300", lg, tg, upstream=0.05)                      # after_nms_lambda
+    tg2 = tg.copy()
+    tg2[rng.choice(300, size=40, replace=False)] = -1              # ignored label: neither positive nor negative
+    ap_case("ignore300", lg, tg2)
+    ap_case("nopos", rng.uniform(0, 1, size=40).astype(np.float32), np.zeros(40, np.float32))
+    ap_case("allpos", rng.uniform(0, 1, size=16).astype(np.float32), np.ones(16, np.float32))
+    tie = np.round(rng.uniform(0, 1, size=64), 1).astype(np.float32)
+    ap_case("ties64", tie, (rng.uniform(size=64) < 0.3).astype(np.float32))
+    # an NMS output as the loss sees it: many exact zeros
+    z = rng.uniform(0, 1, size=400).astype(np.float32)
+    z[rng.uniform(size=400) < 0.7] = 0
+    ap_case("zeros400", z, (rng.uniform(size=400) < 0.05).astype(np.float32))
+    np.savez_compressed(os.path.join(OUT, "aploss.npz"), **apg)
+
+    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz", "aploss.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 

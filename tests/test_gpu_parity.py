@@ -579,3 +579,99 @@ def test_iou_and_forward_in_one_call(G):
             (out1[0] * w).sum().backward()
             (out2[0] * w).sum().backward()
             assert torch.equal(s1.grad, s2.grad), (B, N)
+
+
+# ------------------------------------------------------------------------------------------------
+# the after-NMS AP loss (lib/loss/aploss.py), the consumer of the rescored scores
+# ------------------------------------------------------------------------------------------------
+APLOSS_TOL = 2e-5          # fp32 sums over <= 4096 terms in a different association than torch.sum
+
+
+def test_aploss_against_reference_vectors():
+    """APLoss/backpropAPLoss (HIP) vs vectors captured from lib/loss/aploss.py: loss, gradient after an upstream
+    scale, return shapes (scalar; shape (1,) zeros when no positive), CPU-in/CPU-out."""
+    from conftest import Golden
+    from groomed_nms_amd.aploss import APLoss
+    g = Golden("aploss.npz")
+    crit = APLoss()
+    for tag in g.cases():
+        lg = torch.from_numpy(g[f"{tag}/logits"]).cuda().requires_grad_(True)
+        tg = torch.from_numpy(g[f"{tag}/targets"]).cuda()
+        loss = crit(lg, tg)
+        want = g[f"{tag}/loss"]
+        if tag == "nopos":
+            assert loss.shape == (1,) and float(loss.detach()) == 0.0
+        else:
+            assert loss.dim() == 0, tag
+        np.testing.assert_allclose(loss.detach().cpu().numpy().reshape(-1), want.reshape(-1), atol=APLOSS_TOL, err_msg=tag)
+        up = float(g[f"{tag}/upstream"])
+        (loss.sum() * up).backward()
+        np.testing.assert_allclose(lg.grad.cpu().numpy(), g[f"{tag}/grad"], atol=APLOSS_TOL, rtol=1e-4, err_msg=tag)
+    # CPU tensors in -> CPU tensors out (the reference runs wherever its inputs live, aploss.py:21-24)
+    lg = torch.from_numpy(g["u50_10/logits"]).requires_grad_(True)
+    loss = crit(lg, torch.from_numpy(g["u50_10/targets"]))
+    assert not loss.is_cuda
+    loss.backward()
+    assert not lg.grad.is_cuda
+    np.testing.assert_allclose(lg.grad.numpy() * float(g["u50_10/upstream"]), g["u50_10/grad"], atol=APLOSS_TOL, rtol=1e-4)
+
+
+def test_aploss_against_oracle_random():
+    """Seeded cases up to the 4096-box limit against the C oracle: wide logits (saturating ranks), ties, labels other
+    than 0/1 ignored, ragged counts and the `active` mask of the batched entry; one launch for the whole batch."""
+    import oracle.oracle as O
+    from groomed_nms_amd.aploss import ap_loss_batched
+    rng = np.random.default_rng(5)
+    for B, N, spread, npos in ((4, 500, 1.0, 20), (3, 4096, 1.0, 300), (2, 1000, 6.0, 64), (5, 37, 0.2, 5), (2, 2048, 3.0, 1500)):
+        lg = (rng.standard_normal((B, N)) * spread).astype(np.float32)
+        if spread < 1:
+            lg = np.round(lg * 8) / 8                                    # ties
+        tg = np.zeros((B, N), np.float32)
+        for b in range(B):
+            tg[b, rng.choice(N, size=min(npos, N), replace=False)] = 1
+            tg[b, rng.choice(N, size=N // 10, replace=False)] = -1      # "ignore" labels (neither positive nor negative)
+        tg[B - 1, :] = np.where(tg[B - 1] == 1, 0, tg[B - 1]) if B > 3 else tg[B - 1]   # one image without positives
+        counts = np.array([N] + [max(1, (N * 2) // 3)] * (B - 1), np.int32)
+        active = rng.uniform(size=(B, N)) < 0.8
+        for use_counts, use_active in ((False, False), (True, False), (False, True)):
+            lt = torch.from_numpy(lg).cuda().requires_grad_(True)
+            loss = ap_loss_batched(lt, torch.from_numpy(tg).cuda(),
+                                   active=torch.from_numpy(active).cuda() if use_active else None,
+                                   counts=torch.from_numpy(counts).cuda() if use_counts else None)
+            w = torch.arange(1, B + 1, device="cuda", dtype=torch.float32)
+            (loss * w).sum().backward()
+            for b in range(B):
+                n = int(counts[b]) if use_counts else N
+                sel = active[b, :n] if use_active else np.ones(n, bool)
+                ol, og = O.aploss(lg[b, :n][sel], tg[b, :n][sel])
+                assert abs(float(loss[b]) - ol) <= APLOSS_TOL, (B, N, b, use_counts, use_active)
+                want = np.zeros(N, np.float32)
+                want[:n][sel] = og * (b + 1)
+                np.testing.assert_allclose(lt.grad[b].cpu().numpy(), want, atol=APLOSS_TOL, rtol=2e-4,
+                                           err_msg=str((B, N, b, use_counts, use_active)))
+
+
+def test_aploss_properties_and_limits():
+    """Size-independent properties at the limit: perfectly separated scores give loss 0, inverted ones the known
+    closed form, the gradient sums to ~0 over positives+negatives weights..., N above the limit raises."""
+    from groomed_nms_amd import _lib
+    from groomed_nms_amd.aploss import ap_loss_batched
+    N, F = 4096, 128
+    tg = torch.zeros((2, N), device="cuda")
+    tg[:, :F] = 1
+    lg = torch.empty((2, N), device="cuda")
+    lg[0, :F] = 10.0; lg[0, F:] = -10.0                    # all positives above all negatives by > delta: AP = 1
+    lg[1, :F] = -10.0; lg[1, F:] = 10.0                    # all positives below every negative
+    lg = lg.requires_grad_(True)
+    loss = ap_loss_batched(lg, tg)
+    assert abs(float(loss[0])) < 1e-6
+    # inverted: each positive has rank a = 0.5*(F-1)+1 among positives (equal logits -> 0.5 each, +0.5 self +0.5), b = N-F
+    a = 0.5 * (F - 1) + 1.0
+    assert abs(float(loss[1]) - (1 - a / (a + (N - F)))) < 1e-5
+    loss.sum().backward()
+    assert float(lg.grad[0].abs().max()) == 0.0 or float(loss[0]) < 1e-6
+    assert torch.isfinite(lg.grad).all()
+    # positives are pushed up, negatives down
+    assert (lg.grad[1, :F] < 0).all() and (lg.grad[1, F:] >= 0).all()
+    with pytest.raises(_lib.GnmsError):
+        ap_loss_batched(torch.zeros((1, 5000), device="cuda"), torch.zeros((1, 5000), device="cuda"))

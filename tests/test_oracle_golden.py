@@ -154,3 +154,18 @@ def test_classic_nms_family(golden_misc):
             assert list(NO.girshick_nms(dets, thr, shift=0)) == list(g[f"{tag}/girshick_nms_shift0_{thr}"])
         for method in (0, 1, 2):
             assert list(NO.soft_nms(dets, method=method)) == list(g[f"{tag}/soft_nms_m{method}"]), (tag, method)
+
+
+def test_aploss_oracle_against_reference():
+    """the after-NMS AP loss (lib/loss/aploss.py) -- oracle vs vectors captured from the reference."""
+    from conftest import Golden
+    g = Golden("aploss.npz")
+    cases = g.cases()
+    assert len(cases) >= 13
+    for tag in cases:
+        loss, grad = O.aploss(g[f"{tag}/logits"], g[f"{tag}/targets"])
+        up = float(g[f"{tag}/upstream"])
+        np.testing.assert_allclose(loss, g[f"{tag}/loss"][0], atol=1e-5, err_msg=tag)
+        np.testing.assert_allclose(grad * up, g[f"{tag}/grad"], atol=1e-6, rtol=1e-4, err_msg=tag)
+    loss, grad = O.aploss(g["nopos/logits"], g["nopos/targets"])
+    assert loss == 0.0 and not grad.any()
