@@ -644,7 +644,7 @@ def test_aploss_against_oracle_random():
                 n = int(counts[b]) if use_counts else N
                 sel = active[b, :n] if use_active else np.ones(n, bool)
                 ol, og = O.aploss(lg[b, :n][sel], tg[b, :n][sel])
-                assert abs(float(loss[b]) - ol) <= APLOSS_TOL, (B, N, b, use_counts, use_active)
+                assert abs(float(loss[b].detach()) - ol) <= APLOSS_TOL, (B, N, b, use_counts, use_active)
                 want = np.zeros(N, np.float32)
                 want[:n][sel] = og * (b + 1)
                 np.testing.assert_allclose(lt.grad[b].cpu().numpy(), want, atol=APLOSS_TOL, rtol=2e-4,
