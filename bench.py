@@ -195,11 +195,22 @@ def main():
             "config": {"workload": "%d images/GPU x %d %s %dD boxes/image, nms_threshold 0.4, linear pruning, grouped+masked, group_size 100"
                                    % (B, N, args.kind, args.dim), "boxes_per_image": N, "images_per_gpu": B,
                        "scores_presorted": bool(args.sorted_scores), "hip_graph_replay": bool(args.graph), "parallelism": "images sharded, dp%d" % world},
-            "roofline": dict(roof(t_mask, alg_bytes, "bitmask_kernel"), kernel="bitmask_kernel (gnms_forward: one full read of the NxN fp32 matrix)"),
-            "roofline_iou": dict(roof(t_iou, alg_bytes_iou, "iou2d_kernel" if args.dim == 2 else "iou3d_kernel"),
-                                 kernel=("iou2d_kernel" if args.dim == 2 else "iou3d_kernel") + " (one full write of the NxN fp32 matrix)"),
+            "roofline": None,
             "phase_ms": {"iou2d": round(t_iou, 4), "nms_forward": round(t_fwd, 4), "nms_backward": round(t_bwd, 4)},
         }
+        iou_name = "iou2d_kernel" if args.dim == 2 else "iou3d_kernel"
+        r_iou = dict(roof(t_iou, alg_bytes_iou, iou_name), kernel=iou_name + " (one full write of the NxN fp32 matrix; the same tile code runs as "
+                     "iou2d_sort_kernel inside gnms_forward_with_iou2d)")
+        r_mask = dict(roof(t_mask, alg_bytes, "bitmask_kernel"), kernel="bitmask_kernel (gnms_forward: one full read of the NxN fp32 matrix)")
+        one_call = args.dim == 2 and not args.two_calls and not args.graph
+        if one_call:
+            # the timed step hands the boxes over, so the layer never reads the matrix back: the IoU write is the dominant kernel
+            out["roofline"], out["roofline_matrix_in"] = r_iou, r_mask
+            t_one = event_time_ms(lambda: G.differentiable_nms_with_iou2d_batched(s_det, boxes, iou_out=iou_buf), 20, stream)
+            out["phase_ms"] = {"iou2d_plus_nms_forward_one_call": round(t_one, 4), "nms_backward": round(t_bwd, 4),
+                               "separately": {"iou2d": round(t_iou, 4), "nms_forward_matrix_in": round(t_fwd, 4)}}
+        else:
+            out["roofline"], out["roofline_iou"] = r_mask, r_iou
         if args.dim == 2:
             # ---- reported SEPARATELY (never part of `value`): the from-boxes path, same outputs bit for bit, no N x N matrix ----
             def fused_step():

@@ -233,6 +233,16 @@ extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N,
                         workspace_bytes, stream, false);
 }
 
+namespace {
+int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, const int32_t* counts, const gnms_params* params,
+                       float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid,
+                       void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted);
+}
+
+// The matrix is an OUTPUT here, so the layer does not have to read it back: with the boxes at hand the grouped modes
+// take their threshold bits and the few P[i, head] entries straight from the boxes (bit-identical arithmetic, the
+// from-boxes kernels), which replaces the 537 MB read of bitmask_kernel (~100 us at B=8, N=4096) by bitmask_boxes_kernel
+// (~51 us, compute bound).  The ungrouped / soft-sorted modes read the matrix they just wrote.
 extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
                                        const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
                                        int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
@@ -244,8 +254,12 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     // fused launch: sort on 512 threads (P2 >= 512), <= 32 KiB of LDS per workgroup (P2 <= 4096), one sort workgroup per image in slice 0
     const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) &&
                       (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::kTileRows) >= B;
+    const bool from_boxes = params->group_boxes && !params->presorted && ((uintptr_t)boxes % 16 == 0);
     if (!fuse) {
         if (B > 0 && N > 0 && (rc = gnms_iou2d(boxes, boxes, B, N, N, iou_out, ld, stream))) return rc;
+        if (from_boxes)
+            return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
+                                      workspace_bytes, stream, false);
         return forward_impl("gnms_forward_with_iou2d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid,
                             ninvalid, workspace, workspace_bytes, stream, false);
     }
@@ -270,6 +284,9 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     }
 #undef GNMS_LAUNCH_FUSED
     GNMS_CHECK_LAUNCH();
+    if (from_boxes)
+        return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
+                                  workspace_bytes, stream, true);
     return forward_impl("gnms_forward_with_iou2d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid,
                         ninvalid, workspace, workspace_bytes, stream, true);
 }
@@ -319,9 +336,10 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
 // ------------------------------------------------------------------------------------------------
 // from-boxes path: same layer, the N x N matrix never materialised (grouped modes)
 // ------------------------------------------------------------------------------------------------
-extern "C" int gnms_forward_from_boxes(const float* boxes, const float* scores, int B, int N, const int32_t* counts,
-                                       const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
-                                       int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, const int32_t* counts, const gnms_params* params,
+                       float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid,
+                       void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted) {
     int rc = check_common("gnms_forward_from_boxes", B, N, N, params, workspace, workspace_bytes);
     if (rc) return rc;
     if (!params->group_boxes || params->presorted) {
@@ -343,11 +361,13 @@ extern "C" int gnms_forward_from_boxes(const float* boxes, const float* scores, 
     const int P2 = next_pow2(N);
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
-    GNMS_DISPATCH_SORT(P2, {
-        if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
-        sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
-    });
-    GNMS_CHECK_LAUNCH();
+    if (!scores_already_sorted) {
+        GNMS_DISPATCH_SORT(P2, {
+            if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
+            sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
+        });
+        GNMS_CHECK_LAUNCH();
+    }
     bitmask_boxes_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(boxes, N, counts, P.nms_threshold, ws, L);
     GNMS_CHECK_LAUNCH();
     const size_t llds = leaders_lds_bytes(N);
@@ -374,6 +394,14 @@ extern "C" int gnms_forward_from_boxes(const float* boxes, const float* scores, 
     });
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
+}
+}  // namespace
+
+extern "C" int gnms_forward_from_boxes(const float* boxes, const float* scores, int B, int N, const int32_t* counts,
+                                       const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
+                                       int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream) {
+    return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
+                              workspace_bytes, stream, false);
 }
 
 extern "C" int gnms_backward_from_boxes(const float* grad_prob, const float* boxes, const float* scores, int B, int N,

@@ -664,7 +664,7 @@ def test_aploss_properties_and_limits():
     lg[1, :F] = -10.0; lg[1, F:] = 10.0                    # all positives below every negative
     lg = lg.requires_grad_(True)
     loss = ap_loss_batched(lg, tg)
-    assert abs(float(loss[0])) < 1e-6
+    assert abs(float(loss[0].detach())) < 1e-6
     # inverted: each positive has rank a = 0.5*(F-1)+1 among positives (equal logits -> 0.5 each, +0.5 self +0.5), b = N-F
     a = 0.5 * (F - 1) + 1.0
     assert abs(float(loss[1]) - (1 - a / (a + (N - F)))) < 1e-5
