@@ -192,7 +192,7 @@ __device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
 struct ImgPtrs {
     int* order; float* sscore; int* rankof; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen; int* hlist;
     float* plead; float* pre; float* r2; int* sidx; float* xsol; float* gx; int* leadc; int* leadr; u64* leadw; int* leadpfx;
-    int* misc; u64* W;
+    int* misc; int* xidx; float4* xbox; u64* W;
 };
 
 __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_layout& L, int b) {
@@ -204,6 +204,7 @@ __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_lay
     I.pre = (float*)(p + L.off_pre); I.r2 = (float*)(p + L.off_r2); I.sidx = (int*)(p + L.off_sidx);
     I.xsol = (float*)(p + L.off_xsol); I.gx = (float*)(p + L.off_gx); I.leadc = (int*)(p + L.off_leadc); I.leadr = (int*)(p + L.off_leadr);
     I.leadw = (u64*)(p + L.off_leadw); I.leadpfx = (int*)(p + L.off_leadpfx); I.misc = (int*)(p + L.off_misc);
+    I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox);
     I.W = (u64*)(p + L.off_W);
     return I;
 }
@@ -233,15 +234,44 @@ __device__ __forceinline__ float overlap_at(const float* __restrict__ src, long 
 // ------------------------------------------------------------------------------------------------
 // K1: stable descending argsort of the scores (lib/groomed_nms.py:41; get_groups :213)
 // ------------------------------------------------------------------------------------------------
+// Second, independent sort of the from-boxes path: the boxes by ascending x centre (NaN last).  bitmask_boxes_kernel walks
+// its COLUMNS in this order, so that the 256 columns of a wave tile are spatial neighbours and the rows that cannot touch
+// their hull are skipped.  Thread t owns elements t*E .. t*E+E-1; `keys` = P 64-bit LDS slots.
+template <int E>
+__device__ __forceinline__ void sort_boxes_by_x(const float* __restrict__ boxes, int n, const ImgPtrs& I, u64* keys, int P) {
+    const float4* bx = reinterpret_cast<const float4*>(boxes);
+    u64 r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = threadIdx.x * E + e;
+        r[e] = ~0ull;
+        if (i < n) {
+            const float4 v = bx[i];
+            r[e] = ((u64)(~gnms_desc_key(v.x + v.z)) << 32) | (unsigned)i;
+        }
+    }
+    block_sort<E, u64>(r, keys, P);
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const int idx = (int)(keys[k] & 0xffffffffu);
+        I.xidx[k] = idx;
+        I.xbox[k] = bx[idx];
+    }
+}
+
 template <int E>
 __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restrict__ scores, int N, const int* __restrict__ counts,
-                                                           char* ws, gnms_ws_layout L, int P, long long* __restrict__ order_out) {
+                                                           char* ws, gnms_ws_layout L, int P, long long* __restrict__ order_out,
+                                                           const float* __restrict__ boxes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
     const int b = blockIdx.x;
     const int n = gnms_count(counts, b, N);
     const float* s = scores + (size_t)b * N;
     ImgPtrs I = img_ptrs(ws, L, b);
+    if (blockIdx.y == 1) {                      // from-boxes path only: grid (B, 2)
+        sort_boxes_by_x<E>(boxes + (size_t)b * N * 4, n, I, keys, P);
+        return;
+    }
     u64 r[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -367,29 +397,28 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2b: threshold bit matrix straight from the boxes (the from-boxes path: the N x N fp32 matrix never exists).
-// Same wave tile (64 rank-rows x 256 RANK columns; boxes are gathered through `order`, 16 B each), the overlap
-// of each pair is recomputed with pair_iou and thresholded in registers.  Only tiles a leader can reach are
-// computed (leader rank < end of the row block): half the pairs.  Bound: fp32 VALU (about 24 ops per pair,
-// 10 of them the IEEE division that keeps the decision bit-identical to the matrix path); HBM traffic is
-// 16 N bytes in and N^2/8 bytes out per image.
+// K2b: threshold bit matrix straight from the boxes (the from-boxes path: no read of the N x N fp32 matrix).
+// Wave tile = 64 rank-rows (block kb) x 256 columns; the overlap of each pair is recomputed from the two boxes and
+// thresholded in registers, bit-identical to thresholding the matrix.  Bound: fp32 VALU; HBM traffic is 16 N bytes in
+// and <= N^2/8 bytes out per image.
 // ------------------------------------------------------------------------------------------------
-// Tile enumeration: only the tiles a leader can reach exist (column chunk c < ceil(64(kb+1)/256) = (kb>>2)+1), and they
-// are numbered in ONE dimension so that every wave of every workgroup has equal work.  (A (chunk, kb) grid with early
-// exits put all the work on the workgroups with blockIdx.x == 0, i.e. -- blocks are dealt round-robin to the 8 XCDs -- on
-// XCDs 0 and 4: measured 99 us instead of 40.)  Tiles before row block kb = 4q + r:  2q(q+1) + r(q+1).
-__device__ __forceinline__ void tri_tile(int id, int* kb, int* chunk) {
-    int q = (int)((sqrtf(1.0f + 2.0f * (float)id) - 1.0f) * 0.5f);
-    while (2 * q * (q + 1) > id) --q;
-    while (2 * (q + 1) * (q + 2) <= id) ++q;
-    const int rem = id - 2 * q * (q + 1);
-    const int r = rem / (q + 1);
-    *kb = 4 * q + r;
-    *chunk = rem - r * (q + 1);
+// Columns in X ORDER + row culling.
+// The column a lane owns only decides WHICH word it writes (W[kb][rank of the column]); the order in which columns are
+// dealt to lanes is free.  Dealing them by ascending x centre (sort_boxes_by_x) makes the 256 columns of a wave tile
+// spatial neighbours: their hull is a narrow strip of the image, and a row box that does not reach into the hull has
+// intersection 0 with all 256 columns -> its bit is 0 in every word and the row is skipped (exact: with finite positive
+// areas and thr >= 0, inter = +0 and uni > 0 give 0 <= thr).  On detector-like inputs (boxes ~100 px on a 1760 px wide
+// canvas) a tile keeps 15-20 % of its 64 rows.  The price: the rank triangle can no longer be skipped per tile (a tile
+// holds columns of every rank); words no leader scan reads (column rank >= 64 (kb+1)) are computed but not stored.
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
 }
-__host__ __device__ inline int tri_tile_count(int NB) {                // number of reachable tiles for NB row blocks
-    const int q = NB >> 2, r = NB & 3;
-    return 2 * q * (q + 1) + r * (q + 1);
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
@@ -397,33 +426,56 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
     const int n = gnms_count(counts, b, N);
+    const int nchunk = (N + 255) >> 8;
     const int tile = blockIdx.x * 4 + wave;
-    if (tile >= tri_tile_count(L.NB)) return;
-    int kb, chunk;
-    tri_tile(tile, &kb, &chunk);
+    const int kb = tile / nchunk, chunk = tile - kb * nchunk;
     const int k0 = kb * 64;
     const int c0 = chunk * 256;
-    if (k0 >= n || c0 >= n) return;                                  // (ragged images)
+    if (kb >= L.NB || k0 >= n || c0 >= n) return;                    // (ragged images)
     ImgPtrs I = img_ptrs(ws, L, b);
     const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * N;
     float4 cb[4];
     float carea[4];
-    int col[4];
+    int crank[4];
+    bool need = false, cok = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        col[j] = c0 + 4 * lane + j;
-        cb[j] = bx[I.order[col[j] < n ? col[j] : n - 1]];
+        const int p = c0 + 4 * lane + j;
+        const int pp = p < n ? p : n - 1;                             // clamped duplicates: harmless in the hull, never stored
+        cb[j] = I.xbox[pp];
+        crank[j] = (p < n) ? I.rankof[I.xidx[pp]] : 0x7fffffff;
+        need |= crank[j] < k0 + 64;                                   // a leader must outrank at least one row of the block
         carea[j] = (cb[j].z - cb[j].x) * (cb[j].w - cb[j].y);
+        cok &= (carea[j] > 0.0f) && (carea[j] < INFINITY);
     }
+    if (!__any(need)) return;
     const float4 rb = bx[I.order[min(k0 + lane, n - 1)]];
     const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
     const int nrows = min(64, n - k0);
+    // Decision !(fl(inter/uni) <= thr) WITHOUT the division.  With d = fma(-thr, uni, inter) (one rounding, sign exact):
+    //   inter/uni - thr = d/uni,  so  |d| > guard*uni  puts the exact quotient more than `guard` (8 ulp of the threshold)
+    // away from thr, hence its fp32 rounding on the same side, and the pair is decided by the sign of d.  That needs
+    // uni > 0 and finite, which holds whenever both boxes have a positive finite area (inter <= min(area) in fp32 as in
+    // exact arithmetic because subtraction/multiplication round monotonically, so uni >= max(area) > 0): checked once per
+    // column box and per row.  Rows/columns that fail, and the pairs inside the guard band, take the exact IEEE division.
     const float guard = fmaxf(fabsf(thr), 1.0f) * 9.6e-7f;            // 8 ulp at the threshold's magnitude (>= 1 for tiny thresholds)
-    unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    const bool cols_ok = __all(cok);
+    const bool row_fine = (rarea > 0.0f) && (rarea < INFINITY);
+    const u64 rows_ok = __ballot(row_fine);
+    // hull of the tile's columns and the rows that reach into it
+    float hx0 = fminf(fminf(cb[0].x, cb[1].x), fminf(cb[2].x, cb[3].x)), hx1 = fmaxf(fmaxf(cb[0].z, cb[1].z), fmaxf(cb[2].z, cb[3].z));
+    float hy0 = fminf(fminf(cb[0].y, cb[1].y), fminf(cb[2].y, cb[3].y)), hy1 = fmaxf(fmaxf(cb[0].w, cb[1].w), fmaxf(cb[2].w, cb[3].w));
+    hx0 = wave_min_f(hx0); hy0 = wave_min_f(hy0); hx1 = wave_max_f(hx1); hy1 = wave_max_f(hy1);
+    const bool cull = cols_ok && (thr >= 0.0f);
+    const bool reaches = (rb.z > hx0) && (rb.x < hx1) && (rb.w > hy0) && (rb.y < hy1);
+    const u64 active = __ballot((lane < nrows) && (!(cull && row_fine) || reaches));
+    unsigned wd[2] [4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-#pragma unroll 4
-        for (int rr = 0; rr < 32; ++rr) {
+        unsigned todo = (unsigned)(half ? (active >> 32) : (active & 0xffffffffull));
+        while (todo) {                                                // wave-uniform loop over the surviving rows
+            const int rr = __builtin_ctz(todo);
+            todo &= todo - 1u;
             const int r = half * 32 + rr;
             const float ax1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.x), r));
             const float ay1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.y), r));
@@ -431,11 +483,7 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
             const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), r));
             const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), r));
             const unsigned bit = 1u << rr;
-            // Decision !(inter/uni <= thr).  q = inter * rcp(uni) is within 2.5 ulp of the correctly rounded quotient
-            // (v_rcp_f32: 1 ulp, the product: 0.5 ulp, the quotient's own rounding: 0.5 ulp), so it decides every pair
-            // whose q is further than `guard` (8 ulp) from the threshold; the few pairs inside the guard band -- and
-            // those where q is not finite -- take the exact IEEE division.  Same bits as the matrix path, 1/3 fewer VALU ops.
-            float inter4[4], uni4[4], q4[4];
+            float inter4[4], uni4[4], d4[4];
             bool unsure = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -443,22 +491,22 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
                 const float h = fmaxf(fminf(ay2, cb[j].w) - fmaxf(ay1, cb[j].y), 0.0f);
                 inter4[j] = w * h;
                 uni4[j] = (aa + carea[j]) - inter4[j];                    // row box is `a`, column (leader) box is `b`
-                q4[j] = inter4[j] * __builtin_amdgcn_rcpf(uni4[j]);
-                unsure |= !(fabsf(q4[j] - thr) > guard);                  // also true for NaN / inf
+                d4[j] = __builtin_fmaf(-thr, uni4[j], inter4[j]);
+                unsure |= !(fabsf(d4[j]) > guard * uni4[j]);              // also true for NaN
             }
-            if (__any(unsure)) {
+            if (!(cols_ok && ((rows_ok >> r) & 1ull)) || __any(unsure)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) q4[j] = inter4[j] / uni4[j];
+                for (int j = 0; j < 4; ++j) wd[half][j] |= !(inter4[j] / uni4[j] <= thr) ? bit : 0u;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wd[half][j] |= (d4[j] > 0.0f) ? bit : 0u;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wd[half][j] |= !(q4[j] <= thr) ? bit : 0u;
         }
     }
-    const u64 rowmask = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
     u64* Wk = I.W + (size_t)kb * L.NC;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (col[j] < n) Wk[col[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
+        if (crank[j] < k0 + 64) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -128,13 +128,19 @@ template <bool VEC, int E>
 __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                                                 int N, const int* __restrict__ counts, float* __restrict__ out,
                                                                                 long ld, char* ws, gnms_ws_layout L, int P2,
-                                                                                long long* __restrict__ order_out) {
+                                                                                long long* __restrict__ order_out, int xsort) {
     using namespace gnms_iou;
     if (blockIdx.z == gridDim.z - 1) {
-        const int b = blockIdx.y * gridDim.x + blockIdx.x;          // image to sort
-        if (b >= (int)gridDim.z - 1) return;
+        const int nimg = (int)gridDim.z - 1;
+        int b = blockIdx.y * gridDim.x + blockIdx.x;                // image to sort: [0, B) by score, [B, 2B) by x centre (from-boxes layer)
+        if (b >= (xsort ? 2 * nimg : nimg)) return;
         extern __shared__ __attribute__((aligned(16))) char smem[];
         u64* keys = reinterpret_cast<u64*>(smem);
+        if (b >= nimg) {
+            b -= nimg;
+            sort_boxes_by_x<E>(boxes + (size_t)b * N * 4, gnms_count(counts, b, N), img_ptrs(ws, L, b), keys, P2);
+            return;
+        }
         const int n = gnms_count(counts, b, N);
         const float* s = scores + (size_t)b * N;
         ImgPtrs I = img_ptrs(ws, L, b);
@@ -166,6 +172,9 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
     iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, blockIdx.z, blockIdx.y * kTileRows, blockIdx.x * kWGCols + wave * kWaveCols, lane);
 }
 
+// workgroups (4 wave tiles each) of bitmask_boxes_kernel per image: (row blocks) x (256-column chunks)
+inline int bitmask_boxes_blocks(int N) { return gnms_div_up(((N + 63) / 64) * ((N + 255) / 256), 4); }
+
 int forward_impl(const char* fn, const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
                  const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid,
                  int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted) {
@@ -189,7 +198,7 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     if (!scores_already_sorted) {
         GNMS_DISPATCH_SORT(P2, {
             if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
-            sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
+            sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order, nullptr);
         });
         GNMS_CHECK_LAUNCH();
     }
@@ -252,9 +261,9 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     if (B > 0 && N > 0) GNMS_CHECK_ARG(boxes && scores && iou_out && prob, "gnms_forward_with_iou2d: null pointer");
     const int P2 = next_pow2(N);
     // fused launch: sort on 512 threads (P2 >= 512), <= 32 KiB of LDS per workgroup (P2 <= 4096), one sort workgroup per image in slice 0
-    const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) &&
-                      (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::kTileRows) >= B;
     const bool from_boxes = params->group_boxes && !params->presorted && ((uintptr_t)boxes % 16 == 0);
+    const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) &&
+                      (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::kTileRows) >= 2 * B;
     if (!fuse) {
         if (B > 0 && N > 0 && (rc = gnms_iou2d(boxes, boxes, B, N, N, iou_out, ld, stream))) return rc;
         if (from_boxes)
@@ -269,12 +278,13 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou_out % 16 == 0);
     dim3 grid(gnms_div_up(N, gnms_iou::kWGCols), gnms_div_up(N, gnms_iou::kTileRows), B + 1);
     const int threads = gnms_iou::kWavesPerWG * 64;                                   // 512: E = P2 / 512
+    const int xs = from_boxes ? 1 : 0;
 #define GNMS_LAUNCH_FUSED(EE)                                                                                                           \
     do {                                                                                                                                \
         if (vec) iou2d_sort_kernel<true, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,               \
-                                                                            (char*)workspace, L, P2, (long long*)order);               \
+                                                                            (char*)workspace, L, P2, (long long*)order, xs);           \
         else iou2d_sort_kernel<false, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,                  \
-                                                                         (char*)workspace, L, P2, (long long*)order);                  \
+                                                                         (char*)workspace, L, P2, (long long*)order, xs);              \
     } while (0)
     switch (P2 / threads) {
         case 1: GNMS_LAUNCH_FUSED(1); break;
@@ -364,11 +374,11 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     if (!scores_already_sorted) {
         GNMS_DISPATCH_SORT(P2, {
             if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
-            sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order);
-        });
+            sort_scores_kernel<E><<<dim3(B, 2), sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order, boxes);
+        });                                        // y = 0: scores (descending), y = 1: boxes by x centre
         GNMS_CHECK_LAUNCH();
     }
-    bitmask_boxes_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(boxes, N, counts, P.nms_threshold, ws, L);
+    bitmask_boxes_kernel<<<dim3(bitmask_boxes_blocks(N), 1, B), 256, 0, st>>>(boxes, N, counts, P.nms_threshold, ws, L);
     GNMS_CHECK_LAUNCH();
     const size_t llds = leaders_lds_bytes(N);
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
@@ -456,8 +466,8 @@ extern "C" int gnms_profile_bitmask_boxes(const float* boxes, int B, int N, cons
     if (rc) return rc;
     if (B == 0 || N == 0) return GNMS_OK;
     const gnms_ws_layout L = gnms_make_layout(N);
-    bitmask_boxes_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, (hipStream_t)stream>>>(boxes, N, counts, nms_threshold,
-                                                                                                            (char*)workspace, L);
+    bitmask_boxes_kernel<<<dim3(bitmask_boxes_blocks(N), 1, B), 256, 0, (hipStream_t)stream>>>(boxes, N, counts, nms_threshold,
+                                                                                               (char*)workspace, L);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -507,7 +517,7 @@ extern "C" int gnms_get_groups(const float* scores, const float* iou, int N, int
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
-        sort_scores_kernel<E><<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr);
+        sort_scores_kernel<E><<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr, nullptr);
     });
     GNMS_CHECK_LAUNCH();
     if ((rc = run_grouping(iou, 1, N, ld, nullptr, group_threshold, ws, L, st))) return rc;

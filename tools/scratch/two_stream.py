@@ -1,0 +1,43 @@
+"""experiment: IoU matrix write on a side stream while the from-boxes NMS chain runs on the main stream"""
+import sys, os, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import groomed_nms_amd as G
+from groomed_nms_amd import overlaps, synthetic
+
+B, N = 8, 4096
+boxes_np, scores_np = synthetic.batch_2d(1000, B, N, "clustered")
+dev = torch.device("cuda", 0)
+boxes = torch.from_numpy(boxes_np).to(dev)
+scores = torch.from_numpy(scores_np).to(dev).requires_grad_(True)
+w = torch.linspace(-1.0, 2.0, N, device=dev).repeat(B, 1).contiguous()
+iou_buf = torch.empty((B, N, N), dtype=torch.float32, device=dev)
+side = torch.cuda.Stream()
+
+def seq():
+    prob = G.differentiable_nms_with_iou2d_batched(scores, boxes, iou_out=iou_buf)[0]
+    scores.grad = None
+    torch.autograd.backward(prob, w)
+
+def two():
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        overlaps.iou_batched(boxes, out=iou_buf)
+    prob = G.differentiable_nms_from_boxes_batched(scores, boxes)[0]
+    scores.grad = None
+    torch.autograd.backward(prob, w)
+    main.wait_stream(side)
+
+def chain_only():
+    prob = G.differentiable_nms_from_boxes_batched(scores, boxes)[0]
+    scores.grad = None
+    torch.autograd.backward(prob, w)
+
+for name, fn in (("one-call sequential", seq), ("two streams", two), ("chain only", chain_only), ("two streams", two), ("one-call sequential", seq)):
+    for _ in range(10): fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200): fn()
+    torch.cuda.synchronize()
+    print("%-22s %.4f ms/step" % (name, (time.perf_counter() - t0) / 200 * 1e3))
