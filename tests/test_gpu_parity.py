@@ -675,3 +675,49 @@ def test_aploss_properties_and_limits():
     assert (lg.grad[1, :F] < 0).all() and (lg.grad[1, F:] >= 0).all()
     with pytest.raises(_lib.GnmsError):
         ap_loss_batched(torch.zeros((1, 5000), device="cuda"), torch.zeros((1, 5000), device="cuda"))
+
+
+def test_from_boxes_decisions_on_adversarial_boxes(G):
+    """The from-boxes bit matrix decides pairs without the division and skips rows that cannot touch a column tile's hull;
+    both shortcuts must give the matrix path's bits on degenerate input: zero-area / inverted / NaN / infinite boxes,
+    duplicates (IoU exactly 1), boxes that only touch, IoU values within an ulp of the threshold, thresholds 0, 1 and
+    negative, everything in one column of the image (no culling possible) and everything spread out (all culled)."""
+    from groomed_nms_amd import overlaps
+    rng = np.random.default_rng(77)
+    N = 700
+
+    def grid_boxes(step):                       # touching / overlapping-by-a-hair neighbours
+        i = np.arange(N)
+        x = (i % 40) * step
+        y = (i // 40) * step
+        return np.stack([x, y, x + 10, y + 10], 1).astype(np.float32)
+
+    cases = {}
+    b = rng.uniform(0, 100, (N, 4)).astype(np.float32); b[:, 2:] += b[:, :2]
+    b[5] = [10, 10, 10, 30]; b[6] = [50, 50, 40, 40]; b[7] = [np.nan, 0, 5, 5]; b[8] = [0, 0, np.inf, 5]
+    b[9] = [-np.inf, -np.inf, np.inf, np.inf]; b[10:20] = b[20]                       # degenerate + duplicates
+    cases["degenerate"] = b
+    cases["touching"] = grid_boxes(10.0)
+    cases["hair"] = grid_boxes(9.999999)
+    tall = rng.uniform(0, 5, (N, 4)).astype(np.float32); tall[:, 1] = rng.uniform(0, 3000, N); tall[:, 2] = tall[:, 0] + 50
+    tall[:, 3] = tall[:, 1] + rng.uniform(20, 90, N).astype(np.float32)
+    cases["one_column"] = tall
+    far = np.zeros((N, 4), np.float32); far[:, 0] = np.arange(N) * 100; far[:, 2] = far[:, 0] + 30; far[:, 3] = 30
+    cases["spread"] = far
+    # pairs whose IoU sits right at the threshold: box k = [0, 0, 10, h_k] against [0, 0, 10, 10] has IoU h_k/10 (h_k < 10)
+    at = np.zeros((N, 4), np.float32); at[:, 2] = 10
+    at[:, 3] = np.nextafter(np.float32(4.0), np.float32(5.0)) + (np.arange(N) - N // 2).astype(np.float32) * np.float32(4.8e-7)
+    at[0, 3] = 10
+    cases["at_threshold"] = at
+    for name, bx in cases.items():
+        sc = rng.permutation(N).astype(np.float32) / N
+        bt = torch.from_numpy(np.stack([bx, bx[::-1].copy()])).cuda()
+        st = torch.from_numpy(np.stack([sc, sc])).cuda()
+        iou = overlaps.iou_batched(bt)
+        for thr in (0.4, 0.0, 1.0, -0.5, 0.39999998):
+            out1 = G.differentiable_nms_from_boxes_batched(st, bt, nms_threshold=thr)
+            out2 = G.differentiable_nms_batched(st, iou, nms_threshold=thr)
+            out3 = G.differentiable_nms_with_iou2d_batched(st, bt, nms_threshold=thr)
+            for a, b2, c in zip(out1, out2, out3):
+                assert torch.equal(a, b2) or torch.allclose(a, b2, atol=0, rtol=0, equal_nan=True), (name, thr)
+                assert torch.equal(c, b2) or torch.allclose(c, b2, atol=0, rtol=0, equal_nan=True), (name, thr)
