@@ -144,6 +144,11 @@ def test_iou3d(G, O, golden_box3d):
         assert torch.equal(ref_c, keep)                                          # inputs are const (unlike lib/core.py:379-380)
         ov = overlaps.iou3d_batched(torch.from_numpy(p).cuda().unsqueeze(0), from_params=True, nms_overlap=True)[0]
         np.testing.assert_allclose(ov.cpu().numpy(), g[f"{case}/nms_overlap"], atol=TOL)
+        # the fused NMS-overlap kernel re-associates 0.5*(1+giou) (one reciprocal instead of two divisions): it must stay within
+        # a few ulp of the exact-order kernel applied to the same records
+        pt = torch.from_numpy(p).cuda().unsqueeze(0)
+        exact = 0.5 * (1.0 + overlaps.iou3d_batched(pt, from_params=True, method="generalized")[0])
+        np.testing.assert_allclose(ov.cpu().numpy(), exact.cpu().numpy(), atol=2e-6, rtol=0)
     bev, i3 = overlaps.iou3d_approximate(torch.from_numpy(g["rect/corners_a"]).cuda(), torch.from_numpy(g["rect/corners_b"]).cuda(),
                                          mode="combinations", method="generalized")
     np.testing.assert_allclose(i3.cpu().numpy(), g["rect/iou_3d"], atol=1e-6)
