@@ -112,9 +112,11 @@ int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* coun
 
 }  // namespace
 
-extern "C" size_t gnms_workspace_bytes(int B, int N, const gnms_params* /*params*/) {
+extern "C" size_t gnms_workspace_bytes(int B, int N, const gnms_params* params) {
     if (B <= 0 || N <= 0) return 0;
-    return gnms_make_layout(N).per_image * (size_t)B;
+    size_t bytes = gnms_make_layout(N).per_image * (size_t)B;
+    if (params && !params->group_boxes) bytes += gnms::ungrouped_scratch_bytes(B, N);   // the sorted strictly-lower-triangular matrix
+    return bytes;
 }
 
 namespace {
@@ -217,11 +219,14 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
             GNMS_CHECK_LAUNCH();
         }
     } else {
-        const size_t lds = (size_t)((N + 3) & ~3) * 4 + 64 * 65 * 4 + 64 * 4;
-        if ((rc = allow_lds(ungrouped_forward_kernel, lds))) return rc;
+        float* Ps = reinterpret_cast<float*>(ws + (size_t)B * L.per_image);      // scratch behind the per-image regions
+        const size_t plds = (size_t)N * 4;
+        if ((rc = allow_lds(ungrouped_permute_kernel, plds))) return rc;
         ungrouped_prepare_kernel<<<dim3(gnms_div_up(N, 1024), B), 1024, 0, st>>>(N, counts, P, ws, L);
         GNMS_CHECK_LAUNCH();
-        ungrouped_forward_kernel<<<B, 1024, lds, st>>>(iou, scores, N, (long)ld, counts, P, ws, L);
+        ungrouped_permute_kernel<<<dim3(N, B), 256, plds, st>>>(iou, N, (long)ld, counts, P, ws, L, Ps);
+        GNMS_CHECK_LAUNCH();
+        ungrouped_solve_forward_kernel<<<dim3(L.NB, B), 256, 0, st>>>(scores, N, counts, P, ws, L, Ps);
         GNMS_CHECK_LAUNCH();
     }
     GNMS_DISPATCH_SORT(P2, {
@@ -335,10 +340,15 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
         solve_groups_kernel<true, false><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
         GNMS_CHECK_LAUNCH();
     } else {
-        const size_t lds = (size_t)((N + 3) & ~3) * 4 + 64 * 65 * 4 + 64 * 4;
-        if ((rc = allow_lds(ungrouped_backward_kernel, lds))) return rc;
-        ungrouped_backward_kernel<<<B, 1024, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
+        const float* Ps = reinterpret_cast<const float*>(ws + (size_t)B * L.per_image);   // written by the forward pass
+        ungrouped_backward_prepare_kernel<<<dim3(gnms_div_up(N, 1024), B), 1024, 0, st>>>(N, ws, L);
         GNMS_CHECK_LAUNCH();
+        ungrouped_solve_backward_kernel<<<dim3(L.NB, B), 256, 0, st>>>(N, counts, P, ws, L, Ps, grad_scores);
+        GNMS_CHECK_LAUNCH();
+        if (grad_iou) {
+            ungrouped_grad_iou_kernel<<<dim3(gnms_div_up(N, 256), N, B), 256, 0, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_iou);
+            GNMS_CHECK_LAUNCH();
+        }
     }
     return GNMS_OK;
 }

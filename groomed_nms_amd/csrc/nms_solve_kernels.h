@@ -101,137 +101,229 @@ __global__ __launch_bounds__(64) void solve_groups_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// ungrouped: one workgroup (1024 threads) per image, blocked substitution, ONE pass over the matrix.
-// dynamic LDS: float xin[N] (x or the running transpose accumulator, by input column), float T[64*65],
-//              float xb[64]
-// `rem` (unused by this mode) carries pos_of[input index] = NMS position.
+// ungrouped mode (group_boxes=False, lib/groomed_nms.py:72-73, 111): x = (I + P)^-1 s with P = tril(f(iou_sorted), -1) is a
+// forward substitution over all N boxes, the backward a substitution with the transpose.  Three steps:
+//   U1  ungrouped_permute_kernel   Ps[i][j] = f(iou[order[i]][order[j]]) for j < i, into a scratch matrix in NMS-position
+//       space (the reference makes the same copy, :48).  One workgroup per row: the input row is read coalesced into LDS,
+//       the column permutation is an LDS gather, the stores are coalesced.  4N^2 bytes in, 2N^2 out.
+//   U2  ungrouped_solve_forward_kernel   one workgroup per block of 64 positions, ALL blocks in flight: block b streams
+//       its 64 x 64b strip of Ps tile by tile (next tile prefetched into registers), and consumes x of block c as soon as
+//       block c publishes it (mailbox in global memory, decoupled look-back: a block only waits for lower-numbered blocks,
+//       which are dispatched first).  The sequential part is 64 dependent steps inside a 64 x 64 diagonal tile.
+//   U3  ungrouped_solve_backward_kernel  the same with the transpose, blocks published from the last to the first.
+// `rem` (unused by this mode) carries pos_of[input index] = NMS position; the bit-matrix region `W` holds the two mailboxes;
+// `xsol` the backward solution by position.  (The first version did all of this in ONE workgroup per image, row by
+// row: 17.4 ms per step at B=8, N=4096.)
 // ------------------------------------------------------------------------------------------------
+// Mailbox between the blocks of one image: one 64-bit word per position = (1 << 32 | float bits), written and polled with
+// single 8-byte agent-scope atomics -- the value validates itself, so a consumer needs ONE memory round trip per block
+// (flag + fence + data would be two and an L2 write-back).  Zeroed (= empty) by the prepare kernels.  The words live in the
+// bit-matrix region W, which this mode does not use: [0, N) forward, [N, 2N) backward (only touched when there are >= 2 blocks).
+__device__ __forceinline__ void mail_put(u64* slot, float v) {
+    __hip_atomic_store(slot, (1ull << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float mail_get(const u64* slot) {
+    u64 w;
+    while (((w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0) __builtin_amdgcn_s_sleep(1);
+    return __uint_as_float((unsigned)(w & 0xffffffffu));
+}
+__host__ __device__ inline size_t ungrouped_ld(int N) { return (size_t)((N + 3) & ~3); }
+__host__ __device__ inline size_t ungrouped_scratch_bytes(int B, int N) { return (size_t)B * N * ungrouped_ld(N) * sizeof(float); }
+
 __global__ __launch_bounds__(1024) void ungrouped_prepare_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws,
                                                                  gnms_ws_layout L) {
     const int b = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
+    const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     I.rem[P.presorted ? k : I.order[k]] = k;       // order is a permutation of [0,N) (identity on the padding)
+    if (k >= n) I.pre[k] = 0.0f;
+    if (L.NB >= 2) I.W[k] = 0ull;                  // forward mailbox
 }
 
-__global__ __launch_bounds__(1024) void ungrouped_forward_kernel(const float* __restrict__ iou, const float* __restrict__ scores, int N,
-                                                                 long ld, const int* __restrict__ counts, gnms_params P, char* ws,
-                                                                 gnms_ws_layout L) {
+__global__ __launch_bounds__(256) void ungrouped_permute_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                                                gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ Ps_all) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* xin = reinterpret_cast<float*>(smem);
-    float* T = xin + ((N + 3) & ~3);
-    float* xb = T + 64 * 65;
-    const int b = blockIdx.x;
+    float* rowbuf = reinterpret_cast<float*>(smem);
+    const int b = blockIdx.y, i = blockIdx.x;
     const int n = gnms_count(counts, b, N);
+    if (i >= n || i == 0) return;
     ImgPtrs I = img_ptrs(ws, L, b);
-    const float* m = iou + (size_t)b * N * ld;
-    const float* s = scores + (size_t)b * N;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < N; c += blockDim.x) { xin[c] = 0.0f; if (c >= n) I.pre[c] = 0.0f; }
+    const int ri = P.presorted ? i : I.order[i];
+    const float* row = iou + ((size_t)b * N + ri) * ld;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) rowbuf[c] = row[c];
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 64) {
-        const int rows = min(64, n - i0);
-        // (1) contributions of every solved column (xin is still 0 for unsolved ones)
-        for (int a = wave; a < rows; a += 16) {
-            const int ci = P.presorted ? (i0 + a) : I.order[i0 + a];
-            const float* row = m + (size_t)ci * ld;
-            float sum = 0.0f;
-            for (int c = lane; c < n; c += 64) {
-                const float x = xin[c];
-                if (x != 0.0f) sum += gnms_prune(row[c], P.nms_threshold, P.temperature, P.pruning_method) * x;
-            }
+    float* out = Ps_all + ((size_t)b * N + i) * ungrouped_ld(N);
+    for (int j = threadIdx.x; j < i; j += blockDim.x) {
+        const int cj = P.presorted ? j : I.order[j];
+        out[j] = gnms_prune(rowbuf[cj], P.nms_threshold, P.temperature, P.pruning_method);
+    }
+}
+
+// 256 threads: thread t owns row t>>2 of the block and 16 consecutive columns (t&3)*16.. of every 64-column tile
+__device__ __forceinline__ void ungrouped_load_tile(const float* __restrict__ p, bool live, float4 (&dst)[4]) {
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-            if (lane == 0) xb[a] = s[ci] - sum;
-        }
-        // (2) diagonal tile T[a][bb], bb < a
-        for (int e = threadIdx.x; e < rows * rows; e += blockDim.x) {
-            const int a = e / rows, bb = e - a * rows;
-            if (bb < a) {
-                const int ca = P.presorted ? (i0 + a) : I.order[i0 + a];
-                const int cb = P.presorted ? (i0 + bb) : I.order[i0 + bb];
-                T[a * 65 + bb] = gnms_prune(m[(size_t)ca * ld + cb], P.nms_threshold, P.temperature, P.pruning_method);
-            }
-        }
+    for (int q = 0; q < 4; ++q) dst[q] = live ? reinterpret_cast<const float4*>(p)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void ungrouped_solve_forward_kernel(const float* __restrict__ scores, int N, const int* __restrict__ counts,
+                                                                      gnms_params P, char* ws, gnms_ws_layout L,
+                                                                      const float* __restrict__ Ps_all) {
+    __shared__ float xc[64];
+    __shared__ float tb[64];
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int n = gnms_count(counts, b, N);
+    const int i0 = blk * 64;
+    if (i0 >= n) return;                                       // nobody waits for a block past the end
+    const int rows = min(64, n - i0);
+    const int nblk = (n + 63) >> 6;
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const size_t ldp = ungrouped_ld(N);
+    const float* Ps = Ps_all + (size_t)b * N * ldp;
+    const float* s = scores + (size_t)b * N;
+    u64* mail = I.W;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = t >> 2, cg = (t & 3) * 16;
+    const bool live = r < rows;
+    const float* strip = Ps + (size_t)(i0 + r) * ldp + cg;
+    // wave 0: row `lane` of the diagonal tile in registers (independent of every x); entries on/above the diagonal are not used
+    float4 trow[16];
+    if (wave == 0) {
+        const float4* p = reinterpret_cast<const float4*>(Ps + (size_t)(i0 + min(lane, rows - 1)) * ldp + i0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) trow[q] = p[q];
+    }
+    float acc = 0.0f;
+    float4 cur[4], nxt[4];
+    if (blk > 0) ungrouped_load_tile(strip, live, cur);
+    for (int c = 0; c < blk; ++c) {
+        if (c + 1 < blk) ungrouped_load_tile(strip + (size_t)(c + 1) * 64, live, nxt);
+        __syncthreads();                                       // xc of the previous tile is consumed
+        if (t < 64) xc[t] = mail_get(mail + c * 64 + t);
         __syncthreads();
-        if (wave == 0) {
-            float x = (lane < rows) ? xb[lane] : 0.0f;
-            for (int bb = 0; bb < rows - 1; ++bb) {
-                const float xbb = __shfl(x, bb, 64);
-                if (lane > bb && lane < rows) x -= T[lane * 65 + bb] * xbb;
-            }
-            if (lane < rows) {
-                const int ci = P.presorted ? (i0 + lane) : I.order[i0 + lane];
-                xin[ci] = x;
-                I.pre[i0 + lane] = x;
-            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc += cur[q].x * xc[cg + 4 * q] + cur[q].y * xc[cg + 4 * q + 1] + cur[q].z * xc[cg + 4 * q + 2] + cur[q].w * xc[cg + 4 * q + 3];
+            cur[q] = nxt[q];
         }
-        __syncthreads();
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if ((t & 3) == 0 && live) tb[r] = s[P.presorted ? (i0 + r) : I.order[i0 + r]] - acc;
+    __syncthreads();
+    if (wave == 0) {
+        float x = (lane < rows) ? tb[lane] : 0.0f;
+        const float* tr = reinterpret_cast<const float*>(trow);
+#pragma unroll
+        for (int bb = 0; bb < 63; ++bb) {                       // 63 dependent steps: v_readlane + multiply + subtract, no LDS
+            const float xbb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), bb));
+            const float upd = x - tr[bb] * xbb;
+            x = (lane > bb && lane < rows) ? upd : x;
+        }
+        if (lane < rows) {
+            I.pre[i0 + lane] = x;
+            if (blk + 1 < nblk) mail_put(mail + i0 + lane, x);
+        }
     }
 }
 
-__global__ __launch_bounds__(1024) void ungrouped_backward_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
-                                                                  gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores,
-                                                                  float* __restrict__ grad_iou) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ain = reinterpret_cast<float*>(smem);        // sum_{solved i} P(i, c) y_i, by input column c
-    float* T = ain + ((N + 3) & ~3);
-    float* yb = T + 64 * 65;
-    const int b = blockIdx.x;
+__global__ __launch_bounds__(1024) void ungrouped_backward_prepare_kernel(int N, char* ws, gnms_ws_layout L) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < N && L.NB >= 2) img_ptrs(ws, L, blockIdx.y).W[N + k] = 0ull;       // backward mailbox
+}
+
+__global__ __launch_bounds__(256) void ungrouped_solve_backward_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws,
+                                                                       gnms_ws_layout L, const float* __restrict__ Ps_all,
+                                                                       float* __restrict__ grad_scores) {
+    __shared__ float red[64 * 65];
+    __shared__ float yc[64];
+    const int b = blockIdx.y;
     const int n = gnms_count(counts, b, N);
-    ImgPtrs I = img_ptrs(ws, L, b);
-    const float* m = iou + (size_t)b * N * ld;
-    float* gi = grad_iou ? grad_iou + (size_t)b * N * ld : nullptr;
-    float* gs = grad_scores + (size_t)b * N;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < N; c += blockDim.x) { ain[c] = 0.0f; if (c >= n) gs[c] = 0.0f; }
-    __syncthreads();
     const int nblk = (n + 63) >> 6;
-    for (int blk = nblk - 1; blk >= 0; --blk) {
-        const int i0 = blk << 6;
-        const int rows = min(64, n - i0);
-        for (int e = threadIdx.x; e < rows * rows; e += blockDim.x) {
-            const int a = e / rows, bb = e - a * rows;
-            if (bb < a) {
-                const int ca = P.presorted ? (i0 + a) : I.order[i0 + a];
-                const int cb = P.presorted ? (i0 + bb) : I.order[i0 + bb];
-                T[a * 65 + bb] = gnms_prune(m[(size_t)ca * ld + cb], P.nms_threshold, P.temperature, P.pruning_method);
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            int ci = 0;
-            float y = 0.0f;
-            if (lane < rows) {
-                ci = P.presorted ? (i0 + lane) : I.order[i0 + lane];
-                y = I.gx[i0 + lane] - ain[ci];
-            }
-            for (int a = rows - 1; a > 0; --a) {
-                const float ya = __shfl(y, a, 64);
-                if (lane < a) y -= T[a * 65 + lane] * ya;
-            }
-            if (lane < rows) { yb[lane] = y; gs[ci] = y; }
-        }
-        __syncthreads();
-        // right-looking update: every column owned by one thread; rows of the block stream through
-        for (int c = threadIdx.x; c < n; c += blockDim.x) {
-            const int pc = I.rem[c];                        // NMS position of input column c
-            const float xc = I.pre[pc];
-            float a_c = ain[c];
-            for (int a = 0; a < rows; ++a) {
-                const int ci = P.presorted ? (i0 + a) : I.order[i0 + a];
-                const size_t off = (size_t)ci * ld + c;
-                const float v = m[off];
-                const float y = yb[a];
-                const bool live = pc < i0 + a;              // strictly lower triangle in NMS order
-                if (live && pc < i0) a_c += gnms_prune(v, P.nms_threshold, P.temperature, P.pruning_method) * y;
-                if (gi) gi[off] = live ? (-(y * xc)) * gnms_prune_grad(v, P.nms_threshold, P.temperature, P.pruning_method) : 0.0f;
-            }
-            ain[c] = a_c;
-        }
-        __syncthreads();
+    ImgPtrs I = img_ptrs(ws, L, b);
+    float* gs = grad_scores + (size_t)b * N;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if ((int)blockIdx.x >= nblk) {                              // padding positions get no gradient
+        for (int k = (int)blockIdx.x * 64 + t; k < min(N, ((int)blockIdx.x + 1) * 64); k += blockDim.x)
+            if (k >= n) gs[P.presorted ? k : I.order[k]] = 0.0f;
+        return;
     }
+    const int blk = nblk - 1 - (int)blockIdx.x;                 // the LAST block has no dependency: it is dispatched first
+    const int i0 = blk * 64;
+    const int rows = min(64, n - i0);
+    const size_t ldp = ungrouped_ld(N);
+    const float* Ps = Ps_all + (size_t)b * N * ldp;
+    u64* mail = I.W + N;
+    const int r = t >> 2, cg = (t & 3) * 16;
+    // wave 0: column `lane` of the diagonal tile in registers (tcol[a] = T[a][lane], used for a > lane)
+    float tcol[64];
+    if (wave == 0) {
+#pragma unroll
+        for (int a = 0; a < 64; ++a) tcol[a] = Ps[(size_t)(i0 + min(a, rows - 1)) * ldp + i0 + lane];
+    }
+    float part[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) part[q] = 0.0f;
+    float4 cur[4], nxt[4];
+    // tile (c, blk): rows 64c + r, columns i0 + cg ..
+    const float* colstrip = Ps + (size_t)r * ldp + i0 + cg;
+    if (nblk - 1 > blk) ungrouped_load_tile(colstrip + (size_t)(nblk - 1) * 64 * ldp, (nblk - 1) * 64 + r < n, cur);
+    for (int c = nblk - 1; c > blk; --c) {
+        if (c - 1 > blk) ungrouped_load_tile(colstrip + (size_t)(c - 1) * 64 * ldp, true, nxt);
+        __syncthreads();
+        if (t < 64) yc[t] = (c * 64 + t < n) ? mail_get(mail + c * 64 + t) : 0.0f;
+        __syncthreads();
+        const float y = yc[r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            part[4 * q] += cur[q].x * y; part[4 * q + 1] += cur[q].y * y; part[4 * q + 2] += cur[q].z * y; part[4 * q + 3] += cur[q].w * y;
+            cur[q] = nxt[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[r * 65 + cg + q] = part[q];
+    __syncthreads();
+    if (wave == 0) {
+        float sum = 0.0f;
+        for (int rr = 0; rr < 64; ++rr) sum += red[rr * 65 + lane];
+        int ci = 0;
+        float y = 0.0f;
+        if (lane < rows) {
+            ci = P.presorted ? (i0 + lane) : I.order[i0 + lane];
+            y = I.gx[i0 + lane] - sum;
+        }
+#pragma unroll
+        for (int a = 63; a > 0; --a) {
+            const float ya = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), a));
+            const float upd = y - tcol[a] * ya;
+            y = (lane < a && a < rows) ? upd : y;
+        }
+        if (lane < rows) {
+            I.xsol[i0 + lane] = y;
+            gs[ci] = y;
+            if (blk > 0) mail_put(mail + i0 + lane, y);
+        } else if (i0 + lane < N) {
+            gs[i0 + lane] = 0.0f;                               // padding behind a ragged image (order is the identity there)
+        }
+    }
+}
+
+// dL/diou[r][c] = -(y_r x_c) f'(iou[r][c]) where column c precedes row r in NMS order, else 0 (input index space, coalesced)
+__global__ __launch_bounds__(256) void ungrouped_grad_iou_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                                                 gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_iou) {
+    const int b = blockIdx.z, rr = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = gnms_count(counts, b, N);
+    if (c >= N) return;
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const size_t off = ((size_t)b * N + rr) * ld + c;
+    float g = 0.0f;
+    if (rr < n && c < n) {
+        const int pr = I.rem[rr], pc = I.rem[c];
+        if (pc < pr) g = (-(I.xsol[pr] * I.pre[pc])) * gnms_prune_grad(iou[off], P.nms_threshold, P.temperature, P.pruning_method);
+    }
+    grad_iou[off] = g;
 }
 
 }  // namespace gnms
