@@ -215,7 +215,7 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
         if (!P.mask_group_boxes) {
             const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
             if ((rc = allow_lds(solve_groups_kernel<false, false>, lds))) return rc;
-            solve_groups_kernel<false, false><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, nullptr, nullptr);
+            solve_groups_kernel<false, false><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, nullptr, nullptr);
             GNMS_CHECK_LAUNCH();
         }
     } else {
@@ -337,7 +337,7 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
     } else if (P.group_boxes) {
         const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
         if ((rc = allow_lds(solve_groups_kernel<true, false>, lds))) return rc;
-        solve_groups_kernel<true, false><<<dim3(N, B), 64, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
+        solve_groups_kernel<true, false><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
         GNMS_CHECK_LAUNCH();
     } else {
         const float* Ps = reinterpret_cast<const float*>(ws + (size_t)B * L.per_image);   // written by the forward pass
@@ -404,7 +404,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     if (!P.mask_group_boxes) {
         const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
         if ((rc = allow_lds(solve_groups_kernel<false, true>, lds))) return rc;
-        solve_groups_kernel<false, true><<<dim3(N, B), 64, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, nullptr, nullptr);
+        solve_groups_kernel<false, true><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, nullptr, nullptr);
         GNMS_CHECK_LAUNCH();
     }
     GNMS_DISPATCH_SORT(P2, {
@@ -445,7 +445,7 @@ extern "C" int gnms_backward_from_boxes(const float* grad_prob, const float* box
     GNMS_CHECK_LAUNCH();
     const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
     if ((rc = allow_lds(solve_groups_kernel<true, true>, lds))) return rc;
-    solve_groups_kernel<true, true><<<dim3(N, B), 64, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, grad_scores, nullptr);
+    solve_groups_kernel<true, true><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, grad_scores, nullptr);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

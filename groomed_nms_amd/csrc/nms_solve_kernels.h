@@ -16,85 +16,93 @@ constexpr int kGroupTileCap = 128;    // groups up to this size keep P_g in LDS 
 constexpr int kGroupMaxMembers = 2048;
 
 // ------------------------------------------------------------------------------------------------
-// unmasked groups: one wave per group (launched per rank; only heads work).
+// unmasked groups: grid (kSolveGroupWGs, B) x 256 threads.  Every workgroup first settles its share of the trivial boxes
+// (padding, boxes in no group, groups of one), then walks the head list of the multi-member groups (hlist, built by
+// groups_kernel) with stride gridDim.x: one workgroup per group, tile fill by all 4 waves, substitution with a barrier per
+// step.  (The first version launched one 64-thread workgroup per BOX with 90 KB of LDS each: 32768 workgroups, one per CU
+// at a time, ~200 us of pure dispatch at B=8, N=4096.)
 // dynamic LDS: int sc[G], int sq[G], float acc[G], float Pl[tile*(tile+1)]   with G = kGroupMaxMembers
 // ------------------------------------------------------------------------------------------------
+constexpr int kSolveGroupWGs = 128;
+
 template <bool BWD, bool BOXES>
-__global__ __launch_bounds__(64) void solve_groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
-                                                          gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores,
-                                                          float* __restrict__ grad_iou) {
+__global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                                           gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores,
+                                                           float* __restrict__ grad_iou) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sc = reinterpret_cast<int*>(smem);
     int* sq = sc + kGroupMaxMembers;
     float* acc = reinterpret_cast<float*>(sq + kGroupMaxMembers);
     float* Pl = acc + kGroupMaxMembers;
-    const int b = blockIdx.y, k = blockIdx.x;
+    const int b = blockIdx.y;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
-    const int lane = threadIdx.x;
-    if (k >= n) {
-        if (lane == 0) { if (BWD) grad_scores[(size_t)b * N + k] = 0.0f; else I.pre[k] = 0.0f; }
-        return;
+    const int tid = threadIdx.x, T = blockDim.x;
+    float* gs = BWD ? grad_scores + (size_t)b * N : nullptr;
+    // ---- trivial boxes ----
+    for (int k = blockIdx.x * T + tid; k < N; k += gridDim.x * T) {
+        if (k >= n) { if (BWD) gs[k] = 0.0f; else I.pre[k] = 0.0f; continue; }
+        const int h = I.head[k];
+        const int c = I.order[k];
+        const int q = P.presorted ? c : k;
+        if (h < 0) { if (BWD) gs[c] = 0.0f; else I.pre[q] = 0.0f; }                       // in no group: zero row of M
+        else if (h == k && I.glen[k] == 1) { if (BWD) gs[c] = I.gx[q]; else I.pre[q] = I.sscore[k]; }
     }
-    const int h = I.head[k];
-    if (h < 0) {   // in no group: zero row of M
-        if (lane == 0) {
-            const int c = I.order[k];
-            if (BWD) grad_scores[(size_t)b * N + c] = 0.0f; else I.pre[P.presorted ? c : k] = 0.0f;
-        }
-        return;
-    }
-    if (h != k) return;
+    // ---- multi-member groups ----
     const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
     float* gi = (BWD && grad_iou && !BOXES) ? grad_iou + (size_t)b * N * ld : nullptr;
-    const int g = I.glen[k], start = I.gstart[k];
-    const bool tiled = g <= kGroupTileCap;
-    const int ts = g + 1;   // padded tile stride
-
-    for (int t = lane; t < g; t += 64) {
-        const int mk = I.gsorted[start + t];
-        const int c = I.order[mk];
-        const int q = P.presorted ? c : mk;
-        int slot = t;
-        if (P.presorted) {      // NMS order inside the group = ascending input index
-            slot = 0;
-            for (int u = 0; u < g; ++u) slot += (I.order[I.gsorted[start + u]] < c) ? 1 : 0;
-        }
-        sc[slot] = c; sq[slot] = q;
-        acc[slot] = BWD ? I.gx[q] : I.sscore[mk];
-    }
-    __syncthreads();
-    if (tiled) {
-        for (int e = lane; e < g * g; e += 64) {
-            const int a = e / g, bb = e - a * g;
-            Pl[a * ts + bb] = (bb < a) ? gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb]), P.nms_threshold, P.temperature, P.pruning_method) : 0.0f;
+    const int nheads = I.misc[1];
+    for (int hi = blockIdx.x; hi < nheads; hi += gridDim.x) {
+        const int k = I.hlist[hi];
+        const int g = I.glen[k], start = I.gstart[k];
+        const bool tiled = g <= kGroupTileCap;
+        const int ts = g + 1;   // padded tile stride
+        __syncthreads();        // the previous group's LDS is consumed
+        for (int t = tid; t < g; t += T) {
+            const int mk = I.gsorted[start + t];
+            const int c = I.order[mk];
+            const int q = P.presorted ? c : mk;
+            int slot = t;
+            if (P.presorted) {      // NMS order inside the group = ascending input index
+                slot = 0;
+                for (int u = 0; u < g; ++u) slot += (I.order[I.gsorted[start + u]] < c) ? 1 : 0;
+            }
+            sc[slot] = c; sq[slot] = q;
+            acc[slot] = BWD ? I.gx[q] : I.sscore[mk];
         }
         __syncthreads();
-    }
-    auto Pab = [&](int a, int bb) -> float {
-        return tiled ? Pl[a * ts + bb] : gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb]), P.nms_threshold, P.temperature, P.pruning_method);
-    };
-    if (!BWD) {
-        for (int bb = 0; bb < g - 1; ++bb) {
-            const float xb = acc[bb];
-            for (int a = bb + 1 + lane; a < g; a += 64) acc[a] -= Pab(a, bb) * xb;
-            __syncthreads();
-        }
-        for (int t = lane; t < g; t += 64) I.pre[sq[t]] = acc[t];
-    } else {
-        for (int bb = g - 1; bb > 0; --bb) {
-            const float yb = acc[bb];
-            for (int a = lane; a < bb; a += 64) acc[a] -= Pab(bb, a) * yb;
-            __syncthreads();
-        }
-        for (int t = lane; t < g; t += 64) grad_scores[(size_t)b * N + sc[t]] = acc[t];
-        if (gi) {
-            for (int e = lane; e < g * g; e += 64) {
+        if (tiled) {
+            for (int e = tid; e < g * g; e += T) {
                 const int a = e / g, bb = e - a * g;
-                if (bb >= a) continue;
-                const size_t off = (size_t)sc[a] * ld + sc[bb];
-                const float d = gnms_prune_grad(m[off], P.nms_threshold, P.temperature, P.pruning_method);
-                gi[off] = (-(acc[a] * I.pre[sq[bb]])) * d;
+                Pl[a * ts + bb] = (bb < a) ? gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb]), P.nms_threshold, P.temperature, P.pruning_method) : 0.0f;
+            }
+            __syncthreads();
+        }
+        auto Pab = [&](int a, int bb) -> float {
+            return tiled ? Pl[a * ts + bb] : gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb]), P.nms_threshold, P.temperature, P.pruning_method);
+        };
+        if (!BWD) {
+            for (int bb = 0; bb < g - 1; ++bb) {
+                const float xb = acc[bb];
+                for (int a = bb + 1 + tid; a < g; a += T) acc[a] -= Pab(a, bb) * xb;
+                __syncthreads();
+            }
+            for (int t = tid; t < g; t += T) I.pre[sq[t]] = acc[t];
+        } else {
+            for (int bb = g - 1; bb > 0; --bb) {
+                const float yb = acc[bb];
+                for (int a = tid; a < bb; a += T) acc[a] -= Pab(bb, a) * yb;
+                __syncthreads();
+            }
+            for (int t = tid; t < g; t += T) gs[sc[t]] = acc[t];
+            if (gi) {
+                for (int e = tid; e < g * g; e += T) {
+                    const int a = e / g, bb = e - a * g;
+                    if (bb >= a) continue;
+                    const size_t off = (size_t)sc[a] * ld + sc[bb];
+                    const float d = gnms_prune_grad(m[off], P.nms_threshold, P.temperature, P.pruning_method);
+                    gi[off] = (-(acc[a] * I.pre[sq[bb]])) * d;
+                }
             }
         }
     }
