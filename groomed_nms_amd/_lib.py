@@ -105,5 +105,19 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` (default: the current device) as a void*."""
+    if _raw_stream is not None:           # ~0.3 us; torch.cuda.current_stream() builds a Stream object (~10 us)
+        if device is None:
+            idx = torch.cuda.current_device()
+        elif isinstance(device, int):
+            idx = device
+        else:
+            idx = torch.device(device).index
+            if idx is None:
+                idx = torch.cuda.current_device()
+        return ctypes.c_void_p(_raw_stream(idx))
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
