@@ -318,6 +318,32 @@ extern "C" int gnms_corners_of_cuboid(const float* params, int64_t count, float*
     return GNMS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// "projected" 2D boxes of the NMS (lib/loss/rpn_3d.py:746-768, diff_nms_boxes_2d == "projected"): cuboid corners
+// (get_corners_of_cuboid) -> image plane with the 4x4 projection p2 (lib/math_3d.py:47-72: rows 0,1 divided by row 2 where
+// |row 2| > 1e-2) -> min/max over the 8 corners -> times the image's scale factor.  One thread per box.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void project_boxes3d_kernel(const float* __restrict__ params, const float* __restrict__ p2,
+                                                              const float* __restrict__ scale, int N, long total, float4* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / N);
+    const float* P = p2 + (size_t)b * 16;
+    float cx[8], cy[8], cz[8];
+    corners_of(params + i * 7, cx, cy, cz);
+    float x1 = INFINITY, y1 = INFINITY, x2 = -INFINITY, y2 = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float u = ((P[0] * cx[k] + P[1] * cy[k]) + P[2] * cz[k]) + P[3];          // torch.matmul(p2, [x y z 1]^T), math_3d.py:66
+        float v = ((P[4] * cx[k] + P[5] * cy[k]) + P[6] * cz[k]) + P[7];
+        const float w = ((P[8] * cx[k] + P[9] * cy[k]) + P[10] * cz[k]) + P[11];
+        if (fabsf(w) > 1e-2f) { u = u / w; v = v / w; }                           // :67, :69
+        x1 = fminf(x1, u); x2 = fmaxf(x2, u); y1 = fminf(y1, v); y2 = fmaxf(y2, v);   // rpn_3d.py:762-765
+    }
+    const float sf = scale ? scale[b] : 1.0f;
+    out[i] = make_float4(x1 * sf, y1 * sf, x2 * sf, y2 * sf);                     // :767
+}
+
 // The per-box records are tiny (32 B/box); they live in a stream-ordered allocation so the public
 // entry points stay allocation-free for the caller.  hipMallocAsync/hipFreeAsync are stream ordered.
 static int iou3d_common(const float* in_a, const float* in_b, bool from_params, int B, int M, int N, int method, float* iou_bev,
@@ -355,4 +381,16 @@ extern "C" int gnms_iou3d_approximate(const float* corners_a, const float* corne
 extern "C" int gnms_iou3d_from_params(const float* params_a, const float* params_b, int B, int M, int N, int method,
                                       float* iou_bev, float* iou_3d, int64_t ld, void* stream) {
     return iou3d_common(params_a, params_b, true, B, M, N, method, iou_bev, iou_3d, ld, stream);
+}
+
+extern "C" int gnms_project_boxes3d(const float* params, const float* p2, const float* scale, int B, int N, float* boxes2d, void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && N >= 0, "gnms_project_boxes3d: negative size");
+    if (B == 0 || N == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(params && p2 && boxes2d, "gnms_project_boxes3d: null pointer");
+    GNMS_CHECK_ARG((uintptr_t)boxes2d % 16 == 0, "gnms_project_boxes3d: boxes2d must be 16-byte aligned");
+    const long total = (long)B * N;
+    project_boxes3d_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, p2, scale, N, total,
+                                                                                             reinterpret_cast<float4*>(boxes2d));
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
 }

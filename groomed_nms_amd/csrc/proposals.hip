@@ -1,0 +1,151 @@
+// proposals.hip -- what sits directly in front of the NMS layer: box decode and the score top-K that picks
+// the boxes the layer sees, on the device, so that scores/boxes never bounce through host NumPy.
+//
+// Reference:
+//   lib/rpn_util.py:872-934      bbox_transform_inv      anchors + deltas (de-normalised by stds/means) -> x1 y1 x2 y2
+//   lib/loss/rpn_3d.py:731-737   torch.sort(scores[fg], descending) -> the first min(500, #fg) foreground boxes go to the NMS
+//   lib/rpn_util.py:1258-1266    the same selection at inference (argsort of -score, first nms_topN)
+// The reference's selection then goes through .cpu()/.numpy() (rpn_3d.py:740-744); here it stays in HBM: gnms_select_topk
+// emits the indices AND the gathered scores/boxes in the padded [B][K] layout gnms_forward_with_iou2d consumes.
+#include "nms_kernels.h"
+
+namespace {
+
+using namespace gnms;
+
+// lib/rpn_util.py:886-927, same operation order
+__global__ __launch_bounds__(256) void bbox_transform_inv_kernel(const float4* __restrict__ anchors, const float4* __restrict__ deltas, long A,
+                                                                 long total, float4 means, float4 stds, int use_means, int use_stds,
+                                                                 float4* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float4 b = anchors[i % A];
+    float4 d = deltas[i];
+    const float widths = b.z - b.x + 1.0f;                              // :887
+    const float heights = b.w - b.y + 1.0f;                             // :888
+    const float ctr_x = b.x + 0.5f * widths;                            // :889
+    const float ctr_y = b.y + 0.5f * heights;                           // :890
+    if (use_stds) { d.x *= stds.x; d.y *= stds.y; d.z *= stds.z; d.w *= stds.w; }       // :903-907
+    if (use_means) { d.x += means.x; d.y += means.y; d.z += means.z; d.w += means.w; }   // :909-913
+    const float pcx = d.x * widths + ctr_x;                             // :915
+    const float pcy = d.y * heights + ctr_y;                            // :916
+    const float pw = expf(d.z) * widths;                                // :917
+    const float ph = expf(d.w) * heights;                               // :918
+    out[i] = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw - 1.0f, pcy + 0.5f * ph - 1.0f);   // :924-934
+}
+
+// One workgroup per image: stable descending sort of the candidates' scores, the first min(K, #candidates) leave.
+template <int E>
+__global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restrict__ scores, int A, const int* __restrict__ cand, int F,
+                                                           const int* __restrict__ cand_counts, int K, int P,
+                                                           const float4* __restrict__ boxes, long long* __restrict__ sel_idx,
+                                                           int* __restrict__ sel_count, float* __restrict__ sel_scores,
+                                                           float4* __restrict__ sel_boxes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);
+    const int b = blockIdx.x;
+    const int f = gnms_count(cand_counts, b, F);
+    const float* s = scores + (size_t)b * A;
+    const int* cd = cand ? cand + (size_t)b * F : nullptr;
+    u64 r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = threadIdx.x * E + e;
+        r[e] = ~0ull;
+        if (i < f) {
+            int a = cd ? cd[i] : i;
+            a = a < 0 ? 0 : (a >= A ? A - 1 : a);                       // a bad index must not turn into an out-of-bounds read
+            r[e] = ((u64)gnms_desc_key(s[a]) << 32) | (unsigned)i;      // ties: the earlier candidate first
+        }
+    }
+    block_sort<E, u64>(r, keys, P);
+    const int m = f < K ? f : K;
+    if (threadIdx.x == 0 && sel_count) sel_count[b] = m;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        long long idx = -1;
+        float sc = 0.0f;
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < m) {
+            const int i = (int)(keys[k] & 0xffffffffu);
+            int a = cd ? cd[i] : i;
+            a = a < 0 ? 0 : (a >= A ? A - 1 : a);
+            idx = a;
+            sc = s[a];
+            if (boxes) bx = boxes[(size_t)b * A + a];
+        }
+        if (sel_idx) sel_idx[(size_t)b * K + k] = idx;                  // padded with -1 / 0 behind the count
+        if (sel_scores) sel_scores[(size_t)b * K + k] = sc;
+        if (sel_boxes) sel_boxes[(size_t)b * K + k] = bx;
+    }
+}
+
+int next_pow2(int n) {
+    int p = 64;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int gnms_bbox_transform_inv(const float* anchors, const float* deltas, int B, int A, const float* means, const float* stds,
+                                       float* out, void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && A >= 0, "gnms_bbox_transform_inv: negative size");
+    if (B == 0 || A == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(anchors && deltas && out, "gnms_bbox_transform_inv: null pointer");
+    GNMS_CHECK_ARG(((uintptr_t)anchors % 16 == 0) && ((uintptr_t)deltas % 16 == 0) && ((uintptr_t)out % 16 == 0),
+                   "gnms_bbox_transform_inv: pointers must be 16-byte aligned");
+    const float4 m = means ? make_float4(means[0], means[1], means[2], means[3]) : make_float4(0.f, 0.f, 0.f, 0.f);   // host pointers
+    const float4 s = stds ? make_float4(stds[0], stds[1], stds[2], stds[3]) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const long total = (long)B * A;
+    bbox_transform_inv_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const float4*>(anchors), reinterpret_cast<const float4*>(deltas), (long)A, total, m, s, means != nullptr, stds != nullptr,
+        reinterpret_cast<float4*>(out));
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t* candidates, int F, const int32_t* candidate_counts, int K,
+                                const float* boxes, int64_t* sel_index, int32_t* sel_count, float* sel_scores, float* sel_boxes,
+                                void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && A >= 0 && F >= 0 && K >= 0, "gnms_select_topk: negative size");
+    if (B == 0 || K == 0) return GNMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (!candidates) F = A;
+    if (A == 0 || F == 0) {
+        if (sel_count) GNMS_CHECK_HIP(hipMemsetAsync(sel_count, 0, sizeof(int32_t) * B, st));
+        if (sel_index) GNMS_CHECK_HIP(hipMemsetAsync(sel_index, 0xff, sizeof(int64_t) * (size_t)B * K, st));
+        if (sel_scores) GNMS_CHECK_HIP(hipMemsetAsync(sel_scores, 0, sizeof(float) * (size_t)B * K, st));
+        if (sel_boxes) GNMS_CHECK_HIP(hipMemsetAsync(sel_boxes, 0, sizeof(float) * 4 * (size_t)B * K, st));
+        return GNMS_OK;
+    }
+    GNMS_CHECK_ARG(scores != nullptr, "gnms_select_topk: scores is NULL");
+    if (F > GNMS_MAX_BOXES) {
+        gnms_set_error("gnms_select_topk: %d candidates per image exceed GNMS_MAX_BOXES=%d", F, GNMS_MAX_BOXES);
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    GNMS_CHECK_ARG(!boxes || ((uintptr_t)boxes % 16 == 0), "gnms_select_topk: boxes must be 16-byte aligned");
+    GNMS_CHECK_ARG(!sel_boxes || ((uintptr_t)sel_boxes % 16 == 0), "gnms_select_topk: sel_boxes must be 16-byte aligned");
+    GNMS_CHECK_ARG(!sel_boxes || boxes, "gnms_select_topk: sel_boxes needs boxes");
+    const int P2 = next_pow2(F);
+    const size_t lds = (size_t)P2 * 8;
+    const int threads = P2 <= 1024 ? P2 : 1024;
+#define GNMS_TOPK(EE)                                                                                                                  \
+    do {                                                                                                                               \
+        if (lds > 64 * 1024)                                                                                                           \
+            GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk_kernel<EE>),                                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                \
+        select_topk_kernel<EE><<<B, threads, lds, st>>>(scores, A, candidates, F, candidate_counts, K, P2,                            \
+                                                        reinterpret_cast<const float4*>(boxes), (long long*)sel_index, sel_count,      \
+                                                        sel_scores, reinterpret_cast<float4*>(sel_boxes));                            \
+    } while (0)
+    switch (P2 <= 1024 ? 1 : P2 / 1024) {
+        case 1: GNMS_TOPK(1); break;
+        case 2: GNMS_TOPK(2); break;
+        case 4: GNMS_TOPK(4); break;
+        case 8: GNMS_TOPK(8); break;
+        default: GNMS_TOPK(16); break;
+    }
+#undef GNMS_TOPK
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}

@@ -205,6 +205,24 @@ int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int3
 int gnms_aploss(const float* logits, const float* targets, int B, int N, const int32_t* counts, float positive_label,
                 float negative_label, float* loss, float* grad, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * In front of the layer: decode and selection of the boxes the NMS sees, on the device.
+ * ------------------------------------------------------------------------------------------------ */
+/* lib/rpn_util.py:872-934 bbox_transform_inv.  anchors [A][4] (x1 y1 x2 y2), deltas [B][A][4] (dx dy dw dh; NOT modified,
+ * the reference scales its argument in place, :903-913), means / stds: HOST pointers to 4 floats or NULL; out [B][A][4]. */
+int gnms_bbox_transform_inv(const float* anchors, const float* deltas, int B, int A, const float* means, const float* stds,
+                            float* out, void* stream);
+/* lib/loss/rpn_3d.py:731-737 (and lib/rpn_util.py:1258-1266): per image the candidates' scores sorted descending (stable: ties
+ * keep candidate order), the first min(K, #candidates) selected.  scores [B][A]; candidates [B][F] int32 indices into [0, A)
+ * with candidate_counts [B] (NULL: all F), or candidates == NULL: every one of the A boxes is a candidate; F <= GNMS_MAX_BOXES.
+ * Outputs (any may be NULL), padded behind sel_count[b]: sel_index [B][K] int64 (-1), sel_scores [B][K] (0),
+ * sel_boxes [B][K][4] gathered from boxes [B][A][4] (0) -- the padded layout gnms_forward_with_iou2d takes with counts. */
+int gnms_select_topk(const float* scores, int B, int A, const int32_t* candidates, int F, const int32_t* candidate_counts, int K,
+                     const float* boxes, int64_t* sel_index, int32_t* sel_count, float* sel_scores, float* sel_boxes, void* stream);
+/* lib/loss/rpn_3d.py:746-768 ("projected" 2D boxes): params [B][N][7] = x y z w h l ry -> cuboid corners (lib/math_3d.py:364-435)
+ * -> projected with p2 [B][16] (4x4 row-major, lib/math_3d.py:47-72) -> min/max over the corners -> times scale[b] (NULL: 1). */
+int gnms_project_boxes3d(const float* params, const float* p2, const float* scale, int B, int N, float* boxes2d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

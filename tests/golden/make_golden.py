@@ -15,6 +15,7 @@ Reference entry points exercised (file:line under /root/reference):
   lib/math_3d.py:364      get_corners_of_cuboid
   lib/nms/py_cpu_nms.py:10 py_cpu_nms             lib/nms_others.py:6,119 navneeth_soft_nms, girshick_nms
   lib/loss/aploss.py:14   backpropAPLoss / APLoss (the consumer of the rescored scores)
+  lib/rpn_util.py:872     bbox_transform_inv      lib/math_3d.py:47       project_3d_points_in_4D_format   
 Known-answer vectors KAT-1/KAT-2 come from test/test_differentiable_nms_forward.py:127-140.
 
 Inputs are stored next to outputs: RNG streams differ across library versions, so nothing is ever
@@ -415,7 +416,64 @@ def main():
     ap_case("zeros400", z, (rng.uniform(size=400) < 0.05).astype(np.float32))
     np.savez_compressed(os.path.join(OUT, "aploss.npz"), **apg)
 
-    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz", "aploss.npz"):
+    # ------------------------------------------------------------------ in front of the layer
+    # lib/rpn_util.py imports torchvision (via lib/augmentations.py) and the compiled lib.nms.gpu_nms at module top: stubbed
+    class _Stub2(types.ModuleType):
+        def __getattr__(self, key):
+            if key.startswith("__"):
+                raise AttributeError(key)
+            return object
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional", "lib.nms.gpu_nms"):
+        if name not in sys.modules:
+            sys.modules[name] = _Stub2(name)
+    import lib.rpn_util as rpn_util  # noqa: E402
+    rng = np.random.default_rng(4242)
+    pg = {}
+    # (1) bbox_transform_inv (lib/rpn_util.py:872-934): 2-D and 3-D deltas, with and without means/stds (the function scales its
+    #     `deltas` argument in place: clones go in)
+    for tag, B, A in (("d2_64", 0, 64), ("d3_3x500", 3, 500), ("d3_1x7", 1, 7)):
+        ctr = rng.uniform(0, 1760, size=(A, 2))
+        wh = rng.uniform(8, 200, size=(A, 2))
+        anchors = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+        deltas = (rng.standard_normal((max(B, 1), A, 4)) * np.array([0.3, 0.3, 0.4, 0.4])).astype(np.float32)
+        if B == 0:
+            deltas = deltas[0]
+        means = np.array([0.01, -0.02, 0.1, 0.05], np.float32)
+        stds = np.array([0.14, 0.12, 0.3, 0.25], np.float32)
+        pg[f"decode/{tag}/anchors"], pg[f"decode/{tag}/deltas"] = anchors, deltas
+        pg[f"decode/{tag}/means"], pg[f"decode/{tag}/stds"] = means, stds
+        pg[f"decode/{tag}/out_plain"] = rpn_util.bbox_transform_inv(torch.from_numpy(anchors), torch.from_numpy(deltas.copy())).numpy()
+        pg[f"decode/{tag}/out_norm"] = rpn_util.bbox_transform_inv(torch.from_numpy(anchors), torch.from_numpy(deltas.copy()),
+                                                                  means=means, stds=stds).numpy()
+    # (2) projected 2D boxes (lib/loss/rpn_3d.py:746-768): the reference's corner and projection functions, composed as the loss does
+    p2 = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884],
+                   [0.0, 0.0, 0.0, 1.0]], np.float32)
+    for tag, n in (("p64", 64), ("p500", 500)):
+        par = np.stack([rng.uniform(-20, 20, n), rng.uniform(0.5, 2.5, n), rng.uniform(4, 60, n), rng.uniform(1.4, 2.0, n),
+                        rng.uniform(1.3, 2.0, n), rng.uniform(3, 5, n), rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+        if tag == "p64":
+            par[:4, 2] = [0.004, -0.003, 1.0, 2.0]       # cuboids straddling the camera plane: |z| <= 1e-2 keeps the undivided value
+        t = [torch.from_numpy(par[:, i].copy()) for i in range(7)]
+        corners = math_3d.get_corners_of_cuboid(x3d=t[0], y3d=t[1], z3d=t[2], w3d=t[3], h3d=t[4], l3d=t[5], ry3d=t[6])   # N x 3 x 8
+        flat = corners.transpose(1, 2).reshape((-1, 3)).transpose(0, 1)
+        proj = math_3d.project_3d_points_in_4D_format(torch.from_numpy(p2), flat, pad_ones=True)
+        c2 = proj.transpose(0, 1).reshape((-1, 8, 4)).transpose(1, 2)
+        box = torch.stack([c2[:, 0].min(1)[0], c2[:, 1].min(1)[0], c2[:, 0].max(1)[0], c2[:, 1].max(1)[0]], 1) * 0.7
+        pg[f"project/{tag}/params"], pg[f"project/{tag}/p2"], pg[f"project/{tag}/scale"] = par, p2, np.float32(0.7)
+        pg[f"project/{tag}/boxes"] = box.numpy()
+    # (3) selection (lib/loss/rpn_3d.py:731-737): torch.sort of the foreground scores, first min(K, #fg)
+    for tag, A, F, K in (("t2000_700_500", 2000, 700, 500), ("t2000_120_500", 2000, 120, 500), ("t300_300_50", 300, 300, 50)):
+        sc = rng.permutation(A).astype(np.float32) / A                        # distinct: torch.sort is not stable
+        fg = np.sort(rng.choice(A, size=F, replace=False)).astype(np.int64)
+        st = torch.from_numpy(sc)
+        _, sorted_index = torch.sort(st[torch.from_numpy(fg)], descending=True)
+        num = min(K, sorted_index.shape[0])
+        sel = torch.from_numpy(fg)[sorted_index[:num]]
+        pg[f"topk/{tag}/scores"], pg[f"topk/{tag}/fg"], pg[f"topk/{tag}/K"] = sc, fg.astype(np.int32), np.int32(K)
+        pg[f"topk/{tag}/selected"] = sel.numpy()
+    np.savez_compressed(os.path.join(OUT, "proposals.npz"), **pg)
+
+    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz", "aploss.npz", "proposals.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 

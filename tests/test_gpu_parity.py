@@ -726,3 +726,71 @@ def test_from_boxes_decisions_on_adversarial_boxes(G):
             for a, b2, c in zip(out1, out2, out3):
                 assert torch.equal(a, b2) or torch.allclose(a, b2, atol=0, rtol=0, equal_nan=True), (name, thr)
                 assert torch.equal(c, b2) or torch.allclose(c, b2, atol=0, rtol=0, equal_nan=True), (name, thr)
+
+
+# ------------------------------------------------------------------------------------------------
+# decode + projected boxes + score top-K in front of the layer
+# ------------------------------------------------------------------------------------------------
+def test_proposals_against_reference_vectors_and_oracle():
+    """bbox_transform_inv / projected_boxes_2d / select_topk (HIP) vs the reference's vectors and the NumPy oracle; then the
+    whole front end chained into the layer: decode -> top-K (gathered, padded) -> gnms_forward_with_iou2d with counts."""
+    from conftest import Golden
+    import oracle.proposals_oracle as PO
+    import oracle.oracle as O
+    from groomed_nms_amd import proposals as PR
+    import groomed_nms_amd as G
+    g = Golden("proposals.npz")
+    # decode: expf differs from libm by an ulp -> relative 1e-6 on widths of a few hundred pixels
+    for tag in ("d2_64", "d3_3x500", "d3_1x7"):
+        a = torch.from_numpy(g[f"decode/{tag}/anchors"]).cuda()
+        d = torch.from_numpy(g[f"decode/{tag}/deltas"]).cuda()
+        keep = d.clone()
+        out = PR.bbox_transform_inv(a, d)
+        assert out.shape == d.shape and torch.equal(d, keep)
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"decode/{tag}/out_plain"], rtol=2e-6, atol=2e-4, err_msg=tag)
+        out = PR.bbox_transform_inv(a, d, means=g[f"decode/{tag}/means"], stds=g[f"decode/{tag}/stds"])
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"decode/{tag}/out_norm"], rtol=2e-6, atol=2e-4, err_msg=tag)
+        cpu = PR.bbox_transform_inv(torch.from_numpy(g[f"decode/{tag}/anchors"]), torch.from_numpy(g[f"decode/{tag}/deltas"]))
+        assert not cpu.is_cuda and cpu.shape == d.shape                      # CPU in -> CPU out, like the reference
+    assert PR.bbox_transform_inv(torch.zeros((0, 4)), torch.zeros((0, 4))).shape == (0, 4)      # lib/rpn_util.py:881-882
+    # projection (sinf/cosf + a 4-term dot product in another association than torch.matmul): 1e-4 relative, 5e-3 px
+    for tag in ("p64", "p500"):
+        par = torch.from_numpy(g[f"project/{tag}/params"]).cuda().unsqueeze(0).repeat(2, 1, 1)
+        out = PR.projected_boxes_2d(par, g[f"project/{tag}/p2"], float(g[f"project/{tag}/scale"]))
+        for b in range(2):
+            np.testing.assert_allclose(out[b].cpu().numpy(), g[f"project/{tag}/boxes"], rtol=1e-4, atol=5e-3, err_msg=tag)
+    # selection: bit-exact indices, padding, ragged candidate lists, all-boxes mode, ties keep candidate order
+    for tag in ("t2000_700_500", "t2000_120_500", "t300_300_50"):
+        sc, fg, K = g[f"topk/{tag}/scores"], g[f"topk/{tag}/fg"], int(g[f"topk/{tag}/K"])
+        boxes = np.random.default_rng(1).uniform(0, 100, (len(sc), 4)).astype(np.float32)
+        F = len(fg)
+        cand = np.zeros((2, F), np.int32); cand[0] = fg; cand[1, :F // 2] = fg[::2][:F // 2]
+        cnt = np.array([F, F // 2], np.int32)
+        idx, num, ssel, bsel = PR.select_topk(torch.from_numpy(np.stack([sc, sc])).cuda(), K, torch.from_numpy(cand).cuda(),
+                                              torch.from_numpy(cnt).cuda(), torch.from_numpy(np.stack([boxes, boxes])).cuda())
+        want0 = g[f"topk/{tag}/selected"]
+        want1 = PO.select_topk(sc, cand[1, :F // 2], K)
+        for b, want in ((0, want0), (1, want1)):
+            m = len(want)
+            assert int(num[b]) == m
+            assert np.array_equal(idx[b, :m].cpu().numpy(), want) and (idx[b, m:] == -1).all()
+            assert np.array_equal(ssel[b, :m].cpu().numpy(), sc[want]) and (ssel[b, m:] == 0).all()
+            assert np.array_equal(bsel[b, :m].cpu().numpy(), boxes[want]) and (bsel[b, m:] == 0).all()
+    sc = np.round(np.random.default_rng(3).uniform(0, 1, (1, 5000)), 2).astype(np.float32)       # heavy ties, no candidate list
+    idx, num, ssel, _ = PR.select_topk(torch.from_numpy(sc).cuda(), 600)
+    assert int(num[0]) == 600 and np.array_equal(idx[0].cpu().numpy(), O.argsort_desc(sc[0])[:600])
+    # chained: decode -> top-K -> one-call layer on the padded selection == oracle on the compacted selection
+    tag = "d3_3x500"
+    a = torch.from_numpy(g[f"decode/{tag}/anchors"]).cuda()
+    d = torch.from_numpy(g[f"decode/{tag}/deltas"]).cuda()
+    boxes = PR.bbox_transform_inv(a, d, means=g[f"decode/{tag}/means"], stds=g[f"decode/{tag}/stds"])
+    rng = np.random.default_rng(9)
+    scores = torch.from_numpy(rng.permutation(3 * 500).reshape(3, 500).astype(np.float32) / 1500).cuda()
+    fgc = np.array([500, 220, 3], np.int32)
+    cand = np.stack([rng.permutation(500) for _ in range(3)]).astype(np.int32)
+    idx, num, ssel, bsel = PR.select_topk(scores, 256, torch.from_numpy(cand).cuda(), torch.from_numpy(fgc).cuda(), boxes)
+    out = G.differentiable_nms_with_iou2d_batched(ssel, bsel, counts=num)
+    for b in range(3):
+        m = int(num[b])
+        ref = O.differentiable_nms(ssel[b, :m].cpu().numpy(), O.iou2d(bsel[b, :m].cpu().numpy(), bsel[b, :m].cpu().numpy()))
+        np.testing.assert_allclose(out[0][b, :m].cpu().numpy(), ref["prob"], atol=TOL)

@@ -169,3 +169,24 @@ def test_aploss_oracle_against_reference():
         np.testing.assert_allclose(grad * up, g[f"{tag}/grad"], atol=1e-6, rtol=1e-4, err_msg=tag)
     loss, grad = O.aploss(g["nopos/logits"], g["nopos/targets"])
     assert loss == 0.0 and not grad.any()
+
+
+def test_proposals_oracle_against_reference():
+    """decode, projected boxes and the score top-K in front of the layer -- oracle vs vectors captured from
+    lib/rpn_util.py::bbox_transform_inv, lib/math_3d.py::get_corners_of_cuboid + project_3d_points_in_4D_format, torch.sort."""
+    from conftest import Golden
+    import oracle.proposals_oracle as PO
+    g = Golden("proposals.npz")
+    for tag in ("d2_64", "d3_3x500", "d3_1x7"):
+        a, d = g[f"decode/{tag}/anchors"], g[f"decode/{tag}/deltas"]
+        keep = d.copy()
+        np.testing.assert_allclose(PO.bbox_transform_inv(a, d), g[f"decode/{tag}/out_plain"], rtol=2e-6, atol=2e-4)
+        np.testing.assert_allclose(PO.bbox_transform_inv(a, d, g[f"decode/{tag}/means"], g[f"decode/{tag}/stds"]),
+                                   g[f"decode/{tag}/out_norm"], rtol=2e-6, atol=2e-4)
+        assert np.array_equal(d, keep)
+    for tag in ("p64", "p500"):
+        got = PO.projected_boxes_2d(g[f"project/{tag}/params"], g[f"project/{tag}/p2"], float(g[f"project/{tag}/scale"]))
+        np.testing.assert_allclose(got, g[f"project/{tag}/boxes"], rtol=1e-4, atol=5e-3)
+    for tag in ("t2000_700_500", "t2000_120_500", "t300_300_50"):
+        sel = PO.select_topk(g[f"topk/{tag}/scores"], g[f"topk/{tag}/fg"], int(g[f"topk/{tag}/K"]))
+        assert np.array_equal(sel, g[f"topk/{tag}/selected"]), tag
