@@ -239,12 +239,9 @@ extern "C" int gnms_aploss(const float* logits, const float* targets, int B, int
         return GNMS_ERR_UNSUPPORTED;
     }
     GNMS_CHECK_ARG(logits && targets && grad, "gnms_aploss: null pointer");
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (N > 2 * kApThreads)      // > 64 KiB of dynamic LDS; set per call: the attribute is per device and the call is cheap
         GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aploss_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kApThreads * 4 * 4 * 6));
-        attr_set = true;
-    }
 #define GNMS_APLOSS_LAUNCH(E) \
     aploss_kernel<E><<<B, kApThreads, (size_t)kApThreads * E * 4 * 6, st>>>(logits, targets, N, counts, positive_label, negative_label, loss, grad)
     if (N <= kApThreads) GNMS_APLOSS_LAUNCH(1);

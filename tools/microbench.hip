@@ -175,7 +175,7 @@ int main(int argc, char** argv) {
     }
     printf("attribute               %8.1f us\n", time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); }));
     if (P2 == 4096) {
-        printf("sort_scores<4>          %8.1f us\n", time_us([&] { sort_scores_kernel<4><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr); }));
+        printf("sort_scores<4>          %8.1f us\n", time_us([&] { sort_scores_kernel<4><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr, nullptr); }));
         printf("groups<4>               %8.1f us\n", time_us([&] { groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); }));
 #ifdef GNMS_TIMING
         {
