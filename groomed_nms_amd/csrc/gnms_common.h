@@ -156,6 +156,16 @@ __device__ __forceinline__ unsigned gnms_or_scan32(unsigned v) {
     v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);   // row_bcast:31 -> rows 2,3
     return v;                                                                       // inclusive OR-scan over the 64 lanes
 }
+// the same network with additions: inclusive prefix sum over the 64 lanes (Hillis-Steele inside each row of 16, then the row carries)
+__device__ __forceinline__ unsigned gnms_add_scan32(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);   // row_bcast:15 -> rows 1,3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);   // row_bcast:31 -> rows 2,3
+    return v;
+}
 __device__ __forceinline__ unsigned long long gnms_or_scan64(unsigned long long v) {
     const unsigned lo = gnms_or_scan32((unsigned)(v & 0xffffffffu));
     const unsigned hi = gnms_or_scan32((unsigned)(v >> 32));

@@ -179,6 +179,61 @@ __device__ __forceinline__ void block_sort(K (&r)[E], K* keys, int P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stable LSD radix pass over P = blockDim.x * E 32-bit keys in LDS, 7 bits per pass (128 digits), in place.
+// Element order is the LDS order; wave w owns the 64*E consecutive slots [w*64E, (w+1)*64E), lane l reads slots e*64 + l
+// (conflict-free), so a round e covers 64 consecutive elements and the stable rank inside the wave is
+//   (same-digit elements of earlier rounds, kept in a per-wave histogram) + popcount(same-digit lanes below me),
+// the same-digit lane mask coming from 7 ballots.  A (digit-major, wave-minor) exclusive scan of the 128 x #waves histogram
+// gives every (wave, digit) its base.  5 barriers per pass; 2 passes sort 14-bit keys (the groups' leader ranks), where the
+// merge-path block_sort needs ~15 us for 4096 keys and this needs ~4.
+// hist: 128 * (blockDim.x / 64) + 16 unsigned words of LDS.
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void block_radix_pass7(unsigned* keys, int shift, unsigned* hist) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    unsigned* wtot = hist + 128 * nw;
+    for (int i = t; i < 128 * nw; i += blockDim.x) hist[i] = 0u;
+    unsigned k[E], rnk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) k[e] = keys[wave * 64 * E + e * 64 + lane];
+    __syncthreads();
+    const u64 below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned d = (k[e] >> shift) & 127u;
+        u64 same = ~0ull;
+#pragma unroll
+        for (int bit = 0; bit < 7; ++bit) {
+            const bool on = (d >> bit) & 1u;
+            const u64 bl = __ballot(on);
+            same &= on ? bl : ~bl;
+        }
+        const unsigned prior = hist[wave * 128 + d];
+        rnk[e] = prior + (unsigned)__builtin_popcountll(same & below);
+        if ((same & below) == 0ull) hist[wave * 128 + d] = prior + (unsigned)__builtin_popcountll(same);   // the digit's lowest lane
+        __builtin_amdgcn_wave_barrier();                                // the next round reads what this one wrote (same wave: in order)
+    }
+    __syncthreads();
+    // exclusive scan in (digit, wave) order: entry j = d * nw + w lives at hist[w * 128 + d]; thread t owns j = 2t, 2t + 1
+    const int j0 = 2 * t, j1 = 2 * t + 1;
+    const int lw = 31 - __builtin_clz(nw);                               // #waves is a power of two
+    const int a0 = (j0 & (nw - 1)) * 128 + (j0 >> lw), a1 = (j1 & (nw - 1)) * 128 + (j1 >> lw);
+    const unsigned c0 = hist[a0], c1 = hist[a1];
+    const unsigned inc = gnms_add_scan32(c0 + c1);                       // DPP prefix sum: no ds_bpermute round trips
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    // sum of the totals of the waves before mine (<= 16 of them): lane w < wave holds total w, lane 63 of the scan has the sum
+    const unsigned carry = (unsigned)__builtin_amdgcn_readlane((int)gnms_add_scan32((lane < wave) ? wtot[lane] : 0u), 63);
+    const unsigned ex = carry + inc - (c0 + c1);
+    hist[a0] = ex;
+    hist[a1] = ex + c0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[hist[wave * 128 + ((k[e] >> shift) & 127u)] + rnk[e]] = k[e];
+    __syncthreads();
+}
+
 template <typename K>
 __device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
     int lo = 0, hi = n;
@@ -712,7 +767,7 @@ __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restr
 // ------------------------------------------------------------------------------------------------
 // K4: attribution.  One wave per rank block: walk the leaders with rank < 64(kb+1) in order, 64 per step;
 // an exclusive OR-scan across lanes tells each leader which bits it is the FIRST to claim.
-//   rem[k] = rank of the leader that removed rank k (k itself for a leader).
+//   rem[k] = rank of the leader that removed rank k (k itself for a leader), gpos[k] = that leader's ordinal.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
     u64 up = shfl_up_u64(v, 1);                                     // lane i <- lane i-1
@@ -747,6 +802,7 @@ __global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restr
         while (mine) {
             const int bit = __builtin_ctzll(mine);
             I.rem[k0 + bit] = lr;
+            I.gpos[k0 + bit] = t;                     // ordinal of that leader (groups_kernel's sort key; it overwrites gpos afterwards)
             mine &= mine - 1;
         }
         acc |= gnms_wave_or(w);
@@ -765,7 +821,7 @@ template <int E, bool BOXES>
 __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                                       gnms_params P, char* ws, gnms_ws_layout L, int Ppow2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned* keys = reinterpret_cast<unsigned*>(smem);          // (leader rank << 14) | rank : 28 bits (N <= 16384)
+    unsigned* keys = reinterpret_cast<unsigned*>(smem);          // (leader ordinal << 14) | rank : 28 bits (N <= 16384)
     unsigned* info = keys + Ppow2;                               // per rank: head | pos << 14, or ~0 (in no group)
     const int b = blockIdx.x;
     const int n = gnms_count(counts, b, N);
@@ -776,11 +832,12 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
     GNMS_T0();
     unsigned r[E];
     float v_lead[E], s_lead[E], s_own[E];
-    int c_own[E], lr_own[E];
+    int c_own[E], lr_own[E], g_own[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = threadIdx.x * E + e;
         lr_own[e] = (k < n) ? I.rem[k] : 0;
+        g_own[e] = (k < n) ? I.gpos[k] : 0;
         c_own[e] = (k < n) ? I.order[k] : 0;
         s_own[e] = (k < n) ? I.sscore[k] : 0.0f;
     }
@@ -796,11 +853,23 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = threadIdx.x * E + e;
-        r[e] = (k < n && v_lead[e] > thr) ? (((unsigned)lr_own[e] << 14) | (unsigned)k) : ~0u;   // strict > (:249)
+        // key = (ordinal of the leader << 14) | rank: the ordinal (attribute_kernel left it in gpos) needs only log2(#leaders)
+        // bits, i.e. ONE 7-bit radix pass for up to 127 groups
+        r[e] = (k < n && v_lead[e] > thr) ? (((unsigned)g_own[e] << 14) | (unsigned)k) : ~0u;   // strict > (:249)
         info[k] = ~0u;
     }
     GNMS_TACC(8);
-    block_sort<E, unsigned>(r, keys, Ppow2);
+    // group by leader: the keys start in rank order, so a STABLE sort on the leader bits alone yields (leader, rank) order
+    __shared__ unsigned radix_hist[128 * 16 + 16];
+#pragma unroll
+    for (int e = 0; e < E; ++e) keys[threadIdx.x * E + e] = r[e];
+    __syncthreads();
+    {
+        const int G = I.misc[0];                                           // number of leaders; the all-ones digit is reserved for the padding keys
+        block_radix_pass7<E>(keys, 14, radix_hist);
+        if (G > 127) block_radix_pass7<E>(keys, 21, radix_hist);
+        if (G > 16383) block_radix_pass7<E>(keys, 28, radix_hist);
+    }
     GNMS_TACC(9);
     // ---- phase 2: runs of equal leader are the groups; cap, head, position.  Thread t owns sorted positions
     //      t*E .. t*E+E-1; the start of each position's run comes from a max-scan of the run-start flags

@@ -176,10 +176,16 @@ int main(int argc, char** argv) {
     printf("attribute               %8.1f us\n", time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); }));
     if (P2 == 4096) {
         printf("sort_scores<4>          %8.1f us\n", time_us([&] { sort_scores_kernel<4><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr, nullptr); }));
-        printf("groups<4>               %8.1f us\n", time_us([&] { groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); }));
+        // groups_kernel consumes the leader ordinals attribute_kernel leaves in gpos (and overwrites gpos): time the pair
+        {
+            const float ta = time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); });
+            const float tag = time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); });
+            printf("groups<4>               %8.1f us (attribute + groups %.1f)\n", tag - ta, tag);
+        }
 #ifdef GNMS_TIMING
         {
             long long z[16] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
+            attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L);
             groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); CK(hipDeviceSynchronize());
             CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
             printf("  groups phases (cycles, thread0): keys %lld | sort %lld | runs %lld | rescoring %lld\n", z[8], z[9], z[10], z[11]);
