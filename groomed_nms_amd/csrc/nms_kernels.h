@@ -155,6 +155,7 @@ __device__ __forceinline__ void block_sort(K (&r)[E], K* keys, int P) {
     // ---- phase 2: pairwise merge passes ----
     for (int p = run; p < P; p <<= 1) {
         const int d0 = t * E;
+        if (d0 >= P) { __syncthreads(); __syncthreads(); continue; }      // P < blockDim.x * E: the surplus threads only keep the barriers
         const int base = d0 & ~(2 * p - 1);
         const int d = d0 - base;                                        // diagonal inside the pair [A | B], |A| = |B| = p
         const K* A = keys + base;
@@ -1053,7 +1054,9 @@ __global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __rest
         if (nv <= T) {
             u64 r1[1] = {keys[t]};
             __syncthreads();
-            block_sort<1, u64>(r1, keys, T);
+            int pe = 64;                                                   // typically ~100 valid boxes: 128 keys, one merge pass instead of four
+            while (pe < nv) pe <<= 1;
+            block_sort<1, u64>(r1, keys, pe);
         } else {
             u64 r[E];
 #pragma unroll
