@@ -612,7 +612,9 @@ __device__ __forceinline__ size_t leaders_lds_layout(int NB, size_t* off_acc, si
     return o;
 }
 
-__global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
+// The four per-image stages K3..K6 are written as device functions (`*_body`, 1024 threads, image index `b`) so that they
+// run either as kernels of their own (thin wrappers below) or back to back inside ONE launch (tail_kernel).
+__device__ __forceinline__ void leaders_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t oa, ol, oc, op;
     leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -621,7 +623,6 @@ __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restr
     u64* lmask = reinterpret_cast<u64*>(smem + ol);              // [NB]
     int* pair_b = reinterpret_cast<int*>(smem + op);             // [kSBPairs]
     int* pair_bp = pair_b + kSBPairs;
-    const int b = blockIdx.x;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -765,6 +766,10 @@ __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restr
     }
 }
 
+__global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
+    leaders_body(N, counts, ws, L, (int)blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4: attribution.  One wave per rank block: walk the leaders with rank < 64(kb+1) in order, 64 per step;
 // an exclusive OR-scan across lanes tells each leader which bits it is the FIRST to claim.
@@ -776,13 +781,13 @@ __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
     return gnms_or_scan64(up);                                      // DPP inclusive OR-scan (gnms_common.h)
 }
 
-__global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
-    const int b = blockIdx.y, kb = blockIdx.x;
+// one wave: rank block kb of image b
+__device__ __forceinline__ void attribute_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int kb,
+                                               const int lane) {
     const int n = gnms_count(counts, b, N);
     const int k0 = kb << 6;
     if (k0 >= n) return;
     ImgPtrs I = img_ptrs(ws, L, b);
-    const int lane = threadIdx.x;
     const int nrows = min(64, n - k0);
     const u64 want = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
     const u64* slab = I.W + (size_t)kb * L.NC;
@@ -810,6 +815,10 @@ __global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restr
     }
 }
 
+__global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
+    attribute_body(N, counts, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K5: groups.  member(k) = iou[order[k]][order[rem[k]]] > thr (strict, :249); sort (leader, rank) in LDS;
 // runs of equal leader are the groups, their first group_size+1 entries survive (:253-255), the first
@@ -819,12 +828,11 @@ __global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restr
 // (q = rank for hard sort, q = input index when presorted).
 // ------------------------------------------------------------------------------------------------
 template <int E, bool BOXES>
-__global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
-                                                      gnms_params P, char* ws, gnms_ws_layout L, int Ppow2) {
+__device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                            gnms_params P, char* ws, gnms_ws_layout L, int Ppow2, const int b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* keys = reinterpret_cast<unsigned*>(smem);          // (leader ordinal << 14) | rank : 28 bits (N <= 16384)
     unsigned* info = keys + Ppow2;                               // per rank: head | pos << 14, or ~0 (in no group)
-    const int b = blockIdx.x;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
@@ -979,6 +987,12 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
     GNMS_TACC(11);
 }
 
+template <int E, bool BOXES>
+__global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                                      gnms_params P, char* ws, gnms_ws_layout L, int Ppow2) {
+    groups_body<E, BOXES>(iou, N, ld, counts, P, ws, L, Ppow2, (int)blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K6: finalize (lib/groomed_nms.py:111-129).  r2 = clamp(pre,0,1); r = r2 with (< valid_thr) zeroed;
 // the reference then sorts r descending (:116-121).  After thresholding every invalid box is an exact 0,
@@ -988,14 +1002,13 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
 // reference returns it.
 // ------------------------------------------------------------------------------------------------
 template <int E>
-__global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
-                                                        int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
-                                                        long long* __restrict__ invalid, int* __restrict__ nvalid,
-                                                        int* __restrict__ ninvalid) {
+__device__ __forceinline__ void finalize_body(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
+                                              int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
+                                              long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
+                                              const int b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);                     // [Ppow2]
     __shared__ u64 wave_tot[16];
-    const int b = blockIdx.x;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const float vthr = P.valid_box_prob_threshold;
@@ -1088,6 +1101,35 @@ __global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __rest
         if (nvalid) nvalid[b] = nv;
         if (ninvalid) ninvalid[b] = ni;
     }
+}
+
+template <int E>
+__global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
+                                                        int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
+                                                        long long* __restrict__ invalid, int* __restrict__ nvalid,
+                                                        int* __restrict__ ninvalid) {
+    finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3..K6 in ONE launch (masked groups): leaders -> attribution -> groups + rescoring -> finalize, one workgroup of 1024 threads
+// per image.  All four stages are per-image and already ran one workgroup per image (attribution: one wave per rank block,
+// here 16 waves striding the blocks), so nothing is lost in parallelism; three kernel boundaries (launch, drain, refill) go.
+// Ppow2 >= 1024 (smaller images pad their keys).  dynamic LDS = max(leaders table, Ppow2 * 8).
+// ------------------------------------------------------------------------------------------------
+template <int E, bool BOXES>
+__global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
+                                                    char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob,
+                                                    long long* __restrict__ valid, long long* __restrict__ invalid, int* __restrict__ nvalid,
+                                                    int* __restrict__ ninvalid) {
+    const int b = blockIdx.x;
+    leaders_body(N, counts, ws, L, b);
+    __syncthreads();
+    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body(N, counts, ws, L, b, kb, threadIdx.x & 63);
+    __syncthreads();
+    groups_body<E, BOXES>(src, N, ld, counts, P, ws, L, Ppow2, b);
+    __syncthreads();
+    finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
 }
 
 }  // namespace

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <cstdlib>
 #include "iou_tile.h"
 #include "nms_solve_kernels.h"
 
@@ -177,6 +178,31 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
 // workgroups (4 wave tiles each) of bitmask_boxes_kernel per image: (row blocks) x (256-column chunks)
 inline int bitmask_boxes_blocks(int N) { return gnms_div_up(((N + 63) / 64) * ((N + 255) / 256), 4); }
 
+// K3..K6 as one launch or four?  Measured (HIP-graph replay, B=8): one launch wins 2-2.5 us per step up to N=2048 (three
+// kernel boundaries less) and loses 1.5 us at N=4096 (the attribution runs on one CU instead of 64).  GNMS_TAIL=0/1 forces.
+bool use_tail_kernel(int N) {
+    static const int forced = [] { const char* e = getenv("GNMS_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return forced >= 0 ? forced == 1 : N <= 2048;
+}
+
+// K3..K6 in one launch (masked groups); src = the matrix (BOXES false) or the boxes (BOXES true)
+template <bool BOXES>
+int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* counts, const gnms_params& P, char* ws, const gnms_ws_layout& L,
+                float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, hipStream_t st) {
+    int P2 = next_pow2(N);
+    if (P2 < 1024) P2 = 1024;                                   // the fused kernel always runs 1024 threads
+    const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
+    const size_t lds = llds > glds ? llds : glds;
+    int rc;
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(tail_kernel<E, BOXES>, lds))) return rc;
+        tail_kernel<E, BOXES><<<B, 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
+                                                    ninvalid);
+    });
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
 int forward_impl(const char* fn, const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
                  const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid,
                  int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted) {
@@ -205,6 +231,14 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
         GNMS_CHECK_LAUNCH();
     }
 
+    if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N)) {
+        const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
+        dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
+        if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, P.nms_threshold, ws, L);
+        else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, P.nms_threshold, ws, L);
+        GNMS_CHECK_LAUNCH();
+        return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
+    }
     if (P.group_boxes) {
         if ((rc = run_grouping(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;
         GNMS_DISPATCH_SORT(P2, {
@@ -390,6 +424,8 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     }
     bitmask_boxes_kernel<<<dim3(bitmask_boxes_blocks(N), 1, B), 256, 0, st>>>(boxes, N, counts, P.nms_threshold, ws, L);
     GNMS_CHECK_LAUNCH();
+    if (P.mask_group_boxes && use_tail_kernel(N))
+        return launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
     const size_t llds = leaders_lds_bytes(N);
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
     leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
