@@ -4,6 +4,9 @@
 #include <string.h>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "iou_tile.h"
 #include "nms_solve_kernels.h"
 
@@ -58,12 +61,23 @@ int next_pow2(int n) {
 
 size_t leaders_lds_bytes(int N) { const int NB = (N + 63) / 64; return (size_t)kSBPairs * 64 * 8 + 2 * (size_t)((NB + 1) & ~1) * 8 + 2 * kSBPairs * 4; }
 
-template <typename K>
-int allow_lds(K kernel, size_t bytes) {
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once per (device, kernel); the attribute call is not free
+// (a driver round trip per launch adds up on the small-N path), so what has been granted is remembered.
+int allow_lds_raw(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return GNMS_OK;
-    GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    GNMS_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& g = granted[std::make_pair(dev, kernel)];
+    if (g >= bytes) return GNMS_OK;
+    GNMS_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    g = bytes;
     return GNMS_OK;
 }
+template <typename K>
+int allow_lds(K kernel, size_t bytes) { return allow_lds_raw(reinterpret_cast<const void*>(kernel), bytes); }
 
 int check_common(const char* fn, int B, int N, int64_t ld, const gnms_params* P, const void* ws, size_t ws_bytes) {
     GNMS_CHECK_ARG(P != nullptr, "%s: params is NULL", fn);
