@@ -794,3 +794,50 @@ def test_proposals_against_reference_vectors_and_oracle():
         m = int(num[b])
         ref = O.differentiable_nms(ssel[b, :m].cpu().numpy(), O.iou2d(bsel[b, :m].cpu().numpy(), bsel[b, :m].cpu().numpy()))
         np.testing.assert_allclose(out[0][b, :m].cpu().numpy(), ref["prob"], atol=TOL)
+
+
+def test_fuzz_layer_against_oracle(G, O):
+    """Seeded fuzz over sizes, box statistics, thresholds, group sizes, pruning functions and ragged counts: the one-call entry
+    (from-boxes kernels, fused tail for small N), the matrix-in entry and the oracle must agree on every image -- probabilities
+    and gradients within TOL (bit-exact between the two HIP paths), valid / invalid as sets."""
+    from groomed_nms_amd import synthetic, overlaps
+    rng = np.random.default_rng(20260928)
+    for trial in range(120):
+        B = int(rng.integers(1, 5))
+        N = int(rng.choice([1, 2, 7, 63, 64, 65, 130, 257, 300, 520, 1025, 2300]))
+        kind = "clustered" if rng.uniform() < 0.7 else "uniform"
+        per = int(rng.choice([2, 8, 40, 150]))
+        boxes, scores = synthetic.batch_2d(int(rng.integers(1 << 30)), B, N, kind, per=per)
+        if rng.uniform() < 0.3:
+            boxes = np.round(boxes / 8) * 8                                    # exact duplicates and exactly touching boxes
+        kw = dict(nms_threshold=float(rng.choice([0.2, 0.4, 0.55, 0.75])), group_size=int(rng.choice([0, 1, 3, 100])),
+                  valid_box_prob_threshold=float(rng.choice([0.0, 0.3, 0.6])),
+                  return_sorted_prob=bool(rng.uniform() < 0.2))
+        pm = rng.choice(["linear", "linear", "sigmoidal", "soft_nms"])
+        kw.update(pruning_method=str(pm), temperature=0.01 if pm == "linear" else 0.3)
+        mask = bool(rng.uniform() < 0.8)
+        counts_np = np.array([N] + [int(rng.integers(1, N + 1)) for _ in range(B - 1)], np.int32)
+        counts = torch.from_numpy(counts_np).cuda()
+        bt = torch.from_numpy(boxes).cuda()
+        w = torch.from_numpy(rng.uniform(-1, 2, (B, N)).astype(np.float32)).cuda()
+        s1 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        out1 = G.differentiable_nms_with_iou2d_batched(s1, bt, counts=counts, mask_group_boxes=mask, **kw)
+        out2 = G.differentiable_nms_batched(s2, overlaps.iou_batched(bt), counts=counts, mask_group_boxes=mask, **kw)
+        tag = (trial, B, N, kind, per, kw, mask)
+        for a, b2 in zip(out1[:6], out2):
+            assert torch.equal(a, b2) or torch.allclose(a, b2, atol=0, rtol=0, equal_nan=True), tag
+        (out1[0] * w).sum().backward()
+        (out2[0] * w).sum().backward()
+        assert torch.equal(s1.grad, s2.grad), tag
+        for b in range(B):
+            n = int(counts_np[b])
+            ref = O.differentiable_nms(scores[b, :n], O.iou2d(boxes[b, :n], boxes[b, :n]), grad_prob=w[b, :n].cpu().numpy(),
+                                       mask_group_boxes=mask, **kw)
+            if np.isnan(ref["prob"]).any():
+                continue                                                       # zero-area duplicates: NaN self-overlap, order undefined
+            np.testing.assert_allclose(out1[0][b, :n].detach().cpu().numpy(), ref["prob"], atol=TOL, err_msg=str(tag))
+            np.testing.assert_allclose(s1.grad[b, :n].cpu().numpy(), ref["grad_scores"], atol=TOL, rtol=1e-4, err_msg=str(tag))
+            if not kw["return_sorted_prob"]:
+                nv, ni = int(out1[4][b]), int(out1[5][b])
+                check_index_lists(out1[2][b, :nv].cpu().numpy(), out1[3][b, :ni].cpu().numpy(), ref["valid"], ref["invalid"])
