@@ -66,6 +66,8 @@ _SIGNATURES = {
     "gnms_select_topk": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                          c_vp]),
     "gnms_project_boxes3d": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp]),
+    "gnms_best_targets": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_float, c_vp, c_vp,
+                                          c_vp, c_vp]),
     "gnms_aploss": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
 }
 

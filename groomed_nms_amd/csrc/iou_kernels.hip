@@ -344,6 +344,87 @@ __global__ __launch_bounds__(256) void project_boxes3d_kernel(const float* __res
     out[i] = make_float4(x1 * sf, y1 * sf, x2 * sf, y2 * sf);                     // :767
 }
 
+// ------------------------------------------------------------------------------------------------
+// Best box per ground truth after the NMS (lib/loss/rpn_3d.py:801-825):
+//     score[i][j] = 0.5 * (1 + GIoU3D(pred_i, gt_j)) * IoU2D(pred_i, gt_j)           (:819)
+//     best[j] = argmax_i score[i][j]  (:820), kept only if score > beta (:822)  ->  targets[best[j]] = 1  (:826)
+// One workgroup per (ground truth, image): the N x M score matrices of the reference are never materialised -- every thread
+// evaluates its predictions against the one ground truth in registers (exact operation order of iou3d_kernel / iou2d_tile) and
+// the workgroup reduces (score, index) to the FIRST maximum; a NaN score is a maximum, as in torch.max, and then fails `> beta`.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool better_target(float s, int i, float bs, int bi) {   // (s,i) beats (bs,bi): larger, NaN largest, first index
+    const bool sn = s != s, bn = bs != bs;
+    if (bi < 0) return true;
+    if (sn != bn) return sn;
+    if (!sn && s != bs) return s > bs;
+    return i < bi;
+}
+
+__global__ __launch_bounds__(256) void best_targets_kernel(const float* __restrict__ pred_params, const float* __restrict__ pred_boxes,
+                                                           const float* __restrict__ gt_params, const float* __restrict__ gt_boxes, int N, int M,
+                                                           const int* __restrict__ pred_counts, const int* __restrict__ gt_counts, float beta,
+                                                           long long* __restrict__ best_index, float* __restrict__ best_score,
+                                                           float* __restrict__ targets) {
+    __shared__ float ws_s[4];
+    __shared__ int ws_i[4];
+    const int j = blockIdx.x, b = blockIdx.y;
+    const int n = gnms_count(pred_counts, b, N), m = gnms_count(gt_counts, b, M);
+    if (j >= m) {
+        if (threadIdx.x == 0) { if (best_index) best_index[(size_t)b * M + j] = -1; if (best_score) best_score[(size_t)b * M + j] = 0.0f; }
+        return;
+    }
+    float cx[8], cy[8], cz[8], g[kRec];
+    corners_of(gt_params + ((size_t)b * M + j) * 7, cx, cy, cz);
+    aabb_record(cx, cy, cz, g);
+    const float4 gb = reinterpret_cast<const float4*>(gt_boxes)[(size_t)b * M + j];
+    const float garea = (gb.z - gb.x) * (gb.w - gb.y);
+    float bs = 0.0f;
+    int bi = -1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float r[kRec];
+        corners_of(pred_params + ((size_t)b * N + i) * 7, cx, cy, cz);
+        aabb_record(cx, cy, cz, r);
+        // prediction = box "a" (rows), ground truth = box "b" (columns): iou3d_kernel<METHOD 1> for one pair
+        const float vol = r[0] + g[0];
+        const float yi = relu0(fminf(r[2], g[2]) - fmaxf(r[1], g[1]));
+        const float w = relu0(fminf(r[4], g[4]) - fmaxf(r[3], g[3]));
+        const float h = relu0(fminf(r[6], g[6]) - fmaxf(r[5], g[5]));
+        const float i3 = (w * h) * yi;
+        const float u3 = vol - i3;
+        float q = i3 / u3;
+        const float xh = relu0(fmaxf(r[4], g[4]) - fminf(r[3], g[3]));
+        const float yh = relu0(fmaxf(r[2], g[2]) - fminf(r[1], g[1]));
+        const float zh = relu0(fmaxf(r[6], g[6]) - fminf(r[5], g[5]));
+        const float vh = (xh * yh) * zh;
+        q = q - ((vh - u3) / vh);
+        // iou2d_tile for one pair
+        const float4 pb = reinterpret_cast<const float4*>(pred_boxes)[(size_t)b * N + i];
+        const float w2 = relu0(fminf(pb.z, gb.z) - fmaxf(pb.x, gb.x));
+        const float h2 = relu0(fminf(pb.w, gb.w) - fmaxf(pb.y, gb.y));
+        const float in2 = w2 * h2;
+        const float iou2 = in2 / (((pb.z - pb.x) * (pb.w - pb.y) + garea) - in2);
+        const float sc = (0.5f * (1.0f + q)) * iou2;                                   // rpn_3d.py:819
+        if (better_target(sc, i, bs, bi)) { bs = sc; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float os = __shfl_xor(bs, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (oi >= 0 && better_target(os, oi, bs, bi)) { bs = os; bi = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { ws_s[wave] = bs; ws_i[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int wv = 1; wv < 4; ++wv)
+            if (ws_i[wv] >= 0 && better_target(ws_s[wv], ws_i[wv], bs, bi)) { bs = ws_s[wv]; bi = ws_i[wv]; }
+        const bool keep = bi >= 0 && bs > beta;                                        // :822 (false for NaN)
+        if (best_index) best_index[(size_t)b * M + j] = keep ? bi : -1;
+        if (best_score) best_score[(size_t)b * M + j] = bi >= 0 ? bs : 0.0f;
+        if (keep && targets) targets[(size_t)b * N + bi] = 1.0f;                       // :826 (several ground truths may pick the same box)
+    }
+}
+
 // The per-box records are tiny (32 B/box); they live in a stream-ordered allocation so the public
 // entry points stay allocation-free for the caller.  hipMallocAsync/hipFreeAsync are stream ordered.
 static int iou3d_common(const float* in_a, const float* in_b, bool from_params, int B, int M, int N, int method, float* iou_bev,
@@ -391,6 +472,26 @@ extern "C" int gnms_project_boxes3d(const float* params, const float* p2, const 
     const long total = (long)B * N;
     project_boxes3d_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, p2, scale, N, total,
                                                                                              reinterpret_cast<float4*>(boxes2d));
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+extern "C" int gnms_best_targets(const float* pred_params, const float* pred_boxes2d, const float* gt_params, const float* gt_boxes2d, int B,
+                                 int N, int M, const int32_t* pred_counts, const int32_t* gt_counts, float beta, int64_t* best_index,
+                                 float* best_score, float* targets, void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && N >= 0 && M >= 0, "gnms_best_targets: negative size");
+    hipStream_t st = (hipStream_t)stream;
+    if (targets && B > 0 && N > 0) GNMS_CHECK_HIP(hipMemsetAsync(targets, 0, sizeof(float) * (size_t)B * N, st));   // :800 "all other boxes 0"
+    if (B == 0 || M == 0) return GNMS_OK;
+    if (N == 0) {
+        if (best_index) GNMS_CHECK_HIP(hipMemsetAsync(best_index, 0xff, sizeof(int64_t) * (size_t)B * M, st));
+        if (best_score) GNMS_CHECK_HIP(hipMemsetAsync(best_score, 0, sizeof(float) * (size_t)B * M, st));
+        return GNMS_OK;
+    }
+    GNMS_CHECK_ARG(pred_params && pred_boxes2d && gt_params && gt_boxes2d, "gnms_best_targets: null pointer");
+    GNMS_CHECK_ARG(((uintptr_t)pred_boxes2d % 16 == 0) && ((uintptr_t)gt_boxes2d % 16 == 0), "gnms_best_targets: 2D boxes must be 16-byte aligned");
+    best_targets_kernel<<<dim3(M, B), 256, 0, st>>>(pred_params, pred_boxes2d, gt_params, gt_boxes2d, N, M, pred_counts, gt_counts, beta,
+                                                    (long long*)best_index, best_score, targets);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

@@ -5,6 +5,7 @@ Host-side mirror of the reference pieces that sit directly in front of the layer
   select_topk               lib/loss/rpn_3d.py:731-737 / lib/rpn_util.py:1258-1266 (sort by score, keep the first K) -- without
                             the .cpu()/.numpy() round trip of rpn_3d.py:740-744
   projected_boxes_2d        lib/loss/rpn_3d.py:746-768 (cuboid -> corners -> projection -> 2D box)
+  best_targets              lib/loss/rpn_3d.py:801-825 (best box per ground truth after the NMS)
 All arithmetic runs in HIP kernels behind the C ABI (include/groomed_nms_hip.h); no CPU implementation lives here.
 """
 import ctypes
@@ -14,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 
-__all__ = ["bbox_transform_inv", "select_topk", "projected_boxes_2d"]
+__all__ = ["bbox_transform_inv", "select_topk", "projected_boxes_2d", "best_targets"]
 
 
 def _device():
@@ -98,3 +99,26 @@ def projected_boxes_2d(params, p2, scale_factor=None):
     with torch.cuda.device(dev):
         check(lib.gnms_project_boxes3d(ptr(p), ptr(P), ptr(sc), B, N, ptr(out), stream_ptr()), "gnms_project_boxes3d")
     return out
+
+
+def best_targets(pred_params, pred_boxes, gt_params, gt_boxes, beta, pred_counts=None, gt_counts=None):
+    """lib/loss/rpn_3d.py:801-825 for a whole batch: pred_params [B,N,7], pred_boxes [B,N,4], gt_params [B,M,7], gt_boxes [B,M,4]
+    (GPU) -> (targets [B,N] fp32 in {0,1}, best_index [B,M] int64 with -1 where no box scores above beta, best_score [B,M])."""
+    if not pred_params.is_cuda:
+        raise _lib.GnmsError("best_targets expects GPU tensors")
+    lib = _lib.load()
+    dev = pred_params.device
+    pp = pred_params.detach().to(torch.float32).contiguous()
+    pb = pred_boxes.detach().to(device=dev, dtype=torch.float32)[..., :4].contiguous()
+    gp = gt_params.detach().to(device=dev, dtype=torch.float32).contiguous()
+    gb = gt_boxes.detach().to(device=dev, dtype=torch.float32)[..., :4].contiguous()
+    B, N, M = pp.shape[0], pp.shape[1], gp.shape[1]
+    pc = pred_counts.to(device=dev, dtype=torch.int32).contiguous() if pred_counts is not None else None
+    gc = gt_counts.to(device=dev, dtype=torch.int32).contiguous() if gt_counts is not None else None
+    targets = torch.empty((B, N), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, M), dtype=torch.int64, device=dev)
+    score = torch.empty((B, M), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.gnms_best_targets(ptr(pp), ptr(pb), ptr(gp), ptr(gb), B, N, M, ptr(pc), ptr(gc), float(beta), ptr(idx), ptr(score),
+                                    ptr(targets), stream_ptr()), "gnms_best_targets")
+    return targets, idx, score

@@ -223,6 +223,15 @@ int gnms_select_topk(const float* scores, int B, int A, const int32_t* candidate
  * -> projected with p2 [B][16] (4x4 row-major, lib/math_3d.py:47-72) -> min/max over the corners -> times scale[b] (NULL: 1). */
 int gnms_project_boxes3d(const float* params, const float* p2, const float* scale, int B, int N, float* boxes2d, void* stream);
 
+/* lib/loss/rpn_3d.py:801-825: the best box per ground truth after the NMS.
+ * score[i][j] = 0.5 * (1 + GIoU3D(pred_i, gt_j)) * IoU2D(pred_i, gt_j); best[j] = first argmax over the predictions, kept if
+ * score > beta (self.best_target_box_beta); targets[b][best] = 1, everything else 0.
+ * pred_params [B][N][7], gt_params [B][M][7] = x y z w h l ry; pred_boxes2d [B][N][4], gt_boxes2d [B][M][4]; counts NULL = all.
+ * Outputs (any may be NULL): best_index [B][M] int64 (-1: none / below beta), best_score [B][M], targets [B][N] fp32. */
+int gnms_best_targets(const float* pred_params, const float* pred_boxes2d, const float* gt_params, const float* gt_boxes2d, int B, int N,
+                      int M, const int32_t* pred_counts, const int32_t* gt_counts, float beta, int64_t* best_index, float* best_score,
+                      float* targets, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,3 +63,25 @@ def select_topk(scores, candidates, k):
     cand = np.arange(scores.shape[0]) if candidates is None else np.asarray(candidates, np.int64)
     order = O.argsort_desc(scores[cand])                                                 # torch.sort(descending=True), :732
     return cand[order[:min(k, len(order))]]                                              # :733-737
+
+
+def best_targets(pred_params, pred_boxes, gt_params, gt_boxes, beta):
+    """lib/loss/rpn_3d.py:801-825: -> (targets [N] in {0,1}, best_index [M] (-1: none above beta), best_score [M])."""
+    pc = O.corners_of_cuboid(np.asarray(pred_params, f32))                              # :772 / :805
+    gc = O.corners_of_cuboid(np.asarray(gt_params, f32))
+    _, i3 = O.iou3d_approximate(pc, gc, generalized=True)                               # :813
+    i2 = O.iou2d(np.asarray(pred_boxes, f32)[:, :4], np.asarray(gt_boxes, f32)[:, :4])  # :814
+    score = (f32(0.5) * (f32(1.0) + i3)) * i2                                           # :819
+    n, m = score.shape
+    targets = np.zeros(n, f32)
+    best = np.full(m, -1, np.int64)
+    bscore = np.zeros(m, f32)
+    for j in range(m):
+        col = score[:, j]
+        nan = np.isnan(col)
+        i = int(np.argmax(nan)) if nan.any() else int(np.argmax(col))                   # torch.max: NaN is a maximum, first index
+        bscore[j] = col[i]
+        if col[i] > beta:                                                               # :822
+            best[j] = i
+            targets[i] = 1                                                              # :826
+    return targets, best, bscore

@@ -471,6 +471,41 @@ def main():
         sel = torch.from_numpy(fg)[sorted_index[:num]]
         pg[f"topk/{tag}/scores"], pg[f"topk/{tag}/fg"], pg[f"topk/{tag}/K"] = sc, fg.astype(np.int32), np.int32(K)
         pg[f"topk/{tag}/selected"] = sel.numpy()
+    # (4) best box per ground truth after the NMS (lib/loss/rpn_3d.py:801-825): the reference's overlap functions, composed as there
+    for tag, n, m in (("b300_6", 300, 6), ("b500_1", 500, 1), ("b40_12", 40, 12)):
+        def cuboids(k):
+            return np.stack([rng.uniform(-20, 20, k), rng.uniform(0.5, 2.5, k), rng.uniform(6, 50, k), rng.uniform(1.4, 2.0, k),
+                             rng.uniform(1.3, 2.0, k), rng.uniform(3, 5, k), rng.uniform(-np.pi, np.pi, k)], 1).astype(np.float32)
+        gt = cuboids(m)
+        pred = cuboids(n)
+        near = rng.integers(0, m, size=n // 2)                                  # half of the predictions sit near a ground truth
+        pred[: n // 2] = gt[near] + (rng.standard_normal((n // 2, 7)) * [0.4, 0.1, 0.6, 0.05, 0.05, 0.1, 0.1]).astype(np.float32)
+
+        def corners(par):
+            t = [torch.from_numpy(par[:, i].copy()) for i in range(7)]
+            return math_3d.get_corners_of_cuboid(x3d=t[0], y3d=t[1], z3d=t[2], w3d=t[3], h3d=t[4], l3d=t[5], ry3d=t[6])
+
+        def boxes2d(par):                                                       # any consistent 2D boxes: the projected ones
+            c = corners(par)
+            flat = c.transpose(1, 2).reshape((-1, 3)).transpose(0, 1)
+            pr = math_3d.project_3d_points_in_4D_format(torch.from_numpy(p2), flat, pad_ones=True)
+            c2 = pr.transpose(0, 1).reshape((-1, 8, 4)).transpose(1, 2)
+            return torch.stack([c2[:, 0].min(1)[0], c2[:, 1].min(1)[0], c2[:, 0].max(1)[0], c2[:, 1].max(1)[0]], 1).numpy()
+        pb, gb = boxes2d(pred), boxes2d(gt)
+        _, iou3 = core.iou3d_approximate(corners(pred).clone(), corners(gt).clone(), mode="combinations", method="generalized")
+        iou2 = core.iou(torch.from_numpy(pb), torch.from_numpy(gb), mode="combinations")
+        scores_with_gt = 0.5 * (1 + iou3) * iou2
+        _, max_idx = torch.max(scores_with_gt, dim=0)
+        beta = 0.3
+        sel = max_idx[scores_with_gt.gather(0, max_idx.unsqueeze(0)).squeeze(0) > beta].flatten()
+        tg = np.zeros(n, np.float32)
+        tg[sel.numpy()] = 1
+        pg[f"best/{tag}/pred_params"], pg[f"best/{tag}/pred_boxes"] = pred, pb
+        pg[f"best/{tag}/gt_params"], pg[f"best/{tag}/gt_boxes"] = gt, gb
+        pg[f"best/{tag}/beta"] = np.float32(beta)
+        pg[f"best/{tag}/scores_with_gt"] = scores_with_gt.numpy()
+        pg[f"best/{tag}/max_indices"] = max_idx.numpy()
+        pg[f"best/{tag}/targets"] = tg
     np.savez_compressed(os.path.join(OUT, "proposals.npz"), **pg)
 
     for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz", "aploss.npz", "proposals.npz"):

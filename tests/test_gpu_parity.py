@@ -841,3 +841,37 @@ def test_fuzz_layer_against_oracle(G, O):
             if not kw["return_sorted_prob"]:
                 nv, ni = int(out1[4][b]), int(out1[5][b])
                 check_index_lists(out1[2][b, :nv].cpu().numpy(), out1[3][b, :ni].cpu().numpy(), ref["valid"], ref["invalid"])
+
+
+def test_best_targets_against_reference_vectors_and_oracle():
+    """SURVEY 8-f3 (lib/loss/rpn_3d.py:801-825): gnms_best_targets vs the reference's vectors and the oracle; ragged counts, a
+    ground truth nobody overlaps (index -1), two ground truths choosing the same box, first-index ties."""
+    from conftest import Golden
+    import oracle.proposals_oracle as PO
+    from groomed_nms_amd import proposals as PR
+    g = Golden("proposals.npz")
+    for tag in ("b300_6", "b500_1", "b40_12"):
+        pp, pb = g[f"best/{tag}/pred_params"], g[f"best/{tag}/pred_boxes"]
+        gp, gb = g[f"best/{tag}/gt_params"], g[f"best/{tag}/gt_boxes"]
+        beta = float(g[f"best/{tag}/beta"])
+        n, m = len(pp), len(gp)
+        # image 0: the golden case; image 1: ragged (first half of the predictions, all but the last ground truth)
+        P = torch.from_numpy(np.stack([pp, pp])).cuda(); PB = torch.from_numpy(np.stack([pb, pb])).cuda()
+        Gp = torch.from_numpy(np.stack([gp, gp])).cuda(); GB = torch.from_numpy(np.stack([gb, gb])).cuda()
+        pc = torch.tensor([n, max(1, n // 2)], dtype=torch.int32).cuda(); gc = torch.tensor([m, max(1, m - 1)], dtype=torch.int32).cuda()
+        tg, idx, sc = PR.best_targets(P, PB, Gp, GB, beta, pc, gc)
+        assert np.array_equal(tg[0].cpu().numpy(), g[f"best/{tag}/targets"]), tag
+        np.testing.assert_allclose(sc[0].cpu().numpy(), g[f"best/{tag}/scores_with_gt"].max(0), atol=TOL)
+        n1, m1 = max(1, n // 2), max(1, m - 1)
+        otg, oidx, osc = PO.best_targets(pp[:n1], pb[:n1], gp[:m1], gb[:m1], beta)
+        assert np.array_equal(tg[1, :n1].cpu().numpy(), otg) and not tg[1, n1:].any()
+        assert np.array_equal(idx[1, :m1].cpu().numpy(), oidx) and (idx[1, m1:] == -1).all()
+        np.testing.assert_allclose(sc[1, :m1].cpu().numpy(), osc, atol=TOL)
+    # far-away ground truth -> no target; duplicate predictions -> the first one wins; two ground truths sharing the best box
+    pp = np.array([[0, 1, 20, 1.6, 1.5, 4, 0.1]] * 3 + [[10, 1, 30, 1.6, 1.5, 4, 0.0]], np.float32)
+    pb = np.array([[100, 100, 200, 180]] * 3 + [[400, 100, 480, 170]], np.float32)
+    gp = np.array([[0, 1, 20, 1.6, 1.5, 4, 0.1], [0.1, 1, 20.2, 1.6, 1.5, 4, 0.1], [-40, 1, 80, 1.6, 1.5, 4, 0.0]], np.float32)
+    gb = np.array([[100, 100, 200, 180], [102, 100, 203, 181], [900, 300, 950, 340]], np.float32)
+    tg, idx, sc = PR.best_targets(*(torch.from_numpy(a).cuda().unsqueeze(0) for a in (pp, pb, gp, gb)), 0.3)
+    assert idx[0].tolist() == [0, 0, -1] and tg[0].tolist() == [1.0, 0.0, 0.0, 0.0]
+    assert abs(float(sc[0, 0]) - 1.0) < 1e-6 and float(sc[0, 2]) == 0.0

@@ -190,3 +190,21 @@ def test_proposals_oracle_against_reference():
     for tag in ("t2000_700_500", "t2000_120_500", "t300_300_50"):
         sel = PO.select_topk(g[f"topk/{tag}/scores"], g[f"topk/{tag}/fg"], int(g[f"topk/{tag}/K"]))
         assert np.array_equal(sel, g[f"topk/{tag}/selected"]), tag
+
+
+def test_best_targets_oracle_against_reference():
+    """best box per ground truth after the NMS (lib/loss/rpn_3d.py:801-825) -- oracle vs the reference's
+    iou3d_approximate x iou composition."""
+    from conftest import Golden
+    import oracle.proposals_oracle as PO
+    g = Golden("proposals.npz")
+    for tag in ("b300_6", "b500_1", "b40_12"):
+        tg, best, bscore = PO.best_targets(g[f"best/{tag}/pred_params"], g[f"best/{tag}/pred_boxes"], g[f"best/{tag}/gt_params"],
+                                           g[f"best/{tag}/gt_boxes"], float(g[f"best/{tag}/beta"]))
+        ref = g[f"best/{tag}/scores_with_gt"]
+        np.testing.assert_allclose(bscore, ref.max(0), atol=1e-4)
+        # the argmax may differ only where two predictions score within the tolerance of each other
+        for j, i in enumerate(g[f"best/{tag}/max_indices"]):
+            k = int(np.argmax(ref[:, j]))
+            assert ref[k, j] - ref[int(i), j] <= 1e-6
+        assert np.array_equal(tg, g[f"best/{tag}/targets"]), tag
