@@ -781,9 +781,14 @@ __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
     return gnms_or_scan64(up);                                      // DPP inclusive OR-scan (gnms_common.h)
 }
 
-// one wave: rank block kb of image b
-__device__ __forceinline__ void attribute_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int kb,
-                                               const int lane) {
+// one wave: rank block kb of image b.  Besides the attribution it evaluates, in parallel over all rank blocks, the overlap of
+// every rank with the leader that removed it (plead[k], groups_kernel's membership test) -- as a prologue of groups_kernel these
+// N dependent gathers ran on ONE CU (50 us of its 180 at N=16384).  `src` = the matrix (BOXES false) or the boxes.
+template <bool BOXES>
+__device__ __forceinline__ void attribute_body(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, char* ws,
+                                               gnms_ws_layout L, const int b, const int kb, const int lane) {
+    __shared__ int att_lead[16][64];                   // per wave: ordinal of the leader that claimed rank k0 + i
+    int* my_lead = att_lead[(threadIdx.x >> 6) & 15];
     const int n = gnms_count(counts, b, N);
     const int k0 = kb << 6;
     if (k0 >= n) return;
@@ -792,6 +797,8 @@ __device__ __forceinline__ void attribute_body(int N, const int* __restrict__ co
     const u64 want = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
     const u64* slab = I.W + (size_t)kb * L.NC;
     const int nl = I.leadpfx[kb + 1];                 // leaders with rank < k0 + 64
+    my_lead[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
     u64 acc = 0;
     for (int base = 0; base < nl && (acc & want) != want; base += 64) {
         const int t = base + lane;
@@ -808,15 +815,25 @@ __device__ __forceinline__ void attribute_body(int N, const int* __restrict__ co
         while (mine) {
             const int bit = __builtin_ctzll(mine);
             I.rem[k0 + bit] = lr;
-            I.gpos[k0 + bit] = t;                     // ordinal of that leader (groups_kernel's sort key; it overwrites gpos afterwards)
+            my_lead[bit] = t;
             mine &= mine - 1;
         }
         acc |= gnms_wave_or(w);
     }
+    __builtin_amdgcn_wave_barrier();                  // LDS is in order within a wave: every claimed slot is visible below
+    if (lane < nrows) {
+        const int k = k0 + lane;
+        const int g = my_lead[lane];                  // every rank is claimed: by an earlier leader, or by itself
+        I.gpos[k] = g;                                // ordinal of the leader (groups_kernel's sort key; it overwrites gpos afterwards)
+        const float* m = src + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);
+        I.plead[k] = overlap_at<BOXES>(m, ld, I.order[k], I.leadc[g]);    // likewise overwritten by groups_kernel's own plead
+    }
 }
 
-__global__ __launch_bounds__(64) void attribute_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
-    attribute_body(N, counts, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
+template <bool BOXES>
+__global__ __launch_bounds__(64) void attribute_kernel(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, char* ws,
+                                                       gnms_ws_layout L) {
+    attribute_body<BOXES>(src, ld, N, counts, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -855,7 +872,7 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
         const int k = threadIdx.x * E + e;
         v_lead[e] = 0.0f; s_lead[e] = 0.0f;
         if (k < n) {
-            v_lead[e] = overlap_at<BOXES>(m, ld, c_own[e], I.order[lr_own[e]]);   // iou of the box against the leader that removed it
+            v_lead[e] = I.plead[k];                     // iou of the box against the leader that removed it (attribute_kernel)
             s_lead[e] = I.sscore[lr_own[e]];
         }
     }
@@ -1013,6 +1030,7 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     ImgPtrs I = img_ptrs(ws, L, b);
     const float vthr = P.valid_box_prob_threshold;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, T = blockDim.x;
+    GNMS_T0();
     // classify
     u64 key[E];
     int cls[E];                                                    // 0 nan, 1 valid, 2 invalid, 3 padding
@@ -1062,6 +1080,7 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
         }
     }
     __syncthreads();
+    GNMS_TACC(12);
     // sort the valid keys: they sit in keys[0..nv), padded with ~0
     if (nv > 1) {
         if (nv <= T) {
@@ -1071,13 +1090,39 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
             while (pe < nv) pe <<= 1;
             block_sort<1, u64>(r1, keys, pe);
         } else {
-            u64 r[E];
+            // more valid boxes than threads: sort next_pow2(nv) keys, not all Ppow2 (the valid keys are compacted at the front)
+            int pe = 2 * T;
+            while (pe < nv) pe <<= 1;
+            bool done = false;
+            if constexpr (E >= 4) {
+                if (pe == 2 * T) {
+                    u64 r[2];
+                    r[0] = keys[t * 2]; r[1] = keys[t * 2 + 1];
+                    __syncthreads();
+                    block_sort<2, u64>(r, keys, pe);
+                    done = true;
+                }
+            }
+            if constexpr (E >= 8) {
+                if (!done && pe == 4 * T) {
+                    u64 r[4];
 #pragma unroll
-            for (int e = 0; e < E; ++e) r[e] = keys[t * E + e];
-            __syncthreads();
-            block_sort<E, u64>(r, keys, Ppow2);
+                    for (int e = 0; e < 4; ++e) r[e] = keys[t * 4 + e];
+                    __syncthreads();
+                    block_sort<4, u64>(r, keys, pe);
+                    done = true;
+                }
+            }
+            if (!done) {
+                u64 r[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) r[e] = keys[t * E + e];
+                __syncthreads();
+                block_sort<E, u64>(r, keys, Ppow2);
+            }
         }
     }
+    GNMS_TACC(13);
     float* pb = prob + (size_t)b * N;
     for (int j = t; j < N; j += T) {
         if (j < nv) {
@@ -1097,6 +1142,7 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
         }
         pb[j] = out;
     }
+    GNMS_TACC(14);
     if (t == 0) {
         if (nvalid) nvalid[b] = nv;
         if (ninvalid) ninvalid[b] = ni;
@@ -1125,7 +1171,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     const int b = blockIdx.x;
     leaders_body(N, counts, ws, L, b);
     __syncthreads();
-    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body(N, counts, ws, L, b, kb, threadIdx.x & 63);
+    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<BOXES>(src, ld, N, counts, ws, L, b, kb, threadIdx.x & 63);
     __syncthreads();
     groups_body<E, BOXES>(src, N, ld, counts, P, ws, L, Ppow2, b);
     __syncthreads();

@@ -120,7 +120,7 @@ int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* coun
     if (rc) return rc;
     leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<<<dim3(L.NB, B), 64, 0, st>>>(N, counts, ws, L);
+    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -444,7 +444,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
     leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<<<dim3(L.NB, B), 64, 0, st>>>(N, counts, ws, L);
+    attribute_kernel<true><<<dim3(L.NB, B), 64, 0, st>>>(boxes, (long)N, N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(groups_kernel<E, true>, sort_lds))) return rc;

@@ -173,25 +173,33 @@ int main(int argc, char** argv) {
         // restore W for the kernels below
         bitmask_kernel<true><<<dim3((N + kMaskWaves * 256 - 1) / (kMaskWaves * 256), L.NB, B), kMaskWaves * 64>>>(d_iou, N, N, nullptr, 0.4f, ws, L);
     }
-    printf("attribute               %8.1f us\n", time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); }));
+    printf("attribute               %8.1f us\n", time_us([&] { attribute_kernel<false><<<dim3(L.NB, B), 64>>>(d_iou, (long)N, N, nullptr, ws, L); }));
     if (P2 == 4096) {
         printf("sort_scores<4>          %8.1f us\n", time_us([&] { sort_scores_kernel<4><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr, nullptr); }));
         // groups_kernel consumes the leader ordinals attribute_kernel leaves in gpos (and overwrites gpos): time the pair
         {
-            const float ta = time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); });
-            const float tag = time_us([&] { attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L); groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); });
+            const float ta = time_us([&] { attribute_kernel<false><<<dim3(L.NB, B), 64>>>(d_iou, (long)N, N, nullptr, ws, L); });
+            const float tag = time_us([&] { attribute_kernel<false><<<dim3(L.NB, B), 64>>>(d_iou, (long)N, N, nullptr, ws, L); groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); });
             printf("groups<4>               %8.1f us (attribute + groups %.1f)\n", tag - ta, tag);
         }
 #ifdef GNMS_TIMING
         {
             long long z[16] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
-            attribute_kernel<<<dim3(L.NB, B), 64>>>(N, nullptr, ws, L);
+            attribute_kernel<false><<<dim3(L.NB, B), 64>>>(d_iou, (long)N, N, nullptr, ws, L);
             groups_kernel<4, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); CK(hipDeviceSynchronize());
             CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
             printf("  groups phases (cycles, thread0): keys %lld | sort %lld | runs %lld | rescoring %lld\n", z[8], z[9], z[10], z[11]);
         }
 #endif
         printf("finalize<4>             %8.1f us\n", time_us([&] { finalize_kernel<4><<<B, T, sort_lds>>>(N, nullptr, P, ws, L, P2, d_prob, nullptr, nullptr, nullptr, nullptr); }));
+#ifdef GNMS_TIMING
+        {
+            long long z[16] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
+            finalize_kernel<4><<<B, T, sort_lds>>>(N, nullptr, P, ws, L, P2, d_prob, nullptr, nullptr, nullptr, nullptr); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
+            printf("  finalize phases (cycles, thread0): classify+compact %lld | sort %lld | write %lld\n", z[12], z[13], z[14]);
+        }
+#endif
         std::vector<u64> hk((size_t)B * P2);
         for (auto& v : hk) v = ((u64)rand() << 32) ^ (u64)rand() ^ ((u64)rand() << 17);
         u64 *din, *dout; CK(hipMalloc(&din, hk.size() * 8)); CK(hipMalloc(&dout, hk.size() * 8));
@@ -209,6 +217,31 @@ int main(int argc, char** argv) {
         std::vector<u64> ho(hk.size()); CK(hipMemcpy(ho.data(), dout, ho.size() * 8, hipMemcpyDeviceToHost));
         bool ok = true; for (int b = 0; b < B; ++b) for (int i = 1; i < P2; ++i) if (ho[(size_t)b * P2 + i - 1] > ho[(size_t)b * P2 + i]) ok = false;
         printf("sorted ok: %d\n", (int)ok);
+    }
+    if (P2 == 16384) {
+        long long* d_valid; CK(hipMalloc(&d_valid, (size_t)B * N * 8 * 2));
+        int* d_nv; CK(hipMalloc(&d_nv, B * 8));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_scores_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(groups_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(finalize_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+        printf("sort_scores<16>         %8.1f us\n", time_us([&] { sort_scores_kernel<16><<<B, T, sort_lds>>>(d_scores, N, nullptr, ws, L, P2, nullptr, nullptr); }));
+        {
+            const float ta = time_us([&] { attribute_kernel<false><<<dim3(L.NB, B), 64>>>(d_iou, (long)N, N, nullptr, ws, L); });
+            const float tag = time_us([&] { attribute_kernel<false><<<dim3(L.NB, B), 64>>>(d_iou, (long)N, N, nullptr, ws, L); groups_kernel<16, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2); });
+            printf("groups<16>              %8.1f us (attribute + groups %.1f)\n", tag - ta, tag);
+        }
+        printf("finalize<16>            %8.1f us\n", time_us([&] { finalize_kernel<16><<<B, T, sort_lds>>>(N, nullptr, P, ws, L, P2, d_prob, d_valid, d_valid + (size_t)B * N, d_nv, d_nv + B); }));
+#ifdef GNMS_TIMING
+        {
+            long long z[16] = {0}; CK(hipMemcpy(img_ptrs(ws, L, 0).gx, z, sizeof(z), hipMemcpyHostToDevice));
+            attribute_kernel<false><<<dim3(L.NB, B), 64>>>(d_iou, (long)N, N, nullptr, ws, L);
+            groups_kernel<16, false><<<B, T, sort_lds>>>(d_iou, N, N, nullptr, P, ws, L, P2);
+            finalize_kernel<16><<<B, T, sort_lds>>>(N, nullptr, P, ws, L, P2, d_prob, d_valid, d_valid + (size_t)B * N, d_nv, d_nv + B); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(z, img_ptrs(ws, L, 0).gx, sizeof(z), hipMemcpyDeviceToHost));
+            printf("  groups phases (cycles, thread0): keys %lld | sort %lld | runs %lld | rescoring %lld\n", z[8], z[9], z[10], z[11]);
+            printf("  finalize phases (cycles, thread0): classify+compact %lld | sort %lld | write %lld\n", z[12], z[13], z[14]);
+        }
+#endif
     }
     return 0;
 }
