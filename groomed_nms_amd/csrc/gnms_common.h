@@ -166,6 +166,17 @@ __device__ __forceinline__ unsigned gnms_add_scan32(unsigned v) {
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);   // row_bcast:31 -> rows 2,3
     return v;
 }
+// inclusive running maximum of signed ints (identity INT_MIN comes in through bound_ctrl=0 -> use old = INT_MIN explicitly)
+__device__ __forceinline__ int gnms_max_scan32(int v) {
+    const int lo = (int)0x80000000;
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x111, 0xF, 0xF, false));   // row_shr:1 (lanes without a source keep `lo`)
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1,3
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2,3
+    return v;
+}
 __device__ __forceinline__ unsigned long long gnms_or_scan64(unsigned long long v) {
     const unsigned lo = gnms_or_scan32((unsigned)(v & 0xffffffffu));
     const unsigned hi = gnms_or_scan32((unsigned)(v >> 32));

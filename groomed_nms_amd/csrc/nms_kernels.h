@@ -734,12 +734,7 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
     {
         // exclusive prefix of popcounts over blocks: thread i < nb owns block i (nb <= 256)
         int cnt = (tid < nb) ? __builtin_popcountll(lmask[tid]) : 0;
-        int inc = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += v;
-        }
+        const int inc = (int)gnms_add_scan32((unsigned)cnt);          // DPP prefix sum
         int* wsum = reinterpret_cast<int*>(Xs);                      // Xs is free now
         if (lane == 63 && wave < 4) wsum[wave] = inc;
         __syncthreads();
@@ -917,13 +912,8 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
             st[e] = last;
         }
         // inclusive max-scan of `last` over the wave, then exclusive value for this thread
-        int inc = last;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(inc, off, 64);
-            if (ln >= off) inc = max(inc, v);
-        }
-        int excl = __shfl_up(inc, 1, 64);
+        const int inc = gnms_max_scan32(last);                         // DPP running maximum
+        int excl = __builtin_amdgcn_update_dpp(-1, inc, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -1)
         if (ln == 0) excl = -1;
         if (ln == 63) wave_last_start[wv] = inc;
         __syncthreads();
@@ -1034,7 +1024,7 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     // classify
     u64 key[E];
     int cls[E];                                                    // 0 nan, 1 valid, 2 invalid, 3 padding
-    u64 packed = 0;                                                // nan | valid << 20 | invalid << 40
+    u64 packed = 0;                                                // nan | valid << 16 | invalid << 32 (each count <= N <= 16384)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int q = t * E + e;
@@ -1047,16 +1037,12 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
             I.r2[q] = r2;
             cls[e] = (rr != rr) ? 0 : ((rr >= vthr) ? 1 : ((rr < vthr) ? 2 : 0)); // vthr NaN: neither list (:118-123)
             key[e] = ((u64)gnms_desc_key(rr) << 32) | (unsigned)q;
-            packed += (cls[e] == 0) ? 1ull : (cls[e] == 1 ? (1ull << 20) : (1ull << 40));
+            packed += (cls[e] == 0) ? 1ull : (cls[e] == 1 ? (1ull << 16) : (1ull << 32));
         }
     }
     // exclusive block scan of the packed counters
-    u64 inc = packed;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const u64 v = shfl_up_u64(inc, off);
-        if (lane >= off) inc += v;
-    }
+    // (two 32-bit DPP prefix sums: the low word carries nan | valid << 16 without overflow between the fields, the high word invalid)
+    const u64 inc = (u64)gnms_add_scan32((unsigned)(packed & 0xffffffffu)) | ((u64)gnms_add_scan32((unsigned)(packed >> 32)) << 32);
     if (lane == 63) wave_tot[wave] = inc;
     for (int i = t; i < Ppow2; i += T) keys[i] = ~0ull;
     __syncthreads();
@@ -1064,26 +1050,40 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     const int nwaves = T >> 6;
     for (int w = 0; w < nwaves; ++w) { const u64 v = wave_tot[w]; if (w < wave) base += v; total += v; }
     u64 run = base + inc - packed;
-    const int n_nan = (int)(total & 0xfffff), nv = (int)((total >> 20) & 0xfffff), ni = (int)(total >> 40);
+    const int n_nan = (int)(total & 0xffff), nv = (int)((total >> 16) & 0xffff), ni = (int)(total >> 32);
     const int n_ge = n_nan + nv;
     // sidx layout: [0,n_nan) NaN by position, [n_nan, n_ge) valid (sorted below), [n_ge, n_ge+ni) invalid by position
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int q = t * E + e;
-        if (cls[e] == 0) { I.sidx[(int)(run & 0xfffff)] = q; run += 1ull; }
-        else if (cls[e] == 1) { keys[(int)((run >> 20) & 0xfffff)] = key[e]; run += 1ull << 20; }
+        if (cls[e] == 0) { I.sidx[(int)(run & 0xffff)] = q; run += 1ull; }
+        else if (cls[e] == 1) { keys[(int)((run >> 16) & 0xffff)] = key[e]; run += 1ull << 16; }
         else if (cls[e] == 2) {
-            const int j = (int)(run >> 40);
+            const int j = (int)(run >> 32);
             I.sidx[n_ge + j] = q;
             if (invalid) invalid[(size_t)b * N + j] = P.presorted ? q : I.order[q];
-            run += 1ull << 40;
+            run += 1ull << 32;
         }
     }
     __syncthreads();
     GNMS_TACC(12);
     // sort the valid keys: they sit in keys[0..nv), padded with ~0
     if (nv > 1) {
-        if (nv <= T) {
+        if (nv <= 256 && 2 * nv <= Ppow2) {
+            // a few valid boxes (typically ~100): rank of each key = number of smaller keys (they are distinct), read as LDS broadcasts
+            u64* sorted = keys + Ppow2 / 2;
+            u64 mine = 0;
+            int rank = 0;
+            if (t < nv) {
+                mine = keys[t];
+                for (int j = 0; j < nv; ++j) rank += (keys[j] < mine) ? 1 : 0;
+            }
+            __syncthreads();
+            if (t < nv) sorted[rank] = mine;
+            __syncthreads();
+            if (t < nv) keys[t] = sorted[t];
+            __syncthreads();
+        } else if (nv <= T) {
             u64 r1[1] = {keys[t]};
             __syncthreads();
             int pe = 64;                                                   // typically ~100 valid boxes: 128 keys, one merge pass instead of four
