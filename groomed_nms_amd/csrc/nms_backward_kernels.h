@@ -33,24 +33,56 @@ __global__ __launch_bounds__(256) void bwd_gx_kernel(const float* __restrict__ g
     I.gx[q] = g;
 }
 
-// masked groups, part 1: one thread per rank (gx fused: position q = rank for hard sort, so the thread that routes
-// dL/dprob to position k is the one that needs it).  dL/ds = gx for every box in a group (heads included: part 2
-// subtracts their members' terms), 0 for boxes in no group.  Not used with return_sorted_prob / presorted (the routing is
-// a permutation there: bwd_gx_kernel runs first).
+// masked groups, default path, ONE launch with two kinds of workgroups (hard sort, unsorted output: position q = rank):
+//   blockIdx.x <  elem_blocks : one thread per rank: gx = dL/dprob where the clamp let it through; dL/ds = gx for every box
+//                               in a group, 0 for boxes in no group -- except the heads of multi-member groups, which belong to
+//   blockIdx.x >= elem_blocks : one WAVE per multi-member group (hlist): dL/ds_head = gx_head - sum_i P_i gx_i.  All lanes fetch
+//                               the members' products in parallel (gx recomputed from dL/dprob, so the two kinds of workgroups
+//                               do not depend on each other); the sum runs SEQUENTIALLY in member order (v_readlane + v_sub):
+//                               deterministic and bit-identical to the left-to-right matmul row of the reference.
+__device__ __forceinline__ float bwd_gx_of(const float* __restrict__ grad_prob_img, const ImgPtrs& I, int k) {
+    const float pre = I.pre[k];
+    return (pre >= 0.0f && pre <= 1.0f) ? grad_prob_img[k] : 0.0f;    // clamp passes the gradient at the bounds only
+}
+
 __global__ __launch_bounds__(256) void bwd_masked_fused_kernel(const float* __restrict__ grad_prob, int N, const int* __restrict__ counts,
-                                                               gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores) {
+                                                               gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores,
+                                                               int elem_blocks) {
     const int b = blockIdx.y;
     const int n = gnms_count(counts, b, N);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
     ImgPtrs I = img_ptrs(ws, L, b);
     float* gs = grad_scores + (size_t)b * N;
+    const float* gp = grad_prob + (size_t)b * N;
+    if ((int)blockIdx.x >= elem_blocks) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int nheads = I.misc[1];
+        const int nhb = (int)gridDim.x - elem_blocks;
+        for (int hi = ((int)blockIdx.x - elem_blocks) * 4 + wave; hi < nheads; hi += nhb * 4) {
+            const int k = I.hlist[hi];
+            const int hstart = I.gstart[k], hlen = I.glen[k];
+            float acc = bwd_gx_of(gp, I, k);
+            for (int base = 1; base < hlen; base += 64) {
+                const int t = base + lane;
+                float prod = 0.0f;
+                if (t < hlen) {
+                    const int mk = I.gsorted[hstart + t];
+                    prod = I.plead[mk] * bwd_gx_of(gp, I, mk);
+                }
+                const int cnt = min(64, hlen - base);
+                for (int u = 0; u < cnt; ++u) acc -= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(prod), u));
+            }
+            if (lane == 0) gs[I.order[k]] = acc;
+        }
+        return;
+    }
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
     if (k >= n) { gs[k] = 0.0f; I.gx[k] = 0.0f; return; }
-    float g = grad_prob[(size_t)b * N + k];
-    const float pre = I.pre[k];
-    if (!(pre >= 0.0f && pre <= 1.0f)) g = 0.0f;                     // clamp passes the gradient at the bounds only
+    const float g = bwd_gx_of(gp, I, k);
     I.gx[k] = g;
-    gs[I.order[k]] = (I.head[k] >= 0) ? g : 0.0f;
+    const int h = I.head[k];
+    if (h == k && I.glen[k] > 1 && I.misc[1] > 0) return;            // written by the head workgroups (hlist holds exactly these)
+    gs[I.order[k]] = (h >= 0) ? g : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void bwd_masked_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,

@@ -373,11 +373,16 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
     }
     if (grad_iou) GNMS_CHECK_HIP(hipMemsetAsync(grad_iou, 0, sizeof(float) * (size_t)B * N * ld, st));
     if (P.group_boxes && P.mask_group_boxes) {
-        if (fused_gx) bwd_masked_fused_kernel<<<ge, 256, 0, st>>>(grad_prob, N, counts, P, ws, L, grad_scores);
-        else bwd_masked_kernel<<<ge, 256, 0, st>>>(N, counts, P, ws, L, grad_scores);
-        GNMS_CHECK_LAUNCH();
-        bwd_masked_heads_kernel<<<dim3(N >= 2048 ? 128 : gnms_div_up(N, 16), B), 256, 0, st>>>(N, P, ws, L, grad_scores);
-        GNMS_CHECK_LAUNCH();
+        const int head_blocks = N >= 2048 ? 128 : gnms_div_up(N, 16);
+        if (fused_gx) {
+            bwd_masked_fused_kernel<<<dim3(ge.x + head_blocks, B), 256, 0, st>>>(grad_prob, N, counts, P, ws, L, grad_scores, (int)ge.x);
+            GNMS_CHECK_LAUNCH();
+        } else {
+            bwd_masked_kernel<<<ge, 256, 0, st>>>(N, counts, P, ws, L, grad_scores);
+            GNMS_CHECK_LAUNCH();
+            bwd_masked_heads_kernel<<<dim3(head_blocks, B), 256, 0, st>>>(N, P, ws, L, grad_scores);
+            GNMS_CHECK_LAUNCH();
+        }
         if (grad_iou) {
             bwd_masked_iou_kernel<<<ge, 256, 0, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_iou);
             GNMS_CHECK_LAUNCH();
