@@ -96,8 +96,10 @@ int gnms_iou3d_from_params(const float* params_a, const float* params_b, int B, 
  * GrooMeD-NMS layer (lib/groomed_nms.py:10-129), hard sort.  Soft sort = gnms_soft_sort + presorted=1.
  * ------------------------------------------------------------------------------------------- */
 
-/* bytes of the workspace gnms_forward needs for (B, N).  The same buffer carries the state that
- * gnms_backward reads, so keep it alive and untouched between the two calls. */
+/* bytes of the workspace gnms_forward needs for (B, N) with these params (NULL: the defaults).  The same buffer carries the
+ * state that gnms_backward reads, so keep it alive and untouched between the two calls.  Grouped modes: ~30 N-sized arrays +
+ * the N^2/8-byte bit matrix per image; ungrouped mode (group_boxes = 0) adds a 4 N^2-byte scratch matrix per image (the
+ * sorted strictly-lower-triangular copy the reference also makes, lib/groomed_nms.py:48). */
 size_t gnms_workspace_bytes(int B, int N, const gnms_params* params);
 
 /* forward.  scores [B][N], iou [B][N][ld].
@@ -116,7 +118,9 @@ int gnms_forward(const float* scores, const float* iou, int B, int N, int64_t ld
 /* gnms_iou2d + gnms_forward in one call, as lib/loss/rpn_3d.py:772-791 runs them back to back: boxes [B][N][4] ->
  * iou_out [B][N][ld] (kept for the caller) -> the outputs of gnms_forward.  The score sort does not depend on the
  * overlaps, so for N <= 4096 it rides in the last grid slice of the IoU launch (one workgroup per image: no launch of its
- * own, no kernel boundary); larger N run the two calls in sequence.  gnms_backward pairs with it unchanged. */
+ * own, no kernel boundary); larger N run the two calls in sequence.  With the boxes at hand the grouped hard-sort modes
+ * take their threshold bits and group overlaps from the boxes (the from-boxes kernels below, bit-identical) instead of
+ * reading back the matrix they just wrote; ungrouped / presorted modes read it.  gnms_backward pairs with it unchanged. */
 int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
                             const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
                             int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
