@@ -23,10 +23,10 @@ using namespace gnms_iou;
 // ------------------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou2d_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
-                                                                 int M, int N, float* __restrict__ out, long ld) {
+                                                                 int M, int N, float* __restrict__ out, long ld, int tile_rows) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    iou2d_tile<VEC>(A, Bx, M, N, out, ld, blockIdx.z, blockIdx.y * kTileRows, blockIdx.x * kWGCols + wave * kWaveCols, lane);
+    iou2d_tile<VEC>(A, Bx, M, N, out, ld, blockIdx.z, blockIdx.y * tile_rows, blockIdx.x * kWGCols + wave * kWaveCols, lane, tile_rows);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,10 +301,11 @@ extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int
     GNMS_CHECK_ARG(ld >= N, "gnms_iou2d: ld (%lld) < N (%d)", (long long)ld, N);
     GNMS_CHECK_ARG(((uintptr_t)boxes_a % 16 == 0) && ((uintptr_t)boxes_b % 16 == 0), "gnms_iou2d: boxes must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, kTileRows), B);
+    const int tr = tile_rows_for(B, M, N);
+    dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
-    if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld);
-    else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld);
+    if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr);
+    else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

@@ -10,6 +10,15 @@ constexpr int kWaveCols = 256;   // 64 lanes x 4 columns
 constexpr int kWavesPerWG = 8;   // tools/bw_variants.hip: 8 waves + non-temporal stores = 5.6 TB/s (4 waves, plain stores: 5.3)
 constexpr int kWGCols = kWaveCols * kWavesPerWG;
 
+// Rows per workgroup.  A wave walks its rows one after the other (one 1-KiB store each), so a launch with few workgroups is
+// bound by that chain, not by HBM: B=8, N=512 is 64 workgroups of 64 rows = 22 us for 8 MB.  Small problems get shorter tiles
+// until the grid has a few workgroups per CU.
+__host__ inline int tile_rows_for(int B, int M, int N) {
+    int rows = kTileRows;
+    while (rows > 8 && (long long)B * ((M + rows - 1) / rows) * ((N + kWGCols - 1) / kWGCols) < 1024) rows >>= 1;
+    return rows;
+}
+
 __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -32,7 +41,8 @@ __device__ __forceinline__ void store_nt_f4(float* p, float a, float b, float c,
 // owns columns c0+lane+64*{0..3} and stores dwords (still coalesced).
 template <bool VEC>
 __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const float* __restrict__ Bx, int M, int N,
-                                           float* __restrict__ out, long ld, int img, int i0, int c0, int lane) {
+                                           float* __restrict__ out, long ld, int img, int i0, int c0, int lane,
+                                           int tile_rows = kTileRows) {
     if (c0 >= N || i0 >= M) return;
     const float* a = A + (size_t)img * M * 4;
     const float* b = Bx + (size_t)img * N * 4;
@@ -49,7 +59,7 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
         bx1[j] = v.x; by1[j] = v.y; bx2[j] = v.z; by2[j] = v.w;
         barea[j] = (v.z - v.x) * (v.w - v.y);                        // lib/core.py:502-503
     }
-    const int rows = min(kTileRows, M - i0);
+    const int rows = min(tile_rows, M - i0);                      // tile_rows <= 64: lane r holds row i0 + r
 
     // row boxes: lane r holds row i0+r; the row loop broadcasts it with v_readlane.  (Scalar loads of the row box --
     // s_load_dwordx4, also issued a row ahead -- measured 6 % slower: 100.7 vs 94.8 us at B=8, N=4096.)

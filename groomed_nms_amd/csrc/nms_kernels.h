@@ -477,26 +477,30 @@ __device__ __forceinline__ float wave_max_f(float v) {
     return v;
 }
 
+// CPL = columns per lane: 4 (wave tile 64 x 256) when there are plenty of tiles, 1 (64 x 64) for small problems, where the 64-row
+// chain of a wave is the critical path and four times as many waves share it.
+template <int CPL>
 __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
                                                             float thr, char* ws, gnms_ws_layout L) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
     const int n = gnms_count(counts, b, N);
-    const int nchunk = (N + 255) >> 8;
+    constexpr int kCols = 64 * CPL;
+    const int nchunk = (N + kCols - 1) / kCols;
     const int tile = blockIdx.x * 4 + wave;
     const int kb = tile / nchunk, chunk = tile - kb * nchunk;
     const int k0 = kb * 64;
-    const int c0 = chunk * 256;
+    const int c0 = chunk * kCols;
     if (kb >= L.NB || k0 >= n || c0 >= n) return;                    // (ragged images)
     ImgPtrs I = img_ptrs(ws, L, b);
     const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * N;
-    float4 cb[4];
-    float carea[4];
-    int crank[4];
+    float4 cb[CPL];
+    float carea[CPL];
+    int crank[CPL];
     bool need = false, cok = true;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = c0 + 4 * lane + j;
+    for (int j = 0; j < CPL; ++j) {
+        const int p = c0 + CPL * lane + j;
         const int pp = p < n ? p : n - 1;                             // clamped duplicates: harmless in the hull, never stored
         cb[j] = I.xbox[pp];
         crank[j] = (p < n) ? I.rankof[I.xidx[pp]] : 0x7fffffff;
@@ -519,13 +523,16 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
     const bool row_fine = (rarea > 0.0f) && (rarea < INFINITY);
     const u64 rows_ok = __ballot(row_fine);
     // hull of the tile's columns and the rows that reach into it
-    float hx0 = fminf(fminf(cb[0].x, cb[1].x), fminf(cb[2].x, cb[3].x)), hx1 = fmaxf(fmaxf(cb[0].z, cb[1].z), fmaxf(cb[2].z, cb[3].z));
-    float hy0 = fminf(fminf(cb[0].y, cb[1].y), fminf(cb[2].y, cb[3].y)), hy1 = fmaxf(fmaxf(cb[0].w, cb[1].w), fmaxf(cb[2].w, cb[3].w));
+    float hx0 = cb[0].x, hx1 = cb[0].z, hy0 = cb[0].y, hy1 = cb[0].w;
+#pragma unroll
+    for (int j = 1; j < CPL; ++j) { hx0 = fminf(hx0, cb[j].x); hx1 = fmaxf(hx1, cb[j].z); hy0 = fminf(hy0, cb[j].y); hy1 = fmaxf(hy1, cb[j].w); }
     hx0 = wave_min_f(hx0); hy0 = wave_min_f(hy0); hx1 = wave_max_f(hx1); hy1 = wave_max_f(hy1);
     const bool cull = cols_ok && (thr >= 0.0f);
     const bool reaches = (rb.z > hx0) && (rb.x < hx1) && (rb.w > hy0) && (rb.y < hy1);
     const u64 active = __ballot((lane < nrows) && (!(cull && row_fine) || reaches));
-    unsigned wd[2] [4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    unsigned wd[2][CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { wd[0][j] = 0u; wd[1][j] = 0u; }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         unsigned todo = (unsigned)(half ? (active >> 32) : (active & 0xffffffffull));
@@ -539,10 +546,10 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
             const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), r));
             const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), r));
             const unsigned bit = 1u << rr;
-            float inter4[4], uni4[4], d4[4];
+            float inter4[CPL], uni4[CPL], d4[CPL];
             bool unsure = false;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CPL; ++j) {
                 const float w = fmaxf(fminf(ax2, cb[j].z) - fmaxf(ax1, cb[j].x), 0.0f);
                 const float h = fmaxf(fminf(ay2, cb[j].w) - fmaxf(ay1, cb[j].y), 0.0f);
                 inter4[j] = w * h;
@@ -552,16 +559,16 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
             }
             if (!(cols_ok && ((rows_ok >> r) & 1ull)) || __any(unsure)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wd[half][j] |= !(inter4[j] / uni4[j] <= thr) ? bit : 0u;
+                for (int j = 0; j < CPL; ++j) wd[half][j] |= !(inter4[j] / uni4[j] <= thr) ? bit : 0u;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wd[half][j] |= (d4[j] > 0.0f) ? bit : 0u;
+                for (int j = 0; j < CPL; ++j) wd[half][j] |= (d4[j] > 0.0f) ? bit : 0u;
             }
         }
     }
     u64* Wk = I.W + (size_t)kb * L.NC;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < CPL; ++j)
         if (crank[j] < k0 + 64) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
 }
 

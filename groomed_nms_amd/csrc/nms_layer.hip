@@ -145,7 +145,7 @@ template <bool VEC, int E>
 __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                                                 int N, const int* __restrict__ counts, float* __restrict__ out,
                                                                                 long ld, char* ws, gnms_ws_layout L, int P2,
-                                                                                long long* __restrict__ order_out, int xsort) {
+                                                                                long long* __restrict__ order_out, int xsort, int tile_rows) {
     using namespace gnms_iou;
     if (blockIdx.z == gridDim.z - 1) {
         const int nimg = (int)gridDim.z - 1;
@@ -186,11 +186,21 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, blockIdx.z, blockIdx.y * kTileRows, blockIdx.x * kWGCols + wave * kWaveCols, lane);
+    iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, blockIdx.z, blockIdx.y * tile_rows, blockIdx.x * kWGCols + wave * kWaveCols, lane, tile_rows);
 }
 
-// workgroups (4 wave tiles each) of bitmask_boxes_kernel per image: (row blocks) x (256-column chunks)
-inline int bitmask_boxes_blocks(int N) { return gnms_div_up(((N + 63) / 64) * ((N + 255) / 256), 4); }
+// bitmask_boxes_kernel: workgroups of 4 wave tiles, (row blocks) x (column chunks) tiles per image; 4 columns per lane
+// (64 x 256 tiles) when that already gives every SIMD a couple of waves, else 1 column per lane (64 x 64 tiles)
+int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
+    const long long tiles4 = (long long)B * ((N + 63) / 64) * ((N + 255) / 256);
+    if (tiles4 >= 2048) {
+        bitmask_boxes_kernel<4><<<dim3(gnms_div_up(((N + 63) / 64) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
+    } else {
+        bitmask_boxes_kernel<1><<<dim3(gnms_div_up(((N + 63) / 64) * ((N + 63) / 64), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
+    }
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
 
 // K3..K6 as one launch or four?  Measured (HIP-graph replay, B=8): one launch wins 2-2.5 us per step up to N=2048 (three
 // kernel boundaries less) and loses 1.5 us at N=4096 (the attribution runs on one CU instead of 64).  GNMS_TAIL=0/1 forces.
@@ -316,7 +326,7 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     // fused launch: sort on 512 threads (P2 >= 512), <= 32 KiB of LDS per workgroup (P2 <= 4096), one sort workgroup per image in slice 0
     const bool from_boxes = params->group_boxes && !params->presorted && ((uintptr_t)boxes % 16 == 0);
     const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) &&
-                      (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::kTileRows) >= 2 * B;
+                      (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::tile_rows_for(B, N, N)) >= 2 * B;
     if (!fuse) {
         if (B > 0 && N > 0 && (rc = gnms_iou2d(boxes, boxes, B, N, N, iou_out, ld, stream))) return rc;
         if (from_boxes)
@@ -329,15 +339,16 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     const gnms_ws_layout L = gnms_make_layout(N);
     const size_t sort_lds = (size_t)P2 * 8;
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou_out % 16 == 0);
-    dim3 grid(gnms_div_up(N, gnms_iou::kWGCols), gnms_div_up(N, gnms_iou::kTileRows), B + 1);
+    const int tr = gnms_iou::tile_rows_for(B, N, N);
+    dim3 grid(gnms_div_up(N, gnms_iou::kWGCols), gnms_div_up(N, tr), B + 1);
     const int threads = gnms_iou::kWavesPerWG * 64;                                   // 512: E = P2 / 512
     const int xs = from_boxes ? 1 : 0;
 #define GNMS_LAUNCH_FUSED(EE)                                                                                                           \
     do {                                                                                                                                \
         if (vec) iou2d_sort_kernel<true, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,               \
-                                                                            (char*)workspace, L, P2, (long long*)order, xs);           \
+                                                                            (char*)workspace, L, P2, (long long*)order, xs, tr);       \
         else iou2d_sort_kernel<false, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,                  \
-                                                                         (char*)workspace, L, P2, (long long*)order, xs);              \
+                                                                         (char*)workspace, L, P2, (long long*)order, xs, tr);          \
     } while (0)
     switch (P2 / threads) {
         case 1: GNMS_LAUNCH_FUSED(1); break;
@@ -441,8 +452,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
         });                                        // y = 0: scores (descending), y = 1: boxes by x centre
         GNMS_CHECK_LAUNCH();
     }
-    bitmask_boxes_kernel<<<dim3(bitmask_boxes_blocks(N), 1, B), 256, 0, st>>>(boxes, N, counts, P.nms_threshold, ws, L);
-    GNMS_CHECK_LAUNCH();
+    if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
     if (P.mask_group_boxes && use_tail_kernel(N))
         return launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
     const size_t llds = leaders_lds_bytes(N);
@@ -531,10 +541,7 @@ extern "C" int gnms_profile_bitmask_boxes(const float* boxes, int B, int N, cons
     if (rc) return rc;
     if (B == 0 || N == 0) return GNMS_OK;
     const gnms_ws_layout L = gnms_make_layout(N);
-    bitmask_boxes_kernel<<<dim3(bitmask_boxes_blocks(N), 1, B), 256, 0, (hipStream_t)stream>>>(boxes, N, counts, nms_threshold,
-                                                                                               (char*)workspace, L);
-    GNMS_CHECK_LAUNCH();
-    return GNMS_OK;
+    return launch_bitmask_boxes(boxes, B, N, counts, nms_threshold, (char*)workspace, L, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
