@@ -113,11 +113,11 @@ __global__ void aabb_from_params_kernel(const float* __restrict__ params, long c
 // pairwise 3D overlap from the records.  METHOD 0 normal, 1 generalized, 2 0.5*(1+generalized).
 template <bool VEC, int METHOD, bool BEV>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M, int N,
-                                                    float* __restrict__ out_bev, float* __restrict__ out3d, long ld) {
+                                                    float* __restrict__ out_bev, float* __restrict__ out3d, long ld, int tile_rows) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int img = blockIdx.z;
-    const int i0 = blockIdx.y * kTileRows;
+    const int i0 = blockIdx.y * tile_rows;
     const int c0 = blockIdx.x * kWGCols + wave * kWaveCols;
     if (c0 >= N) return;
     const float* ra = RA + (size_t)img * M * kRec;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __
         const float4* p = reinterpret_cast<const float4*>(ra + (size_t)myrow * kRec);
         ru = p[0]; rv = p[1];
     }
-    const int rows = min(kTileRows, M - i0);
+    const int rows = min(tile_rows, M - i0);
 
     for (int r = 0; r < rows; ++r) {
         const float avol = bcast(ru.x, r), ay0 = bcast(ru.y, r), ay1 = bcast(ru.z, r), ax0 = bcast(ru.w, r);
@@ -203,11 +203,11 @@ __device__ __forceinline__ f2 relu2(f2 a) { return __builtin_elementwise_max(a, 
 
 template <bool VEC>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M,
-                                                                          int N, float* __restrict__ out, long ld) {
+                                                                          int N, float* __restrict__ out, long ld, int tile_rows) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int img = blockIdx.z;
-    const int i0 = blockIdx.y * kTileRows;
+    const int i0 = blockIdx.y * tile_rows;
     const int c0 = blockIdx.x * kWGCols + wave * kWaveCols;
     if (c0 >= N) return;
     const float* ra = RA + (size_t)img * M * kRec;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const 
         bvol[h][k] = u.x; by0[h][k] = u.y; by1[h][k] = u.z; bx0[h][k] = u.w; bx1[h][k] = v.x; bz0[h][k] = v.y; bz1[h][k] = v.z;
         blx[h][k] = e.x; bly[h][k] = e.y; blz[h][k] = e.z;
     }
-    const int nrows = min(kTileRows, M - i0);
+    const int nrows = min(tile_rows, M - i0);
     for (int r = 0; r < nrows; ++r) {
         // the row record is wave-uniform and read-only: scalar loads (s_load_dwordx4 x 3), no VALU, no LDS.  (Broadcasting it
         // from a lane with 10 v_readlane per row measured 111 instead of 99 us at B=8, N=4096.)
@@ -263,18 +263,20 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const 
 
 template <bool VEC, int METHOD>
 void launch_iou3d(const float* ra, const float* rb, int B, int M, int N, float* bev, float* o3, long ld, hipStream_t st) {
-    dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, kTileRows), B);
-    if (bev) iou3d_kernel<VEC, METHOD, true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, bev, o3, ld);
-    else iou3d_kernel<VEC, METHOD, false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, nullptr, o3, ld);
+    const int tr = tile_rows_for(B, M, N);
+    dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);
+    if (bev) iou3d_kernel<VEC, METHOD, true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, bev, o3, ld, tr);
+    else iou3d_kernel<VEC, METHOD, false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, nullptr, o3, ld, tr);
 }
 
 int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, int method, float* bev, float* o3, int64_t ld,
                        hipStream_t st, bool fast_nms_overlap) {
     const bool vec = (ld % 4 == 0) && ((uintptr_t)o3 % 16 == 0) && (!bev || (uintptr_t)bev % 16 == 0);
     if (method == 2 && !bev && fast_nms_overlap) {
-        dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, kTileRows), B);
-        if (vec) iou3d_nms_fast_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld);
-        else iou3d_nms_fast_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld);
+        const int tr = tile_rows_for(B, M, N);
+        dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);
+        if (vec) iou3d_nms_fast_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr);
+        else iou3d_nms_fast_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
