@@ -354,6 +354,86 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1 for N > 1024: the same two sorts (scores descending; boxes by x centre) spread over R = P/1024 workgroups per image.
+//   sort_runs_kernel   every workgroup sorts one run of 1024 keys in LDS (block_sort<1>) and parks it in global scratch
+//                      (the bit-matrix region W: nothing lives there before K2);
+//   sort_merge_kernel  every workgroup loads ALL runs of its image into LDS and ranks its own 1024 keys: final position =
+//                      own position + sum over the other runs of (number of keys below mine), R-1 branch-free binary searches
+//                      that advance in lock step (their LDS reads overlap).  Keys are distinct (index in the low word).
+// One workgroup per image needs 23 us at N=4096 and 103 us at N=16384 on its single CU; this needs about 10 / 20 us.
+// role (blockIdx.z): 0 = scores, 1 = boxes by x centre (from-boxes path).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 sort_key_of(int role, const float* __restrict__ scores_img, const float* __restrict__ boxes_img, int i) {
+    if (role == 0) return ((u64)gnms_desc_key(scores_img[i]) << 32) | (unsigned)i;
+    const float4 v = reinterpret_cast<const float4*>(boxes_img)[i];
+    return ((u64)(~gnms_desc_key(v.x + v.z)) << 32) | (unsigned)i;
+}
+
+__global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                         const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P) {
+    __shared__ u64 keys[1024];
+    const int r = blockIdx.x, b = blockIdx.y, role = blockIdx.z;
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int i = r * 1024 + (int)threadIdx.x;
+    u64 k[1];
+    k[0] = (i < n) ? sort_key_of(role, scores + (size_t)b * N, boxes ? boxes + (size_t)b * N * 4 : nullptr, i) : ~0ull;
+    block_sort<1, u64>(k, keys, 1024);
+    I.W[(size_t)role * P + i] = k[0];
+    if (r == 0 && role == 0 && threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;   // [2] = "already sorted", cleared below
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                          const int* __restrict__ counts, char* ws, gnms_ws_layout L,
+                                                          long long* __restrict__ order_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* all = reinterpret_cast<u64*>(smem);                          // [R][1024]
+    const int r = blockIdx.x, b = blockIdx.y, role = blockIdx.z;
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int t = threadIdx.x;
+    const u64* runs = I.W + (size_t)role * (R * 1024);
+#pragma unroll
+    for (int q = 0; q < R; ++q) all[q * 1024 + t] = runs[q * 1024 + t];
+    __syncthreads();
+    const u64 mine = all[r * 1024 + t];
+    int same = 1;
+    if (mine != ~0ull) {
+        int pos[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) pos[q] = 0;
+#pragma unroll
+        for (int h = 512; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) pos[q] += (all[q * 1024 + pos[q] + h - 1] < mine) ? h : 0;
+        }
+        int rank = 0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) rank += (q == r) ? t : pos[q] + ((all[q * 1024 + pos[q]] < mine) ? 1 : 0);
+        const int idx = (int)(mine & 0xffffffffu);
+        if (role == 0) {
+            same = (idx == rank);
+            I.order[rank] = idx;
+            I.rankof[idx] = rank;
+            I.sscore[rank] = scores[(size_t)b * N + idx];
+            if (order_out) order_out[(size_t)b * N + rank] = idx;
+        } else {
+            I.xidx[rank] = idx;
+            I.xbox[rank] = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];
+        }
+    }
+    if (role == 0) {
+        // padding ranks map to themselves (order is a permutation of [0, N))
+        for (int k = n + r * 1024 + t; k < N; k += R * 1024) {
+            I.order[k] = k; I.rankof[k] = k; I.sscore[k] = 0.0f;
+            if (order_out) order_out[(size_t)b * N + k] = k;
+        }
+        if (!__syncthreads_and(same) && t == 0) I.misc[2] = 0;        // (every writer stores 0)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: threshold bit matrix -- the ONE full read of the N x N fp32 matrix (HBM-read bound).
 // One wave = 64 rank-rows x 256 input columns.  Rows order[64*kb + r] are contiguous 4N-byte streams
 // whatever the permutation, so the row gather is free; lane t accumulates, for each of its 4 columns c,

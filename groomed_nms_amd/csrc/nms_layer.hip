@@ -202,6 +202,37 @@ int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts
     return GNMS_OK;
 }
 
+// K1: stable descending score sort (+ the x-centre sort of the boxes when `boxes` is given).  One workgroup per image up to
+// 1024 keys, the cooperative two-kernel sort above that.
+int launch_sorts(const float* scores, const float* boxes, int B, int N, const int32_t* counts, char* ws, const gnms_ws_layout& L, int P2,
+                 int64_t* order, hipStream_t st) {
+    int rc;
+    const int roles = boxes ? 2 : 1;
+    if (P2 <= 1024) {
+        sort_scores_kernel<1><<<dim3(B, roles), P2, (size_t)P2 * 8, st>>>(scores, N, counts, ws, L, P2, (long long*)order, boxes);
+        GNMS_CHECK_LAUNCH();
+        return GNMS_OK;
+    }
+    const int R = P2 / 1024;
+    sort_runs_kernel<<<dim3(R, B, roles), 1024, 0, st>>>(scores, boxes, N, counts, ws, L, P2);
+    GNMS_CHECK_LAUNCH();
+    const size_t lds = (size_t)P2 * 8;
+#define GNMS_MERGE(RR)                                                                                                    \
+    do {                                                                                                                  \
+        if ((rc = allow_lds(sort_merge_kernel<RR>, lds))) return rc;                                                      \
+        sort_merge_kernel<RR><<<dim3(RR, B, roles), 1024, lds, st>>>(scores, boxes, N, counts, ws, L, (long long*)order); \
+    } while (0)
+    switch (R) {
+        case 2: GNMS_MERGE(2); break;
+        case 4: GNMS_MERGE(4); break;
+        case 8: GNMS_MERGE(8); break;
+        default: GNMS_MERGE(16); break;
+    }
+#undef GNMS_MERGE
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
 // K3..K6 as one launch or four?  Measured (HIP-graph replay, B=8): one launch wins 2-2.5 us per step up to N=2048 (three
 // kernel boundaries less) and loses 1.5 us at N=4096 (the attribution runs on one CU instead of 64).  GNMS_TAIL=0/1 forces.
 bool use_tail_kernel(int N) {
@@ -247,13 +278,7 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
 
-    if (!scores_already_sorted) {
-        GNMS_DISPATCH_SORT(P2, {
-            if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
-            sort_scores_kernel<E><<<B, sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order, nullptr);
-        });
-        GNMS_CHECK_LAUNCH();
-    }
+    if (!scores_already_sorted && (rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
 
     if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N)) {
         const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
@@ -445,13 +470,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     const int P2 = next_pow2(N);
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
-    if (!scores_already_sorted) {
-        GNMS_DISPATCH_SORT(P2, {
-            if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
-            sort_scores_kernel<E><<<dim3(B, 2), sort_threads, sort_lds, st>>>(scores, N, counts, ws, L, P2, (long long*)order, boxes);
-        });                                        // y = 0: scores (descending), y = 1: boxes by x centre
-        GNMS_CHECK_LAUNCH();
-    }
+    if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
     if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
     if (P.mask_group_boxes && use_tail_kernel(N))
         return launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
