@@ -100,6 +100,8 @@ def main():
         if args.dim == 2 and not args.two_calls:
             # IoU matrix + forward as ONE library call (gnms_forward_with_iou2d): same kernels' work, the score sort rides in the IoU launch
             prob = G.differentiable_nms_with_iou2d_batched(scores, boxes, iou_out=iou_buf)[0]
+        elif args.dim == 3 and not args.two_calls:
+            prob = G.differentiable_nms_with_iou3d_batched(scores, boxes, iou_out=iou_buf)[0]      # gnms_forward_with_iou3d
         else:
             prob = G.differentiable_nms_batched(scores, build_overlaps())[0]
         scores.grad = None

@@ -1,0 +1,52 @@
+// iou3d_pair.h -- the NMS overlap 0.5 * (1 + GIoU3D) of two corner-AABB records, for TWO columns at a time (packed fp32).
+// ONE definition shared by iou3d_nms_fast_kernel (which writes the matrix) and bitmask_rec3d_kernel (which thresholds the same
+// pairs without reading the matrix back): the two must produce the same bits, so they run the same instruction sequence.
+// Reference: lib/core.py:305-421 (iou3d_approximate, method "generalized"), lib/loss/rpn_3d.py:781 (0.5 * (1 + giou)).
+#pragma once
+#include "gnms_common.h"
+
+namespace gnms_iou3d {
+
+constexpr int kRec = 12;   // floats per record: vol, y0, y1, x0, x1, z0, z1, area_bev, len x, len y, len z, 0
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// v_min_f32 / v_max_f32 issued directly, first operand wave-uniform (an SGPR): fminf/fmaxf on values the compiler cannot prove
+// canonical (anything loaded from memory) cost an extra v_max_f32 x, x, x each.  IEEE mode: a NaN operand yields the other operand.
+__device__ __forceinline__ float vmin_s(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax_s(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
+__device__ __forceinline__ f2 min2(float a, f2 b) { return (f2){vmin_s(a, b.x), vmin_s(a, b.y)}; }
+__device__ __forceinline__ f2 max2(float a, f2 b) { return (f2){vmax_s(a, b.x), vmax_s(a, b.y)}; }
+__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 relu2(f2 a) { return __builtin_elementwise_max(a, (f2){0.0f, 0.0f}); }   // arithmetic results are canonical
+
+struct Cols2 {             // two column boxes, field by field
+    f2 x0, x1, y0, y1, z0, z1, vol, lx, ly, lz;
+};
+__device__ __forceinline__ void cols2_set(Cols2& c, int k, const float4 u, const float4 v, const float4 e) {   // record = u | v | e
+    c.vol[k] = u.x; c.y0[k] = u.y; c.y1[k] = u.z; c.x0[k] = u.w; c.x1[k] = v.x; c.z0[k] = v.y; c.z1[k] = v.z;
+    c.lx[k] = e.x; c.ly[k] = e.y; c.lz[k] = e.z;
+}
+struct Row {               // one row box, every field wave-uniform
+    float x0, x1, y0, y1, z0, z1, vol, lx, ly, lz;
+};
+
+// 0.5 * (1 + i3/u3 - (vh - u3)/vh) re-associated to 0.5 * (i3*vh + u3*u3) / (u3*vh): one v_rcp_f32, hull extents from the
+// overlap's own d, everything two columns wide.  Symmetric in (row, column) bit for bit.
+__device__ __forceinline__ f2 nms_overlap3d(const Row& a, const Cols2& b) {
+    const f2 dx = min2(a.x1, b.x1) - max2(a.x0, b.x0);
+    const f2 dy = min2(a.y1, b.y1) - max2(a.y0, b.y0);
+    const f2 dz = min2(a.z1, b.z1) - max2(a.z0, b.z0);
+    const f2 i3 = (relu2(dx) * relu2(dz)) * relu2(dy);                       // lib/core.py:410-415
+    const f2 u3 = (splat(a.vol) + b.vol) - i3;                               // :357, :416
+    const f2 hx = (splat(a.lx) + b.lx) - dx;                                 // :390-406 hull extents
+    const f2 hy = (splat(a.ly) + b.ly) - dy;
+    const f2 hz = (splat(a.lz) + b.lz) - dz;
+    const f2 vh = (hx * hy) * hz;
+    const f2 num = __builtin_elementwise_fma(u3, u3, i3 * vh);
+    const f2 den = u3 * vh;
+    const f2 rc = (f2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    return (num * rc) * (f2){0.5f, 0.5f};
+}
+
+}  // namespace gnms_iou3d

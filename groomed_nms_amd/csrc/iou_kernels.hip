@@ -11,6 +11,7 @@
 // 4 KiB of one row).  Arithmetic follows the oracle/reference operation order exactly and the file
 // is compiled with -ffp-contract=off, so the 2D matrix is bit-identical to torch's CPU result.
 #include "iou_tile.h"
+#include "iou3d_pair.h"
 
 namespace {
 
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou2d_kernel(const float* __
 //   vol: product of the per-axis extents over all 8 corners (get_volume, lib/core.py:434-451)
 //   y0,y1: min/max corner y (:365-368); x/z extents from corners {2,3,6,7} (:383-388, :463-476)
 // ------------------------------------------------------------------------------------------------
-constexpr int kRec = 12;   // floats per record
+using gnms_iou3d::kRec;
 
 __device__ __forceinline__ void aabb_record(const float (&cx)[8], const float (&cy)[8], const float (&cz)[8], float* rec) {
     float mnx = cx[0], mxx = cx[0], mny = cy[0], mxy = cy[0], mnz = cz[0], mxz = cz[0];
@@ -188,18 +189,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __
 // About 24 VALU slots per pair instead of 43.  Result within 1e-6 of the exact expression order (tested at 1e-5 against
 // the reference vectors; north_star tolerance 1e-4); gnms_iou3d_approximate / methods 0 and 1 keep the exact kernel above.
 // ------------------------------------------------------------------------------------------------
-typedef float f2 __attribute__((ext_vector_type(2)));
-// v_min_f32 / v_max_f32 issued directly: fminf/fmaxf on values the compiler cannot prove canonical (anything loaded from
-// memory) cost an extra v_max_f32 x, x, x each.  Hardware semantics (IEEE mode): a NaN operand yields the other operand.
-__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// first operand wave-uniform (an SGPR straight from the scalar load)
-__device__ __forceinline__ float hw_min_s(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
-__device__ __forceinline__ float hw_max_s(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
-__device__ __forceinline__ f2 min2(float a, f2 b) { return (f2){hw_min_s(a, b.x), hw_min_s(a, b.y)}; }
-__device__ __forceinline__ f2 max2(float a, f2 b) { return (f2){hw_max_s(a, b.x), hw_max_s(a, b.y)}; }
-__device__ __forceinline__ f2 splat(float v) { return (f2){v, v}; }
-__device__ __forceinline__ f2 relu2(f2 a) { return __builtin_elementwise_max(a, (f2){0.0f, 0.0f}); }   // arithmetic results are canonical
+using gnms_iou3d::f2;
 
 template <bool VEC>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M,
@@ -214,41 +204,26 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const 
     const float* rb = RB + (size_t)img * N * kRec;
     float* o3 = out + (size_t)img * M * ld;
 
-    f2 bx0[2], bx1[2], by0[2], by1[2], bz0[2], bz1[2], bvol[2], blx[2], bly[2], blz[2];
+    gnms_iou3d::Cols2 cols[2];
     int col[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
         const int cc = col[j] < N ? col[j] : (N - 1);
         const float4* p = reinterpret_cast<const float4*>(rb + (size_t)cc * kRec);
-        const float4 u = p[0], v = p[1], e = p[2];
-        const int h = j >> 1, k = j & 1;
-        bvol[h][k] = u.x; by0[h][k] = u.y; by1[h][k] = u.z; bx0[h][k] = u.w; bx1[h][k] = v.x; bz0[h][k] = v.y; bz1[h][k] = v.z;
-        blx[h][k] = e.x; bly[h][k] = e.y; blz[h][k] = e.z;
+        gnms_iou3d::cols2_set(cols[j >> 1], j & 1, p[0], p[1], p[2]);
     }
     const int nrows = min(tile_rows, M - i0);
     for (int r = 0; r < nrows; ++r) {
         // the row record is wave-uniform and read-only: scalar loads (s_load_dwordx4 x 3), no VALU, no LDS.  (Broadcasting it
         // from a lane with 10 v_readlane per row measured 111 instead of 99 us at B=8, N=4096.)
         const float* rr = ra + (size_t)(i0 + r) * kRec;
-        const float ay0 = rr[1], ay1 = rr[2], ax0 = rr[3], ax1 = rr[4], az0 = rr[5], az1 = rr[6];
-        const f2 avol = splat(rr[0]), alx = splat(rr[8]), aly = splat(rr[9]), alz = splat(rr[10]);
+        gnms_iou3d::Row a;
+        a.vol = rr[0]; a.y0 = rr[1]; a.y1 = rr[2]; a.x0 = rr[3]; a.x1 = rr[4]; a.z0 = rr[5]; a.z1 = rr[6]; a.lx = rr[8]; a.ly = rr[9]; a.lz = rr[10];
         float res[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const f2 dx = min2(ax1, bx1[h]) - max2(ax0, bx0[h]);
-            const f2 dy = min2(ay1, by1[h]) - max2(ay0, by0[h]);
-            const f2 dz = min2(az1, bz1[h]) - max2(az0, bz0[h]);
-            const f2 i3 = (relu2(dx) * relu2(dz)) * relu2(dy);                      // lib/core.py:410-415
-            const f2 u3 = (avol + bvol[h]) - i3;                                     // :357, :416
-            const f2 hx = (alx + blx[h]) - dx;                                       // :390-406 hull extents
-            const f2 hy = (aly + bly[h]) - dy;
-            const f2 hz = (alz + blz[h]) - dz;
-            const f2 vh = (hx * hy) * hz;
-            const f2 num = __builtin_elementwise_fma(u3, u3, i3 * vh);
-            const f2 den = u3 * vh;
-            const f2 rc = (f2){__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-            const f2 q = (num * rc) * (f2){0.5f, 0.5f};
+            const f2 q = gnms_iou3d::nms_overlap3d(a, cols[h]);
             res[2 * h] = q.x; res[2 * h + 1] = q.y;
         }
         const size_t roff = (size_t)(i0 + r) * ld;
@@ -294,6 +269,17 @@ int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, in
 }
 
 }  // namespace
+
+// used by gnms_forward_with_iou3d (nms_layer.hip): per-box records from cuboid parameters, and the NMS-overlap matrix from records
+int gnms_internal_records_from_params(const float* params, long count, float* rec, hipStream_t st) {
+    if (count <= 0) return GNMS_OK;
+    aabb_from_params_kernel<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(params, count, rec);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st) {
+    return iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true);
+}
 
 extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int M, int N, float* out, int64_t ld,
                           void* stream) {

@@ -18,6 +18,7 @@
 //   K6 finalize      clamp / threshold / second sort / valid + invalid lists / output order
 #pragma once
 #include "gnms_common.h"
+#include "iou3d_pair.h"
 
 namespace gnms {
 namespace {   // internal linkage: the header is included by several translation units
@@ -248,7 +249,7 @@ __device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
 struct ImgPtrs {
     int* order; float* sscore; int* rankof; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen; int* hlist;
     float* plead; float* pre; float* r2; int* sidx; float* xsol; float* gx; int* leadc; int* leadr; u64* leadw; int* leadpfx;
-    int* misc; int* xidx; float4* xbox; u64* W;
+    int* misc; int* xidx; float4* xbox; float* rec; u64* W;
 };
 
 __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_layout& L, int b) {
@@ -260,7 +261,7 @@ __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_lay
     I.pre = (float*)(p + L.off_pre); I.r2 = (float*)(p + L.off_r2); I.sidx = (int*)(p + L.off_sidx);
     I.xsol = (float*)(p + L.off_xsol); I.gx = (float*)(p + L.off_gx); I.leadc = (int*)(p + L.off_leadc); I.leadr = (int*)(p + L.off_leadr);
     I.leadw = (u64*)(p + L.off_leadw); I.leadpfx = (int*)(p + L.off_leadpfx); I.misc = (int*)(p + L.off_misc);
-    I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox);
+    I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox); I.rec = (float*)(p + L.off_rec);
     I.W = (u64*)(p + L.off_W);
     return I;
 }
@@ -650,6 +651,76 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < CPL; ++j)
         if (crank[j] < k0 + 64) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2c: threshold bit matrix of the 3D NMS overlap straight from the cuboid records (gnms_forward_with_iou3d: the matrix is an
+// output, the layer does not read it back).  Wave tile = 64 rank-rows x 256 RANK columns (records gathered through `order`);
+// every pair runs gnms_iou3d::nms_overlap3d -- the very instruction sequence iou3d_nms_fast_kernel wrote the matrix with -- and
+// is thresholded in registers: the same bits as bitmask_kernel on that matrix.  Only tiles a leader can reach (column chunk
+// below the end of the row block) exist; they are numbered in one dimension so that every wave has equal work.
+// Bound: fp32 VALU, ~29 slots per pair on N^2/2 pairs.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tri_tile(int id, int* kb, int* chunk) {     // tiles before row block kb = 4q + r:  2q(q+1) + r(q+1)
+    int q = (int)((sqrtf(1.0f + 2.0f * (float)id) - 1.0f) * 0.5f);
+    while (2 * q * (q + 1) > id) --q;
+    while (2 * (q + 1) * (q + 2) <= id) ++q;
+    const int rem = id - 2 * q * (q + 1);
+    const int r = rem / (q + 1);
+    *kb = 4 * q + r;
+    *chunk = rem - r * (q + 1);
+}
+__host__ __device__ inline int tri_tile_count(int NB) {                // number of reachable tiles for NB row blocks
+    const int q = NB >> 2, r = NB & 3;
+    return 2 * q * (q + 1) + r * (q + 1);
+}
+
+__global__ __launch_bounds__(256) void bitmask_rec3d_kernel(int N, const int* __restrict__ counts, float thr, char* ws, gnms_ws_layout L) {
+    using namespace gnms_iou3d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int n = gnms_count(counts, b, N);
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tri_tile_count(L.NB)) return;
+    int kb, chunk;
+    tri_tile(tile, &kb, &chunk);
+    const int k0 = kb * 64, c0 = chunk * 256;
+    if (k0 >= n || c0 >= n) return;
+    ImgPtrs I = img_ptrs(ws, L, b);
+    Cols2 cols[2];
+    int col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        col[j] = c0 + 4 * lane + j;
+        const float4* p = reinterpret_cast<const float4*>(I.rec + (size_t)I.order[col[j] < n ? col[j] : n - 1] * kRec);
+        cols2_set(cols[j >> 1], j & 1, p[0], p[1], p[2]);
+    }
+    const float4* rp = reinterpret_cast<const float4*>(I.rec + (size_t)I.order[min(k0 + lane, n - 1)] * kRec);
+    const float4 ru = rp[0], rv = rp[1], re = rp[2];
+    const int nrows = min(64, n - k0);
+    unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int rend = min(32, nrows - half * 32);
+        for (int rr = 0; rr < rend; ++rr) {
+            const int r = half * 32 + rr;
+            auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r)); };
+            Row a;
+            a.vol = bc(ru.x); a.y0 = bc(ru.y); a.y1 = bc(ru.z); a.x0 = bc(ru.w); a.x1 = bc(rv.x); a.z0 = bc(rv.y); a.z1 = bc(rv.z);
+            a.lx = bc(re.x); a.ly = bc(re.y); a.lz = bc(re.z);
+            const unsigned bit = 1u << rr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f2 q = nms_overlap3d(a, cols[h]);
+                wd[half][2 * h] |= !(q.x <= thr) ? bit : 0u;
+                wd[half][2 * h + 1] |= !(q.y <= thr) ? bit : 0u;
+            }
+        }
+    }
+    u64* Wk = I.W + (size_t)kb * L.NC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (col[j] < n) Wk[col[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
 }
 
 // ------------------------------------------------------------------------------------------------

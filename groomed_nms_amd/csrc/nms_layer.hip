@@ -390,6 +390,82 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
                         ninvalid, workspace, workspace_bytes, stream, true);
 }
 
+// defined in iou_kernels.hip
+int gnms_internal_records_from_params(const float* params, long count, float* rec, hipStream_t st);
+int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st);
+
+namespace {
+// records of all images into the per-image workspace regions
+__global__ __launch_bounds__(256) void scatter_records_kernel(const float* __restrict__ rec_all, int N, char* ws, gnms_ws_layout L) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // float4 index inside the image: N * 3 of them
+    if (i >= N * 3) return;
+    reinterpret_cast<float4*>(img_ptrs(ws, L, b).rec)[i] = reinterpret_cast<const float4*>(rec_all)[(size_t)b * N * 3 + i];
+}
+}  // namespace
+
+// The 3D analogue of gnms_forward_with_iou2d: cuboid parameters -> the NMS overlap matrix 0.5*(1+GIoU3D) (an output, written by
+// iou3d_nms_fast_kernel) -> the layer.  The grouped hard-sort modes take their threshold bits from the records with the same
+// instruction sequence that wrote the matrix (bitmask_rec3d_kernel) instead of reading 4 N^2 bytes back; the O(N) overlaps the
+// group kernels need are gathered from the matrix.
+extern "C" int gnms_forward_with_iou3d(const float* params3d, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
+                                       const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
+                                       int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    int rc = check_common("gnms_forward_with_iou3d", B, N, ld, params, workspace, workspace_bytes);
+    if (rc) return rc;
+    if (B == 0 || N == 0)
+        return forward_impl("gnms_forward_with_iou3d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid, ninvalid,
+                            workspace, workspace_bytes, stream, false);
+    GNMS_CHECK_ARG(params3d && scores && iou_out && prob, "gnms_forward_with_iou3d: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const gnms_params P = *params;
+    const gnms_ws_layout L = gnms_make_layout(N);
+    char* ws = (char*)workspace;
+    // records: contiguous [B][N][12] in the first image's W region would alias the sort scratch -> use a stream-ordered temporary
+    float* rec = nullptr;
+    GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * gnms_iou3d::kRec * sizeof(float), st));
+    rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st);
+    if (!rc) rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st);
+    const bool from_rec = P.group_boxes && P.mask_group_boxes && !P.presorted;
+    if (!rc && from_rec) {
+        scatter_records_kernel<<<dim3(gnms_div_up(N * 3, 256), B), 256, 0, st>>>(rec, N, ws, L);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { gnms_set_error("kernel launch failed: %s", hipGetErrorString(le)); rc = GNMS_ERR_HIP; }
+    }
+    hipError_t fe = hipFreeAsync(rec, st);
+    if (rc) return rc;
+    if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }
+    if (!from_rec)
+        return forward_impl("gnms_forward_with_iou3d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid, ninvalid,
+                            workspace, workspace_bytes, stream, false);
+    const int P2 = next_pow2(N);
+    if ((rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
+    bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+    GNMS_CHECK_LAUNCH();
+    if (use_tail_kernel(N)) return launch_tail<false>(iou_out, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
+    const size_t llds = leaders_lds_bytes(N);
+    if ((rc = allow_lds(leaders_kernel, llds))) return rc;
+    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
+    GNMS_CHECK_LAUNCH();
+    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou_out, (long)ld, N, counts, ws, L);
+    GNMS_CHECK_LAUNCH();
+    const size_t sort_lds = (size_t)P2 * 8;
+    const int sort_threads = P2 <= 1024 ? P2 : 1024;
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(groups_kernel<E, false>, sort_lds))) return rc;
+        groups_kernel<E, false><<<B, sort_threads, sort_lds, st>>>(iou_out, N, (long)ld, counts, P, ws, L, P2);
+    });
+    GNMS_CHECK_LAUNCH();
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
+        finalize_kernel<E><<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
+                                                               ninvalid);
+    });
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
 extern "C" int gnms_backward(const float* grad_prob, const float* scores, const float* iou, int B, int N, int64_t ld,
                              const int32_t* counts, const gnms_params* params, float* grad_scores, float* grad_iou,
                              void* workspace, size_t workspace_bytes, void* stream) {

@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import GnmsParams, check, ptr, stream_ptr
 
 __all__ = ["differentiable_nms", "differentiable_nms_batched", "differentiable_nms_from_boxes_batched",
-           "differentiable_nms_with_iou2d_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
+           "differentiable_nms_with_iou2d_batched", "differentiable_nms_with_iou3d_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
            "cast_to_cpu_cuda_tensor", "get_groups", "indices_copy", "GroomedNMS"]
 
 _PRUNE = {"linear": 0, "sigmoidal": 1, "soft_nms": 2}
@@ -110,6 +110,9 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         dev = scores.device
         scores_c = scores.contiguous()
         boxes_c = boxes.contiguous()
+        three_d = boxes_c.shape[-1] == 7          # [B,N,7] cuboid parameters -> gnms_forward_with_iou3d, [B,N,4] boxes -> ..._iou2d
+        entry, what = (lib.gnms_forward_with_iou3d, "gnms_forward_with_iou3d") if three_d else (lib.gnms_forward_with_iou2d,
+                                                                                                "gnms_forward_with_iou2d")
         iou = iou_out if iou_out is not None else torch.empty((B, N, N), dtype=torch.float32, device=dev)
         prob = torch.empty((B, N), dtype=torch.float32, device=dev)
         order = torch.empty((B, N), dtype=torch.int64, device=dev)
@@ -120,9 +123,8 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            check(lib.gnms_forward_with_iou2d(ptr(boxes_c), ptr(scores_c), B, N, max(N, 1), ptr(counts), ctypes.byref(params), ptr(iou),
-                                              ptr(prob), ptr(order), ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws),
-                                              ws.numel(), stream_ptr(dev)), "gnms_forward_with_iou2d")
+            check(entry(ptr(boxes_c), ptr(scores_c), B, N, max(N, 1), ptr(counts), ctypes.byref(params), ptr(iou), ptr(prob), ptr(order),
+                        ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws), ws.numel(), stream_ptr(dev)), what)
         ctx.params = params
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(scores_c, iou, counts, ws)
@@ -289,6 +291,21 @@ def differentiable_nms_with_iou2d_batched(scores, boxes, counts=None, iou_out=No
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSWithIouFunction.apply(scores.float(), boxes.float(), counts, params, iou_out)
+
+
+def differentiable_nms_with_iou3d_batched(scores, params3d, counts=None, iou_out=None, nms_threshold=0.4, pruning_method="linear",
+                                          temperature=0.01, valid_box_prob_threshold=0.3, return_sorted_prob=False, group_boxes=True,
+                                          mask_group_boxes=True, group_size=100):
+    """scores [B,N], params3d [B,N,7] = (x3d, y3d, z3d, w3d, h3d, l3d, ry3d) -> (prob, order, valid, invalid, nvalid, ninvalid,
+    overlap [B,N,N]): the 3D NMS overlap 0.5*(1+GIoU3D) of lib/loss/rpn_3d.py:778-784 AND the layer on it in one call; identical
+    to overlaps.iou3d_batched(from_params=True, nms_overlap=True) + differentiable_nms_batched."""
+    params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
+                     mask_group_boxes, group_size, False)
+    if counts is not None:
+        counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
+    if params3d.shape[-1] != 7:
+        raise ValueError("params3d must be [B, N, 7]")
+    return _GroomedNMSWithIouFunction.apply(scores.float(), params3d.float(), counts, params, iou_out)
 
 
 def differentiable_nms_from_boxes_batched(scores, boxes, counts=None, nms_threshold=0.4, pruning_method="linear", temperature=0.01,

@@ -126,6 +126,15 @@ int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int 
                             int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* The same for the 3D overlap of lib/loss/rpn_3d.py:778-784 (overlap_in_nms == "3d"): params3d [B][N][7] = x y z w h l ry ->
+ * iou_out [B][N][ld] = 0.5 * (1 + GIoU3D) (as gnms_iou3d_from_params, method 2) -> the outputs of gnms_forward.  Grouped + masked
+ * hard-sort modes threshold the pairs from the cuboid records with the instruction sequence that wrote the matrix (no read-back
+ * of the 4 N^2 bytes); the other modes read the matrix.  gnms_backward pairs with it unchanged. */
+int gnms_forward_with_iou3d(const float* params3d, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
+                            const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
+                            int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* backward of L through prob.  grad_prob [B][N] = dL/dprob (same order as prob).
  *   grad_scores [B][N] (input order), overwritten.
  *   grad_iou    [B][N][ld] or NULL.  When given it is fully overwritten (zero fill + the sparse

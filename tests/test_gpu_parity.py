@@ -875,3 +875,27 @@ def test_best_targets_against_reference_vectors_and_oracle():
     tg, idx, sc = PR.best_targets(*(torch.from_numpy(a).cuda().unsqueeze(0) for a in (pp, pb, gp, gb)), 0.3)
     assert idx[0].tolist() == [0, 0, -1] and tg[0].tolist() == [1.0, 0.0, 0.0, 0.0]
     assert abs(float(sc[0, 0]) - 1.0) < 1e-6 and float(sc[0, 2]) == 0.0
+
+
+def test_iou3d_and_forward_in_one_call(G):
+    """gnms_forward_with_iou3d (threshold bits from the cuboid records, same instruction sequence as the matrix kernel) ==
+    iou3d_batched(from_params, nms_overlap) + differentiable_nms_batched: the matrix, all six outputs and the gradient bit for
+    bit; ragged counts, small and large N, every mode (the non-default ones read the matrix they wrote)."""
+    from groomed_nms_amd import synthetic, overlaps
+    for B, N, kw in ((3, 500, {}), (2, 4096, {}), (1, 64, {}), (2, 1001, dict(nms_threshold=0.6)), (2, 2300, dict(group_size=3)),
+                     (2, 300, dict(mask_group_boxes=False)), (1, 200, dict(group_boxes=False)), (2, 700, dict(return_sorted_prob=True))):
+        par, scores = synthetic.batch_3d(11, B, N, clustered=True, per=16)
+        pt = torch.from_numpy(par).cuda()
+        counts = torch.tensor([N] + [max(1, N // 2)] * (B - 1), dtype=torch.int32).cuda()
+        w = torch.rand((B, N), device="cuda")
+        s1 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        out1 = G.differentiable_nms_with_iou3d_batched(s1, pt, counts=counts, **kw)
+        ov = overlaps.iou3d_batched(pt, from_params=True, nms_overlap=True)
+        out2 = G.differentiable_nms_batched(s2, ov, counts=counts, **kw)
+        assert torch.equal(out1[6], ov), (B, N, kw)
+        for a, b in zip(out1[:6], out2):
+            assert torch.equal(a, b) or torch.allclose(a, b, atol=0, rtol=0, equal_nan=True), (B, N, kw)
+        (out1[0] * w).sum().backward()
+        (out2[0] * w).sum().backward()
+        assert torch.equal(s1.grad, s2.grad), (B, N, kw)
