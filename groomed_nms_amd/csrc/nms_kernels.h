@@ -560,7 +560,9 @@ __device__ __forceinline__ float wave_max_f(float v) {
 
 // CPL = columns per lane: 4 (wave tile 64 x 256) when there are plenty of tiles, 1 (64 x 64) for small problems, where the 64-row
 // chain of a wave is the critical path and four times as many waves share it.
-template <int CPL>
+// KBW = rank blocks per wave: 1, or 4 for large images (the column side -- gathers, ranks, hull -- is then paid once per 256 rows
+// instead of once per 64: at N=16384 a tile keeps ~6 of its 64 rows, so that fixed part dominated).
+template <int CPL, int KBW>
 __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
                                                             float thr, char* ws, gnms_ws_layout L) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -569,30 +571,28 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
     constexpr int kCols = 64 * CPL;
     const int nchunk = (N + kCols - 1) / kCols;
     const int tile = blockIdx.x * 4 + wave;
-    const int kb = tile / nchunk, chunk = tile - kb * nchunk;
-    const int k0 = kb * 64;
+    const int kbg = tile / nchunk, chunk = tile - kbg * nchunk;      // kbg = group of KBW consecutive rank blocks
     const int c0 = chunk * kCols;
-    if (kb >= L.NB || k0 >= n || c0 >= n) return;                    // (ragged images)
+    if (kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n) return; // (ragged images)
     ImgPtrs I = img_ptrs(ws, L, b);
     const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * N;
     float4 cb[CPL];
     float carea[CPL];
     int crank[CPL];
-    bool need = false, cok = true;
+    bool cok = true;
+    int minrank = 0x7fffffff;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
         const int p = c0 + CPL * lane + j;
         const int pp = p < n ? p : n - 1;                             // clamped duplicates: harmless in the hull, never stored
         cb[j] = I.xbox[pp];
         crank[j] = (p < n) ? I.rankof[I.xidx[pp]] : 0x7fffffff;
-        need |= crank[j] < k0 + 64;                                   // a leader must outrank at least one row of the block
+        minrank = min(minrank, crank[j]);
         carea[j] = (cb[j].z - cb[j].x) * (cb[j].w - cb[j].y);
         cok &= (carea[j] > 0.0f) && (carea[j] < INFINITY);
     }
-    if (!__any(need)) return;
-    const float4 rb = bx[I.order[min(k0 + lane, n - 1)]];
-    const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
-    const int nrows = min(64, n - k0);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) minrank = min(minrank, __shfl_xor(minrank, o, 64));
     // Decision !(fl(inter/uni) <= thr) WITHOUT the division.  With d = fma(-thr, uni, inter) (one rounding, sign exact):
     //   inter/uni - thr = d/uni,  so  |d| > guard*uni  puts the exact quotient more than `guard` (8 ulp of the threshold)
     // away from thr, hence its fp32 rounding on the same side, and the pair is decided by the sign of d.  That needs
@@ -601,56 +601,67 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
     // column box and per row.  Rows/columns that fail, and the pairs inside the guard band, take the exact IEEE division.
     const float guard = fmaxf(fabsf(thr), 1.0f) * 9.6e-7f;            // 8 ulp at the threshold's magnitude (>= 1 for tiny thresholds)
     const bool cols_ok = __all(cok);
-    const bool row_fine = (rarea > 0.0f) && (rarea < INFINITY);
-    const u64 rows_ok = __ballot(row_fine);
-    // hull of the tile's columns and the rows that reach into it
+    // hull of the tile's columns
     float hx0 = cb[0].x, hx1 = cb[0].z, hy0 = cb[0].y, hy1 = cb[0].w;
 #pragma unroll
     for (int j = 1; j < CPL; ++j) { hx0 = fminf(hx0, cb[j].x); hx1 = fmaxf(hx1, cb[j].z); hy0 = fminf(hy0, cb[j].y); hy1 = fmaxf(hy1, cb[j].w); }
     hx0 = wave_min_f(hx0); hy0 = wave_min_f(hy0); hx1 = wave_max_f(hx1); hy1 = wave_max_f(hy1);
     const bool cull = cols_ok && (thr >= 0.0f);
-    const bool reaches = (rb.z > hx0) && (rb.x < hx1) && (rb.w > hy0) && (rb.y < hy1);
-    const u64 active = __ballot((lane < nrows) && (!(cull && row_fine) || reaches));
-    unsigned wd[2][CPL];
+#pragma unroll 1
+    for (int kw = 0; kw < KBW; ++kw) {
+        const int kb = kbg * KBW + kw;
+        const int k0 = kb * 64;
+        if (kb >= L.NB || k0 >= n) break;
+        if (minrank >= k0 + 64) continue;                             // a leader must outrank at least one row of the block
+        const float4 rb = bx[I.order[min(k0 + lane, n - 1)]];
+        const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
+        const int nrows = min(64, n - k0);
+        const bool row_fine = (rarea > 0.0f) && (rarea < INFINITY);
+        const u64 rows_ok = __ballot(row_fine);
+        // the rows that reach into the hull
+        const bool reaches = (rb.z > hx0) && (rb.x < hx1) && (rb.w > hy0) && (rb.y < hy1);
+        const u64 active = __ballot((lane < nrows) && (!(cull && row_fine) || reaches));
+        unsigned wd[2][CPL];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) { wd[0][j] = 0u; wd[1][j] = 0u; }
+        for (int j = 0; j < CPL; ++j) { wd[0][j] = 0u; wd[1][j] = 0u; }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        unsigned todo = (unsigned)(half ? (active >> 32) : (active & 0xffffffffull));
-        while (todo) {                                                // wave-uniform loop over the surviving rows
-            const int rr = __builtin_ctz(todo);
-            todo &= todo - 1u;
-            const int r = half * 32 + rr;
-            const float ax1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.x), r));
-            const float ay1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.y), r));
-            const float ax2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.z), r));
-            const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), r));
-            const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), r));
-            const unsigned bit = 1u << rr;
-            float inter4[CPL], uni4[CPL], d4[CPL];
-            bool unsure = false;
+        for (int half = 0; half < 2; ++half) {
+            unsigned todo = (unsigned)(half ? (active >> 32) : (active & 0xffffffffull));
+            while (todo) {                                            // wave-uniform loop over the surviving rows
+                const int rr = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                const int r = half * 32 + rr;
+                const float ax1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.x), r));
+                const float ay1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.y), r));
+                const float ax2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.z), r));
+                const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), r));
+                const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), r));
+                const unsigned bit = 1u << rr;
+                float inter4[CPL], uni4[CPL], d4[CPL];
+                bool unsure = false;
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                const float w = fmaxf(fminf(ax2, cb[j].z) - fmaxf(ax1, cb[j].x), 0.0f);
-                const float h = fmaxf(fminf(ay2, cb[j].w) - fmaxf(ay1, cb[j].y), 0.0f);
-                inter4[j] = w * h;
-                uni4[j] = (aa + carea[j]) - inter4[j];                    // row box is `a`, column (leader) box is `b`
-                d4[j] = __builtin_fmaf(-thr, uni4[j], inter4[j]);
-                unsure |= !(fabsf(d4[j]) > guard * uni4[j]);              // also true for NaN
-            }
-            if (!(cols_ok && ((rows_ok >> r) & 1ull)) || __any(unsure)) {
+                for (int j = 0; j < CPL; ++j) {
+                    const float w = fmaxf(fminf(ax2, cb[j].z) - fmaxf(ax1, cb[j].x), 0.0f);
+                    const float h = fmaxf(fminf(ay2, cb[j].w) - fmaxf(ay1, cb[j].y), 0.0f);
+                    inter4[j] = w * h;
+                    uni4[j] = (aa + carea[j]) - inter4[j];                // row box is `a`, column (leader) box is `b`
+                    d4[j] = __builtin_fmaf(-thr, uni4[j], inter4[j]);
+                    unsure |= !(fabsf(d4[j]) > guard * uni4[j]);          // also true for NaN
+                }
+                if (!(cols_ok && ((rows_ok >> r) & 1ull)) || __any(unsure)) {
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) wd[half][j] |= !(inter4[j] / uni4[j] <= thr) ? bit : 0u;
-            } else {
+                    for (int j = 0; j < CPL; ++j) wd[half][j] |= !(inter4[j] / uni4[j] <= thr) ? bit : 0u;
+                } else {
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) wd[half][j] |= (d4[j] > 0.0f) ? bit : 0u;
+                    for (int j = 0; j < CPL; ++j) wd[half][j] |= (d4[j] > 0.0f) ? bit : 0u;
+                }
             }
         }
-    }
-    u64* Wk = I.W + (size_t)kb * L.NC;
+        u64* Wk = I.W + (size_t)kb * L.NC;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j)
-        if (crank[j] < k0 + 64) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
+        for (int j = 0; j < CPL; ++j)
+            if (crank[j] < k0 + 64) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -192,11 +192,14 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
 // bitmask_boxes_kernel: workgroups of 4 wave tiles, (row blocks) x (column chunks) tiles per image; 4 columns per lane
 // (64 x 256 tiles) when that already gives every SIMD a couple of waves, else 1 column per lane (64 x 64 tiles)
 int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
-    const long long tiles4 = (long long)B * ((N + 63) / 64) * ((N + 255) / 256);
-    if (tiles4 >= 2048) {
-        bitmask_boxes_kernel<4><<<dim3(gnms_div_up(((N + 63) / 64) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
+    const int NB = (N + 63) / 64;
+    const long long tiles4 = (long long)B * NB * ((N + 255) / 256);
+    if (tiles4 >= 32768) {                          // large images: 4 rank blocks per wave (column side paid once per 256 rows)
+        bitmask_boxes_kernel<4, 4><<<dim3(gnms_div_up(((NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
+    } else if (tiles4 >= 2048) {
+        bitmask_boxes_kernel<4, 1><<<dim3(gnms_div_up(NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
     } else {
-        bitmask_boxes_kernel<1><<<dim3(gnms_div_up(((N + 63) / 64) * ((N + 63) / 64), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
+        bitmask_boxes_kernel<1, 1><<<dim3(gnms_div_up(NB * NB, 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
     }
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;

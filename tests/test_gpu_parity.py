@@ -899,3 +899,29 @@ def test_iou3d_and_forward_in_one_call(G):
         (out1[0] * w).sum().backward()
         (out2[0] * w).sum().backward()
         assert torch.equal(s1.grad, s2.grad), (B, N, kw)
+
+
+def test_large_images_take_the_same_decisions(G):
+    """B=8, N=8192 crosses every size switch at once: cooperative sorts (8 runs per image), 4 rank blocks per bit-matrix wave,
+    separate K3..K6 launches.  One-call entry, matrix-free entry and matrix-in entry must agree bit for bit."""
+    from groomed_nms_amd import synthetic, overlaps
+    B, N = 8, 8192
+    boxes, scores = synthetic.batch_2d(21, B, N, "clustered", per=48)
+    bt = torch.from_numpy(boxes).cuda()
+    counts = torch.tensor([N, N - 1, 5000, 4097, 8000, 64, 1, 7777], dtype=torch.int32).cuda()
+    w = torch.rand((B, N), device="cuda")
+    outs, grads = [], []
+    for fn in (lambda s: G.differentiable_nms_with_iou2d_batched(s, bt, counts=counts),
+               lambda s: G.differentiable_nms_from_boxes_batched(s, bt, counts=counts),
+               lambda s: G.differentiable_nms_batched(s, overlaps.iou_batched(bt), counts=counts)):
+        s = torch.from_numpy(scores).cuda().requires_grad_(True)
+        out = fn(s)
+        (out[0] * w).sum().backward()
+        outs.append([o.detach().clone() for o in out[:6]])
+        grads.append(s.grad.clone())
+        del out
+    for k in (1, 2):
+        for a, b in zip(outs[0], outs[k]):
+            assert torch.equal(a, b)
+        assert torch.equal(grads[0], grads[k])
+    assert int(outs[0][4].sum()) > 0
