@@ -425,7 +425,8 @@ extern "C" int gnms_forward_with_iou3d(const float* params3d, const float* score
     const gnms_params P = *params;
     const gnms_ws_layout L = gnms_make_layout(N);
     char* ws = (char*)workspace;
-    // records: contiguous [B][N][12] in the first image's W region would alias the sort scratch -> use a stream-ordered temporary
+    // records of the whole batch in one stream-ordered temporary (the overlap kernel wants them contiguous); the layer's copy goes
+    // into the per-image workspace regions
     float* rec = nullptr;
     GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * gnms_iou3d::kRec * sizeof(float), st));
     rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st);
