@@ -734,6 +734,90 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_kernel(int N, const int* __
         if (col[j] < n) Wk[col[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
 }
 
+// K2c with columns in x order and row culling (the 3D counterpart of bitmask_boxes_kernel).  For GIoU a DISJOINT pair can still
+// exceed the threshold, so "does not reach the hull" is not enough; what holds for two boxes separated in x by a gap g >= 0 is
+//     i3 = 0,   q = u3 / (2 vh),   u3 = vol_a + vol_b <= (lx_a + lx_b) * max(ly) * max(lz),   vh >= (lx_a + lx_b + g) * max(ly) * max(lz)
+//     =>  q <= (lx_a + lx_b) / (2 (lx_a + lx_b + g))  <=  thr     as soon as     g >= (lx_a + lx_b) * (1 / (2 thr) - 1).
+// A row is skipped when its gap to the tile hull satisfies that with the tile's largest lx and an ADDITIVE 1e-3 on the factor
+// (relative margin 2e-3 thr on q: three orders above the fp32 rounding of the matrix kernel, so the thresholded matrix has a 0
+// there too).  Needs finite positive extents on both sides and thr >= 0.01; everything else is evaluated.  xbox holds
+// (x0, lx, x1, -) of the cuboids in x order, xidx their input indices (the second sort role, fed pseudo boxes).
+template <int KBW>
+__global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const int* __restrict__ counts, float thr, char* ws, gnms_ws_layout L) {
+    using namespace gnms_iou3d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int n = gnms_count(counts, b, N);
+    const int nchunk = (N + 255) >> 8;
+    const int tile = blockIdx.x * 4 + wave;
+    const int kbg = tile / nchunk, chunk = tile - kbg * nchunk;
+    const int c0 = chunk * 256;
+    if (kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n) return;
+    ImgPtrs I = img_ptrs(ws, L, b);
+    Cols2 cols[2];
+    int crank[4];
+    int minrank = 0x7fffffff;
+    float hx0 = INFINITY, hx1 = -INFINITY, maxlx = 0.0f;
+    bool cok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = c0 + 4 * lane + j;
+        const int pp = p < n ? p : n - 1;
+        const int idx = I.xidx[pp];
+        const float4* rp = reinterpret_cast<const float4*>(I.rec + (size_t)idx * kRec);
+        const float4 u = rp[0], v = rp[1], e = rp[2];
+        cols2_set(cols[j >> 1], j & 1, u, v, e);
+        crank[j] = (p < n) ? I.rankof[idx] : 0x7fffffff;
+        minrank = min(minrank, crank[j]);
+        hx0 = fminf(hx0, u.w); hx1 = fmaxf(hx1, v.x); maxlx = fmaxf(maxlx, e.x);
+        cok &= (e.x > 0.0f) && (e.y > 0.0f) && (e.z > 0.0f) && (u.x > 0.0f) && (u.x < INFINITY);   // extents and volume positive, finite
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) minrank = min(minrank, __shfl_xor(minrank, o, 64));
+    hx0 = wave_min_f(hx0); hx1 = wave_max_f(hx1); maxlx = wave_max_f(maxlx);
+    const bool cull = __all(cok) && (thr >= 0.01f) && (thr < INFINITY);
+    const float kappa = fmaxf(1.0f / (2.0f * thr) - 1.0f, 0.0f) + 1e-3f;
+#pragma unroll 1
+    for (int kw = 0; kw < KBW; ++kw) {
+        const int kb = kbg * KBW + kw;
+        const int k0 = kb * 64;
+        if (kb >= L.NB || k0 >= n) break;
+        if (minrank >= k0 + 64) continue;
+        const float4* rp = reinterpret_cast<const float4*>(I.rec + (size_t)I.order[min(k0 + lane, n - 1)] * kRec);
+        const float4 ru = rp[0], rv = rp[1], re = rp[2];
+        const int nrows = min(64, n - k0);
+        const bool row_fine = (re.x > 0.0f) && (re.y > 0.0f) && (re.z > 0.0f) && (ru.x > 0.0f) && (ru.x < INFINITY);
+        const float gap = fmaxf(hx0 - rv.x, ru.w - hx1);              // >= 0: the row box lies beside the hull (x0 = ru.w, x1 = rv.x)
+        const bool skip = cull && row_fine && (gap >= 0.0f) && (gap >= (re.x + maxlx) * kappa);
+        const u64 active = __ballot((lane < nrows) && !skip);
+        unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            unsigned todo = (unsigned)(half ? (active >> 32) : (active & 0xffffffffull));
+            while (todo) {
+                const int rr = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                const int r = half * 32 + rr;
+                auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r)); };
+                Row a;
+                a.vol = bc(ru.x); a.y0 = bc(ru.y); a.y1 = bc(ru.z); a.x0 = bc(ru.w); a.x1 = bc(rv.x); a.z0 = bc(rv.y); a.z1 = bc(rv.z);
+                a.lx = bc(re.x); a.ly = bc(re.y); a.lz = bc(re.z);
+                const unsigned bit = 1u << rr;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f2 q = nms_overlap3d(a, cols[h]);
+                    wd[half][2 * h] |= !(q.x <= thr) ? bit : 0u;
+                    wd[half][2 * h + 1] |= !(q.y <= thr) ? bit : 0u;
+                }
+            }
+        }
+        u64* Wk = I.W + (size_t)kb * L.NC;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (crank[j] < k0 + 64) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: leaders (= the boxes classical greedy NMS keeps).  The scan is inherently sequential over rank
 // blocks; what must NOT be on that sequential path is global-memory latency.  Ranks are processed in

@@ -399,11 +399,17 @@ int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int6
 
 namespace {
 // records of all images into the per-image workspace regions
-__global__ __launch_bounds__(256) void scatter_records_kernel(const float* __restrict__ rec_all, int N, char* ws, gnms_ws_layout L) {
+__global__ __launch_bounds__(256) void scatter_records_kernel(const float* __restrict__ rec_all, int N, char* ws, gnms_ws_layout L,
+                                                              float4* __restrict__ xkeys) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // float4 index inside the image: N * 3 of them
     if (i >= N * 3) return;
-    reinterpret_cast<float4*>(img_ptrs(ws, L, b).rec)[i] = reinterpret_cast<const float4*>(rec_all)[(size_t)b * N * 3 + i];
+    const float4 v = reinterpret_cast<const float4*>(rec_all)[(size_t)b * N * 3 + i];
+    reinterpret_cast<float4*>(img_ptrs(ws, L, b).rec)[i] = v;
+    // pseudo boxes (x0, lx, x1, 0) for the x sort: record = {vol y0 y1 x0 | x1 z0 z1 area | lx ly lz 0}
+    if (i % 3 == 0) xkeys[(size_t)b * N + i / 3].x = v.w;
+    else if (i % 3 == 1) xkeys[(size_t)b * N + i / 3].z = v.x;
+    else { xkeys[(size_t)b * N + i / 3].y = v.x; xkeys[(size_t)b * N + i / 3].w = 0.0f; }
 }
 }  // namespace
 
@@ -428,24 +434,34 @@ extern "C" int gnms_forward_with_iou3d(const float* params3d, const float* score
     // records of the whole batch in one stream-ordered temporary (the overlap kernel wants them contiguous); the layer's copy goes
     // into the per-image workspace regions
     float* rec = nullptr;
-    GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * gnms_iou3d::kRec * sizeof(float), st));
+    GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * (gnms_iou3d::kRec + 4) * sizeof(float), st));
+    float4* xkeys = reinterpret_cast<float4*>(rec + (size_t)B * N * gnms_iou3d::kRec);      // [B][N] pseudo boxes for the x sort
     rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st);
     if (!rc) rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st);
     const bool from_rec = P.group_boxes && P.mask_group_boxes && !P.presorted;
     if (!rc && from_rec) {
-        scatter_records_kernel<<<dim3(gnms_div_up(N * 3, 256), B), 256, 0, st>>>(rec, N, ws, L);
+        scatter_records_kernel<<<dim3(gnms_div_up(N * 3, 256), B), 256, 0, st>>>(rec, N, ws, L, xkeys);
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) { gnms_set_error("kernel launch failed: %s", hipGetErrorString(le)); rc = GNMS_ERR_HIP; }
     }
+    const int P2 = next_pow2(N);
+    if (!rc && from_rec) rc = launch_sorts(scores, reinterpret_cast<const float*>(xkeys), B, N, counts, ws, L, P2, order, st);   // + cuboids by x
     hipError_t fe = hipFreeAsync(rec, st);
     if (rc) return rc;
     if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }
     if (!from_rec)
         return forward_impl("gnms_forward_with_iou3d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid, ninvalid,
                             workspace, workspace_bytes, stream, false);
-    const int P2 = next_pow2(N);
-    if ((rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
-    bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+    if (!(P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY)) {
+        // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
+        bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+    } else {
+        const long long tiles = (long long)B * L.NB * ((N + 255) / 256);
+        if (tiles >= 32768)
+            bitmask_rec3d_culled_kernel<4><<<dim3(gnms_div_up(((L.NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+        else
+            bitmask_rec3d_culled_kernel<1><<<dim3(gnms_div_up(L.NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+    }
     GNMS_CHECK_LAUNCH();
     if (use_tail_kernel(N)) return launch_tail<false>(iou_out, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
     const size_t llds = leaders_lds_bytes(N);

@@ -883,6 +883,8 @@ def test_iou3d_and_forward_in_one_call(G):
     bit; ragged counts, small and large N, every mode (the non-default ones read the matrix they wrote)."""
     from groomed_nms_amd import synthetic, overlaps
     for B, N, kw in ((3, 500, {}), (2, 4096, {}), (1, 64, {}), (2, 1001, dict(nms_threshold=0.6)), (2, 2300, dict(group_size=3)),
+                     (2, 900, dict(nms_threshold=0.5)), (2, 900, dict(nms_threshold=0.005)), (2, 900, dict(nms_threshold=0.2)),
+                     (8, 8192, {}),
                      (2, 300, dict(mask_group_boxes=False)), (1, 200, dict(group_boxes=False)), (2, 700, dict(return_sorted_prob=True))):
         par, scores = synthetic.batch_3d(11, B, N, clustered=True, per=16)
         pt = torch.from_numpy(par).cuda()
