@@ -9,6 +9,8 @@
 // the 64 rows of a rank block; no per-thread 64-iteration loop, no shared memory), only tiles that a
 // suppressor can reach are computed (suppressor index < end of the rank block), and the scan runs ON
 // the device (leaders_kernel), so only keep[] and the count cross PCIe.
+#include <vector>
+#include <string.h>
 #include "nms_kernels.h"
 
 namespace {
@@ -124,17 +126,23 @@ extern "C" void _nms(int* keep_out, int* num_out, const float* boxes_host, int b
     char* dev = nullptr;
     const size_t off_keep = (bbytes + 255) / 256 * 256;
     const size_t off_ws = off_keep + ((size_t)(boxes_num + 1) * 4 + 255) / 256 * 256;
-    if (hipMalloc((void**)&dev, off_ws + wbytes) != hipSuccess) { gnms_set_error("_nms: hipMalloc failed"); return; }
+    // stream-ordered allocation on the null stream: the pool keeps the block between calls (the reference pays a cudaMalloc /
+    // cudaFree per call, nms_kernel.cu:100-108,142-143; here that was two thirds of the call)
+    if (hipMallocAsync((void**)&dev, off_ws + wbytes, nullptr) != hipSuccess) { gnms_set_error("_nms: hipMallocAsync failed"); return; }
     int32_t* keep_d = (int32_t*)(dev + off_keep);
     int32_t* num_d = keep_d + boxes_num;                      // staged right behind keep[] on the device
     int rc = GNMS_OK;
     hipError_t e = hipMemcpy(dev, boxes_host, bbytes, hipMemcpyHostToDevice);                        // :103-106
     if (e == hipSuccess)
         rc = gnms_nms_sorted((const float*)dev, boxes_num, boxes_dim, nms_overlap_thresh, keep_d, num_d, dev + off_ws, wbytes, nullptr);
-    int num = 0;
-    if (e == hipSuccess && rc == GNMS_OK) e = hipMemcpy(&num, num_d, sizeof(int), hipMemcpyDeviceToHost);   // blocking: orders after the kernels
-    if (e == hipSuccess && rc == GNMS_OK && num > 0) e = hipMemcpy(keep_out, keep_d, (size_t)num * sizeof(int), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && rc == GNMS_OK) *num_out = num;
-    (void)hipFree(dev);
+    // keep[] and the count come back in ONE blocking copy (it orders after the kernels): boxes_num + 1 ints
+    std::vector<int32_t> host((size_t)boxes_num + 1);
+    if (e == hipSuccess && rc == GNMS_OK) e = hipMemcpy(host.data(), keep_d, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc == GNMS_OK) {
+        const int num = host[boxes_num];
+        if (num > 0) memcpy(keep_out, host.data(), (size_t)num * sizeof(int));
+        *num_out = num;
+    }
+    (void)hipFreeAsync(dev, nullptr);
     if (e != hipSuccess) gnms_set_error("_nms: HIP copy failed");
 }
