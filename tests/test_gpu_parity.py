@@ -927,3 +927,38 @@ def test_large_images_take_the_same_decisions(G):
             assert torch.equal(a, b)
         assert torch.equal(grads[0], grads[k])
     assert int(outs[0][4].sum()) > 0
+
+
+def test_api_edges(G):
+    """What callers actually hand over: strided views, float64, a padded leading dimension, a matrix that requires grad, NumPy
+    float64 in / CPU tensors out (lib/rpn_util.py:1319-1320), empty inputs, an unknown pruning method, impossible shapes."""
+    from groomed_nms_amd import synthetic, overlaps, _lib
+    boxes, scores = synthetic.batch_2d(3, 2, 300, "clustered", per=20)
+    bt = torch.from_numpy(boxes).cuda(); st = torch.from_numpy(scores).cuda()
+    ref = G.differentiable_nms_with_iou2d_batched(st, bt)
+
+    def same(out):
+        for a, b in zip(out[:6], ref[:6]):
+            assert torch.equal(a, b)
+    big = torch.zeros((2, 300, 6), device="cuda"); big[..., 1:5] = bt
+    same(G.differentiable_nms_with_iou2d_batched(st, big[..., 1:5]))                     # strided boxes
+    sbig = torch.zeros((2, 600), device="cuda"); sbig[:, ::2] = st
+    same(G.differentiable_nms_with_iou2d_batched(sbig[:, ::2], bt))                      # strided scores
+    same(G.differentiable_nms_with_iou2d_batched(st.double(), bt.double()))              # float64 -> computed in fp32
+    iou = overlaps.iou_batched(bt)
+    pad = torch.zeros((2, 300, 304), device="cuda"); pad[..., :300] = iou
+    same(G.differentiable_nms_batched(st, pad[..., :300]))                               # leading dimension 304
+    iou_g = iou.clone().requires_grad_(True); s_g = st.clone().requires_grad_(True)
+    out = G.differentiable_nms_batched(s_g, iou_g)
+    (out[0] * torch.rand_like(out[0])).sum().backward()
+    assert iou_g.grad.shape == iou.shape and float(iou_g.grad.abs().sum()) > 0           # sparse dL/diou
+    v, iv, p = G.differentiable_nms(scores[0].astype(np.float64), iou[0].cpu().numpy())
+    assert not p.is_cuda and p.shape == (300,) and v.dtype == torch.int64 and len(v) + len(iv) == 300
+    v, iv, p = G.differentiable_nms(torch.zeros(0, device="cuda"), torch.zeros((0, 0), device="cuda"))
+    assert v.numel() == 0 and iv.numel() == 0 and p.numel() == 0
+    out = G.differentiable_nms_with_iou2d_batched(torch.zeros((0, 5), device="cuda"), torch.zeros((0, 5, 4), device="cuda"))
+    assert out[0].shape == (0, 5)
+    with pytest.raises(NotImplementedError, match="Pruning method not implemented!"):       # lib/groomed_nms.py:177-178
+        G.differentiable_nms(torch.rand(5, device="cuda"), torch.rand((5, 5), device="cuda"), pruning_method="bogus")
+    with pytest.raises(_lib.GnmsError):
+        G.differentiable_nms_batched(torch.rand((1, 20000), device="cuda"), torch.rand((1, 4, 4), device="cuda"))
