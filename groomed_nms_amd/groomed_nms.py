@@ -37,6 +37,15 @@ def _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold
                       int(min(int(group_size), 2 ** 31 - 2)), int(bool(presorted)))
 
 
+def _outputs(B, N, dev):
+    """prob [B,N] fp32; order / valid / invalid [B,N] int64 and nvalid / ninvalid [B] int32 as views of ONE allocation each
+    (finalize_kernel writes every entry, -1 padding included): three allocator calls instead of six on the launch-bound path."""
+    prob = torch.empty((B, N), dtype=torch.float32, device=dev)
+    lists = torch.empty((3, B, N), dtype=torch.int64, device=dev)
+    counts = torch.empty((2, B), dtype=torch.int32, device=dev)
+    return prob, lists[0], lists[1], lists[2], counts[0], counts[1]
+
+
 def _matrix_layout(iou):
     """Returns (tensor, ld) with unit column stride and image stride N*ld, copying only if needed."""
     B, N, _ = iou.shape
@@ -58,12 +67,7 @@ class _GroomedNMSFunction(torch.autograd.Function):
         dev = scores.device
         scores_c = scores.contiguous()
         iou_c, ld = _matrix_layout(iou)
-        prob = torch.empty((B, N), dtype=torch.float32, device=dev)
-        order = torch.empty((B, N), dtype=torch.int64, device=dev)
-        valid = torch.empty((B, N), dtype=torch.int64, device=dev)       # finalize_kernel writes every entry (-1 padding)
-        invalid = torch.empty((B, N), dtype=torch.int64, device=dev)
-        nvalid = torch.empty((B,), dtype=torch.int32, device=dev)
-        ninvalid = torch.empty((B,), dtype=torch.int32, device=dev)
+        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev)
         nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
@@ -114,12 +118,7 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         entry, what = (lib.gnms_forward_with_iou3d, "gnms_forward_with_iou3d") if three_d else (lib.gnms_forward_with_iou2d,
                                                                                                 "gnms_forward_with_iou2d")
         iou = iou_out if iou_out is not None else torch.empty((B, N, N), dtype=torch.float32, device=dev)
-        prob = torch.empty((B, N), dtype=torch.float32, device=dev)
-        order = torch.empty((B, N), dtype=torch.int64, device=dev)
-        valid = torch.empty((B, N), dtype=torch.int64, device=dev)
-        invalid = torch.empty((B, N), dtype=torch.int64, device=dev)
-        nvalid = torch.empty((B,), dtype=torch.int32, device=dev)
-        ninvalid = torch.empty((B,), dtype=torch.int32, device=dev)
+        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev)
         nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
@@ -127,7 +126,8 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
                         ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws), ws.numel(), stream_ptr(dev)), what)
         ctx.params = params
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(scores_c, iou, counts, ws)
+        ctx.save_for_backward(scores_c, counts, ws)
+        ctx.iou = iou            # an OUTPUT without grad_fn (non-differentiable): a plain attribute avoids the saved-output bookkeeping
         ctx.mark_non_differentiable(order, valid, invalid, nvalid, ninvalid, iou)
         return prob, order, valid, invalid, nvalid, ninvalid, iou
 
@@ -136,7 +136,8 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         if grad_prob is None:
             return None, None, None, None, None
         lib = _lib.load()
-        scores_c, iou_c, counts, ws = ctx.saved_tensors
+        scores_c, counts, ws = ctx.saved_tensors
+        iou_c = ctx.iou
         B, N = scores_c.shape
         dev = scores_c.device
         grad_prob = grad_prob.contiguous().float()
@@ -159,12 +160,7 @@ class _GroomedNMSFromBoxesFunction(torch.autograd.Function):
         dev = scores.device
         scores_c = scores.contiguous()
         boxes_c = boxes.contiguous()
-        prob = torch.empty((B, N), dtype=torch.float32, device=dev)
-        order = torch.empty((B, N), dtype=torch.int64, device=dev)
-        valid = torch.empty((B, N), dtype=torch.int64, device=dev)
-        invalid = torch.empty((B, N), dtype=torch.int64, device=dev)
-        nvalid = torch.empty((B,), dtype=torch.int32, device=dev)
-        ninvalid = torch.empty((B,), dtype=torch.int32, device=dev)
+        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev)
         nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
