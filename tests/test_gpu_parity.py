@@ -962,3 +962,28 @@ def test_api_edges(G):
         G.differentiable_nms(torch.rand(5, device="cuda"), torch.rand((5, 5), device="cuda"), pruning_method="bogus")
     with pytest.raises(_lib.GnmsError):
         G.differentiable_nms_batched(torch.rand((1, 20000), device="cuda"), torch.rand((1, 4, 4), device="cuda"))
+
+
+def test_make_graphed_callables(G):
+    """The Python layer (autograd.Function over the C ABI) survives torch.cuda.make_graphed_callables: forward and backward are
+    captured into HIP graphs once and replayed on new scores with the same results and gradients as eager calls."""
+    from groomed_nms_amd import synthetic
+    B, N = 4, 500
+    boxes_np, scores_np = synthetic.batch_2d(5, B, N, "clustered", per=25)
+    boxes = torch.from_numpy(boxes_np).cuda()
+
+    class Layer(torch.nn.Module):
+        def forward(self, scores, bx):
+            return G.differentiable_nms_with_iou2d_batched(scores, bx)[0]
+    layer = Layer()
+    graphed = torch.cuda.make_graphed_callables(layer, (torch.from_numpy(scores_np).cuda().requires_grad_(True), boxes))
+    w = torch.rand((B, N), device="cuda")
+    for trial in range(3):
+        _, sc = synthetic.batch_2d(50 + trial, B, N, "clustered", per=25)
+        s1 = torch.from_numpy(sc).cuda().requires_grad_(True)
+        s2 = torch.from_numpy(sc).cuda().requires_grad_(True)
+        p1 = graphed(s1, boxes)
+        (p1 * w).sum().backward()
+        p2 = layer(s2, boxes)
+        (p2 * w).sum().backward()
+        assert torch.equal(p1, p2) and torch.equal(s1.grad, s2.grad) and float(p1.detach().sum()) > 0
