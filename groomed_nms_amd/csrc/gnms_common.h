@@ -179,6 +179,32 @@ __device__ __forceinline__ int gnms_max_scan32(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2,3
     return v;
 }
+// wave-wide min / max of a float on the VALU (same DPP network; the result is wave-uniform, read from lane 63).  fminf/fmaxf
+// semantics: a NaN operand yields the other operand.
+__device__ __forceinline__ float gnms_wave_min_f(float v) {
+    const int id = 0x7f800000;   // +inf for lanes without a source
+#define GNMS_DPP_MIN(ctrl, rmask) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(id, __float_as_int(v), ctrl, rmask, 0xF, false)))
+    GNMS_DPP_MIN(0x111, 0xF); GNMS_DPP_MIN(0x112, 0xF); GNMS_DPP_MIN(0x114, 0xF); GNMS_DPP_MIN(0x118, 0xF);
+    GNMS_DPP_MIN(0x142, 0xA); GNMS_DPP_MIN(0x143, 0xC);
+#undef GNMS_DPP_MIN
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float gnms_wave_max_f(float v) {
+    const int id = (int)0xff800000;   // -inf
+#define GNMS_DPP_MAX(ctrl, rmask) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(id, __float_as_int(v), ctrl, rmask, 0xF, false)))
+    GNMS_DPP_MAX(0x111, 0xF); GNMS_DPP_MAX(0x112, 0xF); GNMS_DPP_MAX(0x114, 0xF); GNMS_DPP_MAX(0x118, 0xF);
+    GNMS_DPP_MAX(0x142, 0xA); GNMS_DPP_MAX(0x143, 0xC);
+#undef GNMS_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int gnms_wave_min_i(int v) {
+    const int id = 0x7fffffff;
+#define GNMS_DPP_MINI(ctrl, rmask) v = min(v, __builtin_amdgcn_update_dpp(id, v, ctrl, rmask, 0xF, false))
+    GNMS_DPP_MINI(0x111, 0xF); GNMS_DPP_MINI(0x112, 0xF); GNMS_DPP_MINI(0x114, 0xF); GNMS_DPP_MINI(0x118, 0xF);
+    GNMS_DPP_MINI(0x142, 0xA); GNMS_DPP_MINI(0x143, 0xC);
+#undef GNMS_DPP_MINI
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ unsigned long long gnms_or_scan64(unsigned long long v) {
     const unsigned lo = gnms_or_scan32((unsigned)(v & 0xffffffffu));
     const unsigned hi = gnms_or_scan32((unsigned)(v >> 32));

@@ -547,16 +547,8 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
 // areas and thr >= 0, inter = +0 and uni > 0 give 0 <= thr).  On detector-like inputs (boxes ~100 px on a 1760 px wide
 // canvas) a tile keeps 15-20 % of its 64 rows.  The price: the rank triangle can no longer be skipped per tile (a tile
 // holds columns of every rank); words no leader scan reads (column rank >= 64 (kb+1)) are computed but not stored.
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_min_f(float v) { return gnms_wave_min_f(v); }   // DPP network: no ds_bpermute round trips
+__device__ __forceinline__ float wave_max_f(float v) { return gnms_wave_max_f(v); }
 
 // CPL = columns per lane: 4 (wave tile 64 x 256) when there are plenty of tiles, 1 (64 x 64) for small problems, where the 64-row
 // chain of a wave is the critical path and four times as many waves share it.
@@ -591,8 +583,7 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
         carea[j] = (cb[j].z - cb[j].x) * (cb[j].w - cb[j].y);
         cok &= (carea[j] > 0.0f) && (carea[j] < INFINITY);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) minrank = min(minrank, __shfl_xor(minrank, o, 64));
+    minrank = gnms_wave_min_i(minrank);
     // Decision !(fl(inter/uni) <= thr) WITHOUT the division.  With d = fma(-thr, uni, inter) (one rounding, sign exact):
     //   inter/uni - thr = d/uni,  so  |d| > guard*uni  puts the exact quotient more than `guard` (8 ulp of the threshold)
     // away from thr, hence its fp32 rounding on the same side, and the pair is decided by the sign of d.  That needs
@@ -772,8 +763,7 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
         hx0 = fminf(hx0, u.w); hx1 = fmaxf(hx1, v.x); maxlx = fmaxf(maxlx, e.x);
         cok &= (e.x > 0.0f) && (e.y > 0.0f) && (e.z > 0.0f) && (u.x > 0.0f) && (u.x < INFINITY);   // extents and volume positive, finite
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) minrank = min(minrank, __shfl_xor(minrank, o, 64));
+    minrank = gnms_wave_min_i(minrank);
     hx0 = wave_min_f(hx0); hx1 = wave_max_f(hx1); maxlx = wave_max_f(maxlx);
     const bool cull = __all(cok) && (thr >= 0.01f) && (thr < INFINITY);
     const float kappa = fmaxf(1.0f / (2.0f * thr) - 1.0f, 0.0f) + 1e-3f;
