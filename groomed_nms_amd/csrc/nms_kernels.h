@@ -554,20 +554,39 @@ __device__ __forceinline__ float wave_max_f(float v) { return gnms_wave_max_f(v)
 // chain of a wave is the critical path and four times as many waves share it.
 // KBW = rank blocks per wave: 1, or 4 for large images (the column side -- gathers, ranks, hull -- is then paid once per 256 rows
 // instead of once per 64: at N=16384 a tile keeps ~6 of its 64 rows, so that fixed part dominated).
-template <int CPL, int KBW>
-__global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
+// ROWBUF (N <= 4096, KBW = 1): the workgroup is 16 waves = ALL column chunks of ONE rank block; the words go to an LDS copy of the
+// row W[kb][.] (indexed by column rank) and leave as one coalesced write of the 64 (kb+1) words a leader scan can read.  Without it
+// every lane scatters its 8-byte words to global memory: 1 M scattered stores per launch at B=8, N=4096 = ~15 us of store
+// throughput, about a third of it exposed.
+template <int CPL, int KBW, bool ROWBUF = false>
+__global__ __launch_bounds__(ROWBUF ? 1024 : 256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
                                                             float thr, char* ws, gnms_ws_layout L) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
     const int n = gnms_count(counts, b, N);
     constexpr int kCols = 64 * CPL;
     const int nchunk = (N + kCols - 1) / kCols;
-    const int tile = blockIdx.x * 4 + wave;
-    const int kbg = tile / nchunk, chunk = tile - kbg * nchunk;      // kbg = group of KBW consecutive rank blocks
-    const int c0 = chunk * kCols;
-    if (kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n) return; // (ragged images)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* rowbuf = reinterpret_cast<u64*>(smem);                       // ROWBUF: [NC] words of row kb, by column rank
     ImgPtrs I = img_ptrs(ws, L, b);
+    if (ROWBUF) {
+        const int kbr = blockIdx.x;                                   // one rank block per workgroup, wave w = column chunk w
+        if (kbr * 64 >= n) return;
+        const int need = min(64 * (kbr + 1), L.NC);
+        for (int i = threadIdx.x; i < need; i += blockDim.x) rowbuf[i] = 0ull;
+        __syncthreads();
+    }
+    const int tile = ROWBUF ? (int)blockIdx.x * nchunk + wave : (int)blockIdx.x * 4 + wave;
+    const int kbg = ROWBUF ? (int)blockIdx.x : tile / nchunk;        // kbg = group of KBW consecutive rank blocks
+    const int chunk = ROWBUF ? wave : tile - kbg * nchunk;
+    const int c0 = chunk * kCols;
+    const bool idle = (kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n || chunk >= nchunk);   // (ragged images)
+    if (!ROWBUF && idle) return;
+    if (!idle) {
     const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * N;
+    // the row boxes of the first rank block are requested before the column side is worked on, so that their two dependent loads
+    // (order -> box) overlap the column gathers
+    float4 rb_next = bx[I.order[min(kbg * KBW * 64 + lane, n - 1)]];
     float4 cb[CPL];
     float carea[CPL];
     int crank[CPL];
@@ -603,8 +622,9 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
         const int kb = kbg * KBW + kw;
         const int k0 = kb * 64;
         if (kb >= L.NB || k0 >= n) break;
+        const float4 rb = rb_next;
+        if (KBW > 1 && kw + 1 < KBW && kb + 1 < L.NB && k0 + 64 < n) rb_next = bx[I.order[min(k0 + 64 + lane, n - 1)]];   // next block's rows
         if (minrank >= k0 + 64) continue;                             // a leader must outrank at least one row of the block
-        const float4 rb = bx[I.order[min(k0 + lane, n - 1)]];
         const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
         const int nrows = min(64, n - k0);
         const bool row_fine = (rarea > 0.0f) && (rarea < INFINITY);
@@ -648,10 +668,18 @@ __global__ __launch_bounds__(256) void bitmask_boxes_kernel(const float* __restr
                 }
             }
         }
-        u64* Wk = I.W + (size_t)kb * L.NC;
+        u64* Wk = ROWBUF ? rowbuf : I.W + (size_t)kb * L.NC;
 #pragma unroll
         for (int j = 0; j < CPL; ++j)
             if (crank[j] < k0 + 64) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
+    }
+    }   // !idle
+    if (ROWBUF) {
+        __syncthreads();
+        const int kbr = blockIdx.x;
+        const int need = min(64 * (kbr + 1), L.NC);
+        u64* Wk = I.W + (size_t)kbr * L.NC;
+        for (int i = threadIdx.x; i < need; i += blockDim.x) Wk[i] = rowbuf[i];      // the part of the row a leader scan reads, coalesced
     }
 }
 

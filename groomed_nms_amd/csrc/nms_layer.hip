@@ -196,6 +196,9 @@ int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts
     const long long tiles4 = (long long)B * NB * ((N + 255) / 256);
     if (tiles4 >= 32768) {                          // large images: 4 rank blocks per wave (column side paid once per 256 rows)
         bitmask_boxes_kernel<4, 4><<<dim3(gnms_div_up(((NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
+    } else if (tiles4 >= 2048 && (N + 255) / 256 <= 16) {
+        // one 16-wave workgroup per rank block: words collected in an LDS copy of the row, written out coalesced
+        bitmask_boxes_kernel<4, 1, true><<<dim3(NB, 1, B), 1024, (size_t)L.NC * 8, st>>>(boxes, N, counts, thr, ws, L);
     } else if (tiles4 >= 2048) {
         bitmask_boxes_kernel<4, 1><<<dim3(gnms_div_up(NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
     } else {
