@@ -529,7 +529,8 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (col[j] < n) Wk[rk[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
+        // only words a leader scan can read: the column must outrank some row of the block (the others are never looked at)
+        if (col[j] < n && rk[j] < k0 + 64) Wk[rk[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
     }
 }
 
