@@ -13,8 +13,8 @@
  *   - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host;
  *   - calls are asynchronous and ordered on `stream` (a hipStream_t passed as void*; NULL = the
  *     null stream); no hidden synchronisation and no hidden allocation, except `_nms`, which keeps
- *     the reference's blocking host-pointer contract, and the two gnms_iou3d_* calls, which take a
- *     stream-ordered temporary (hipMallocAsync/hipFreeAsync) of 32 bytes per box;
+ *     the reference's blocking host-pointer contract, and the 3D entries (gnms_iou3d_*, gnms_forward_with_iou3d),
+ *     which take a stream-ordered temporary (hipMallocAsync/hipFreeAsync) of 48-64 bytes per box for the cuboid records;
  *   - a batch is B images of up to N boxes; image b uses the first counts[b] boxes (counts may be
  *     NULL: every image has N).  Scores are [B][N]; overlap matrices are [B][N][ld] row-major with
  *     row stride ld >= N elements (image stride N*ld);
@@ -35,7 +35,7 @@ extern "C" {
 #endif
 
 #define GNMS_ABI_VERSION 1
-#define GNMS_MAX_BOXES 16384 /* per image; the in-LDS sort holds 16384 64-bit keys in 128 KiB of the CU's 160 KiB */
+#define GNMS_MAX_BOXES 16384 /* per image; the in-LDS sorts and merges hold 16384 64-bit keys in 128 KiB of the CU's 160 KiB */
 
 typedef enum gnms_status {
     GNMS_OK = 0,
