@@ -1,7 +1,7 @@
 """ctypes front-end of oracle/libgnms_oracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.  The
-product package groomed_nms_amd/ never does (tests/test_no_oracle_in_product.py enforces it).
+product package groomed_nms_amd/ never does (tests/test_abi_and_host.py::test_product_never_touches_the_oracle enforces it).
 Every function is the CPU restatement of a reference function; the citation is in
 oracle/gnms_oracle.c next to the C body.  Parity status: pinned (tests/test_oracle_golden.py).
 """
