@@ -2,7 +2,10 @@
 """bench.py -- GrooMeD-NMS fwd+bwd boxes/sec on MI355X (BASELINE.json metric).
 
 A step = one pass of the hot path over one batch of synthetic proposals already resident in HBM:
-    pairwise 2D IoU matrix (gnms_iou2d)  ->  GrooMeD-NMS forward (gnms_forward)  ->  backward w.r.t. scores (gnms_backward)
+    pairwise IoU matrix  ->  GrooMeD-NMS forward  ->  backward w.r.t. scores
+as lib/loss/rpn_3d.py:772-791 runs it.  Default (2D): ONE library call builds the matrix and runs the layer
+(gnms_forward_with_iou2d: the matrix is an output, the threshold bits come straight from the boxes), then gnms_backward;
+--two-calls keeps gnms_iou2d and the matrix-in layer gnms_forward apart; --dim 3 uses gnms_forward_with_iou3d.
 Workload at N GPUs (weak scaling): every rank owns `--batch` images x `--boxes` boxes; images are independent
 units, so there is no data-path collective (DESIGN.md "multi-GPU").
 
@@ -10,10 +13,11 @@ units, so there is no data-path collective (DESIGN.md "multi-GPU").
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
-  roofline      the dominant kernel (threshold bit-matrix kernel = the one full read of the N x N fp32 matrix),
-                algorithmic bytes / HIP-event time, against the 8 TB/s HBM peak
-  roofline_iou  same for the IoU kernel (the one full write of the matrix)
-  cpu_baseline  the CPU oracle (a C port of the reference algorithm, single thread) timed on this host, N=1 only
+  roofline            the dominant kernel of the timed step: algorithmic bytes / HIP-event time against the 8 TB/s HBM peak
+                      (default: the IoU write kernel; with --two-calls the bit-matrix kernel, the one full read of the matrix)
+  roofline_matrix_in  / roofline_iou: the other of the two
+  fused_from_boxes    the matrix-free entry (never part of `value`)
+  cpu_baseline        the CPU oracle (a C port of the reference algorithm, single thread) timed on this host, N=1 only
 """
 import argparse
 import json
@@ -202,19 +206,22 @@ def main():
                                    % (B, N, args.kind, args.dim), "boxes_per_image": N, "images_per_gpu": B,
                        "scores_presorted": bool(args.sorted_scores), "hip_graph_replay": bool(args.graph), "parallelism": "images sharded, dp%d" % world},
             "roofline": None,
-            "phase_ms": {"iou2d": round(t_iou, 4), "nms_forward": round(t_fwd, 4), "nms_backward": round(t_bwd, 4)},
+            "phase_ms": {"overlaps": round(t_iou, 4), "nms_forward": round(t_fwd, 4), "nms_backward": round(t_bwd, 4)},
         }
-        iou_name = "iou2d_kernel" if args.dim == 2 else "iou3d_kernel"
-        one_call = args.dim == 2 and not args.two_calls
-        r_iou = dict(roof(t_iou, alg_bytes_iou, "iou2d_sort_kernel" if (one_call and "iou2d_sort_kernel" in pmc) else iou_name), kernel=iou_name + " (one full write of the NxN fp32 matrix; the same tile code runs as "
-                     "iou2d_sort_kernel inside gnms_forward_with_iou2d)")
+        iou_name = "iou2d_kernel" if args.dim == 2 else "iou3d_nms_fast_kernel"
+        one_call = not args.two_calls
+        iou_note = (" (one full write of the NxN fp32 matrix; the same tile code runs as iou2d_sort_kernel inside gnms_forward_with_iou2d)"
+                    if args.dim == 2 else " (one full write of the NxN fp32 matrix, + the per-box record kernels in front of it)")
+        r_iou = dict(roof(t_iou, alg_bytes_iou, "iou2d_sort_kernel" if (one_call and "iou2d_sort_kernel" in pmc) else iou_name),
+                     kernel=iou_name + iou_note)
         r_mask = dict(roof(t_mask, alg_bytes, "bitmask_kernel"), kernel="bitmask_kernel (gnms_forward: one full read of the NxN fp32 matrix)")
         if one_call:
-            # the timed step hands the boxes over, so the layer never reads the matrix back: the IoU write is the dominant kernel
+            # the timed step hands the boxes over, so the layer never reads the matrix back: the matrix write is the dominant kernel
             out["roofline"], out["roofline_matrix_in"] = r_iou, r_mask
-            t_one = event_time_ms(lambda: G.differentiable_nms_with_iou2d_batched(s_det, boxes, iou_out=iou_buf), 20, stream)
-            out["phase_ms"] = {"iou2d_plus_nms_forward_one_call": round(t_one, 4), "nms_backward": round(t_bwd, 4),
-                               "separately": {"iou2d": round(t_iou, 4), "nms_forward_matrix_in": round(t_fwd, 4)}}
+            entry = G.differentiable_nms_with_iou2d_batched if args.dim == 2 else G.differentiable_nms_with_iou3d_batched
+            t_one = event_time_ms(lambda: entry(s_det, boxes, iou_out=iou_buf), 20, stream)
+            out["phase_ms"] = {"overlaps_plus_nms_forward_one_call": round(t_one, 4), "nms_backward": round(t_bwd, 4),
+                               "separately": {"overlaps": round(t_iou, 4), "nms_forward_matrix_in": round(t_fwd, 4)}}
         else:
             out["roofline"], out["roofline_iou"] = r_mask, r_iou
         if args.dim == 2:
