@@ -907,10 +907,15 @@ def test_large_images_take_the_same_decisions(G):
     """B=8, N=8192 crosses every size switch at once: cooperative sorts (8 runs per image), 4 rank blocks per bit-matrix wave,
     separate K3..K6 launches.  One-call entry, matrix-free entry and matrix-in entry must agree bit for bit."""
     from groomed_nms_amd import synthetic, overlaps
-    B, N = 8, 8192
+    _large_image_case(G, 8, 8192, [8192, 8191, 5000, 4097, 8000, 64, 1, 7777])
+    _large_image_case(G, 2, 16384, [16384, 9001])             # the largest image the library takes: 16 sort runs, 256 rank blocks
+
+
+def _large_image_case(G, B, N, count_list):
+    from groomed_nms_amd import synthetic, overlaps
     boxes, scores = synthetic.batch_2d(21, B, N, "clustered", per=48)
     bt = torch.from_numpy(boxes).cuda()
-    counts = torch.tensor([N, N - 1, 5000, 4097, 8000, 64, 1, 7777], dtype=torch.int32).cuda()
+    counts = torch.tensor(count_list, dtype=torch.int32).cuda()
     w = torch.rand((B, N), device="cuda")
     outs, grads = [], []
     for fn in (lambda s: G.differentiable_nms_with_iou2d_batched(s, bt, counts=counts),
