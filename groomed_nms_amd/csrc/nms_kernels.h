@@ -1325,6 +1325,22 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     u64 run = base + inc - packed;
     const int n_nan = (int)(total & 0xffff), nv = (int)((total >> 16) & 0xffff), ni = (int)(total >> 32);
     const int n_ge = n_nan + nv;
+    if (!valid && !invalid && !P.return_sorted_prob) {
+        // the caller wants the probabilities only (training reads just the third return value, lib/loss/rpn_3d.py:791):
+        // no compaction, no sort of the valid boxes -- only the counts and prob
+        float* pbq = prob + (size_t)b * N;
+        for (int j = t; j < N; j += T) {
+            float out = 0.0f;
+            if (j < n) { const float r2j = I.r2[j]; out = P.group_boxes ? r2j : ((r2j < vthr) ? 0.0f : r2j); }   // :124-127
+            pbq[j] = out;
+            I.sidx[j] = j;
+        }
+        if (t == 0) {
+            if (nvalid) nvalid[b] = nv;
+            if (ninvalid) ninvalid[b] = ni;
+        }
+        return;
+    }
     // sidx layout: [0,n_nan) NaN by position, [n_nan, n_ge) valid (sorted below), [n_ge, n_ge+ni) invalid by position
 #pragma unroll
     for (int e = 0; e < E; ++e) {

@@ -37,13 +37,14 @@ def _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold
                       int(min(int(group_size), 2 ** 31 - 2)), int(bool(presorted)))
 
 
-def _outputs(B, N, dev):
+def _outputs(B, N, dev, index_lists=True):
     """prob [B,N] fp32; order / valid / invalid [B,N] int64 and nvalid / ninvalid [B] int32 as views of ONE allocation each
-    (finalize_kernel writes every entry, -1 padding included): three allocator calls instead of six on the launch-bound path."""
+    (finalize_kernel writes every entry, -1 padding included): three allocator calls instead of six on the launch-bound path.
+    index_lists=False: valid / invalid are None (NULL in the C ABI), which lets the layer skip their compaction and sort."""
     prob = torch.empty((B, N), dtype=torch.float32, device=dev)
-    lists = torch.empty((3, B, N), dtype=torch.int64, device=dev)
+    lists = torch.empty((3 if index_lists else 1, B, N), dtype=torch.int64, device=dev)
     counts = torch.empty((2, B), dtype=torch.int32, device=dev)
-    return prob, lists[0], lists[1], lists[2], counts[0], counts[1]
+    return prob, lists[0], (lists[1] if index_lists else None), (lists[2] if index_lists else None), counts[0], counts[1]
 
 
 def _matrix_layout(iou):
@@ -67,7 +68,7 @@ class _GroomedNMSFunction(torch.autograd.Function):
         dev = scores.device
         scores_c = scores.contiguous()
         iou_c, ld = _matrix_layout(iou)
-        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev)
+        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev, getattr(params, "index_lists", True))
         nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
@@ -78,7 +79,7 @@ class _GroomedNMSFunction(torch.autograd.Function):
         ctx.ld = ld
         ctx.set_materialize_grads(False)      # no zero-filled "gradients" for the five index outputs
         ctx.save_for_backward(scores_c, iou_c, counts, ws)
-        ctx.mark_non_differentiable(order, valid, invalid, nvalid, ninvalid)
+        ctx.mark_non_differentiable(*[x for x in (order, valid, invalid, nvalid, ninvalid) if x is not None])
         return prob, order, valid, invalid, nvalid, ninvalid
 
     @staticmethod
@@ -118,7 +119,7 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         entry, what = (lib.gnms_forward_with_iou3d, "gnms_forward_with_iou3d") if three_d else (lib.gnms_forward_with_iou2d,
                                                                                                 "gnms_forward_with_iou2d")
         iou = iou_out if iou_out is not None else torch.empty((B, N, N), dtype=torch.float32, device=dev)
-        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev)
+        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev, getattr(params, "index_lists", True))
         nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
@@ -128,7 +129,7 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(scores_c, counts, ws)
         ctx.iou = iou            # an OUTPUT without grad_fn (non-differentiable): a plain attribute avoids the saved-output bookkeeping
-        ctx.mark_non_differentiable(order, valid, invalid, nvalid, ninvalid, iou)
+        ctx.mark_non_differentiable(*[x for x in (order, valid, invalid, nvalid, ninvalid, iou) if x is not None])
         return prob, order, valid, invalid, nvalid, ninvalid, iou
 
     @staticmethod
@@ -160,7 +161,7 @@ class _GroomedNMSFromBoxesFunction(torch.autograd.Function):
         dev = scores.device
         scores_c = scores.contiguous()
         boxes_c = boxes.contiguous()
-        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev)
+        prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev, getattr(params, "index_lists", True))
         nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
@@ -170,7 +171,7 @@ class _GroomedNMSFromBoxesFunction(torch.autograd.Function):
         ctx.params = params
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(scores_c, boxes_c, counts, ws)
-        ctx.mark_non_differentiable(order, valid, invalid, nvalid, ninvalid)
+        ctx.mark_non_differentiable(*[x for x in (order, valid, invalid, nvalid, ninvalid) if x is not None])
         return prob, order, valid, invalid, nvalid, ninvalid
 
     @staticmethod
@@ -265,12 +266,15 @@ def _sgemm(a, b):
 
 def differentiable_nms_batched(scores, iou, counts=None, nms_threshold=0.4, pruning_method="linear", temperature=0.01,
                                valid_box_prob_threshold=0.3, return_sorted_prob=False, group_boxes=True,
-                               mask_group_boxes=True, group_size=100, presorted=False):
+                               mask_group_boxes=True, group_size=100, presorted=False, index_lists=True):
     """Batched hard-sort GrooMeD-NMS: scores [B,N], iou [B,N,N] (CUDA fp32), counts [B] int32 or None.
     Returns (prob [B,N], order [B,N], valid [B,N], invalid [B,N], nvalid [B], ninvalid [B]); the lists are
-    padded -- the first nvalid[b] / ninvalid[b] entries are meaningful.  No host synchronisation."""
+    padded -- the first nvalid[b] / ninvalid[b] entries are meaningful.  No host synchronisation.
+    index_lists=False (all batched entries): valid / invalid come back as None and the layer skips their compaction and sort --
+    the training call site reads only the probabilities (lib/loss/rpn_3d.py:791 uses `[2]`)."""
     params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
                      mask_group_boxes, group_size, presorted)
+    params.index_lists = bool(index_lists)
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSFunction.apply(scores.float(), iou.float(), counts, params)
@@ -278,12 +282,13 @@ def differentiable_nms_batched(scores, iou, counts=None, nms_threshold=0.4, prun
 
 def differentiable_nms_with_iou2d_batched(scores, boxes, counts=None, iou_out=None, nms_threshold=0.4, pruning_method="linear",
                                           temperature=0.01, valid_box_prob_threshold=0.3, return_sorted_prob=False, group_boxes=True,
-                                          mask_group_boxes=True, group_size=100):
+                                          mask_group_boxes=True, group_size=100, index_lists=True):
     """scores [B,N], boxes [B,N,4] -> (prob, order, valid, invalid, nvalid, ninvalid, iou [B,N,N]): the 2D IoU matrix AND the
     layer on it in one call -- what lib/loss/rpn_3d.py:772-791 does in two steps; identical results, and the matrix is
     returned for the caller's later use.  `iou_out` lets the caller provide the matrix buffer."""
     params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
                      mask_group_boxes, group_size, False)
+    params.index_lists = bool(index_lists)
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSWithIouFunction.apply(scores.float(), boxes.float(), counts, params, iou_out)
@@ -291,12 +296,13 @@ def differentiable_nms_with_iou2d_batched(scores, boxes, counts=None, iou_out=No
 
 def differentiable_nms_with_iou3d_batched(scores, params3d, counts=None, iou_out=None, nms_threshold=0.4, pruning_method="linear",
                                           temperature=0.01, valid_box_prob_threshold=0.3, return_sorted_prob=False, group_boxes=True,
-                                          mask_group_boxes=True, group_size=100):
+                                          mask_group_boxes=True, group_size=100, index_lists=True):
     """scores [B,N], params3d [B,N,7] = (x3d, y3d, z3d, w3d, h3d, l3d, ry3d) -> (prob, order, valid, invalid, nvalid, ninvalid,
     overlap [B,N,N]): the 3D NMS overlap 0.5*(1+GIoU3D) of lib/loss/rpn_3d.py:778-784 AND the layer on it in one call; identical
     to overlaps.iou3d_batched(from_params=True, nms_overlap=True) + differentiable_nms_batched."""
     params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
                      mask_group_boxes, group_size, False)
+    params.index_lists = bool(index_lists)
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     if params3d.shape[-1] != 7:
@@ -306,12 +312,13 @@ def differentiable_nms_with_iou3d_batched(scores, params3d, counts=None, iou_out
 
 def differentiable_nms_from_boxes_batched(scores, boxes, counts=None, nms_threshold=0.4, pruning_method="linear", temperature=0.01,
                                           valid_box_prob_threshold=0.3, return_sorted_prob=False, mask_group_boxes=True,
-                                          group_size=100):
+                                          group_size=100, index_lists=True):
     """From-boxes path: scores [B,N], boxes [B,N,4] = (x1,y1,x2,y2) -> the same six outputs as differentiable_nms_batched,
     bit-identical to building the 2D IoU matrix (overlaps.iou_batched) and running the layer on it, but the N x N matrix is
     never written to or read from HBM.  Grouped modes only (the defaults of scripts/config/groumd_nms.py)."""
     params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, True,
                      mask_group_boxes, group_size, False)
+    params.index_lists = bool(index_lists)
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSFromBoxesFunction.apply(scores.float(), boxes.float(), counts, params)

@@ -992,3 +992,25 @@ def test_make_graphed_callables(G):
         p2 = layer(s2, boxes)
         (p2 * w).sum().backward()
         assert torch.equal(p1, p2) and torch.equal(s1.grad, s2.grad) and float(p1.detach().sum()) > 0
+
+
+def test_probabilities_only_mode(G):
+    """index_lists=False (valid / invalid NULL in the C ABI): same probabilities, counts and gradients, no lists."""
+    from groomed_nms_amd import synthetic, overlaps
+    for B, N in ((3, 700), (2, 4096)):
+        boxes, scores = synthetic.batch_2d(31, B, N, "clustered", per=32)
+        bt = torch.from_numpy(boxes).cuda()
+        w = torch.rand((B, N), device="cuda")
+        for fn in (lambda s, **k: G.differentiable_nms_with_iou2d_batched(s, bt, **k),
+                   lambda s, **k: G.differentiable_nms_from_boxes_batched(s, bt, **k),
+                   lambda s, **k: G.differentiable_nms_batched(s, overlaps.iou_batched(bt), **k)):
+            s1 = torch.from_numpy(scores).cuda().requires_grad_(True)
+            s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
+            full = fn(s1)
+            lean = fn(s2, index_lists=False)
+            assert lean[2] is None and lean[3] is None
+            assert torch.equal(full[0], lean[0]) and torch.equal(full[1], lean[1])
+            assert torch.equal(full[4], lean[4]) and torch.equal(full[5], lean[5])
+            (full[0] * w).sum().backward()
+            (lean[0] * w).sum().backward()
+            assert torch.equal(s1.grad, s2.grad)
