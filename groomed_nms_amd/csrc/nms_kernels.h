@@ -1402,6 +1402,16 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
                     done = true;
                 }
             }
+            if constexpr (E >= 16) {
+                if (!done && pe == 8 * T) {
+                    u64 r[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = keys[t * 8 + e];
+                    __syncthreads();
+                    block_sort<8, u64>(r, keys, pe);
+                    done = true;
+                }
+            }
             if (!done) {
                 u64 r[E];
 #pragma unroll
