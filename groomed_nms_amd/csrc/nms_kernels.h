@@ -1230,11 +1230,13 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
     }
     __syncthreads();
     GNMS_TACC(10);
-    // ---- phase 3 (owner threads again, coalesced stores): group fields and, for MASKED groups, the default
-    //      rescoring  pre_k = s_k - prune(iou[k][head]) * s_head  (I - P restricted to the head column, :95-105,:111) ----
+    // ---- phase 3 (lane-contiguous ranks k = e * blockDim + t: every load and store below is coalesced; with the thread-contiguous
+    //      ownership of phase 1 the stores of a wave were E * 4 bytes apart -- a different 64-byte line per lane at E = 16):
+    //      group fields and, for MASKED groups, the default rescoring
+    //      pre_k = s_k - prune(iou[k][head]) * s_head  (I - P restricted to the head column, :95-105,:111) ----
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int k = threadIdx.x * E + e;
+        const int k = e * (int)blockDim.x + (int)threadIdx.x;
         if (k >= N) continue;
         const unsigned inf = info[k];
         const int h = (k < n && inf != ~0u) ? (int)(inf & 0x3fffu) : -1;
@@ -1243,23 +1245,28 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
         if (h != k) I.glen[k] = 0;                                   // only heads carry an extent
         if (!P.mask_group_boxes) continue;
         float pre = 0.0f, pl = 0.0f;
-        const int q = P.presorted ? c_own[e] : k;
+        const int ck = (k < n) ? I.order[k] : 0;
+        const int q = P.presorted ? ck : k;
+        const float sk = (k < n) ? I.sscore[k] : 0.0f;
         if (h == k) {
-            pre = s_own[e];
+            pre = sk;
         } else if (h >= 0) {
-            float v = v_lead[e], sh = s_lead[e];
+            const int lr = I.rem[k];
+            float v, sh;
             int ch;
-            if (h != lr_own[e]) {                                    // the leader itself is not a member (NaN / <= thr diagonal)
+            if (h != lr) {                                           // the leader itself is not a member (NaN / <= thr diagonal)
                 ch = I.order[h];
-                v = overlap_at<BOXES>(m, ld, c_own[e], ch);
+                v = overlap_at<BOXES>(m, ld, ck, ch);
                 sh = I.sscore[h];
             } else {
                 ch = -1;
+                v = I.plead[k];                                      // overlap with the leader, left there by attribute_kernel
+                sh = I.sscore[lr];
             }
             bool tril = true;                                        // torch.tril in NMS order (:72): always true for hard sort
-            if (P.presorted) { if (ch < 0) ch = I.order[h]; tril = ch < c_own[e]; }
+            if (P.presorted) { if (ch < 0) ch = I.order[h]; tril = ch < ck; }
             if (tril) pl = gnms_prune(v, thr, P.temperature, P.pruning_method);
-            pre = s_own[e] - pl * sh;
+            pre = sk - pl * sh;
         }
         I.plead[k] = pl;
         I.pre[(k < n) ? q : k] = pre;
