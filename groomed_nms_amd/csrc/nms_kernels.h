@@ -1122,41 +1122,21 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
     const float thr = P.nms_threshold;
-    // ---- phase 1: membership key of every rank (thread t owns ranks t*E .. t*E+E-1 throughout) ----
+    // ---- phase 1: membership key of every rank, lane-contiguous ranks (k = e * blockDim + t: coalesced loads), straight into LDS ----
     GNMS_T0();
-    unsigned r[E];
-    float v_lead[E], s_lead[E], s_own[E];
-    int c_own[E], lr_own[E], g_own[E];
+    // key = (ordinal of the leader << 14) | rank: the ordinal (attribute_kernel left it in gpos, with the overlap against that
+    // leader in plead) needs only log2(#leaders) bits, i.e. ONE 7-bit radix pass for up to 127 groups
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int k = threadIdx.x * E + e;
-        lr_own[e] = (k < n) ? I.rem[k] : 0;
-        g_own[e] = (k < n) ? I.gpos[k] : 0;
-        c_own[e] = (k < n) ? I.order[k] : 0;
-        s_own[e] = (k < n) ? I.sscore[k] : 0.0f;
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int k = threadIdx.x * E + e;
-        v_lead[e] = 0.0f; s_lead[e] = 0.0f;
-        if (k < n) {
-            v_lead[e] = I.plead[k];                     // iou of the box against the leader that removed it (attribute_kernel)
-            s_lead[e] = I.sscore[lr_own[e]];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int k = threadIdx.x * E + e;
-        // key = (ordinal of the leader << 14) | rank: the ordinal (attribute_kernel left it in gpos) needs only log2(#leaders)
-        // bits, i.e. ONE 7-bit radix pass for up to 127 groups
-        r[e] = (k < n && v_lead[e] > thr) ? (((unsigned)g_own[e] << 14) | (unsigned)k) : ~0u;   // strict > (:249)
+        const int k = e * (int)blockDim.x + (int)threadIdx.x;
+        unsigned key = ~0u;
+        if (k < n && I.plead[k] > thr) key = ((unsigned)I.gpos[k] << 14) | (unsigned)k;     // strict > (:249)
+        keys[k] = key;
         info[k] = ~0u;
     }
     GNMS_TACC(8);
     // group by leader: the keys start in rank order, so a STABLE sort on the leader bits alone yields (leader, rank) order
     __shared__ unsigned radix_hist[128 * 16 + 16];
-#pragma unroll
-    for (int e = 0; e < E; ++e) keys[threadIdx.x * E + e] = r[e];
     __syncthreads();
     {
         const int G = I.misc[0];                                           // number of leaders; the all-ones digit is reserved for the padding keys
@@ -1199,11 +1179,8 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
             bool big_head = false;
             int hk = 0;
             if (i < n) {
-                if (ky[e] == ~0u) {
-                    I.gsorted[i] = -1;
-                } else {
+                if (ky[e] != ~0u) {
                     const int k = (int)(ky[e] & 0x3fffu);
-                    I.gsorted[i] = k;
                     const int start = st[e] >= 0 ? st[e] : before;
                     const long long pos = i - start;
                     const unsigned hd = keys[start] & 0x3fffu;
@@ -1228,6 +1205,8 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
             }
         }
     }
+    // members in (group, rank) order, written lane-contiguously straight from the sorted keys
+    for (int i = threadIdx.x; i < n; i += blockDim.x) I.gsorted[i] = (keys[i] == ~0u) ? -1 : (int)(keys[i] & 0x3fffu);
     __syncthreads();
     GNMS_TACC(10);
     // ---- phase 3 (lane-contiguous ranks k = e * blockDim + t: every load and store below is coalesced; with the thread-contiguous
