@@ -1280,6 +1280,16 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     const float vthr = P.valid_box_prob_threshold;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, T = blockDim.x;
     GNMS_T0();
+    // clamp: global loads and stores with lane-contiguous positions (coalesced), staged in LDS for the owner threads below,
+    // which need thread-contiguous positions so that the compaction keeps the order
+    float* stage = reinterpret_cast<float*>(smem);                 // [Ppow2] floats inside the key region (not yet in use)
+    for (int q = t; q < n; q += T) {
+        const float pre = I.pre[q];
+        const float r2 = pre < 0.0f ? 0.0f : (pre > 1.0f ? 1.0f : pre);          // torch.clamp keeps NaN
+        I.r2[q] = r2;
+        stage[q] = r2;
+    }
+    __syncthreads();
     // classify
     u64 key[E];
     int cls[E];                                                    // 0 nan, 1 valid, 2 invalid, 3 padding
@@ -1290,10 +1300,8 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
         cls[e] = 3;
         key[e] = ~0ull;
         if (q < n) {
-            const float pre = I.pre[q];
-            const float r2 = pre < 0.0f ? 0.0f : (pre > 1.0f ? 1.0f : pre);      // torch.clamp keeps NaN
+            const float r2 = stage[q];
             const float rr = (r2 < vthr) ? 0.0f : r2;                           // :115
-            I.r2[q] = r2;
             cls[e] = (rr != rr) ? 0 : ((rr >= vthr) ? 1 : ((rr < vthr) ? 2 : 0)); // vthr NaN: neither list (:118-123)
             key[e] = ((u64)gnms_desc_key(rr) << 32) | (unsigned)q;
             packed += (cls[e] == 0) ? 1ull : (cls[e] == 1 ? (1ull << 16) : (1ull << 32));
@@ -1303,6 +1311,7 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     // (two 32-bit DPP prefix sums: the low word carries nan | valid << 16 without overflow between the fields, the high word invalid)
     const u64 inc = (u64)gnms_add_scan32((unsigned)(packed & 0xffffffffu)) | ((u64)gnms_add_scan32((unsigned)(packed >> 32)) << 32);
     if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();                                               // every owner has read its staged values
     for (int i = t; i < Ppow2; i += T) keys[i] = ~0ull;
     __syncthreads();
     u64 base = 0, total = 0;
