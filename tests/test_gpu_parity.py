@@ -934,6 +934,36 @@ def _large_image_case(G, B, N, count_list):
     assert int(outs[0][4].sum()) > 0
 
 
+def test_batches_past_two_to_the_32_matrix_elements(G):
+    """32 images x 16384 boxes = 2^33 matrix elements (32 GiB), 2D and 3D: every offset into the matrix is 64-bit.  Images of the
+    big batch must come out exactly as when they are run alone (outputs, score gradient, matrix)."""
+    from groomed_nms_amd import synthetic
+    B, N = 32, 16384
+    for dim in (2, 3):
+        if dim == 2:
+            boxes, scores = synthetic.batch_2d(5, B, N, "clustered", per=48)
+            fn = G.differentiable_nms_with_iou2d_batched
+        else:
+            boxes, scores = synthetic.batch_3d(5, B, N, True)
+            fn = G.differentiable_nms_with_iou3d_batched
+        bt = torch.from_numpy(boxes).cuda(); st = torch.from_numpy(scores).cuda().requires_grad_(True)
+        w = torch.rand((B, N), device="cuda")
+        out = fn(st, bt)
+        (out[0] * w).sum().backward()
+        assert out[6].shape == (B, N, N)
+        for img in (B - 1, B // 2):
+            s1 = torch.from_numpy(scores[img:img + 1]).cuda().requires_grad_(True)
+            o1 = fn(s1, bt[img:img + 1])
+            (o1[0] * w[img:img + 1]).sum().backward()
+            for a, b in zip(out[:6], o1[:6]):
+                assert torch.equal(a[img:img + 1], b), (dim, img)
+            assert torch.equal(st.grad[img:img + 1], s1.grad)
+            assert torch.equal(out[6][img], o1[6][0])
+        assert int(out[4].sum()) > 0
+        del out, o1
+        torch.cuda.empty_cache()
+
+
 def test_api_edges(G):
     """What callers actually hand over: strided views, float64, a padded leading dimension, a matrix that requires grad, NumPy
     float64 in / CPU tensors out (lib/rpn_util.py:1319-1320), empty inputs, an unknown pruning method, impossible shapes."""
