@@ -49,4 +49,25 @@ __device__ __forceinline__ f2 nms_overlap3d(const Row& a, const Cols2& b) {
     return (num * rc) * (f2){0.5f, 0.5f};
 }
 
+// The same overlap for ONE pair of records with per-lane operands (the layer's O(N) single-entry lookups when it runs beside the
+// matrix write instead of after it).  Same operations in the same order as nms_overlap3d, one column wide: with -ffp-contract=off
+// every product, sum and the v_rcp_f32 round exactly as there, and v_min/v_max do not depend on which operand sits in an SGPR, so
+// the result equals the matrix entry bit for bit (tests/test_gpu_parity.py compares the two paths).
+__device__ __forceinline__ float nms_overlap3d_pair(const float* __restrict__ ra, const float* __restrict__ rb) {
+    const float4 au = reinterpret_cast<const float4*>(ra)[0], av = reinterpret_cast<const float4*>(ra)[1], ae = reinterpret_cast<const float4*>(ra)[2];
+    const float4 bu = reinterpret_cast<const float4*>(rb)[0], bv = reinterpret_cast<const float4*>(rb)[1], be = reinterpret_cast<const float4*>(rb)[2];
+    const float dx = fminf(av.x, bv.x) - fmaxf(au.w, bu.w);
+    const float dy = fminf(au.z, bu.z) - fmaxf(au.y, bu.y);
+    const float dz = fminf(av.z, bv.z) - fmaxf(av.y, bv.y);
+    const float i3 = (fmaxf(dx, 0.0f) * fmaxf(dz, 0.0f)) * fmaxf(dy, 0.0f);
+    const float u3 = (au.x + bu.x) - i3;
+    const float hx = (ae.x + be.x) - dx;
+    const float hy = (ae.y + be.y) - dy;
+    const float hz = (ae.z + be.z) - dz;
+    const float vh = (hx * hy) * hz;
+    const float num = __builtin_fmaf(u3, u3, i3 * vh);
+    const float den = u3 * vh;
+    return (num * __builtin_amdgcn_rcpf(den)) * 0.5f;
+}
+
 }  // namespace gnms_iou3d

@@ -277,15 +277,28 @@ __device__ __forceinline__ float pair_iou(const float4 a, const float4 b) {
     return inter / ((area_a + area_b) - inter);
 }
 
-// overlap accessor of the kernels that need single matrix entries: element [ca][cb] (input indices) either from the
-// N x N matrix or recomputed from the boxes
-template <bool BOXES>
+// Where the kernels that need single overlap entries take them from.  The template parameter is an int so that the existing
+// <false> / <true> instantiations keep meaning "matrix" / "2D boxes".
+constexpr int kFromMatrix = 0;     // src = the N x N matrix of the image, leading dimension ld
+constexpr int kFromBoxes = 1;      // src = the image's boxes [N][4]: lib/core.py iou recomputed (pair_iou, the arithmetic of iou2d_tile)
+constexpr int kFromRecords = 2;    // src = the image's corner-AABB records [N][12]: 0.5 * (1 + GIoU3D) recomputed (iou3d_pair.h)
+
+// element [ca][cb] (input indices)
+template <int SRC>
 __device__ __forceinline__ float overlap_at(const float* __restrict__ src, long ld, int ca, int cb) {
-    if (BOXES) {
+    if (SRC == kFromBoxes) {
         const float4* bx = reinterpret_cast<const float4*>(src);
         return pair_iou(bx[ca], bx[cb]);
     }
+    if (SRC == kFromRecords) return gnms_iou3d::nms_overlap3d_pair(src + (size_t)ca * gnms_iou3d::kRec, src + (size_t)cb * gnms_iou3d::kRec);
     return src[(size_t)ca * ld + cb];
+}
+
+// the image's slice of what the caller passed as `src` (records live in the workspace, not in a caller array)
+template <int SRC>
+__device__ __forceinline__ const float* overlap_src(const float* __restrict__ src, const ImgPtrs& I, int b, int N, long ld) {
+    if (SRC == kFromRecords) return I.rec;
+    return src + (SRC == kFromBoxes ? (size_t)b * N * 4 : (size_t)b * N * ld);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1050,8 +1063,8 @@ __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
 
 // one wave: rank block kb of image b.  Besides the attribution it evaluates, in parallel over all rank blocks, the overlap of
 // every rank with the leader that removed it (plead[k], groups_kernel's membership test) -- as a prologue of groups_kernel these
-// N dependent gathers ran on ONE CU (50 us of its 180 at N=16384).  `src` = the matrix (BOXES false) or the boxes.
-template <bool BOXES>
+// N dependent gathers ran on ONE CU (50 us of its 180 at N=16384).  `src`: see kFromMatrix / kFromBoxes / kFromRecords.
+template <int SRC>
 __device__ __forceinline__ void attribute_body(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, char* ws,
                                                gnms_ws_layout L, const int b, const int kb, const int lane) {
     __shared__ int att_lead[16][64];                   // per wave: ordinal of the leader that claimed rank k0 + i
@@ -1092,15 +1105,15 @@ __device__ __forceinline__ void attribute_body(const float* __restrict__ src, lo
         const int k = k0 + lane;
         const int g = my_lead[lane];                  // every rank is claimed: by an earlier leader, or by itself
         I.gpos[k] = g;                                // ordinal of the leader (groups_kernel's sort key; it overwrites gpos afterwards)
-        const float* m = src + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);
-        I.plead[k] = overlap_at<BOXES>(m, ld, I.order[k], I.leadc[g]);    // likewise overwritten by groups_kernel's own plead
+        const float* m = overlap_src<SRC>(src, I, b, N, ld);
+        I.plead[k] = overlap_at<SRC>(m, ld, I.order[k], I.leadc[g]);    // likewise overwritten by groups_kernel's own plead
     }
 }
 
-template <bool BOXES>
+template <int SRC>
 __global__ __launch_bounds__(64) void attribute_kernel(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, char* ws,
                                                        gnms_ws_layout L) {
-    attribute_body<BOXES>(src, ld, N, counts, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
+    attribute_body<SRC>(src, ld, N, counts, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1111,7 +1124,7 @@ __global__ __launch_bounds__(64) void attribute_kernel(const float* __restrict__
 // Arrays head/gpos/gstart/glen/gsorted/plead are indexed by rank; pre is indexed by NMS position q
 // (q = rank for hard sort, q = input index when presorted).
 // ------------------------------------------------------------------------------------------------
-template <int E, bool BOXES>
+template <int E, int SRC>
 __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                             gnms_params P, char* ws, gnms_ws_layout L, int Ppow2, const int b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1119,7 +1132,7 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
     unsigned* info = keys + Ppow2;                               // per rank: head | pos << 14, or ~0 (in no group)
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
-    const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
+    const float* m = overlap_src<SRC>(iou, I, b, N, ld);                      // kFromBoxes: `iou` holds the boxes [B][N][4]
     const float thr = P.nms_threshold;
     // ---- phase 1: membership key of every rank, lane-contiguous ranks (k = e * blockDim + t: coalesced loads), straight into LDS ----
     GNMS_T0();
@@ -1234,7 +1247,7 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
             int ch;
             if (h != lr) {                                           // the leader itself is not a member (NaN / <= thr diagonal)
                 ch = I.order[h];
-                v = overlap_at<BOXES>(m, ld, ck, ch);
+                v = overlap_at<SRC>(m, ld, ck, ch);
                 sh = I.sscore[h];
             } else {
                 ch = -1;
@@ -1252,10 +1265,10 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
     GNMS_TACC(11);
 }
 
-template <int E, bool BOXES>
+template <int E, int SRC>
 __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                                       gnms_params P, char* ws, gnms_ws_layout L, int Ppow2) {
-    groups_body<E, BOXES>(iou, N, ld, counts, P, ws, L, Ppow2, (int)blockIdx.x);
+    groups_body<E, SRC>(iou, N, ld, counts, P, ws, L, Ppow2, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1456,7 +1469,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __rest
 // here 16 waves striding the blocks), so nothing is lost in parallelism; three kernel boundaries (launch, drain, refill) go.
 // Ppow2 >= 1024 (smaller images pad their keys).  dynamic LDS = max(leaders table, Ppow2 * 8).
 // ------------------------------------------------------------------------------------------------
-template <int E, bool BOXES>
+template <int E, int SRC>
 __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
                                                     char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob,
                                                     long long* __restrict__ valid, long long* __restrict__ invalid, int* __restrict__ nvalid,
@@ -1464,9 +1477,9 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     const int b = blockIdx.x;
     leaders_body(N, counts, ws, L, b);
     __syncthreads();
-    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<BOXES>(src, ld, N, counts, ws, L, b, kb, threadIdx.x & 63);
+    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<SRC>(src, ld, N, counts, ws, L, b, kb, threadIdx.x & 63);
     __syncthreads();
-    groups_body<E, BOXES>(src, N, ld, counts, P, ws, L, Ppow2, b);
+    groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
     __syncthreads();
     finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
 }

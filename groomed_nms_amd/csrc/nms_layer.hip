@@ -247,8 +247,8 @@ bool use_tail_kernel(int N) {
     return forced >= 0 ? forced == 1 : N <= 2048;
 }
 
-// K3..K6 in one launch (masked groups); src = the matrix (BOXES false) or the boxes (BOXES true)
-template <bool BOXES>
+// K3..K6 in one launch (masked groups); SRC/src: kFromMatrix (the matrix), kFromBoxes (the boxes), kFromRecords (src unused)
+template <int BOXES>
 int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* counts, const gnms_params& P, char* ws, const gnms_ws_layout& L,
                 float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, hipStream_t st) {
     int P2 = next_pow2(N);
@@ -338,9 +338,65 @@ extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N,
 }
 
 namespace {
+// Large images (N > 4096): the matrix write takes milliseconds and nothing in the grouped from-boxes layer reads it, so the
+// write goes to a library-owned second stream and the layer's own kernels run beside it on the caller's stream.  A fork and a
+// join through events cost 25-50 us of idle queue each on this hardware, which is why smaller problems stay on one stream
+// (measured: N=4096 loses 0.03 ms/step).  GNMS_TWO_STREAMS=0/1 forces the choice.
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+std::mutex g_side_mu;
+bool use_side_stream(int N) {
+    static const int forced = [] { const char* e = getenv("GNMS_TWO_STREAMS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return forced >= 0 ? forced == 1 : N > 4096;
+}
+// the caller holds g_side_mu
+int side_stream(SideStream** out) {
+    static std::map<int, SideStream> per_dev;
+    int dev = 0;
+    GNMS_CHECK_HIP(hipGetDevice(&dev));
+    SideStream& S = per_dev[dev];
+    if (!S.s) {
+        hipStream_t s = nullptr;
+        // lowest priority: the write's workgroups fill every CU, and the layer's kernels on the caller's stream (some of them one
+        // 128-KiB-LDS workgroup per image) must get the CU slots that free up, not wait for the write to drain
+        int least = 0, greatest = 0;
+        GNMS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        GNMS_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+        GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+        GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
+        S.s = s;
+    }
+    *out = &S;
+    return GNMS_OK;
+}
+// everything enqueued on `st` so far happens before what is enqueued on the side stream from now on
+int side_fork(hipStream_t st, hipStream_t* side) {
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    SideStream* S = nullptr;
+    int rc = side_stream(&S);
+    if (rc) return rc;
+    GNMS_CHECK_HIP(hipEventRecord(S->fork, st));
+    GNMS_CHECK_HIP(hipStreamWaitEvent(S->s, S->fork, 0));
+    *side = S->s;
+    return GNMS_OK;
+}
+// the matrix write that gnms_forward_with_iou2d hands to the from-boxes layer for the side stream
+struct MatrixWrite { float* out; int64_t ld; };
+// everything enqueued on the side stream so far happens before what is enqueued on `st` from now on
+int side_join(hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_side_mu);
+    SideStream* S = nullptr;
+    int rc = side_stream(&S);
+    if (rc) return rc;
+    GNMS_CHECK_HIP(hipEventRecord(S->join, S->s));
+    GNMS_CHECK_HIP(hipStreamWaitEvent(st, S->join, 0));
+    return GNMS_OK;
+}
+}  // namespace
+
+namespace {
 int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, const int32_t* counts, const gnms_params* params,
                        float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid,
-                       void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted);
+                       void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted, const MatrixWrite* mw = nullptr);
 }
 
 // The matrix is an OUTPUT here, so the layer does not have to read it back: with the boxes at hand the grouped modes
@@ -360,6 +416,11 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) &&
                       (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::tile_rows_for(B, N, N)) >= 2 * B;
     if (!fuse) {
+        if (B > 0 && N > 0 && from_boxes && params->mask_group_boxes && use_side_stream(N)) {
+            const MatrixWrite mw = {iou_out, ld};
+            return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
+                                      workspace_bytes, stream, false, &mw);
+        }
         if (B > 0 && N > 0 && (rc = gnms_iou2d(boxes, boxes, B, N, N, iou_out, ld, stream))) return rc;
         if (from_boxes)
             return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
@@ -415,6 +476,65 @@ __global__ __launch_bounds__(256) void scatter_records_kernel(const float* __res
     else if (i % 3 == 1) xkeys[(size_t)b * N + i / 3].z = v.x;
     else { xkeys[(size_t)b * N + i / 3].y = v.x; xkeys[(size_t)b * N + i / 3].w = 0.0f; }
 }
+
+// everything of gnms_forward_with_iou3d that uses the temporary `rec` ([B][N] records, then [B][N] pseudo boxes for the x sort).
+// Masked hard-sorted groups: the whole layer runs from the records (threshold bits AND the O(N) single overlaps, same arithmetic
+// as the matrix kernel), so nothing waits for the matrix; large images write it on the side stream beside the one-launch tail.
+int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
+                          const gnms_params& P, float* iou_out, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
+                          int32_t* nvalid, int32_t* ninvalid, char* ws, const gnms_ws_layout& L, hipStream_t st) {
+    int rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st);
+    if (rc) return rc;
+    const bool from_rec = P.group_boxes && P.mask_group_boxes && !P.presorted;
+    if (!from_rec) return gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st);
+    const bool beside = use_side_stream(N);
+    if (!beside && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st))) return rc;
+    float4* xkeys = reinterpret_cast<float4*>(rec + (size_t)B * N * gnms_iou3d::kRec);
+    scatter_records_kernel<<<dim3(gnms_div_up(N * 3, 256), B), 256, 0, st>>>(rec, N, ws, L, xkeys);
+    GNMS_CHECK_LAUNCH();
+    const int P2 = next_pow2(N);
+    if ((rc = launch_sorts(scores, reinterpret_cast<const float*>(xkeys), B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
+    if (!(P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY)) {
+        // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
+        bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+    } else {
+        const long long tiles = (long long)B * L.NB * ((N + 255) / 256);
+        if (tiles >= 32768)
+            bitmask_rec3d_culled_kernel<4><<<dim3(gnms_div_up(((L.NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+        else
+            bitmask_rec3d_culled_kernel<1><<<dim3(gnms_div_up(L.NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+    }
+    GNMS_CHECK_LAUNCH();
+    if (beside) {                                                 // see forward_boxes_impl for why the fork sits exactly here
+        hipStream_t side = nullptr;
+        if ((rc = side_fork(st, &side))) return rc;
+        rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
+        const int wrc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side);
+        const int jrc = side_join(st);
+        return rc ? rc : (wrc ? wrc : jrc);
+    }
+    if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
+    const size_t llds = leaders_lds_bytes(N);
+    if ((rc = allow_lds(leaders_kernel, llds))) return rc;
+    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
+    GNMS_CHECK_LAUNCH();
+    attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, ws, L);
+    GNMS_CHECK_LAUNCH();
+    const size_t sort_lds = (size_t)P2 * 8;
+    const int sort_threads = P2 <= 1024 ? P2 : 1024;
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(groups_kernel<E, kFromRecords>, sort_lds))) return rc;
+        groups_kernel<E, kFromRecords><<<B, sort_threads, sort_lds, st>>>(nullptr, N, (long)ld, counts, P, ws, L, P2);
+    });
+    GNMS_CHECK_LAUNCH();
+    GNMS_DISPATCH_SORT(P2, {
+        if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
+        finalize_kernel<E><<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
+                                                               ninvalid);
+    });
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
 }  // namespace
 
 // The 3D analogue of gnms_forward_with_iou2d: cuboid parameters -> the NMS overlap matrix 0.5*(1+GIoU3D) (an output, written by
@@ -439,54 +559,13 @@ extern "C" int gnms_forward_with_iou3d(const float* params3d, const float* score
     // into the per-image workspace regions
     float* rec = nullptr;
     GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * (gnms_iou3d::kRec + 4) * sizeof(float), st));
-    float4* xkeys = reinterpret_cast<float4*>(rec + (size_t)B * N * gnms_iou3d::kRec);      // [B][N] pseudo boxes for the x sort
-    rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st);
-    if (!rc) rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st);
-    const bool from_rec = P.group_boxes && P.mask_group_boxes && !P.presorted;
-    if (!rc && from_rec) {
-        scatter_records_kernel<<<dim3(gnms_div_up(N * 3, 256), B), 256, 0, st>>>(rec, N, ws, L, xkeys);
-        hipError_t le = hipGetLastError();
-        if (le != hipSuccess) { gnms_set_error("kernel launch failed: %s", hipGetErrorString(le)); rc = GNMS_ERR_HIP; }
-    }
-    const int P2 = next_pow2(N);
-    if (!rc && from_rec) rc = launch_sorts(scores, reinterpret_cast<const float*>(xkeys), B, N, counts, ws, L, P2, order, st);   // + cuboids by x
-    hipError_t fe = hipFreeAsync(rec, st);
+    rc = forward_with_iou3d_on(rec, params3d, scores, B, N, ld, counts, P, iou_out, prob, order, valid, invalid, nvalid, ninvalid, ws, L, st);
+    const hipError_t fe = hipFreeAsync(rec, st);                  // after the side stream, if any, has joined `st`
     if (rc) return rc;
     if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }
-    if (!from_rec)
+    if (!(P.group_boxes && P.mask_group_boxes && !P.presorted))
         return forward_impl("gnms_forward_with_iou3d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid, ninvalid,
                             workspace, workspace_bytes, stream, false);
-    if (!(P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY)) {
-        // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
-        bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
-    } else {
-        const long long tiles = (long long)B * L.NB * ((N + 255) / 256);
-        if (tiles >= 32768)
-            bitmask_rec3d_culled_kernel<4><<<dim3(gnms_div_up(((L.NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
-        else
-            bitmask_rec3d_culled_kernel<1><<<dim3(gnms_div_up(L.NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
-    }
-    GNMS_CHECK_LAUNCH();
-    if (use_tail_kernel(N)) return launch_tail<false>(iou_out, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
-    const size_t llds = leaders_lds_bytes(N);
-    if ((rc = allow_lds(leaders_kernel, llds))) return rc;
-    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
-    GNMS_CHECK_LAUNCH();
-    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou_out, (long)ld, N, counts, ws, L);
-    GNMS_CHECK_LAUNCH();
-    const size_t sort_lds = (size_t)P2 * 8;
-    const int sort_threads = P2 <= 1024 ? P2 : 1024;
-    GNMS_DISPATCH_SORT(P2, {
-        if ((rc = allow_lds(groups_kernel<E, false>, sort_lds))) return rc;
-        groups_kernel<E, false><<<B, sort_threads, sort_lds, st>>>(iou_out, N, (long)ld, counts, P, ws, L, P2);
-    });
-    GNMS_CHECK_LAUNCH();
-    GNMS_DISPATCH_SORT(P2, {
-        if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
-        finalize_kernel<E><<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
-                                                               ninvalid);
-    });
-    GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
 
@@ -548,7 +627,7 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
 namespace {
 int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, const int32_t* counts, const gnms_params* params,
                        float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid,
-                       void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted) {
+                       void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted, const MatrixWrite* mw) {
     int rc = check_common("gnms_forward_from_boxes", B, N, N, params, workspace, workspace_bytes);
     if (rc) return rc;
     if (!params->group_boxes || params->presorted) {
@@ -572,6 +651,19 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
     if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
     if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
+    if (mw) {
+        // Large images: the rest of the layer is one workgroup per image (K3..K6 in one launch) and the matrix write runs beside
+        // it on the side stream.  The write is forked HERE and not earlier because its workgroups take every free wave slot: a
+        // 16-wave, 128-KiB-LDS workgroup that becomes ready while the write runs is not placed before the write drains (measured:
+        // sort_merge_kernel waited 1.85 ms).  Forked here, the tail's B workgroups are resident before the side stream has seen
+        // the event (same-queue successor ~2 us, cross-queue event ~25 us), and then keep their CUs until the layer is done.
+        hipStream_t side = nullptr;
+        if ((rc = side_fork(st, &side))) return rc;
+        rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
+        int wrc = gnms_iou2d(boxes, boxes, B, N, N, mw->out, mw->ld, side);
+        const int jrc = side_join(st);                          // also after a failure: the caller's stream must cover the write
+        return rc ? rc : (wrc ? wrc : jrc);
+    }
     if (P.mask_group_boxes && use_tail_kernel(N))
         return launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
     const size_t llds = leaders_lds_bytes(N);
