@@ -127,6 +127,9 @@ def main():
             if args.dim == 2 and not args.two_calls:
                 check(lib.gnms_forward_with_iou2d(ptr(boxes), ptr(s_det), B, N, N, None, ctypes.byref(Pg), ptr(iou_buf), ptr(prob_g), None, None,
                                                   None, None, None, ptr(ws_g), ws_g.numel(), sp), "fwd_with_iou2d")
+            elif not args.two_calls:
+                check(lib.gnms_forward_with_iou3d(ptr(boxes), ptr(s_det), B, N, N, None, ctypes.byref(Pg), ptr(iou_buf), ptr(prob_g), None, None,
+                                                  None, None, None, ptr(ws_g), ws_g.numel(), sp), "fwd_with_iou3d")
             else:
                 if args.dim == 2:
                     check(lib.gnms_iou2d(ptr(boxes), ptr(boxes), B, N, N, ptr(iou_buf), N, sp), "iou2d")

@@ -15,6 +15,11 @@
  *     null stream); no hidden synchronisation and no hidden allocation, except `_nms`, which keeps
  *     the reference's blocking host-pointer contract, and the 3D entries (gnms_iou3d_*, gnms_forward_with_iou3d),
  *     which take a stream-ordered temporary (hipMallocAsync/hipFreeAsync) of 48-64 bytes per box for the cuboid records;
+ *   - gnms_forward_with_iou2d / _iou3d on images of more than 4096 boxes issue the matrix write on a library-owned stream
+ *     (one per device, lowest priority) that forks from `stream` and joins it again before the call returns control of the
+ *     ordering to the caller: to the caller everything is still ordered on `stream` (earlier work happens before, later work
+ *     after), also under stream capture (the fork/join is captured as a branch of the graph).  GNMS_TWO_STREAMS=0 in the
+ *     environment keeps every launch on `stream`;
  *   - a batch is B images of up to N boxes; image b uses the first counts[b] boxes (counts may be
  *     NULL: every image has N).  Scores are [B][N]; overlap matrices are [B][N][ld] row-major with
  *     row stride ld >= N elements (image stride N*ld);
@@ -120,7 +125,9 @@ int gnms_forward(const float* scores, const float* iou, int B, int N, int64_t ld
  * overlaps, so for N <= 4096 it rides in the last grid slice of the IoU launch (one workgroup per image: no launch of its
  * own, no kernel boundary); larger N run the two calls in sequence.  With the boxes at hand the grouped hard-sort modes
  * take their threshold bits and group overlaps from the boxes (the from-boxes kernels below, bit-identical) instead of
- * reading back the matrix they just wrote; ungrouped / presorted modes read it.  gnms_backward pairs with it unchanged. */
+ * reading back the matrix they just wrote; ungrouped / presorted modes read it.  N > 4096 (masked groups): nothing in the
+ * layer reads the matrix, so its write runs beside the layer on the library's side stream (see Conventions).
+ * gnms_backward pairs with it unchanged. */
 int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
                             const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
                             int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
@@ -128,8 +135,9 @@ int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int 
 
 /* The same for the 3D overlap of lib/loss/rpn_3d.py:778-784 (overlap_in_nms == "3d"): params3d [B][N][7] = x y z w h l ry ->
  * iou_out [B][N][ld] = 0.5 * (1 + GIoU3D) (as gnms_iou3d_from_params, method 2) -> the outputs of gnms_forward.  Grouped + masked
- * hard-sort modes threshold the pairs from the cuboid records with the instruction sequence that wrote the matrix (no read-back
- * of the 4 N^2 bytes); the other modes read the matrix.  gnms_backward pairs with it unchanged. */
+ * hard-sort modes take the threshold bits and the single group overlaps from the cuboid records with the arithmetic that wrote
+ * the matrix (no read-back of the 4 N^2 bytes; N > 4096: matrix write on the side stream); the other modes read the matrix.
+ * gnms_backward pairs with it unchanged. */
 int gnms_forward_with_iou3d(const float* params3d, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
                             const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
                             int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
