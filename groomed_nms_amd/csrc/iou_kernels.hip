@@ -24,10 +24,12 @@ using namespace gnms_iou;
 // ------------------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou2d_kernel(const float* __restrict__ A, const float* __restrict__ Bx,
-                                                                 int M, int N, float* __restrict__ out, long ld, int tile_rows) {
+                                                                 int M, int N, float* __restrict__ out, long ld, int tile_rows, int row0,
+                                                                 int row_end) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    iou2d_tile<VEC>(A, Bx, M, N, out, ld, blockIdx.z, blockIdx.y * tile_rows, blockIdx.x * kWGCols + wave * kWaveCols, lane, tile_rows);
+    iou2d_tile<VEC>(A, Bx, M, N, out, ld, blockIdx.z, row0 + blockIdx.y * tile_rows, blockIdx.x * kWGCols + wave * kWaveCols, lane, tile_rows,
+                    row_end);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -193,13 +195,15 @@ using gnms_iou3d::f2;
 
 template <bool VEC>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M,
-                                                                          int N, float* __restrict__ out, long ld, int tile_rows) {
+                                                                          int N, float* __restrict__ out, long ld, int tile_rows, int row0,
+                                                                          int row_end) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int img = blockIdx.z;
-    const int i0 = blockIdx.y * tile_rows;
+    const int i0 = row0 + blockIdx.y * tile_rows;                 // a launch may cover the rows [row0, row_end) only
     const int c0 = blockIdx.x * kWGCols + wave * kWaveCols;
-    if (c0 >= N) return;
+    if (row_end > M) row_end = M;
+    if (c0 >= N || i0 >= row_end) return;
     const float* ra = RA + (size_t)img * M * kRec;
     const float* rb = RB + (size_t)img * N * kRec;
     float* o3 = out + (size_t)img * M * ld;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const 
         const float4* p = reinterpret_cast<const float4*>(rb + (size_t)cc * kRec);
         gnms_iou3d::cols2_set(cols[j >> 1], j & 1, p[0], p[1], p[2]);
     }
-    const int nrows = min(tile_rows, M - i0);
+    const int nrows = min(tile_rows, row_end - i0);
     for (int r = 0; r < nrows; ++r) {
         // the row record is wave-uniform and read-only: scalar loads (s_load_dwordx4 x 3), no VALU, no LDS.  (Broadcasting it
         // from a lane with 10 v_readlane per row measured 111 instead of 99 us at B=8, N=4096.)
@@ -245,13 +249,15 @@ void launch_iou3d(const float* ra, const float* rb, int B, int M, int N, float* 
 }
 
 int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, int method, float* bev, float* o3, int64_t ld,
-                       hipStream_t st, bool fast_nms_overlap) {
+                       hipStream_t st, bool fast_nms_overlap, int row0 = 0, int row_end = 0x7fffffff) {
     const bool vec = (ld % 4 == 0) && ((uintptr_t)o3 % 16 == 0) && (!bev || (uintptr_t)bev % 16 == 0);
     if (method == 2 && !bev && fast_nms_overlap) {
         const int tr = tile_rows_for(B, M, N);
-        dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);
-        if (vec) iou3d_nms_fast_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr);
-        else iou3d_nms_fast_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr);
+        if (row_end > M) row_end = M;
+        if (row0 >= row_end) return GNMS_OK;
+        dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(row_end - row0, tr), B);
+        if (vec) iou3d_nms_fast_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr, row0, row_end);
+        else iou3d_nms_fast_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr, row0, row_end);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
@@ -277,8 +283,20 @@ int gnms_internal_records_from_params(const float* params, long count, float* re
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
-int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st) {
-    return iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true);
+int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, int row0, int row_end) {
+    return iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true, row0, row_end);
+}
+// rows [row0, row_end) of every image's square 2D IoU matrix (arguments already checked by the caller)
+int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st, int row0, int row_end) {
+    const int tr = tile_rows_for(B, N, N);
+    if (row_end > N) row_end = N;
+    if (row0 >= row_end) return GNMS_OK;
+    dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(row_end - row0, tr), B);
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes, boxes, N, N, out, (long)ld, tr, row0, row_end);
+    else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes, boxes, N, N, out, (long)ld, tr, row0, row_end);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
 }
 
 extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int M, int N, float* out, int64_t ld,
@@ -292,8 +310,8 @@ extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int
     const int tr = tile_rows_for(B, M, N);
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
-    if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr);
-    else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr);
+    if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr, 0, M);
+    else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr, 0, M);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

@@ -42,8 +42,9 @@ __device__ __forceinline__ void store_nt_f4(float* p, float a, float b, float c,
 template <bool VEC>
 __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const float* __restrict__ Bx, int M, int N,
                                            float* __restrict__ out, long ld, int img, int i0, int c0, int lane,
-                                           int tile_rows = kTileRows) {
-    if (c0 >= N || i0 >= M) return;
+                                           int tile_rows = kTileRows, int row_end = 0x7fffffff) {
+    if (row_end > M) row_end = M;                                 // a launch may cover the rows [row0, row_end) only
+    if (c0 >= N || i0 >= row_end) return;
     const float* a = A + (size_t)img * M * 4;
     const float* b = Bx + (size_t)img * N * 4;
     float* o = out + (size_t)img * M * ld;
@@ -59,7 +60,7 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
         bx1[j] = v.x; by1[j] = v.y; bx2[j] = v.z; by2[j] = v.w;
         barea[j] = (v.z - v.x) * (v.w - v.y);                        // lib/core.py:502-503
     }
-    const int rows = min(tile_rows, M - i0);                      // tile_rows <= 64: lane r holds row i0 + r
+    const int rows = min(tile_rows, row_end - i0);                // tile_rows <= 64: lane r holds row i0 + r
 
     // row boxes: lane r holds row i0+r; the row loop broadcasts it with v_readlane.  (Scalar loads of the row box --
     // s_load_dwordx4, also issued a row ahead -- measured 6 % slower: 100.7 vs 94.8 us at B=8, N=4096.)

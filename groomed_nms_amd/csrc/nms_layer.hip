@@ -10,6 +10,9 @@
 #include "iou_tile.h"
 #include "nms_solve_kernels.h"
 
+// defined in iou_kernels.hip
+int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st, int row0, int row_end);
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
@@ -342,7 +345,7 @@ namespace {
 // write goes to a library-owned second stream and the layer's own kernels run beside it on the caller's stream.  A fork and a
 // join through events cost 25-50 us of idle queue each on this hardware, which is why smaller problems stay on one stream
 // (measured: N=4096 loses 0.03 ms/step).  GNMS_TWO_STREAMS=0/1 forces the choice.
-struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork[2] = {nullptr, nullptr}, join = nullptr; };
 std::mutex g_side_mu;
 bool use_side_stream(int N) {
     static const int forced = [] { const char* e = getenv("GNMS_TWO_STREAMS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
@@ -361,26 +364,37 @@ int side_stream(SideStream** out) {
         int least = 0, greatest = 0;
         GNMS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         GNMS_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
-        GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+        GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.fork[0], hipEventDisableTiming));
+        GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.fork[1], hipEventDisableTiming));
         GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
         S.s = s;
     }
     *out = &S;
     return GNMS_OK;
 }
-// everything enqueued on `st` so far happens before what is enqueued on the side stream from now on
-int side_fork(hipStream_t st, hipStream_t* side) {
+// everything enqueued on `st` so far happens before what is enqueued on the side stream from now on (`which`: a call that
+// forks twice uses a different event each time)
+int side_fork(hipStream_t st, hipStream_t* side, int which = 0) {
     std::lock_guard<std::mutex> lock(g_side_mu);
     SideStream* S = nullptr;
     int rc = side_stream(&S);
     if (rc) return rc;
-    GNMS_CHECK_HIP(hipEventRecord(S->fork, st));
-    GNMS_CHECK_HIP(hipStreamWaitEvent(S->s, S->fork, 0));
+    GNMS_CHECK_HIP(hipEventRecord(S->fork[which], st));
+    GNMS_CHECK_HIP(hipStreamWaitEvent(S->s, S->fork[which], 0));
     *side = S->s;
     return GNMS_OK;
 }
 // the matrix write that gnms_forward_with_iou2d hands to the from-boxes layer for the side stream
 struct MatrixWrite { float* out; int64_t ld; };
+// The write in two launches: rows [0, r) beside the bit-matrix kernel (a VALU-bound kernel of small workgroups, which interleaves
+// with the write's), the rest beside the tail.  r as a percentage of N (GNMS_SPLIT_PCT overrides), rounded down to whole 64-row
+// tiles.  Measured B=8: 2D N=8192 0.625 / 0.575 / 0.568 / 0.595 ms at 0 / 20 / 40 / 50 %, N=16384 2.10 / 2.03 / 2.08 / 2.08;
+// 3D N=8192 0.720 / 0.672 / 0.676 / 0.703, N=16384 2.39 / 2.37 / 2.36 / 2.36 (its write kernel has less VALU to spare).
+int split_rows(int N, int default_pct) {
+    static const int pct = [] { const char* e = getenv("GNMS_SPLIT_PCT"); return e ? atoi(e) : -1; }();
+    const int p = pct >= 0 ? pct : default_pct;
+    return (int)((long long)N * p / 100) & ~63;
+}
 // everything enqueued on the side stream so far happens before what is enqueued on `st` from now on
 int side_join(hipStream_t st) {
     std::lock_guard<std::mutex> lock(g_side_mu);
@@ -391,6 +405,16 @@ int side_join(hipStream_t st) {
     GNMS_CHECK_HIP(hipStreamWaitEvent(st, S->join, 0));
     return GNMS_OK;
 }
+// fork(s) and the one join of a call; the destructor joins on an early (error) return, so that the caller's stream always
+// covers what was put on the side stream
+struct SideScope {
+    hipStream_t st;
+    bool forked = false;
+    explicit SideScope(hipStream_t s) : st(s) {}
+    ~SideScope() { if (forked) side_join(st); }
+    int fork(hipStream_t* side, int which) { const int rc = side_fork(st, side, which); if (!rc) forked = true; return rc; }
+    int join() { forked = false; return side_join(st); }
+};
 }  // namespace
 
 namespace {
@@ -460,7 +484,7 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
 
 // defined in iou_kernels.hip
 int gnms_internal_records_from_params(const float* params, long count, float* rec, hipStream_t st);
-int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st);
+int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, int row0 = 0, int row_end = 0x7fffffff);
 
 namespace {
 // records of all images into the per-image workspace regions
@@ -494,6 +518,13 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     GNMS_CHECK_LAUNCH();
     const int P2 = next_pow2(N);
     if ((rc = launch_sorts(scores, reinterpret_cast<const float*>(xkeys), B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
+    SideScope scope(st);
+    const int r1 = beside ? split_rows(N, 20) : 0;
+    if (r1 > 0) {                                                 // first part of the write beside the bit-matrix kernel
+        hipStream_t side = nullptr;
+        if ((rc = scope.fork(&side, 0))) return rc;
+        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, 0, r1))) return rc;
+    }
     if (!(P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY)) {
         // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
         bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
@@ -507,11 +538,10 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     GNMS_CHECK_LAUNCH();
     if (beside) {                                                 // see forward_boxes_impl for why the fork sits exactly here
         hipStream_t side = nullptr;
-        if ((rc = side_fork(st, &side))) return rc;
-        rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
-        const int wrc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side);
-        const int jrc = side_join(st);
-        return rc ? rc : (wrc ? wrc : jrc);
+        if ((rc = scope.fork(&side, 1))) return rc;
+        if ((rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st))) return rc;
+        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, r1, N))) return rc;
+        return scope.join();
     }
     if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
     const size_t llds = leaders_lds_bytes(N);
@@ -650,6 +680,13 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
     if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
+    SideScope beside(st);
+    const int r1 = mw ? split_rows(N, 20) : 0;
+    if (r1 > 0) {                                              // first part of the write beside the bit-matrix kernel (small workgroups: they interleave)
+        hipStream_t side = nullptr;
+        if ((rc = beside.fork(&side, 0))) return rc;
+        if ((rc = gnms_internal_iou2d_rows(boxes, B, N, mw->out, mw->ld, side, 0, r1))) return rc;
+    }
     if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
     if (mw) {
         // Large images: the rest of the layer is one workgroup per image (K3..K6 in one launch) and the matrix write runs beside
@@ -658,11 +695,10 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
         // sort_merge_kernel waited 1.85 ms).  Forked here, the tail's B workgroups are resident before the side stream has seen
         // the event (same-queue successor ~2 us, cross-queue event ~25 us), and then keep their CUs until the layer is done.
         hipStream_t side = nullptr;
-        if ((rc = side_fork(st, &side))) return rc;
-        rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
-        int wrc = gnms_iou2d(boxes, boxes, B, N, N, mw->out, mw->ld, side);
-        const int jrc = side_join(st);                          // also after a failure: the caller's stream must cover the write
-        return rc ? rc : (wrc ? wrc : jrc);
+        if ((rc = beside.fork(&side, 1))) return rc;
+        if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st))) return rc;
+        if ((rc = gnms_internal_iou2d_rows(boxes, B, N, mw->out, mw->ld, side, r1, N))) return rc;
+        return beside.join();
     }
     if (P.mask_group_boxes && use_tail_kernel(N))
         return launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
