@@ -341,15 +341,16 @@ extern "C" int gnms_forward(const float* scores, const float* iou, int B, int N,
 }
 
 namespace {
-// Large images (N > 4096): the matrix write takes milliseconds and nothing in the grouped from-boxes layer reads it, so the
-// write goes to a library-owned second stream and the layer's own kernels run beside it on the caller's stream.  A fork and a
-// join through events cost 25-50 us of idle queue each on this hardware, which is why smaller problems stay on one stream
-// (measured: N=4096 loses 0.03 ms/step).  GNMS_TWO_STREAMS=0/1 forces the choice.
+// Large images (N > 4096, matrix >= 384 MiB): the matrix write takes longer than the layer behind it and nothing in the masked
+// from-boxes layer reads it, so the write goes to a library-owned second stream and the layer's own kernels run beside it on the
+// caller's stream.  A fork and a join cost 7-25 us of idle queue each and the layer's latency-bound kernels run 1.3-3x slower
+// beside the write, which is why smaller problems stay on one stream (B=8, N=4096: 0.180-0.187 against 0.193 ms, not worth a
+// second code path; B=4: 0.152 against 0.138; N=8192, B=1: even; B=2: 0.246 against 0.306).  GNMS_TWO_STREAMS=0/1 forces.
 struct SideStream { hipStream_t s = nullptr; hipEvent_t fork[2] = {nullptr, nullptr}, join = nullptr; };
 std::mutex g_side_mu;
-bool use_side_stream(int N) {
+bool use_side_stream(int B, int N, int64_t ld) {
     static const int forced = [] { const char* e = getenv("GNMS_TWO_STREAMS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced == 1 : N > 4096;
+    return forced >= 0 ? forced == 1 : (N > 4096 && (long long)B * N * ld * 4 >= (384ll << 20));
 }
 // the caller holds g_side_mu
 int side_stream(SideStream** out) {
@@ -437,10 +438,11 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     const int P2 = next_pow2(N);
     // fused launch: sort on 512 threads (P2 >= 512), <= 32 KiB of LDS per workgroup (P2 <= 4096), one sort workgroup per image in slice 0
     const bool from_boxes = params->group_boxes && !params->presorted && ((uintptr_t)boxes % 16 == 0);
-    const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) &&
+    const bool beside = B > 0 && N > 0 && from_boxes && params->mask_group_boxes && use_side_stream(B, N, ld);
+    const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) && !beside &&
                       (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::tile_rows_for(B, N, N)) >= 2 * B;
     if (!fuse) {
-        if (B > 0 && N > 0 && from_boxes && params->mask_group_boxes && use_side_stream(N)) {
+        if (beside) {
             const MatrixWrite mw = {iou_out, ld};
             return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
                                       workspace_bytes, stream, false, &mw);
@@ -511,7 +513,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     if (rc) return rc;
     const bool from_rec = P.group_boxes && P.mask_group_boxes && !P.presorted;
     if (!from_rec) return gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st);
-    const bool beside = use_side_stream(N);
+    const bool beside = use_side_stream(B, N, ld);
     if (!beside && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st))) return rc;
     float4* xkeys = reinterpret_cast<float4*>(rec + (size_t)B * N * gnms_iou3d::kRec);
     scatter_records_kernel<<<dim3(gnms_div_up(N * 3, 256), B), 256, 0, st>>>(rec, N, ws, L, xkeys);
@@ -682,7 +684,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
     SideScope beside(st);
     const int r1 = mw ? split_rows(N, 20) : 0;
-    if (r1 > 0) {                                              // first part of the write beside the bit-matrix kernel (small workgroups: they interleave)
+    if (r1 > 0) {                        // first part of the write beside the bit-matrix kernel (small workgroups: they interleave)
         hipStream_t side = nullptr;
         if ((rc = beside.fork(&side, 0))) return rc;
         if ((rc = gnms_internal_iou2d_rows(boxes, B, N, mw->out, mw->ld, side, 0, r1))) return rc;
