@@ -31,6 +31,13 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
+    # objects compiled with other flags (GNMS_EXTRA_FLAGS experiments) are stale whatever their timestamps say
+    stamp = os.path.join(CSRC, ".build_flags")
+    flags = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags:
+        force = True
+    with open(stamp, "w") as f:
+        f.write(flags)
     deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     objs, jobs = [], []
     for src in SOURCES:
