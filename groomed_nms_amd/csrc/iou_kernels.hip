@@ -113,6 +113,26 @@ __global__ void aabb_from_params_kernel(const float* __restrict__ params, long c
     o[2] = make_float4(r[8], r[9], r[10], r[11]);
 }
 
+// gnms_forward_with_iou3d: the records once contiguous (the matrix kernel's input), once into the per-image workspace regions (the
+// layer's copy), + the pseudo boxes (x0, lx, x1, 0) its x sort orders the columns by -- one pass over the cuboids
+__global__ __launch_bounds__(256) void aabb_for_layer_kernel(const float* __restrict__ params, int N, float* __restrict__ rec, char* ws,
+                                                             gnms_ws_layout L, float4* __restrict__ xkeys) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const size_t g = (size_t)b * N + i;
+    float cx[8], cy[8], cz[8];
+    corners_of(params + g * 7, cx, cy, cz);
+    float r[kRec];
+    aabb_record(cx, cy, cz, r);
+    const float4 u = make_float4(r[0], r[1], r[2], r[3]), v = make_float4(r[4], r[5], r[6], r[7]), e = make_float4(r[8], r[9], r[10], r[11]);
+    float4* o = reinterpret_cast<float4*>(rec + g * kRec);
+    o[0] = u; o[1] = v; o[2] = e;
+    float4* w = reinterpret_cast<float4*>(ws + (size_t)b * L.per_image + L.off_rec) + (size_t)i * 3;
+    w[0] = u; w[1] = v; w[2] = e;
+    xkeys[g] = make_float4(r[3], r[8], r[4], 0.0f);
+}
+
 // pairwise 3D overlap from the records.  METHOD 0 normal, 1 generalized, 2 0.5*(1+generalized).
 template <bool VEC, int METHOD, bool BEV>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M, int N,
@@ -280,6 +300,13 @@ int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, in
 int gnms_internal_records_from_params(const float* params, long count, float* rec, hipStream_t st) {
     if (count <= 0) return GNMS_OK;
     aabb_from_params_kernel<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(params, count, rec);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+int gnms_internal_records_for_layer(const float* params, int B, int N, float* rec, char* ws, const gnms_ws_layout& L, float* xkeys,
+                                    hipStream_t st) {
+    if (B <= 0 || N <= 0) return GNMS_OK;
+    aabb_for_layer_kernel<<<dim3(gnms_div_up(N, 256), B), 256, 0, st>>>(params, N, rec, ws, L, reinterpret_cast<float4*>(xkeys));
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

@@ -486,40 +486,28 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
 
 // defined in iou_kernels.hip
 int gnms_internal_records_from_params(const float* params, long count, float* rec, hipStream_t st);
+int gnms_internal_records_for_layer(const float* params, int B, int N, float* rec, char* ws, const gnms_ws_layout& L, float* xkeys, hipStream_t st);
 int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, int row0 = 0, int row_end = 0x7fffffff);
 
 namespace {
-// records of all images into the per-image workspace regions
-__global__ __launch_bounds__(256) void scatter_records_kernel(const float* __restrict__ rec_all, int N, char* ws, gnms_ws_layout L,
-                                                              float4* __restrict__ xkeys) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // float4 index inside the image: N * 3 of them
-    if (i >= N * 3) return;
-    const float4 v = reinterpret_cast<const float4*>(rec_all)[(size_t)b * N * 3 + i];
-    reinterpret_cast<float4*>(img_ptrs(ws, L, b).rec)[i] = v;
-    // pseudo boxes (x0, lx, x1, 0) for the x sort: record = {vol y0 y1 x0 | x1 z0 z1 area | lx ly lz 0}
-    if (i % 3 == 0) xkeys[(size_t)b * N + i / 3].x = v.w;
-    else if (i % 3 == 1) xkeys[(size_t)b * N + i / 3].z = v.x;
-    else { xkeys[(size_t)b * N + i / 3].y = v.x; xkeys[(size_t)b * N + i / 3].w = 0.0f; }
-}
-
 // everything of gnms_forward_with_iou3d that uses the temporary `rec` ([B][N] records, then [B][N] pseudo boxes for the x sort).
 // Masked hard-sorted groups: the whole layer runs from the records (threshold bits AND the O(N) single overlaps, same arithmetic
 // as the matrix kernel), so nothing waits for the matrix; large images write it on the side stream beside the one-launch tail.
 int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
                           const gnms_params& P, float* iou_out, float* prob, int64_t* order, int64_t* valid, int64_t* invalid,
                           int32_t* nvalid, int32_t* ninvalid, char* ws, const gnms_ws_layout& L, hipStream_t st) {
-    int rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st);
-    if (rc) return rc;
     const bool from_rec = P.group_boxes && P.mask_group_boxes && !P.presorted;
-    if (!from_rec) return gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st);
+    int rc;
+    if (!from_rec) {
+        if ((rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st))) return rc;
+        return gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st);
+    }
+    float* xkeys = rec + (size_t)B * N * gnms_iou3d::kRec;         // [B][N] pseudo boxes
+    if ((rc = gnms_internal_records_for_layer(params3d, B, N, rec, ws, L, xkeys, st))) return rc;
     const bool beside = use_side_stream(B, N, ld);
     if (!beside && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st))) return rc;
-    float4* xkeys = reinterpret_cast<float4*>(rec + (size_t)B * N * gnms_iou3d::kRec);
-    scatter_records_kernel<<<dim3(gnms_div_up(N * 3, 256), B), 256, 0, st>>>(rec, N, ws, L, xkeys);
-    GNMS_CHECK_LAUNCH();
     const int P2 = next_pow2(N);
-    if ((rc = launch_sorts(scores, reinterpret_cast<const float*>(xkeys), B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
+    if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
     SideScope scope(st);
     const int r1 = beside ? split_rows(N, 20) : 0;
     if (r1 > 0) {                                                 // first part of the write beside the bit-matrix kernel
