@@ -796,6 +796,47 @@ def test_proposals_against_reference_vectors_and_oracle():
         np.testing.assert_allclose(out[0][b, :m].cpu().numpy(), ref["prob"], atol=TOL)
 
 
+def test_training_step_chain_against_oracle(G, O):
+    """What lib/loss/rpn_3d.py does per step at its own sizes (:740-793, :1117-1131), on the GPU end to end: top-K selection ->
+    overlaps + GrooMeD-NMS in one call -> after-NMS AP loss on the rescored probabilities -> backward to the raw scores.  Loss and
+    dL/dscores against the same chain of oracle pieces (the ranking loss sums thousands of sigmoid-free step terms: APLOSS_TOL)."""
+    from groomed_nms_amd import proposals as PR, synthetic
+    from groomed_nms_amd.aploss import ap_loss_batched
+    import oracle.proposals_oracle as PO
+    rng = np.random.default_rng(17)
+    B, A, K = 4, 1500, 500
+    boxes_np, scores_np = synthetic.batch_2d(17, B, A, "clustered", per=24)
+    fg_counts = np.array([A, 900, 400, 37], np.int32)                       # the last two images have fewer candidates than K
+    cand = np.stack([rng.permutation(A) for _ in range(B)]).astype(np.int32)
+    labels_all = (rng.uniform(size=(B, A)) < 0.08).astype(np.float32)       # label of every anchor; gathered along with the selection
+    scores = torch.from_numpy(scores_np).cuda().requires_grad_(True)
+    boxes = torch.from_numpy(boxes_np).cuda()
+    idx, num, ssel, bsel = PR.select_topk(scores.detach(), K, torch.from_numpy(cand).cuda(), torch.from_numpy(fg_counts).cuda(), boxes)
+    safe = idx.clamp(min=0).long()
+    s_sel = torch.gather(scores, 1, safe) * (idx >= 0)                      # differentiable gather of the selected scores
+    out = G.differentiable_nms_with_iou2d_batched(s_sel, bsel, counts=num)
+    prob, order = out[0], out[1]
+    # the loss ranks the rescored probabilities; their targets follow the layer's order (prob is in sorted-rank order)
+    lab_sel = torch.gather(torch.from_numpy(labels_all).cuda(), 1, safe)
+    lab_rank = torch.gather(lab_sel, 1, order.clamp(min=0))
+    loss = ap_loss_batched(prob, lab_rank, counts=num)
+    wl = torch.tensor([1.0, 0.5, 2.0, 1.5], device="cuda")
+    (loss * wl).sum().backward()
+    for b in range(B):
+        m = int(num[b])
+        sel = PO.select_topk(scores_np[b], cand[b, :fg_counts[b]], K)
+        assert np.array_equal(idx[b, :m].cpu().numpy(), sel)
+        sb, bb = scores_np[b][sel], boxes_np[b][sel]
+        fwd = O.differentiable_nms(sb, O.iou2d(bb, bb))
+        lab = labels_all[b][sel][fwd["order"]]
+        ol, og = O.aploss(fwd["prob"], lab)
+        assert abs(float(loss[b].detach()) - ol) <= APLOSS_TOL, b
+        bwd = O.differentiable_nms(sb, O.iou2d(bb, bb), grad_prob=og * float(wl[b]))
+        want = np.zeros(A, np.float32)
+        want[sel] = bwd["grad_scores"]
+        np.testing.assert_allclose(scores.grad[b].cpu().numpy(), want, atol=2 * APLOSS_TOL, rtol=2e-4, err_msg=str(b))
+
+
 def test_fuzz_layer_against_oracle(G, O):
     """Seeded fuzz over sizes, box statistics, thresholds, group sizes, pruning functions and ragged counts: the one-call entry
     (from-boxes kernels, fused tail for small N), the matrix-in entry and the oracle must agree on every image -- probabilities
