@@ -427,7 +427,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
 // The matrix is an OUTPUT here, so the layer does not have to read it back: with the boxes at hand the grouped modes
 // take their threshold bits and the few P[i, head] entries straight from the boxes (bit-identical arithmetic, the
 // from-boxes kernels), which replaces the 537 MB read of bitmask_kernel (~100 us at B=8, N=4096) by bitmask_boxes_kernel
-// (~51 us, compute bound).  The ungrouped / soft-sorted modes read the matrix they just wrote.
+// (~25 us, compute bound).  The ungrouped / soft-sorted modes read the matrix they just wrote.
 extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
                                        const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
                                        int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
