@@ -18,6 +18,8 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   roofline_matrix_in  / roofline_iou: the other of the two
   fused_from_boxes    the matrix-free entry (never part of `value`)
   cpu_baseline        the CPU oracle (a C port of the reference algorithm, single thread) timed on this host, N=1 only
+  parity              (with cpu_baseline) max |d prob| and max |d grad_scores| of the timed entry against that oracle on every image of
+                      rank 0's batch, and whether the valid-index sets agree -- the "max-|dscore| vs ref" half of BASELINE.json's metric
 """
 import argparse
 import json
@@ -257,6 +259,15 @@ def main():
                                          "decisions_per_s": round(pairs / (t_mb * 1e-3), 1)}}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
+            # the GPU results of the timed entry, for the parity figure BASELINE.json's metric asks for (max |dscore| vs the CPU path)
+            entry = (G.differentiable_nms_with_iou2d_batched if args.dim == 2 else G.differentiable_nms_with_iou3d_batched) \
+                if not args.two_calls else None
+            s_par = scores.detach().clone().requires_grad_(True)
+            g_out = entry(s_par, boxes) if entry else G.differentiable_nms_batched(s_par, build_overlaps())
+            torch.autograd.backward(g_out[0], w)
+            g_prob, g_valid, g_nvalid, g_grad = g_out[0].detach().cpu().numpy(), g_out[2].cpu().numpy(), g_out[4].cpu().numpy(), s_par.grad.cpu().numpy()
+            d_prob = d_grad = 0.0
+            sets_equal, checked = True, 0
             t0 = time.perf_counter()
             k = 0
             while k < 4 or (time.perf_counter() - t0) < args.cpu_seconds:      # bounded sample: whole images, >= 4 of them
@@ -266,11 +277,20 @@ def main():
                 else:
                     c = O.corners_of_cuboid(boxes_np[b])
                     m = 0.5 * (1.0 + O.iou3d_approximate(c, c, generalized=True)[1])
-                O.differentiable_nms(scores_np[b], m, grad_prob=np.linspace(-1, 2, N).astype(np.float32))
+                res = O.differentiable_nms(scores_np[b], m, grad_prob=np.linspace(-1, 2, N).astype(np.float32))
+                if k < B:                                                       # first pass over an image: compare (outside the timed sum)
+                    tp = time.perf_counter()
+                    d_prob = max(d_prob, float(np.abs(g_prob[b] - res["prob"]).max()))
+                    d_grad = max(d_grad, float(np.abs(g_grad[b] - res["grad_scores"]).max()))
+                    sets_equal &= set(g_valid[b, :g_nvalid[b]].tolist()) == set(res["valid"].tolist())
+                    checked += 1
+                    t0 += time.perf_counter() - tp
                 k += 1
                 if k >= 4096:
                     break
             tc = time.perf_counter() - t0
+            out["parity"] = {"max_abs_dscore": d_prob, "max_abs_dgrad_scores": d_grad, "valid_index_sets_equal": bool(sets_equal),
+                             "images_checked": checked, "against": "oracle/ (CPU restatement of lib/groomed_nms.py + lib/core.py), tolerance 1e-4"}
             out["cpu_baseline"] = {"value": round(k * N / tc, 1), "unit": "boxes/s", "cores": 1, "kind": "port",
                                    "sample": "%d image passes over rank 0's batch of %d images (N=%d) in %.1f s: oracle/gnms_oracle.c overlap matrix + "
                                              "nms fwd+bwd, single thread" % (k, B, N, tc)}
