@@ -99,7 +99,7 @@ extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float t
     GNMS_CHECK_LAUNCH();
     classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, ws, L);
     GNMS_CHECK_LAUNCH();
-    const size_t lds = (size_t)kSBPairs * 64 * 8 + 2 * (size_t)((L.NB + 1) & ~1) * 8 + 2 * kSBPairs * 4;
+    const size_t lds = leaders_lds_size(L.NB);
     if (lds > 64 * 1024)
         GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L);

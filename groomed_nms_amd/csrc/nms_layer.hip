@@ -62,7 +62,7 @@ int next_pow2(int n) {
         else { constexpr int E = 16; __VA_ARGS__; }                      \
     } while (0)
 
-size_t leaders_lds_bytes(int N) { const int NB = (N + 63) / 64; return (size_t)kSBPairs * 64 * 8 + 2 * (size_t)((NB + 1) & ~1) * 8 + 2 * kSBPairs * 4; }
+size_t leaders_lds_bytes(int N) { return leaders_lds_size((N + 63) / 64); }
 
 // Kernels that need more than 64 KiB of dynamic LDS must be told so once per (device, kernel); the attribute call is not free
 // (a driver round trip per launch adds up on the small-N path), so what has been granted is remembered.

@@ -137,7 +137,7 @@ int main(int argc, char** argv) {
     printf("empty kernel            %8.1f us\n", time_us([&] { empty_kernel<<<B, 1024>>>(nullptr); }));
     printf("iou2d                   %8.1f us\n", time_us([&] { gnms_iou2d(d_boxes, d_boxes, B, N, N, d_iou, N, nullptr); }));
     printf("forward (all)           %8.1f us\n", time_us([&] { gnms_forward(d_scores, d_iou, B, N, N, nullptr, &P, d_prob, nullptr, nullptr, nullptr, nullptr, nullptr, ws, wsb, nullptr); }));
-    const size_t llds = (size_t)kSBPairs * 64 * 8 + 2 * (size_t)((L.NB + 1) & ~1) * 8 + 2 * kSBPairs * 4;
+    const size_t llds = leaders_lds_size(L.NB);
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)llds));
     printf("leaders                 %8.1f us\n", time_us([&] { leaders_kernel<<<B, 1024, llds>>>(N, nullptr, ws, L); }));
 #ifdef GNMS_TIMING
