@@ -113,6 +113,26 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _Noop:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOOP = _Noop()
+
+
+def on_device(dev):
+    """Context that makes `dev` the current HIP device for the library call -- a no-op object when it already is
+    (torch.cuda.device() costs ~4 us per entry, twice per training step on the launch-bound path)."""
+    idx = dev.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NOOP
+    return torch.cuda.device(dev)
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 

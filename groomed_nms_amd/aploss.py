@@ -9,7 +9,7 @@ per image.  No CPU implementation lives here: without the library or a GPU the c
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream_ptr
+from ._lib import check, ptr, stream_ptr, on_device
 
 __all__ = ["APLoss", "backpropAPLoss", "ap_loss_batched"]
 
@@ -29,7 +29,7 @@ def _launch(logits2d, targets2d, counts, positive_label, negative_label):
     dev = logits2d.device
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
     grad = torch.empty((B, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.gnms_aploss(ptr(logits2d), ptr(targets2d), B, N, ptr(counts), float(positive_label), float(negative_label),
                               ptr(loss), ptr(grad), stream_ptr()), "gnms_aploss")
     return loss, grad

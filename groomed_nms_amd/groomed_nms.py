@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import GnmsParams, check, ptr, stream_ptr
+from ._lib import GnmsParams, check, ptr, stream_ptr, on_device
 
 __all__ = ["differentiable_nms", "differentiable_nms_batched", "differentiable_nms_from_boxes_batched",
            "differentiable_nms_with_iou2d_batched", "differentiable_nms_with_iou3d_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
@@ -35,6 +35,18 @@ def _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold
     return GnmsParams(float(nms_threshold), float(temperature), float(valid_box_prob_threshold), _PRUNE[pruning_method],
                       int(bool(return_sorted_prob)), int(bool(group_boxes)), int(bool(mask_group_boxes)),
                       int(min(int(group_size), 2 ** 31 - 2)), int(bool(presorted)))
+
+
+_WS_BYTES = {}
+
+
+def _workspace_bytes(lib, B, N, params):
+    """gnms_workspace_bytes, remembered per (B, N, group_boxes) -- the only fields it depends on (include/groomed_nms_hip.h)."""
+    key = (B, N, params.group_boxes)
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _WS_BYTES[key] = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
+    return nbytes
 
 
 def _outputs(B, N, dev, index_lists=True):
@@ -69,9 +81,9 @@ class _GroomedNMSFunction(torch.autograd.Function):
         scores_c = scores.contiguous()
         iou_c, ld = _matrix_layout(iou)
         prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev, getattr(params, "index_lists", True))
-        nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
+        nbytes = _workspace_bytes(lib, B, N, params)
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.gnms_forward(ptr(scores_c), ptr(iou_c), B, N, ld, ptr(counts), ctypes.byref(params), ptr(prob), ptr(order),
                                    ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws), ws.numel(), stream_ptr(dev)),
                   "gnms_forward")
@@ -95,7 +107,7 @@ class _GroomedNMSFunction(torch.autograd.Function):
         grad_iou = None
         if ctx.needs_input_grad[1]:
             grad_iou = torch.empty((B, N, ctx.ld), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.gnms_backward(ptr(grad_prob), ptr(scores_c), ptr(iou_c), B, N, ctx.ld, ptr(counts), ctypes.byref(ctx.params),
                                     ptr(grad_scores), ptr(grad_iou), ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_backward")
         if grad_iou is not None and ctx.ld != N:
@@ -120,9 +132,9 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
                                                                                                 "gnms_forward_with_iou2d")
         iou = iou_out if iou_out is not None else torch.empty((B, N, N), dtype=torch.float32, device=dev)
         prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev, getattr(params, "index_lists", True))
-        nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
+        nbytes = _workspace_bytes(lib, B, N, params)
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(entry(ptr(boxes_c), ptr(scores_c), B, N, max(N, 1), ptr(counts), ctypes.byref(params), ptr(iou), ptr(prob), ptr(order),
                         ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws), ws.numel(), stream_ptr(dev)), what)
         ctx.params = params
@@ -143,7 +155,7 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         dev = scores_c.device
         grad_prob = grad_prob.contiguous().float()
         grad_scores = torch.empty_like(scores_c)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.gnms_backward(ptr(grad_prob), ptr(scores_c), ptr(iou_c), B, N, max(N, 1), ptr(counts), ctypes.byref(ctx.params),
                                     ptr(grad_scores), None, ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_backward")
         return grad_scores, None, None, None, None
@@ -162,9 +174,9 @@ class _GroomedNMSFromBoxesFunction(torch.autograd.Function):
         scores_c = scores.contiguous()
         boxes_c = boxes.contiguous()
         prob, order, valid, invalid, nvalid, ninvalid = _outputs(B, N, dev, getattr(params, "index_lists", True))
-        nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(params))
+        nbytes = _workspace_bytes(lib, B, N, params)
         ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.gnms_forward_from_boxes(ptr(boxes_c), ptr(scores_c), B, N, ptr(counts), ctypes.byref(params), ptr(prob), ptr(order),
                                               ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws), ws.numel(), stream_ptr(dev)),
                   "gnms_forward_from_boxes")
@@ -184,7 +196,7 @@ class _GroomedNMSFromBoxesFunction(torch.autograd.Function):
         dev = scores_c.device
         grad_prob = grad_prob.contiguous().float()
         grad_scores = torch.empty_like(scores_c)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.gnms_backward_from_boxes(ptr(grad_prob), ptr(boxes_c), ptr(scores_c), B, N, ptr(counts), ctypes.byref(ctx.params),
                                                ptr(grad_scores), ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_backward_from_boxes")
         return grad_scores, None, None, None
@@ -211,7 +223,7 @@ class _SoftSortFunction(torch.autograd.Function):
         one = GnmsParams()
         lib.gnms_default_params(ctypes.byref(one))
         ws = torch.empty((max(lib.gnms_workspace_bytes(1, max(N, 1), ctypes.byref(one)), 256),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with on_device(dev):
             check(lib.gnms_soft_sort(ptr(scores_c), ptr(m_c), N, ld, float(temperature), ptr(C), ptr(soft_scores), ptr(soft_matrix),
                                      ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_soft_sort")
         ctx.temperature = float(temperature)
@@ -421,7 +433,7 @@ def pruning_function(iou, nms_threshold=0.4, temperature=0.01, pruning_method="l
     dev = out_device if out_device.type == "cuda" else _device()
     x = iou.detach().to(device=dev, dtype=torch.float32).contiguous()
     out = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.gnms_pruning_function(ptr(x), x.numel(), float(nms_threshold), float(temperature), _PRUNE[pruning_method],
                                         ptr(out), stream_ptr(dev)), "gnms_pruning_function")
     return out.to(out_device)
@@ -465,7 +477,7 @@ def get_groups(iou_unsorted, group_threshold, scores_unsorted, group_size=100, r
     one = GnmsParams()
     lib.gnms_default_params(ctypes.byref(one))
     ws = torch.empty((max(lib.gnms_workspace_bytes(1, n, ctypes.byref(one)), 256),), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.gnms_get_groups(ptr(scores), ptr(iou), n, n, float(group_threshold), int(min(int(group_size), 2 ** 31 - 2)),
                                   ptr(group_of), ptr(pos), ptr(ngroups), ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_get_groups")
     g = int(ngroups.item())

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream_ptr
+from ._lib import check, ptr, stream_ptr, on_device
 from .groomed_nms import _device
 
 __all__ = ["iou", "intersect", "iou3d_approximate", "get_corners_of_cuboid", "iou_batched", "iou3d_batched"]
@@ -111,7 +111,7 @@ def get_corners_of_cuboid(x3d, y3d, z3d, w3d, h3d, l3d, ry3d, iou_3d_convention=
     params = torch.stack([c.to(device=dev, dtype=torch.float32).reshape(-1) for c in cols], dim=1).contiguous()
     n = params.shape[0]
     corners = torch.empty((n, 3, 8), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.gnms_corners_of_cuboid(ptr(params), n, ptr(corners), stream_ptr(dev)), "gnms_corners_of_cuboid")
     return _back(corners, kind, out_device)
 

@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream_ptr
+from ._lib import check, ptr, stream_ptr, on_device
 
 __all__ = ["bbox_transform_inv", "select_topk", "projected_boxes_2d", "best_targets"]
 
@@ -46,7 +46,7 @@ def bbox_transform_inv(boxes, deltas, means=None, stds=None):
     B, A = d.shape[0], d.shape[1]
     out = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
     m, s = _f4(means), _f4(stds)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.gnms_bbox_transform_inv(ptr(a), ptr(d), B, A, m, s, ptr(out), stream_ptr()), "gnms_bbox_transform_inv")
     out = out if three else out[0]
     return out if was_cuda else out.cpu()
@@ -74,7 +74,7 @@ def select_topk(scores, k, candidates=None, candidate_counts=None, boxes=None):
     num = torch.empty((B,), dtype=torch.int32, device=dev)
     ssel = torch.empty((B, k), dtype=torch.float32, device=dev)
     bsel = torch.empty((B, k, 4), dtype=torch.float32, device=dev) if bx is not None else None
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.gnms_select_topk(ptr(s), B, A, ptr(cand), F, ptr(cnt), int(k), ptr(bx), ptr(idx), ptr(num), ptr(ssel), ptr(bsel),
                                    stream_ptr()), "gnms_select_topk")
     return idx, num, ssel, bsel
@@ -96,7 +96,7 @@ def projected_boxes_2d(params, p2, scale_factor=None):
         sc = torch.as_tensor(scale_factor, dtype=torch.float32, device=dev).reshape(-1)
         sc = (sc.expand(B) if sc.numel() == 1 else sc).contiguous()
     out = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.gnms_project_boxes3d(ptr(p), ptr(P), ptr(sc), B, N, ptr(out), stream_ptr()), "gnms_project_boxes3d")
     return out
 
@@ -118,7 +118,7 @@ def best_targets(pred_params, pred_boxes, gt_params, gt_boxes, beta, pred_counts
     targets = torch.empty((B, N), dtype=torch.float32, device=dev)
     idx = torch.empty((B, M), dtype=torch.int64, device=dev)
     score = torch.empty((B, M), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.gnms_best_targets(ptr(pp), ptr(pb), ptr(gp), ptr(gb), B, N, M, ptr(pc), ptr(gc), float(beta), ptr(idx), ptr(score),
                                     ptr(targets), stream_ptr()), "gnms_best_targets")
     return targets, idx, score
