@@ -1005,6 +1005,51 @@ def test_batches_past_two_to_the_32_matrix_elements(G):
         torch.cuda.empty_cache()
 
 
+def test_host_threads_share_the_side_stream(G):
+    """Three host threads, each on its own torch stream, call the large-image one-call entries at once: the library's side
+    stream and its fork/join events are shared per device, every result must still equal the single-threaded one."""
+    import threading
+    from groomed_nms_amd import synthetic
+
+    def make(seed, dim, B, N):
+        if dim == 2:
+            b, s = synthetic.batch_2d(seed, B, N, "clustered", per=48)
+            return G.differentiable_nms_with_iou2d_batched, torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+        b, s = synthetic.batch_3d(seed, B, N, True)
+        return G.differentiable_nms_with_iou3d_batched, torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+
+    cases = [make(1, 2, 2, 8192), make(2, 3, 2, 8192), make(3, 2, 1, 16384)]
+    refs = []
+    for fn, b, s in cases:
+        sg = s.clone().requires_grad_(True)
+        out = fn(sg, b)
+        out[0].sum().backward()
+        refs.append(([o.clone() for o in out[:7]], sg.grad.clone()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for it in range(6):
+                k = (tid + it) % len(cases)
+                fn, b, s = cases[k]
+                sg = s.clone().requires_grad_(True)
+                out = fn(sg, b)
+                out[0].sum().backward()
+                st.synchronize()
+                if not all(torch.equal(a, r) for a, r in zip(out[:7], refs[k][0])) or not torch.equal(sg.grad, refs[k][1]):
+                    errors.append((tid, it, k))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:5]
+
+
 def test_api_edges(G):
     """What callers actually hand over: strided views, float64, a padded leading dimension, a matrix that requires grad, NumPy
     float64 in / CPU tensors out (lib/rpn_util.py:1319-1320), empty inputs, an unknown pruning method, impossible shapes."""
