@@ -5,36 +5,44 @@ A step = one pass of the hot path over one batch of synthetic proposals already 
     pairwise IoU matrix  ->  GrooMeD-NMS forward  ->  backward w.r.t. scores
 as lib/loss/rpn_3d.py:772-791 runs it.  Default (2D): ONE library call builds the matrix and runs the layer
 (gnms_forward_with_iou2d: the matrix is an output, the threshold bits come straight from the boxes), then gnms_backward;
---two-calls keeps gnms_iou2d and the matrix-in layer gnms_forward apart; --dim 3 uses gnms_forward_with_iou3d.
-Workload at N GPUs (weak scaling): every rank owns `--batch` images x `--boxes` boxes; images are independent
-units, so there is no data-path collective (DESIGN.md "multi-GPU").
+--two-calls keeps the overlap kernel and the matrix-in layer gnms_forward apart; --dim 3 uses gnms_forward_with_iou3d.
+The matrix is written into one of >= 3 rotating buffers (more than 256 MiB apart in time), so that the 256 MiB Infinity Cache
+cannot absorb part of the write between repetitions.
+
+Multi-GPU (weak scaling): every rank owns `--batch` images x `--boxes` boxes; images are independent units, so the layer has no
+data-path collective (DESIGN.md "multi-GPU"); one 4-byte RCCL all-reduce per step (dist.StepHeartbeat) puts a real collective
+round trip into the curve, as SURVEY.md 8-e asks.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 8 ...          # starts 8 ranks itself (torch.distributed.run, one process per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 ...
 
 Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
-  roofline            the dominant kernel of the timed step: algorithmic bytes / HIP-event time against the 8 TB/s HBM peak
-                      (default: the IoU write kernel; with --two-calls the bit-matrix kernel, the one full read of the matrix)
-  roofline_matrix_in  / roofline_iou: the other of the two
-  fused_from_boxes    the matrix-free entry (never part of `value`)
+  roofline            the dominant HBM-bound launch of the timed step: algorithmic bytes / its HIP-event duration INSIDE the step
+                      sequence (the library brackets the launch with events on its launch stream, gnms_profile_events), against the
+                      8 TB/s HBM peak; `ceiling` = what a plain store (load) stream reaches on this device over the same buffers.
+                      default: the launch that writes the matrix; --two-calls: bitmask_kernel, the one full read of the matrix
+  roofline_iou / roofline_matrix_in   the other of the two under --two-calls
   cpu_baseline        the CPU oracle (a C port of the reference algorithm, single thread) timed on this host, N=1 only
-  parity              (with cpu_baseline) max |d prob| and max |d grad_scores| of the timed entry against that oracle on every image of
-                      rank 0's batch, and whether the valid-index sets agree -- the "max-|dscore| vs ref" half of BASELINE.json's metric
+  parity              max |d prob| and max |d grad_scores| of the timed entry against that oracle on every image of rank 0's batch,
+                      and whether the valid-index sets agree -- the "max-|dscore| vs ref" half of BASELINE.json's metric
+  other_kind          the same step on the other box generator (uniform <-> clustered), 1 GPU only
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+REF_CPU_SURVEY = 459.0      # BASELINE.md section 2: reference lib/groomed_nms.py + lib/core.py iou, torch CPU, 8 threads, uniform N=4096 (not published)
 
 
 def parse():
@@ -47,156 +55,223 @@ def parse():
     ap.add_argument("--kind", default="clustered", choices=["uniform", "clustered"])
     ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="2: lib/core.py iou; 3: 0.5*(1+GIoU3D) of the corner AABBs from (x,y,z,w,h,l,ry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--two-calls", action="store_true", help="gnms_iou2d and gnms_forward as two library calls (no fused score sort)")
+    ap.add_argument("--no-other-kind", action="store_true")
+    ap.add_argument("--two-calls", action="store_true", help="overlap kernel and gnms_forward as two library calls (matrix-in layer)")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step (IoU + forward + backward through the C ABI, preallocated buffers) in a HIP graph and replay "
                          "it: removes the per-launch host cost that bounds small problems (N <= 1024)")
     ap.add_argument("--sorted-scores", action="store_true",
                     help="feed scores already sorted by descending value, as both reference call sites do (lib/loss/rpn_3d.py:731-737, "
-                         "lib/rpn_util.py:1258-1266): the bit-matrix kernel then reads only the reachable half of the matrix")
+                         "lib/rpn_util.py:1258-1266)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: keep processing images of the batch for about this long")
+    ap.add_argument("--pmc-summary", default=None,
+                    help="JSON written by tools/pmc.sh in the same session ({kernel: HBM bytes per launch}); fills roofline.traffic (else null)")
     return ap.parse_args()
 
 
-def event_time_ms(fn, iters, stream):
-    """Average duration of fn() over `iters` launches, HIP events on the stream the kernels run on."""
-    start = torch.cuda.Event(enable_timing=True)
-    end = torch.cuda.Event(enable_timing=True)
-    fn()
-    torch.cuda.synchronize()
-    start.record(stream)
-    for _ in range(iters):
-        fn()
-    end.record(stream)
-    end.synchronize()
-    return start.elapsed_time(end) / iters
+def launch_ranks_if_needed(args):
+    """`--gpus N` with no launcher around us: become the launcher.  Fails loudly when the node has fewer GPUs."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, ws))
+        return
+    if args.gpus <= 1:
+        return
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit("bench.py: --gpus %d requested but this node has %d visible GPU(s); refusing to time fewer GPUs than asked" % (args.gpus, have))
+    from groomed_nms_amd import dist as gdist
+    sys.exit(gdist.relaunch_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
 
 def main():
     args = parse()
+    launch_ranks_if_needed(args)
+    import torch
     import groomed_nms_amd as G
     from groomed_nms_amd import overlaps, synthetic, _lib, dist as gdist
+    from groomed_nms_amd._lib import GnmsParams, ptr, stream_ptr, check
     world, rank, local_rank = gdist.env_world()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     gdist.init(backend="nccl")                     # RCCL; no-op at world size 1
     lib = _lib.load()
     B, N = args.batch, args.boxes
+    P = GnmsParams()
+    lib.gnms_default_params(ctypes.byref(P))
+    thr = float(P.nms_threshold)
 
-    # every rank owns its own `B` images (weak scaling): rank r draws the images [r*B, (r+1)*B) of the global batch
-    if args.dim == 2:
-        boxes_np, scores_np = synthetic.batch_2d(1000 + rank, B, N, args.kind)
-    else:
-        boxes_np, scores_np = synthetic.batch_3d(1000 + rank, B, N, clustered=(args.kind == "clustered"))
-    if args.sorted_scores:
-        o = np.argsort(-scores_np, axis=1, kind="stable")
-        scores_np = np.take_along_axis(scores_np, o, axis=1)
-        boxes_np = np.take_along_axis(boxes_np, o[:, :, None], axis=1)
-    boxes = torch.from_numpy(np.ascontiguousarray(boxes_np)).to(dev)
-    scores = torch.from_numpy(np.ascontiguousarray(scores_np)).to(dev).requires_grad_(True)
-    w = torch.linspace(-1.0, 2.0, N, device=dev).repeat(B, 1).contiguous()
-    iou_buf = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-
-    def build_overlaps():
+    def make_inputs(kind):
+        # every rank owns its own `B` images (weak scaling): rank r draws the images [r*B, (r+1)*B) of the global batch
         if args.dim == 2:
-            return overlaps.iou_batched(boxes, out=iou_buf)
-        return overlaps.iou3d_batched(boxes, from_params=True, nms_overlap=True, out=iou_buf)
-
-    def step():
-        if args.dim == 2 and not args.two_calls:
-            # IoU matrix + forward as ONE library call (gnms_forward_with_iou2d): same kernels' work, the score sort rides in the IoU launch
-            prob = G.differentiable_nms_with_iou2d_batched(scores, boxes, iou_out=iou_buf)[0]
-        elif args.dim == 3 and not args.two_calls:
-            prob = G.differentiable_nms_with_iou3d_batched(scores, boxes, iou_out=iou_buf)[0]      # gnms_forward_with_iou3d
+            b_np, s_np = synthetic.batch_2d(1000 + rank, B, N, kind)
         else:
-            prob = G.differentiable_nms_batched(scores, build_overlaps())[0]
-        scores.grad = None
-        torch.autograd.backward(prob, w)          # dL/dprob = w
-        return prob
+            b_np, s_np = synthetic.batch_3d(1000 + rank, B, N, clustered=(kind == "clustered"))
+        if args.sorted_scores:
+            o = np.argsort(-s_np, axis=1, kind="stable")
+            s_np = np.take_along_axis(s_np, o, axis=1)
+            b_np = np.take_along_axis(b_np, o[:, :, None], axis=1)
+        return np.ascontiguousarray(b_np), np.ascontiguousarray(s_np)
+
+    boxes_np, scores_np = make_inputs(args.kind)
+    w_np = np.linspace(-1.0, 2.0, N).astype(np.float32)                 # dL/dprob, the SAME fp32 values on the GPU and in the oracle
+    w = torch.from_numpy(np.tile(w_np, (B, 1))).to(dev).contiguous()
+    # rotating matrix buffers: the write of step i lands 3+ buffers (> 768 MiB, or 3 buffers) after the last write to the same lines
+    mat_bytes = 4 * B * N * N
+    n_buf = int(min(max(3, -(-(768 << 20) // max(mat_bytes, 1))), 64))
+    iou_bufs = [torch.empty((B, N, N), dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    state = {"i": 0}
+
+    def next_buf():
+        state["i"] = (state["i"] + 1) % n_buf
+        return iou_bufs[state["i"]]
+
+    def make_step(boxes, scores):
+        def build_overlaps(out):
+            if args.dim == 2:
+                return overlaps.iou_batched(boxes, out=out)
+            return overlaps.iou3d_batched(boxes, from_params=True, nms_overlap=True, out=out, nms_threshold=thr)
+
+        def step():
+            buf = next_buf()
+            if args.dim == 2 and not args.two_calls:
+                prob = G.differentiable_nms_with_iou2d_batched(scores, boxes, iou_out=buf)[0]       # gnms_forward_with_iou2d
+            elif args.dim == 3 and not args.two_calls:
+                prob = G.differentiable_nms_with_iou3d_batched(scores, boxes, iou_out=buf)[0]       # gnms_forward_with_iou3d
+            else:
+                prob = G.differentiable_nms_batched(scores, build_overlaps(buf))[0]
+            scores.grad = None
+            torch.autograd.backward(prob, w)          # dL/dprob = w
+            return prob
+        return step, build_overlaps
+
+    boxes = torch.from_numpy(boxes_np).to(dev)
+    scores = torch.from_numpy(scores_np).to(dev).requires_grad_(True)
+    step, build_overlaps = make_step(boxes, scores)
+    eager_step = step
 
     if args.graph:
-        import ctypes
-        from groomed_nms_amd._lib import GnmsParams, ptr, stream_ptr, check
-        Pg = GnmsParams()
-        lib.gnms_default_params(ctypes.byref(Pg))
-        ws_g = torch.empty((lib.gnms_workspace_bytes(B, N, ctypes.byref(Pg)),), dtype=torch.uint8, device=dev)
+        ws_g = torch.empty((lib.gnms_workspace_bytes(B, N, ctypes.byref(P)),), dtype=torch.uint8, device=dev)
         prob_g = torch.empty((B, N), dtype=torch.float32, device=dev)
         grad_g = torch.empty((B, N), dtype=torch.float32, device=dev)
         s_det = scores.detach()
 
-        def raw_step():
+        def raw_step(buf):
             sp = stream_ptr(dev)
             if args.dim == 2 and not args.two_calls:
-                check(lib.gnms_forward_with_iou2d(ptr(boxes), ptr(s_det), B, N, N, None, ctypes.byref(Pg), ptr(iou_buf), ptr(prob_g), None, None,
+                check(lib.gnms_forward_with_iou2d(ptr(boxes), ptr(s_det), B, N, N, None, ctypes.byref(P), ptr(buf), ptr(prob_g), None, None,
                                                   None, None, None, ptr(ws_g), ws_g.numel(), sp), "fwd_with_iou2d")
             elif not args.two_calls:
-                check(lib.gnms_forward_with_iou3d(ptr(boxes), ptr(s_det), B, N, N, None, ctypes.byref(Pg), ptr(iou_buf), ptr(prob_g), None, None,
+                check(lib.gnms_forward_with_iou3d(ptr(boxes), ptr(s_det), B, N, N, None, ctypes.byref(P), ptr(buf), ptr(prob_g), None, None,
                                                   None, None, None, ptr(ws_g), ws_g.numel(), sp), "fwd_with_iou3d")
             else:
                 if args.dim == 2:
-                    check(lib.gnms_iou2d(ptr(boxes), ptr(boxes), B, N, N, ptr(iou_buf), N, sp), "iou2d")
+                    check(lib.gnms_iou2d(ptr(boxes), ptr(boxes), B, N, N, ptr(buf), N, sp), "iou2d")
                 else:
-                    check(lib.gnms_iou3d_from_params(ptr(boxes), ptr(boxes), B, N, N, 2, None, ptr(iou_buf), N, sp), "iou3d")
-                check(lib.gnms_forward(ptr(s_det), ptr(iou_buf), B, N, N, None, ctypes.byref(Pg), ptr(prob_g), None, None, None, None, None,
+                    check(lib.gnms_nms_overlap3d_from_params(ptr(boxes), B, N, thr, ptr(buf), N, sp), "overlap3d")
+                check(lib.gnms_forward(ptr(s_det), ptr(buf), B, N, N, None, ctypes.byref(P), ptr(prob_g), None, None, None, None, None,
                                        ptr(ws_g), ws_g.numel(), sp), "fwd")
-            check(lib.gnms_backward(ptr(w), ptr(s_det), ptr(iou_buf), B, N, N, None, ctypes.byref(Pg), ptr(grad_g), None, ptr(ws_g),
+            check(lib.gnms_backward(ptr(w), ptr(s_det), ptr(buf), B, N, N, None, ctypes.byref(P), ptr(grad_g), None, ptr(ws_g),
                                     ws_g.numel(), sp), "bwd")
 
-        raw_step()
+        raw_step(iou_bufs[0])
         torch.cuda.synchronize()
-        hip_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(hip_graph):
-            raw_step()
-        step = hip_graph.replay       # noqa: F811  one replay = one full step
-    dt = gdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
+        graphs = []
+        for buf in iou_bufs[:3]:                      # one captured step per rotating buffer
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                raw_step(buf)
+            graphs.append(g)
 
-    # ---------------- per-kernel roofline (rank 0), HIP events on the launch stream -----------------
+        def step():   # noqa: F811  one replay = one full step
+            state["i"] = (state["i"] + 1) % len(graphs)
+            graphs[state["i"]].replay()
+
+        def eager_step():   # noqa: F811  the same C-ABI sequence, launched eagerly (events cannot be recorded under replay)
+            raw_step(next_buf())
+
+    heartbeat = gdist.StepHeartbeat(dev)
+    dt = gdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, heartbeat)
+
     out = None
     if rank == 0:
-        import ctypes
-        from groomed_nms_amd._lib import GnmsParams, ptr, stream_ptr, check
-        stream = torch.cuda.current_stream(dev)
+        one_call = not args.two_calls
         per_box = 16.0 if args.dim == 2 else 28.0
-        alg_bytes = B * (4.0 * N * N + 16.0 * N)          # SURVEY 8(d): NMS forward 4N^2 + 16N per image
+        alg_write = B * (4.0 * N * N + per_box * N)       # SURVEY 8(d): IoU-2D 4N^2 + 16N, IoU-3D (params) 4N^2 + 28N per image
+        alg_read = B * (4.0 * N * N + 16.0 * N)           # NMS forward given the matrix: 4N^2 + 16N per image
         if args.sorted_scores:                            # only the columns a leader of the row block can sit in are needed
-            alg_bytes = B * (sum(64 * min(N, 64 * (kb + 1)) for kb in range((N + 63) // 64)) * 4.0 + 16.0 * N)
-        alg_bytes_iou = B * (4.0 * N * N + per_box * N)   # IoU-2D 4N^2 + 16N, IoU-3D (params) 4N^2 + 28N
-        t_iou = event_time_ms(build_overlaps, 20, stream)
-        P = GnmsParams()
-        lib.gnms_default_params(ctypes.byref(P))
-        ws = torch.empty((lib.gnms_workspace_bytes(B, N, ctypes.byref(P)),), dtype=torch.uint8, device=dev)
-        prob = torch.empty((B, N), dtype=torch.float32, device=dev)
-        s_det = scores.detach()
-        check(lib.gnms_forward(ptr(s_det), ptr(iou_buf), B, N, N, None, ctypes.byref(P), ptr(prob), None, None, None, None, None,
-                               ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_forward")
-        t_mask = event_time_ms(lambda: check(lib.gnms_profile_bitmask(ptr(iou_buf), B, N, N, None, P.nms_threshold, ptr(ws),
-                                                                     ws.numel(), stream_ptr(dev)), "bitmask"), 20, stream)
-        t_fwd = event_time_ms(lambda: check(lib.gnms_forward(ptr(s_det), ptr(iou_buf), B, N, N, None, ctypes.byref(P), ptr(prob), None,
-                                                             None, None, None, None, ptr(ws), ws.numel(), stream_ptr(dev)), "fwd"), 20, stream)
-        gs = torch.empty((B, N), dtype=torch.float32, device=dev)
-        t_bwd = event_time_ms(lambda: check(lib.gnms_backward(ptr(w), ptr(s_det), ptr(iou_buf), B, N, N, None, ctypes.byref(P), ptr(gs),
-                                                              None, ptr(ws), ws.numel(), stream_ptr(dev)), "bwd"), 20, stream)
+            alg_read = B * (sum(64 * min(N, 64 * (kb + 1)) for kb in range((N + 63) // 64)) * 4.0 + 16.0 * N)
 
-        # HBM traffic per launch from the committed PMC passes (profiles/), valid only for the configuration they were taken on
+        # ---- roofline: the SAME step sequence once more, the library bracketing its HBM-bound launches with events ----
+        def collect(slot):
+            ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+            check(lib.gnms_profile_collect(slot, ctypes.byref(ms), ctypes.byref(n)), "profile_collect")
+            return ms.value, n.value
+
+        k_roof = max(10, min(args.steps, 200))
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        check(lib.gnms_profile_events(1), "profile_events")
+        for _ in range(k_roof):
+            eager_step()
+        torch.cuda.synchronize()
+        check(lib.gnms_profile_events(0), "profile_events")
+        ms_write, n_write = collect(0)
+        ms_read, n_read = collect(1)
+
+        # achievable ceilings: a plain non-temporal store / load stream over the same rotating buffers
+        def stream_rate(fn, nbytes):
+            stream = torch.cuda.current_stream(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(2):
+                fn(next_buf())
+            torch.cuda.synchronize()
+            e0.record(stream)
+            reps = max(6, 2 * n_buf)
+            for _ in range(reps):
+                fn(next_buf())
+            e1.record(stream)
+            e1.synchronize()
+            return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        sink = torch.zeros(4, dtype=torch.float32, device=dev)
+        n_fl = B * N * N // 4 * 4
+        fill_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill(ptr(b), n_fl, stream_ptr(dev)), "fill"), 4.0 * n_fl) if n_fl else 0.0
+        for b_ in iou_bufs:
+            b_.fill_(0.25)
+        read_gbs = stream_rate(lambda b: check(lib.gnms_profile_read(ptr(b), n_fl, ptr(sink), stream_ptr(dev)), "read"), 4.0 * n_fl) if n_fl else 0.0
+
         pmc = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-                ps = json.load(f)
-            c = ps["config"]
-            if (c["images_per_gpu"], c["boxes_per_image"], c["kind"]) == (B, N, args.kind) and args.dim == 2:
-                pmc = {k: v["traffic_bytes_per_launch"] for k, v in ps["kernels"].items()}
-        except (OSError, KeyError, ValueError):
-            pmc = {}
+        if args.pmc_summary:
+            with open(args.pmc_summary) as f:
+                pmc = json.load(f).get("traffic_bytes_per_launch", {})
 
-        def roof(t_ms, nbytes, kname):
-            ach = nbytes / (t_ms * 1e-3) / 1e9
+        def roof(ms_sum, launches, nbytes_per_step, kname, ceiling, what):
+            if launches == 0 or ms_sum <= 0:
+                return None
+            per_step_ms = ms_sum / k_roof
+            ach = nbytes_per_step / (per_step_ms * 1e-3) / 1e9
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": (round(pmc[kname]) if kname in pmc else None), "algorithmic_bytes": round(nbytes), "kernel_ms": round(t_ms, 4)}
+                    "traffic": (round(pmc[kname]) if kname in pmc else None), "algorithmic_bytes": round(nbytes_per_step),
+                    "kernel": kname, "kernel_ms": round(per_step_ms, 4), "launches_per_step": round(launches / k_roof, 2),
+                    "ceiling": {"what": what, "GB/s": round(ceiling, 1), "frac_of_ceiling": round(ach / ceiling, 4) if ceiling else None},
+                    "measured": "HIP events around the launch inside %d repetitions of the timed step sequence, %d rotating %d-MiB matrix buffers"
+                                % (k_roof, n_buf, mat_bytes >> 20)}
+
+        if args.dim == 2:
+            wname = "iou2d_kernel" if (args.two_calls or not one_call) else lib_write_kernel_name(B, N)
+        else:
+            wname = "iou3d_nms_fast_kernel"
+        r_write = roof(ms_write, n_write, alg_write, wname, fill_gbs, "plain non-temporal float4 store stream (gnms_profile_fill)")
+        r_read = roof(ms_read, n_read, alg_read, "bitmask_kernel", read_gbs, "plain non-temporal float4 load stream (gnms_profile_read)")
 
         total_boxes = world * B * N * args.steps
+        value = total_boxes / dt
         out = {
             "metric": "GrooMeD-NMS fwd+bwd boxes/sec (pairwise IoU + differentiable_nms forward + backward wrt scores)",
-            "value": round(total_boxes / dt, 1),
+            "value": round(value, 1),
             "unit": "boxes/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -209,75 +284,54 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%d images/GPU x %d %s %dD boxes/image, nms_threshold 0.4, linear pruning, grouped+masked, group_size 100"
                                    % (B, N, args.kind, args.dim), "boxes_per_image": N, "images_per_gpu": B,
-                       "scores_presorted": bool(args.sorted_scores), "hip_graph_replay": bool(args.graph), "parallelism": "images sharded, dp%d" % world},
+                       "scores_presorted": bool(args.sorted_scores), "hip_graph_replay": bool(args.graph), "parallelism": "images sharded, dp%d" % world,
+                       "collective": "one 4-byte RCCL all-reduce per step" if world > 1 else "none (1 GPU)",
+                       "matrix_buffers": n_buf},
             "roofline": None,
-            "phase_ms": {"overlaps": round(t_iou, 4), "nms_forward": round(t_fwd, 4), "nms_backward": round(t_bwd, 4)},
+            "reference_cpu_survey": {"value": REF_CPU_SURVEY, "unit": "boxes/s", "ratio_per_gpu": round(value / world / REF_CPU_SURVEY, 1),
+                                     "note": "reference lib/groomed_nms.py + lib/core.py iou on torch CPU, 8 threads, uniform N=4096, measured in the "
+                                             "survey container (BASELINE.md section 2); not a published number, hence vs_baseline null"},
         }
-        iou_name = "iou2d_kernel" if args.dim == 2 else "iou3d_nms_fast_kernel"
-        one_call = not args.two_calls
-        iou_note = (" (one full write of the NxN fp32 matrix; the same tile code runs as iou2d_sort_kernel inside gnms_forward_with_iou2d)"
-                    if args.dim == 2 else " (one full write of the NxN fp32 matrix, + the per-box record kernels in front of it)")
-        r_iou = dict(roof(t_iou, alg_bytes_iou, "iou2d_sort_kernel" if (one_call and "iou2d_sort_kernel" in pmc) else iou_name),
-                     kernel=iou_name + iou_note)
-        r_mask = dict(roof(t_mask, alg_bytes, "bitmask_kernel"), kernel="bitmask_kernel (gnms_forward: one full read of the NxN fp32 matrix)")
         if one_call:
-            # the timed step hands the boxes over, so the layer never reads the matrix back: the matrix write is the dominant kernel
-            out["roofline"], out["roofline_matrix_in"] = r_iou, r_mask
-            entry = G.differentiable_nms_with_iou2d_batched if args.dim == 2 else G.differentiable_nms_with_iou3d_batched
-            t_one = event_time_ms(lambda: entry(s_det, boxes, iou_out=iou_buf), 20, stream)
-            out["phase_ms"] = {"overlaps_plus_nms_forward_one_call": round(t_one, 4), "nms_backward": round(t_bwd, 4),
-                               "separately": {"overlaps": round(t_iou, 4), "nms_forward_matrix_in": round(t_fwd, 4)}}
+            out["roofline"] = r_write
         else:
-            out["roofline"], out["roofline_iou"] = r_mask, r_iou
-        if args.dim == 2:
-            # ---- reported SEPARATELY (never part of `value`): the from-boxes path, same outputs bit for bit, no N x N matrix ----
-            def fused_step():
-                p = G.differentiable_nms_from_boxes_batched(scores, boxes)[0]
-                scores.grad = None
-                torch.autograd.backward(p, w)
-            k_f = max(5, args.steps // 4)
-            for _ in range(3):
-                fused_step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(k_f):
-                fused_step()
-            torch.cuda.synchronize()
-            t_fused = (time.perf_counter() - t0) / k_f
-            prob_b = torch.empty((B, N), dtype=torch.float32, device=dev)
-            check(lib.gnms_forward_from_boxes(ptr(boxes), ptr(s_det), B, N, None, ctypes.byref(P), ptr(prob_b), None, None, None, None, None,
-                                              ptr(ws), ws.numel(), stream_ptr(dev)), "fwd_boxes")      # fills the x-order the kernel needs
-            t_mb = event_time_ms(lambda: check(lib.gnms_profile_bitmask_boxes(ptr(boxes), B, N, None, P.nms_threshold, ptr(ws), ws.numel(),
-                                                                             stream_ptr(dev)), "bitmask_boxes"), 20, stream)
-            pairs = B * N * (N - 1) // 2            # decisions the layer needs: every (leader candidate, lower-ranked box) pair
-            out["fused_from_boxes"] = {
-                "value": round(B * N / t_fused, 1), "unit": "boxes/s (1 GPU, this rank)", "ms_per_step": round(t_fused * 1e3, 4), "steps": k_f,
-                "note": "gnms_forward_from_boxes + gnms_backward_from_boxes: identical outputs (tests/test_gpu_parity.py::"
-                        "test_from_boxes_path_is_bit_identical), the NxN matrix is never materialised; not comparable with `value`",
-                "bitmask_boxes_kernel": {"bound": "fp32-vector, rows culled against the hull of x-sorted column tiles (data dependent)",
-                                         "kernel_ms": round(t_mb, 4), "pair_decisions": pairs,
-                                         "decisions_per_s": round(pairs / (t_mb * 1e-3), 1)}}
+            out["roofline"], out["roofline_iou"] = r_read, r_write
+
+        if world == 1 and not args.no_other_kind and not args.graph:
+            other = "uniform" if args.kind == "clustered" else "clustered"
+            ob_np, os_np = make_inputs(other)
+            ob = torch.from_numpy(ob_np).to(dev)
+            osc = torch.from_numpy(os_np).to(dev).requires_grad_(True)
+            ostep, _ = make_step(ob, osc)
+            k_o = max(10, args.steps // 2)
+            dto = gdist.timed_steps(ostep, k_o, max(3, args.warmup // 2), torch.cuda.synchronize)
+            out["other_kind"] = {"kind": other, "value": round(B * N * k_o / dto, 1), "unit": "boxes/s", "ms_per_step": round(dto / k_o * 1e3, 4),
+                                 "steps": k_o}
+
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
             # the GPU results of the timed entry, for the parity figure BASELINE.json's metric asks for (max |dscore| vs the CPU path)
-            entry = (G.differentiable_nms_with_iou2d_batched if args.dim == 2 else G.differentiable_nms_with_iou3d_batched) \
-                if not args.two_calls else None
             s_par = scores.detach().clone().requires_grad_(True)
-            g_out = entry(s_par, boxes) if entry else G.differentiable_nms_batched(s_par, build_overlaps())
+            if args.two_calls:
+                g_out = G.differentiable_nms_batched(s_par, build_overlaps(iou_bufs[0]))
+            elif args.dim == 2:
+                g_out = G.differentiable_nms_with_iou2d_batched(s_par, boxes)
+            else:
+                g_out = G.differentiable_nms_with_iou3d_batched(s_par, boxes)
             torch.autograd.backward(g_out[0], w)
             g_prob, g_valid, g_nvalid, g_grad = g_out[0].detach().cpu().numpy(), g_out[2].cpu().numpy(), g_out[4].cpu().numpy(), s_par.grad.cpu().numpy()
             d_prob = d_grad = 0.0
             sets_equal, checked = True, 0
             t0 = time.perf_counter()
             k = 0
-            while k < 4 or (time.perf_counter() - t0) < args.cpu_seconds:      # bounded sample: whole images, >= 4 of them
+            while k < min(4, B) or (time.perf_counter() - t0) < args.cpu_seconds:      # bounded sample: whole images
                 b = k % B
                 if args.dim == 2:
                     m = O.iou2d(boxes_np[b], boxes_np[b])
                 else:
                     c = O.corners_of_cuboid(boxes_np[b])
-                    m = 0.5 * (1.0 + O.iou3d_approximate(c, c, generalized=True)[1])
-                res = O.differentiable_nms(scores_np[b], m, grad_prob=np.linspace(-1, 2, N).astype(np.float32))
+                    m = (np.float32(0.5) * (np.float32(1.0) + O.iou3d_approximate(c, c, generalized=True)[1])).astype(np.float32)
+                res = O.differentiable_nms(scores_np[b], m, grad_prob=w_np)
                 if k < B:                                                       # first pass over an image: compare (outside the timed sum)
                     tp = time.perf_counter()
                     d_prob = max(d_prob, float(np.abs(g_prob[b] - res["prob"]).max()))
@@ -299,6 +353,14 @@ def main():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def lib_write_kernel_name(B, N):
+    """Name (as rocprofv3 lists it) of the launch that writes the matrix inside gnms_forward_with_iou2d for this problem size."""
+    from groomed_nms_amd import _lib
+    lib = _lib.load()
+    name = lib.gnms_profile_write_kernel_name(B, N)
+    return name.decode() if name else "iou2d_kernel"
 
 
 if __name__ == "__main__":

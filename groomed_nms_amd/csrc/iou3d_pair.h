@@ -49,11 +49,53 @@ __device__ __forceinline__ f2 nms_overlap3d(const Row& a, const Cols2& b) {
     return (num * rc) * (f2){0.5f, 0.5f};
 }
 
+// The reference's own operation order for the same two columns (lib/core.py:357-419 + lib/loss/rpn_3d.py:781: i3/u3, then
+// - (vh - u3)/vh, then 0.5 * (1 + .)), two IEEE divisions per pair: what iou3d_kernel<METHOD 2> and the CPU oracle compute, bit
+// for bit.  Only the guard band below pays for it.
+__device__ __forceinline__ f2 nms_overlap3d_exact(const Row& a, const Cols2& b) {
+    const f2 vol = splat(a.vol) + b.vol;                                     // :357
+    const f2 yi = relu2(min2(a.y1, b.y1) - max2(a.y0, b.y0));                // :371-376
+    const f2 w = relu2(min2(a.x1, b.x1) - max2(a.x0, b.x0));                 // intersect(bev) :410
+    const f2 h = relu2(min2(a.z1, b.z1) - max2(a.z0, b.z0));
+    const f2 i3 = (w * h) * yi;                                              // :415
+    const f2 u3 = vol - i3;                                                  // :416
+    const f2 xh = relu2(max2(a.x1, b.x1) - min2(a.x0, b.x0));                // :390-406
+    const f2 yh = relu2(max2(a.y1, b.y1) - min2(a.y0, b.y0));
+    const f2 zh = relu2(max2(a.z1, b.z1) - min2(a.z0, b.z0));
+    const f2 vh = (xh * yh) * zh;
+    const f2 e = vh - u3;
+    f2 q;
+    q.x = i3.x / u3.x - e.x / vh.x;                                          // :417-419
+    q.y = i3.y / u3.y - e.y / vh.y;
+    return (f2){0.5f, 0.5f} * ((f2){1.0f, 1.0f} + q);                        // rpn_3d.py:781
+}
+
+// GUARD BAND.  The layer decides `overlap > nms_threshold` (lib/groomed_nms.py:249-250) on the matrix entries, and the re-associated
+// expression above differs from the reference's order by up to ~2e-6 (both are a handful of fp32 roundings of a value in [0, 1]).
+// Entries within kGuard3D = 8e-6 of the threshold (4x that bound) -- and anything that is not a finite value of sane magnitude --
+// are therefore REPLACED by the exact-order value: outside the band both expressions lie on the same side of the threshold, inside
+// it the entry IS the reference's fp32 value, so thresholding the written matrix takes exactly the reference's decisions.  The
+// matrix kernel, the bit-matrix kernels and the single-pair lookups all go through these two functions, hence agree bit for bit.
+// A few dozen pairs per image fall into the band (N = 4096 .. 16384): one wave-uniform branch per row.
+constexpr float kGuard3D = 8e-6f;
+__device__ __forceinline__ bool in_guard3d(float q, float thr) { return !(fabsf(q - thr) > kGuard3D) || !(fabsf(q) <= 2.0f); }
+
+__device__ __forceinline__ f2 nms_overlap3d_guarded(const Row& a, const Cols2& b, float thr) {
+    f2 q = nms_overlap3d(a, b);
+    const bool gx = in_guard3d(q.x, thr), gy = in_guard3d(q.y, thr);
+    if (__any(gx || gy)) {
+        const f2 e = nms_overlap3d_exact(a, b);
+        q.x = gx ? e.x : q.x;
+        q.y = gy ? e.y : q.y;
+    }
+    return q;
+}
+
 // The same overlap for ONE pair of records with per-lane operands (the layer's O(N) single-entry lookups when it runs beside the
-// matrix write instead of after it).  Same operations in the same order as nms_overlap3d, one column wide: with -ffp-contract=off
-// every product, sum and the v_rcp_f32 round exactly as there, and v_min/v_max do not depend on which operand sits in an SGPR, so
-// the result equals the matrix entry bit for bit (tests/test_gpu_parity.py compares the two paths).
-__device__ __forceinline__ float nms_overlap3d_pair(const float* __restrict__ ra, const float* __restrict__ rb) {
+// matrix write instead of after it).  Same operations in the same order as nms_overlap3d / nms_overlap3d_exact, one column wide:
+// with -ffp-contract=off every product, sum, division and the v_rcp_f32 round exactly as there, and v_min/v_max do not depend on
+// which operand sits in an SGPR, so the result equals the matrix entry bit for bit (tests/test_gpu_parity.py compares the paths).
+__device__ __forceinline__ float nms_overlap3d_pair(const float* __restrict__ ra, const float* __restrict__ rb, float thr) {
     const float4 au = reinterpret_cast<const float4*>(ra)[0], av = reinterpret_cast<const float4*>(ra)[1], ae = reinterpret_cast<const float4*>(ra)[2];
     const float4 bu = reinterpret_cast<const float4*>(rb)[0], bv = reinterpret_cast<const float4*>(rb)[1], be = reinterpret_cast<const float4*>(rb)[2];
     const float dx = fminf(av.x, bv.x) - fmaxf(au.w, bu.w);
@@ -67,7 +109,16 @@ __device__ __forceinline__ float nms_overlap3d_pair(const float* __restrict__ ra
     const float vh = (hx * hy) * hz;
     const float num = __builtin_fmaf(u3, u3, i3 * vh);
     const float den = u3 * vh;
-    return (num * __builtin_amdgcn_rcpf(den)) * 0.5f;
+    float q = (num * __builtin_amdgcn_rcpf(den)) * 0.5f;
+    if (in_guard3d(q, thr)) {                                                // exact order (nms_overlap3d_exact, one column wide)
+        const float xh = fmaxf(fmaxf(av.x, bv.x) - fminf(au.w, bu.w), 0.0f);
+        const float yh = fmaxf(fmaxf(au.z, bu.z) - fminf(au.y, bu.y), 0.0f);
+        const float zh = fmaxf(fmaxf(av.z, bv.z) - fminf(av.y, bv.y), 0.0f);
+        const float vhe = (xh * yh) * zh;
+        const float g = i3 / u3 - (vhe - u3) / vhe;
+        q = 0.5f * (1.0f + g);
+    }
+    return q;
 }
 
 }  // namespace gnms_iou3d

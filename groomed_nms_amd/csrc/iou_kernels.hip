@@ -10,6 +10,7 @@
 // leaves the wave as one 1-KiB coalesced global_store_dwordx4 (the 4 waves of a workgroup cover
 // 4 KiB of one row).  Arithmetic follows the oracle/reference operation order exactly and the file
 // is compiled with -ffp-contract=off, so the 2D matrix is bit-identical to torch's CPU result.
+#include "gnms_prof.h"
 #include "iou_tile.h"
 #include "iou3d_pair.h"
 
@@ -216,7 +217,7 @@ using gnms_iou3d::f2;
 template <bool VEC>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M,
                                                                           int N, float* __restrict__ out, long ld, int tile_rows, int row0,
-                                                                          int row_end) {
+                                                                          int row_end, float thr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int img = blockIdx.z;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const 
         float res[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const f2 q = gnms_iou3d::nms_overlap3d(a, cols[h]);
+            const f2 q = gnms_iou3d::nms_overlap3d_guarded(a, cols[h], thr);   // entries near `thr`: the reference's exact order
             res[2 * h] = q.x; res[2 * h + 1] = q.y;
         }
         const size_t roff = (size_t)(i0 + r) * ld;
@@ -269,18 +270,20 @@ void launch_iou3d(const float* ra, const float* rb, int B, int M, int N, float* 
 }
 
 int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, int method, float* bev, float* o3, int64_t ld,
-                       hipStream_t st, bool fast_nms_overlap, int row0 = 0, int row_end = 0x7fffffff) {
+                       hipStream_t st, bool fast_nms_overlap, int row0 = 0, int row_end = 0x7fffffff, float guard_thr = 0.0f) {
     const bool vec = (ld % 4 == 0) && ((uintptr_t)o3 % 16 == 0) && (!bev || (uintptr_t)bev % 16 == 0);
     if (method == 2 && !bev && fast_nms_overlap) {
         const int tr = tile_rows_for(B, M, N);
         if (row_end > M) row_end = M;
         if (row0 >= row_end) return GNMS_OK;
         dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(row_end - row0, tr), B);
-        if (vec) iou3d_nms_fast_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr, row0, row_end);
-        else iou3d_nms_fast_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr, row0, row_end);
+        GnmsProfScope prof(kProfMatrixWrite, st);
+        if (vec) iou3d_nms_fast_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr, row0, row_end, guard_thr);
+        else iou3d_nms_fast_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr, row0, row_end, guard_thr);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
+    GnmsProfScope prof(kProfMatrixWrite, st);
     if (vec) {
         if (method == 0) launch_iou3d<true, 0>(ra, rb, B, M, N, bev, o3, ld, st);
         else if (method == 1) launch_iou3d<true, 1>(ra, rb, B, M, N, bev, o3, ld, st);
@@ -310,8 +313,8 @@ int gnms_internal_records_for_layer(const float* params, int B, int N, float* re
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
-int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, int row0, int row_end) {
-    return iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true, row0, row_end);
+int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int row0, int row_end) {
+    return iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true, row0, row_end, thr);
 }
 // rows [row0, row_end) of every image's square 2D IoU matrix (arguments already checked by the caller)
 int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st, int row0, int row_end) {
@@ -320,6 +323,7 @@ int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64
     if (row0 >= row_end) return GNMS_OK;
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(row_end - row0, tr), B);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    GnmsProfScope prof(kProfMatrixWrite, st);
     if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes, boxes, N, N, out, (long)ld, tr, row0, row_end);
     else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes, boxes, N, N, out, (long)ld, tr, row0, row_end);
     GNMS_CHECK_LAUNCH();
@@ -337,6 +341,7 @@ extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int
     const int tr = tile_rows_for(B, M, N);
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    GnmsProfScope prof(kProfMatrixWrite, st);
     if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr, 0, M);
     else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr, 0, M);
     GNMS_CHECK_LAUNCH();
@@ -481,7 +486,8 @@ static int iou3d_common(const float* in_a, const float* in_b, bool from_params, 
         aabb_from_corners_kernel<<<(unsigned)((na + 255) / 256), 256, 0, st>>>(in_a, (long)na, ra);
         aabb_from_corners_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(in_b, (long)nb, rb);
     }
-    int rc = iou3d_from_records(ra, rb, B, M, N, method, iou_bev, iou_3d, ld, st, from_params);
+    // always the reference's operation order: the caller's later threshold is unknown here (gnms_nms_overlap3d_from_params takes it)
+    int rc = iou3d_from_records(ra, rb, B, M, N, method, iou_bev, iou_3d, ld, st, false);
     hipError_t fe = hipFreeAsync(rec, st);
     if (rc != GNMS_OK) return rc;
     if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }
@@ -496,6 +502,22 @@ extern "C" int gnms_iou3d_approximate(const float* corners_a, const float* corne
 extern "C" int gnms_iou3d_from_params(const float* params_a, const float* params_b, int B, int M, int N, int method,
                                       float* iou_bev, float* iou_3d, int64_t ld, void* stream) {
     return iou3d_common(params_a, params_b, true, B, M, N, method, iou_bev, iou_3d, ld, stream);
+}
+
+extern "C" int gnms_nms_overlap3d_from_params(const float* params3d, int B, int N, float nms_threshold, float* out, int64_t ld, void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && N >= 0, "gnms_nms_overlap3d_from_params: negative size");
+    if (B == 0 || N == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(params3d && out, "gnms_nms_overlap3d_from_params: null pointer");
+    GNMS_CHECK_ARG(ld >= N, "gnms_nms_overlap3d_from_params: ld < N");
+    hipStream_t st = (hipStream_t)stream;
+    float* rec = nullptr;
+    GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * kRec * sizeof(float), st));
+    int rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st);
+    if (!rc) rc = iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true, 0, 0x7fffffff, nms_threshold);
+    const hipError_t fe = hipFreeAsync(rec, st);
+    if (rc != GNMS_OK) return rc;
+    if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }
+    return GNMS_OK;
 }
 
 extern "C" int gnms_project_boxes3d(const float* params, const float* p2, const float* scale, int B, int N, float* boxes2d, void* stream) {

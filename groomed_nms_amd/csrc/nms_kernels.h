@@ -284,13 +284,14 @@ constexpr int kFromBoxes = 1;      // src = the image's boxes [N][4]: lib/core.p
 constexpr int kFromRecords = 2;    // src = the image's corner-AABB records [N][12]: 0.5 * (1 + GIoU3D) recomputed (iou3d_pair.h)
 
 // element [ca][cb] (input indices)
+// thr: the layer's nms_threshold (records only: entries inside the guard band around it take the reference's exact order, iou3d_pair.h)
 template <int SRC>
-__device__ __forceinline__ float overlap_at(const float* __restrict__ src, long ld, int ca, int cb) {
+__device__ __forceinline__ float overlap_at(const float* __restrict__ src, long ld, int ca, int cb, float thr) {
     if (SRC == kFromBoxes) {
         const float4* bx = reinterpret_cast<const float4*>(src);
         return pair_iou(bx[ca], bx[cb]);
     }
-    if (SRC == kFromRecords) return gnms_iou3d::nms_overlap3d_pair(src + (size_t)ca * gnms_iou3d::kRec, src + (size_t)cb * gnms_iou3d::kRec);
+    if (SRC == kFromRecords) return gnms_iou3d::nms_overlap3d_pair(src + (size_t)ca * gnms_iou3d::kRec, src + (size_t)cb * gnms_iou3d::kRec, thr);
     return src[(size_t)ca * ld + cb];
 }
 
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_kernel(int N, const int* __
             const unsigned bit = 1u << rr;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f2 q = nms_overlap3d(a, cols[h]);
+                const f2 q = nms_overlap3d_guarded(a, cols[h], thr);
                 wd[half][2 * h] |= !(q.x <= thr) ? bit : 0u;
                 wd[half][2 * h + 1] |= !(q.y <= thr) ? bit : 0u;
             }
@@ -842,7 +843,7 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
                 const unsigned bit = 1u << rr;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const f2 q = nms_overlap3d(a, cols[h]);
+                    const f2 q = nms_overlap3d_guarded(a, cols[h], thr);
                     wd[half][2 * h] |= !(q.x <= thr) ? bit : 0u;
                     wd[half][2 * h + 1] |= !(q.y <= thr) ? bit : 0u;
                 }
@@ -1101,7 +1102,7 @@ __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
 // every rank with the leader that removed it (plead[k], groups_kernel's membership test) -- as a prologue of groups_kernel these
 // N dependent gathers ran on ONE CU (50 us of its 180 at N=16384).  `src`: see kFromMatrix / kFromBoxes / kFromRecords.
 template <int SRC>
-__device__ __forceinline__ void attribute_body(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, char* ws,
+__device__ __forceinline__ void attribute_body(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, float thr, char* ws,
                                                gnms_ws_layout L, const int b, const int kb, const int lane) {
     __shared__ int att_lead[16][64];                   // per wave: ordinal of the leader that claimed rank k0 + i
     int* my_lead = att_lead[(threadIdx.x >> 6) & 15];
@@ -1142,14 +1143,14 @@ __device__ __forceinline__ void attribute_body(const float* __restrict__ src, lo
         const int g = my_lead[lane];                  // every rank is claimed: by an earlier leader, or by itself
         I.gpos[k] = g;                                // ordinal of the leader (groups_kernel's sort key; it overwrites gpos afterwards)
         const float* m = overlap_src<SRC>(src, I, b, N, ld);
-        I.plead[k] = overlap_at<SRC>(m, ld, I.order[k], I.leadc[g]);    // likewise overwritten by groups_kernel's own plead
+        I.plead[k] = overlap_at<SRC>(m, ld, I.order[k], I.leadc[g], thr);    // likewise overwritten by groups_kernel's own plead
     }
 }
 
 template <int SRC>
-__global__ __launch_bounds__(64) void attribute_kernel(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, char* ws,
-                                                       gnms_ws_layout L) {
-    attribute_body<SRC>(src, ld, N, counts, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
+__global__ __launch_bounds__(64) void attribute_kernel(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, float thr,
+                                                       char* ws, gnms_ws_layout L) {
+    attribute_body<SRC>(src, ld, N, counts, thr, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1283,7 +1284,7 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
             int ch;
             if (h != lr) {                                           // the leader itself is not a member (NaN / <= thr diagonal)
                 ch = I.order[h];
-                v = overlap_at<SRC>(m, ld, ck, ch);
+                v = overlap_at<SRC>(m, ld, ck, ch, thr);
                 sh = I.sscore[h];
             } else {
                 ch = -1;
@@ -1513,7 +1514,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     const int b = blockIdx.x;
     leaders_body(N, counts, ws, L, b);
     __syncthreads();
-    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<SRC>(src, ld, N, counts, ws, L, b, kb, threadIdx.x & 63);
+    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63);
     __syncthreads();
     groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
     __syncthreads();

@@ -7,6 +7,9 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <atomic>
+#include <vector>
+#include "gnms_prof.h"
 #include "iou_tile.h"
 #include "nms_solve_kernels.h"
 
@@ -26,6 +29,107 @@ void gnms_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* gnms_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// profiling: event pairs around the HBM-bound launches (bench.py's roofline is computed from these)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ProfState {
+    std::atomic<bool> armed{false};
+    std::mutex mu;
+    std::vector<hipEvent_t> pool;                                  // recycled events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs[kProfSlots];
+    hipEvent_t open_start[kProfSlots] = {nullptr, nullptr};
+    hipEvent_t take() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+};
+ProfState& prof() { static ProfState P; return P; }
+}  // namespace
+
+bool gnms_prof_armed() { return prof().armed.load(std::memory_order_relaxed); }
+void gnms_prof_begin(int slot, hipStream_t st) {
+    ProfState& P = prof();
+    std::lock_guard<std::mutex> lock(P.mu);
+    hipEvent_t e = P.take();
+    if (!e) return;
+    if (hipEventRecord(e, st) != hipSuccess) { P.pool.push_back(e); return; }
+    P.open_start[slot] = e;
+}
+void gnms_prof_end(int slot, hipStream_t st) {
+    ProfState& P = prof();
+    std::lock_guard<std::mutex> lock(P.mu);
+    hipEvent_t s0 = P.open_start[slot];
+    P.open_start[slot] = nullptr;
+    if (!s0) return;
+    hipEvent_t e = P.take();
+    if (!e || hipEventRecord(e, st) != hipSuccess) { if (e) P.pool.push_back(e); P.pool.push_back(s0); return; }
+    P.pairs[slot].emplace_back(s0, e);
+}
+
+extern "C" int gnms_profile_events(int enable) {
+    prof().armed.store(enable != 0, std::memory_order_relaxed);
+    return GNMS_OK;
+}
+
+extern "C" int gnms_profile_collect(int slot, double* ms_sum, int* launches) {
+    GNMS_CHECK_ARG(slot >= 0 && slot < kProfSlots && ms_sum && launches, "gnms_profile_collect: bad argument");
+    ProfState& P = prof();
+    std::lock_guard<std::mutex> lock(P.mu);
+    double sum = 0.0;
+    int n = 0;
+    for (auto& pr : P.pairs[slot]) {
+        float ms = 0.0f;
+        GNMS_CHECK_HIP(hipEventSynchronize(pr.second));
+        GNMS_CHECK_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+        sum += ms;
+        ++n;
+        P.pool.push_back(pr.first);
+        P.pool.push_back(pr.second);
+    }
+    P.pairs[slot].clear();
+    *ms_sum = sum;
+    *launches = n;
+    return GNMS_OK;
+}
+
+namespace {
+// plain streams: what the HBM delivers to a kernel that does nothing else (the achievable ceiling the roofline is quoted beside)
+__global__ __launch_bounds__(512) void prof_fill_kernel(float4* __restrict__ dst, size_t n4, float v) {
+    const float4 x = make_float4(v, v, v, v);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float* p = reinterpret_cast<float*>(dst + i);
+        __builtin_nontemporal_store(x.x, p); __builtin_nontemporal_store(x.y, p + 1);
+        __builtin_nontemporal_store(x.z, p + 2); __builtin_nontemporal_store(x.w, p + 3);
+    }
+}
+__global__ __launch_bounds__(512) void prof_read_kernel(const float4* __restrict__ src, size_t n4, float* __restrict__ sink) {
+    float acc = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float* p = reinterpret_cast<const float*>(src + i);
+        acc += __builtin_nontemporal_load(p) + __builtin_nontemporal_load(p + 1) + __builtin_nontemporal_load(p + 2) + __builtin_nontemporal_load(p + 3);
+    }
+    if (acc == 123456.789f) *sink = acc;                          // never true for the data it is run on; keeps the loads alive
+}
+}  // namespace
+
+extern "C" int gnms_profile_fill(float* dst, size_t count, void* stream) {
+    GNMS_CHECK_ARG(dst && count % 4 == 0 && (uintptr_t)dst % 16 == 0, "gnms_profile_fill: dst must be 16-byte aligned, count a multiple of 4");
+    if (count == 0) return GNMS_OK;
+    prof_fill_kernel<<<256 * 16, 512, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(dst), count / 4, 0.5f);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+extern "C" int gnms_profile_read(const float* src, size_t count, float* sink, void* stream) {
+    GNMS_CHECK_ARG(src && sink && count % 4 == 0 && (uintptr_t)src % 16 == 0, "gnms_profile_read: src must be 16-byte aligned, count a multiple of 4");
+    if (count == 0) return GNMS_OK;
+    prof_read_kernel<<<256 * 16, 512, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(src), count / 4, sink);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
 extern "C" int gnms_abi_version(void) { return GNMS_ABI_VERSION; }
 
 extern "C" void gnms_default_params(gnms_params* p) {
@@ -115,15 +219,18 @@ int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* coun
                  hipStream_t st) {
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
     dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
-    if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
-    else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
+    {
+        GnmsProfScope prof(kProfMatrixRead, st);
+        if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
+        else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
+    }
     GNMS_CHECK_LAUNCH();
     const size_t lds = leaders_lds_bytes(N);
     int rc = allow_lds(leaders_kernel, lds);
     if (rc) return rc;
     leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, ws, L);
+    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, thr, ws, L);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -293,8 +400,11 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N)) {
         const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
         dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
-        if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, P.nms_threshold, ws, L);
-        else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, P.nms_threshold, ws, L);
+        {
+            GnmsProfScope prof(kProfMatrixRead, st);
+            if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, P.nms_threshold, ws, L);
+            else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, P.nms_threshold, ws, L);
+        }
         GNMS_CHECK_LAUNCH();
         return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
     }
@@ -424,6 +534,22 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
                        void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted, const MatrixWrite* mw = nullptr);
 }
 
+namespace {
+// fused launch: sort on 512 threads (P2 >= 512), <= 32 KiB of LDS per workgroup (P2 <= 4096), one sort workgroup per image in the last slice
+bool sorts_ride_in_iou_launch(int B, int N) {
+    const int P2 = next_pow2(N);
+    return B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 &&
+           (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::tile_rows_for(B, N, N)) >= 2 * B;
+}
+}  // namespace
+
+// name, as a kernel trace lists it, of the launch that writes the matrix inside gnms_forward_with_iou2d (default parameters, aligned boxes)
+extern "C" const char* gnms_profile_write_kernel_name(int B, int N) {
+    if (B <= 0 || N <= 0) return "";
+    if (!use_side_stream(B, N, N) && sorts_ride_in_iou_launch(B, N)) return "iou2d_sort_kernel";
+    return "iou2d_kernel";
+}
+
 // The matrix is an OUTPUT here, so the layer does not have to read it back: with the boxes at hand the grouped modes
 // take their threshold bits and the few P[i, head] entries straight from the boxes (bit-identical arithmetic, the
 // from-boxes kernels), which replaces the 537 MB read of bitmask_kernel (~100 us at B=8, N=4096) by bitmask_boxes_kernel
@@ -436,11 +562,9 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     if (rc) return rc;
     if (B > 0 && N > 0) GNMS_CHECK_ARG(boxes && scores && iou_out && prob, "gnms_forward_with_iou2d: null pointer");
     const int P2 = next_pow2(N);
-    // fused launch: sort on 512 threads (P2 >= 512), <= 32 KiB of LDS per workgroup (P2 <= 4096), one sort workgroup per image in slice 0
     const bool from_boxes = params->group_boxes && !params->presorted && ((uintptr_t)boxes % 16 == 0);
     const bool beside = B > 0 && N > 0 && from_boxes && params->mask_group_boxes && use_side_stream(B, N, ld);
-    const bool fuse = B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 && ((uintptr_t)boxes % 16 == 0) && !beside &&
-                      (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::tile_rows_for(B, N, N)) >= 2 * B;
+    const bool fuse = ((uintptr_t)boxes % 16 == 0) && !beside && sorts_ride_in_iou_launch(B, N);
     if (!fuse) {
         if (beside) {
             const MatrixWrite mw = {iou_out, ld};
@@ -469,11 +593,14 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
         else iou2d_sort_kernel<false, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,                  \
                                                                          (char*)workspace, L, P2, (long long*)order, xs, tr);          \
     } while (0)
-    switch (P2 / threads) {
-        case 1: GNMS_LAUNCH_FUSED(1); break;
-        case 2: GNMS_LAUNCH_FUSED(2); break;
-        case 4: GNMS_LAUNCH_FUSED(4); break;
-        default: GNMS_LAUNCH_FUSED(8); break;
+    {
+        GnmsProfScope prof(kProfMatrixWrite, st);
+        switch (P2 / threads) {
+            case 1: GNMS_LAUNCH_FUSED(1); break;
+            case 2: GNMS_LAUNCH_FUSED(2); break;
+            case 4: GNMS_LAUNCH_FUSED(4); break;
+            default: GNMS_LAUNCH_FUSED(8); break;
+        }
     }
 #undef GNMS_LAUNCH_FUSED
     GNMS_CHECK_LAUNCH();
@@ -487,7 +614,7 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
 // defined in iou_kernels.hip
 int gnms_internal_records_from_params(const float* params, long count, float* rec, hipStream_t st);
 int gnms_internal_records_for_layer(const float* params, int B, int N, float* rec, char* ws, const gnms_ws_layout& L, float* xkeys, hipStream_t st);
-int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, int row0 = 0, int row_end = 0x7fffffff);
+int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int row0 = 0, int row_end = 0x7fffffff);
 
 namespace {
 // everything of gnms_forward_with_iou3d that uses the temporary `rec` ([B][N] records, then [B][N] pseudo boxes for the x sort).
@@ -500,12 +627,12 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     int rc;
     if (!from_rec) {
         if ((rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st))) return rc;
-        return gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st);
+        return gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st, P.nms_threshold);
     }
     float* xkeys = rec + (size_t)B * N * gnms_iou3d::kRec;         // [B][N] pseudo boxes
     if ((rc = gnms_internal_records_for_layer(params3d, B, N, rec, ws, L, xkeys, st))) return rc;
     const bool beside = use_side_stream(B, N, ld);
-    if (!beside && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st))) return rc;
+    if (!beside && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st, P.nms_threshold))) return rc;
     const int P2 = next_pow2(N);
     if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
     SideScope scope(st);
@@ -513,7 +640,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     if (r1 > 0) {                                                 // first part of the write beside the bit-matrix kernel
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 0))) return rc;
-        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, 0, r1))) return rc;
+        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, r1))) return rc;
     }
     if (!(P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY)) {
         // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
@@ -530,7 +657,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 1))) return rc;
         if ((rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st))) return rc;
-        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, r1, N))) return rc;
+        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, r1, N))) return rc;
         return scope.join();
     }
     if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
@@ -538,7 +665,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
     leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, ws, L);
+    attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L);
     GNMS_CHECK_LAUNCH();
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
@@ -696,7 +823,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
     leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<true><<<dim3(L.NB, B), 64, 0, st>>>(boxes, (long)N, N, counts, ws, L);
+    attribute_kernel<true><<<dim3(L.NB, B), 64, 0, st>>>(boxes, (long)N, N, counts, P.nms_threshold, ws, L);
     GNMS_CHECK_LAUNCH();
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(groups_kernel<E, true>, sort_lds))) return rc;
@@ -849,6 +976,31 @@ __global__ void prune_kernel(const float* __restrict__ x, long long count, float
         out[i] = gnms_prune(x[i], thr, temp, method);
 }
 }  // namespace
+
+namespace {
+__global__ void prune_grad_kernel(const float* __restrict__ x, const float* __restrict__ g, long long count, float thr, float temp, int method,
+                                  float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+        out[i] = g[i] * gnms_prune_grad(x[i], thr, temp, method);
+}
+}  // namespace
+
+extern "C" int gnms_pruning_function_backward(const float* iou, const float* grad_out, int64_t count, float nms_threshold, float temperature,
+                                              int pruning_method, float* grad_iou, void* stream) {
+    if (pruning_method < 0 || pruning_method > 2) {
+        gnms_set_error("gnms_pruning_function_backward: Pruning method not implemented! (pruning_method=%d)", pruning_method);
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    GNMS_CHECK_ARG(count >= 0, "gnms_pruning_function_backward: negative count");
+    if (count == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(iou && grad_out && grad_iou, "gnms_pruning_function_backward: null pointer");
+    long long blocks = (count + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    prune_grad_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(iou, grad_out, (long long)count, nms_threshold, temperature,
+                                                                         pruning_method, grad_iou);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
 
 extern "C" int gnms_pruning_function(const float* iou, int64_t count, float nms_threshold, float temperature, int pruning_method,
                                      float* out, void* stream) {

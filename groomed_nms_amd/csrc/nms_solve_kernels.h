@@ -74,12 +74,12 @@ __global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restri
         if (tiled) {
             for (int e = tid; e < g * g; e += T) {
                 const int a = e / g, bb = e - a * g;
-                Pl[a * ts + bb] = (bb < a) ? gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb]), P.nms_threshold, P.temperature, P.pruning_method) : 0.0f;
+                Pl[a * ts + bb] = (bb < a) ? gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb], P.nms_threshold), P.nms_threshold, P.temperature, P.pruning_method) : 0.0f;
             }
             __syncthreads();
         }
         auto Pab = [&](int a, int bb) -> float {
-            return tiled ? Pl[a * ts + bb] : gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb]), P.nms_threshold, P.temperature, P.pruning_method);
+            return tiled ? Pl[a * ts + bb] : gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb], P.nms_threshold), P.nms_threshold, P.temperature, P.pruning_method);
         };
         if (!BWD) {
             for (int bb = 0; bb < g - 1; ++bb) {
@@ -135,7 +135,9 @@ __device__ __forceinline__ float mail_get(const u64* slot) {
     while (((w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0) __builtin_amdgcn_s_sleep(1);
     return __uint_as_float((unsigned)(w & 0xffffffffu));
 }
-__host__ __device__ inline size_t ungrouped_ld(int N) { return (size_t)((N + 3) & ~3); }
+// row pitch of the scratch matrix: whole 64-column tiles, because the solves load the diagonal tile of the last row block in full
+// (columns i0 .. i0+63; the entries past N are never used, but they must lie inside the allocation)
+__host__ __device__ inline size_t ungrouped_ld(int N) { return (size_t)((N + 63) & ~63); }
 __host__ __device__ inline size_t ungrouped_scratch_bytes(int B, int N) { return (size_t)B * N * ungrouped_ld(N) * sizeof(float); }
 
 __global__ __launch_bounds__(1024) void ungrouped_prepare_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws,

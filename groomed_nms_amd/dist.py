@@ -65,18 +65,70 @@ def sum_over_ranks(value, device=None):
     return float(t.item())
 
 
-def timed_steps(step, steps, warmup, sync):
+class StepHeartbeat:
+    """The one collective of the pure-NMS scaling runs: a 4-byte all-reduce (SUM of the number of steps each rank
+    has finished) after every step, so that the 1 -> 8 GPU curve contains a real RCCL round trip per iteration.  Enqueued on the
+    compute stream like DDP's gradient all-reduce would be; no host synchronisation.  A no-op when torch.distributed is not
+    initialised.  `check()` (after the timed region) verifies that every rank contributed every step."""
+
+    def __init__(self, device=None):
+        self.on = dist.is_available() and dist.is_initialized()
+        self.steps = 0
+        if self.on:
+            if device is None:
+                device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            self.one = torch.ones(1, dtype=torch.int32, device=device)
+            self.acc = torch.zeros(1, dtype=torch.int32, device=device)
+            self.buf = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def beat(self):
+        self.steps += 1
+        if self.on:
+            self.buf.copy_(self.one)
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)          # 4 bytes over RCCL / xGMI
+            self.acc.add_(self.buf)
+
+    def check(self):
+        if self.on and int(self.acc.item()) != self.steps * dist.get_world_size():
+            raise RuntimeError("step heartbeat: %d contributions, expected %d x %d" % (int(self.acc.item()), self.steps, dist.get_world_size()))
+
+
+def timed_steps(step, steps, warmup, sync, heartbeat=None):
     """warmup untimed steps, then exactly `steps` timed ones bracketed by barrier + device sync on both sides.
-    Returns the MAX over ranks of the elapsed seconds."""
+    Returns the MAX over ranks of the elapsed seconds.  heartbeat: a StepHeartbeat, beaten after every step."""
     for _ in range(warmup):
         step()
+        if heartbeat is not None:
+            heartbeat.beat()
     sync()
     barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+        if heartbeat is not None:
+            heartbeat.beat()
     sync()
     barrier()
     sync()
-    return max_over_ranks(time.perf_counter() - t0)
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    if heartbeat is not None:
+        heartbeat.check()
+    return elapsed
+
+
+def relaunch_under_torchrun(gpus, script, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) under torch.distributed.run on this node
+    and return their exit code.  The driver may also launch the ranks itself (WORLD_SIZE is then set and this is not called)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd, env=env)

@@ -139,9 +139,15 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
                         ptr(valid), ptr(invalid), ptr(nvalid), ptr(ninvalid), ptr(ws), ws.numel(), stream_ptr(dev)), what)
         ctx.params = params
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(scores_c, counts, ws)
-        ctx.iou = iou            # an OUTPUT without grad_fn (non-differentiable): a plain attribute avoids the saved-output bookkeeping
         ctx.mark_non_differentiable(*[x for x in (order, valid, invalid, nvalid, ninvalid, iou) if x is not None])
+        # The masked-group backward (the default) never reads the overlaps, so the matrix is not kept at all.  The unmasked / ungrouped
+        # backward does read it: there it is saved through autograd, whose version counter then catches a caller that overwrites the
+        # (possibly caller-provided) `iou_out` buffer between forward and backward instead of silently producing wrong gradients.
+        ctx.reads_iou = not (params.group_boxes and params.mask_group_boxes)
+        if ctx.reads_iou:
+            ctx.save_for_backward(scores_c, counts, ws, iou)
+        else:
+            ctx.save_for_backward(scores_c, counts, ws)
         return prob, order, valid, invalid, nvalid, ninvalid, iou
 
     @staticmethod
@@ -149,8 +155,11 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         if grad_prob is None:
             return None, None, None, None, None
         lib = _lib.load()
-        scores_c, counts, ws = ctx.saved_tensors
-        iou_c = ctx.iou
+        if ctx.reads_iou:
+            scores_c, counts, ws, iou_c = ctx.saved_tensors
+        else:
+            scores_c, counts, ws = ctx.saved_tensors
+            iou_c = scores_c                                   # any valid device pointer: the masked backward does not dereference it
         B, N = scores_c.shape
         dev = scores_c.device
         grad_prob = grad_prob.contiguous().float()
@@ -217,15 +226,24 @@ class _SoftSortFunction(torch.autograd.Function):
         soft_scores = torch.empty((N,), dtype=torch.float32, device=dev)
         soft_matrix = None
         m_c, ld = None, N
+        square = True
         if matrix is not None:
+            # the reference multiplies C [N,N] into any [N,K] matrix (lib/groomed_nms.py:163 torch.matmul); the fused entry takes the
+            # square case (the layer's), other widths run the convex-combination kernel and then the GEMM with ldb = K
+            if matrix.dim() != 2 or matrix.shape[0] != N:
+                raise ValueError("soft_sort: full_matrix must be [N, K] with N = len(scores) = %d, got %s" % (N, tuple(matrix.shape)))
             m_c = matrix.contiguous()
-            soft_matrix = torch.empty((N, N), dtype=torch.float32, device=dev)
+            square = m_c.shape[1] == N
+            if square:
+                soft_matrix = torch.empty((N, N), dtype=torch.float32, device=dev)
         one = GnmsParams()
         lib.gnms_default_params(ctypes.byref(one))
         ws = torch.empty((max(lib.gnms_workspace_bytes(1, max(N, 1), ctypes.byref(one)), 256),), dtype=torch.uint8, device=dev)
         with on_device(dev):
-            check(lib.gnms_soft_sort(ptr(scores_c), ptr(m_c), N, ld, float(temperature), ptr(C), ptr(soft_scores), ptr(soft_matrix),
-                                     ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_soft_sort")
+            check(lib.gnms_soft_sort(ptr(scores_c), ptr(m_c) if square else None, N, ld, float(temperature), ptr(C), ptr(soft_scores),
+                                     ptr(soft_matrix), ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_soft_sort")
+        if matrix is not None and not square:
+            soft_matrix = _sgemm(C, m_c) if (N > 0 and m_c.shape[1] > 0) else torch.zeros_like(m_c)
         ctx.temperature = float(temperature)
         ctx.set_materialize_grads(False)
         ctx.has_matrix = matrix is not None
@@ -262,6 +280,35 @@ class _SoftSortFunction(torch.autograd.Function):
         d_s = d_s + (dA * (-sg)).sum(dim=0)
         d_s = d_s.index_add(0, order, (dA * sg).sum(dim=1))
         return d_s, (d_m if ctx.has_matrix else None), None
+
+
+class _PruneFunction(torch.autograd.Function):
+    """pruning_function (lib/groomed_nms.py:167-189) on the HIP kernel with its adjoint, so that a caller composing it in an
+    autograd graph gets the gradient the reference's plain torch ops would give."""
+
+    @staticmethod
+    def forward(ctx, x, nms_threshold, temperature, method):
+        lib = _lib.load()
+        xc = x.contiguous()
+        out = torch.empty_like(xc)
+        with on_device(xc.device):
+            check(lib.gnms_pruning_function(ptr(xc), xc.numel(), float(nms_threshold), float(temperature), method, ptr(out),
+                                            stream_ptr(xc.device)), "gnms_pruning_function")
+        ctx.save_for_backward(xc)
+        ctx.args = (float(nms_threshold), float(temperature), method)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (xc,) = ctx.saved_tensors
+        gc = g.contiguous().float()
+        gi = torch.empty_like(xc)
+        thr, temp, method = ctx.args
+        with on_device(xc.device):
+            check(lib.gnms_pruning_function_backward(ptr(xc), ptr(gc), xc.numel(), thr, temp, method, ptr(gi), stream_ptr(xc.device)),
+                  "gnms_pruning_function_backward")
+        return gi, None, None, None
 
 
 def _sgemm(a, b):
@@ -428,15 +475,10 @@ def pruning_function(iou, nms_threshold=0.4, temperature=0.01, pruning_method="l
         return 1 - np.exp(-np.power(iou, 2) / temperature)
     if pruning_method == "linear":
         return iou                                                            # :173-174 (same tensor, as the reference)
-    lib = _lib.load()
     out_device = iou.device
     dev = out_device if out_device.type == "cuda" else _device()
-    x = iou.detach().to(device=dev, dtype=torch.float32).contiguous()
-    out = torch.empty_like(x)
-    with on_device(dev):
-        check(lib.gnms_pruning_function(ptr(x), x.numel(), float(nms_threshold), float(temperature), _PRUNE[pruning_method],
-                                        ptr(out), stream_ptr(dev)), "gnms_pruning_function")
-    return out.to(out_device)
+    x = iou.to(device=dev, dtype=torch.float32)                           # differentiable moves: the gradient flows back to `iou`
+    return _PruneFunction.apply(x, nms_threshold, temperature, _PRUNE[pruning_method]).to(out_device)
 
 
 def sigmoid_numpy(x):

@@ -97,6 +97,14 @@ int gnms_iou3d_approximate(const float* corners_a, const float* corners_b, int B
 int gnms_iou3d_from_params(const float* params_a, const float* params_b, int B, int M, int N, int method,
                            float* iou_bev, float* iou_3d, int64_t ld, void* stream);
 
+/* The matrix both reference callers hand to the NMS in 3D mode: 0.5 * (1 + GIoU3D) of the cuboids' corner AABBs
+ * (lib/loss/rpn_3d.py:778-781, lib/rpn_util.py:1309-1312), params3d [B][N][7] -> out [B][N][ld], when the caller knows the
+ * threshold the layer will apply.  Same values as gnms_iou3d_from_params(method 2) to within 2e-6, but HBM-write bound instead of
+ * division bound: one reciprocal per pair (0.5 * (i3 vh + u3^2) / (u3 vh)), and every entry within 8e-6 of `nms_threshold` is
+ * replaced by the reference's exact operation order, so that `entry > nms_threshold` takes the reference's decision for every
+ * pair.  gnms_forward_with_iou3d writes its matrix with the same kernel. */
+int gnms_nms_overlap3d_from_params(const float* params3d, int B, int N, float nms_threshold, float* out, int64_t ld, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GrooMeD-NMS layer (lib/groomed_nms.py:10-129), hard sort.  Soft sort = gnms_soft_sort + presorted=1.
  * ------------------------------------------------------------------------------------------- */
@@ -134,7 +142,7 @@ int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int 
                             void* stream);
 
 /* The same for the 3D overlap of lib/loss/rpn_3d.py:778-784 (overlap_in_nms == "3d"): params3d [B][N][7] = x y z w h l ry ->
- * iou_out [B][N][ld] = 0.5 * (1 + GIoU3D) (as gnms_iou3d_from_params, method 2) -> the outputs of gnms_forward.  Grouped + masked
+ * iou_out [B][N][ld] = 0.5 * (1 + GIoU3D) (as gnms_nms_overlap3d_from_params with params->nms_threshold) -> the outputs of gnms_forward.  Grouped + masked
  * hard-sort modes take the threshold bits and the single group overlaps from the cuboid records with the arithmetic that wrote
  * the matrix (no read-back of the 4 N^2 bytes; N > 4096: matrix write on the side stream); the other modes read the matrix.
  * gnms_backward pairs with it unchanged. */
@@ -174,6 +182,22 @@ int gnms_profile_bitmask(const float* iou, int B, int N, int64_t ld, const int32
 int gnms_profile_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float nms_threshold, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Per-launch timing of the two HBM-bound launches inside whatever call sequence the caller runs (bench.py's roofline line).
+ * gnms_profile_events(1) arms it: from then on the library records a HIP event on the launch stream before and after every launch
+ * that writes an N x N overlap matrix (slot GNMS_PROF_MATRIX_WRITE: gnms_iou2d, gnms_iou3d_*, gnms_forward_with_iou2d / _iou3d) and
+ * every launch of the kernel that reads one (slot GNMS_PROF_MATRIX_READ: gnms_forward's bit-matrix kernel).  Two in-stream markers
+ * per launch; not capturable in a HIP graph; one profiling thread at a time.  gnms_profile_collect waits for the recorded events
+ * and returns the SUM of the launch durations (ms) and their number since the last collect.  gnms_profile_events(0) disarms.
+ * gnms_profile_fill / gnms_profile_read: a plain non-temporal float4 store / load stream over `count` floats -- the HBM write /
+ * read rate a kernel that does nothing else reaches on this device (the ceiling the roofline fraction is quoted beside). */
+#define GNMS_PROF_MATRIX_WRITE 0
+#define GNMS_PROF_MATRIX_READ 1
+int gnms_profile_events(int enable);
+int gnms_profile_collect(int slot, double* ms_sum, int* launches);
+const char* gnms_profile_write_kernel_name(int B, int N); /* the launch that writes the matrix in gnms_forward_with_iou2d, as a kernel trace names it */
+int gnms_profile_fill(float* dst, size_t count, void* stream);
+int gnms_profile_read(const float* src, size_t count, float* sink, void* stream);
+
 /* get_groups(iou_unsorted, group_threshold, scores_unsorted, group_size)  lib/groomed_nms.py:208-270 for one
  * image.  group_of[N]: index of the box's group (groups numbered in creation order) or -1 if the box is in
  * no group (beyond the cap, or NaN overlap with its leader); pos_in_group[N]: position inside the group
@@ -185,6 +209,9 @@ int gnms_get_groups(const float* scores, const float* iou, int N, int64_t ld, fl
 /* pruning_function(iou, nms_threshold, temperature, pruning_method)  lib/groomed_nms.py:167-189, elementwise */
 int gnms_pruning_function(const float* iou, int64_t count, float nms_threshold, float temperature, int pruning_method,
                           float* out, void* stream);
+/* its adjoint (the reference differentiates the same expressions with autograd): grad_iou[i] = grad_out[i] * f'(iou[i]) */
+int gnms_pruning_function_backward(const float* iou, const float* grad_out, int64_t count, float nms_threshold, float temperature,
+                                   int pruning_method, float* grad_iou, void* stream);
 
 /* soft_sort(scores, full_matrix, temperature)  lib/groomed_nms.py:131-165 for one image.
  * C [N][N] (convex_comb_matrix, including the reference's last-axis broadcast of the row sums, :155),
@@ -203,7 +230,11 @@ int gnms_sgemm(const float* A, const float* B, float* D, int M, int N, int K, in
 
 /* EXACT reference symbol and contract (lib/nms/gpu_nms.hpp:1-2, lib/nms/nms_kernel.cu:91-144):
  * host pointers, boxes_host is boxes_num x boxes_dim fp32 pre-sorted by descending score,
- * keep_out holds boxes_num ints, blocking.  +1-pixel IoU (:24-32), strict '>' (:71). */
+ * keep_out holds boxes_num ints, blocking.  +1-pixel IoU (:24-32), strict '>' (:71).
+ * Limit: boxes_num <= GNMS_MAX_BOXES (the device-side scan keeps one image's leader state in LDS); above it *num_out = 0 and
+ * gnms_last_error() says so (the Python wrapper gpu_nms raises).  The reference's `use_nms and synced` inference branch
+ * (lib/rpn_util.py:1268) feeds every anchor (> 100 k): pre-select the top-K scores first (gnms_select_topk), as its own
+ * GrooMeD branch does (:1258-1266). */
 void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
           float nms_overlap_thresh, int device_id);
 

@@ -4,6 +4,7 @@ product package never reaches into oracle/."""
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -148,3 +149,16 @@ def test_synthetic_generators_are_deterministic():
     assert np.all(b1[..., 2] > b1[..., 0]) and np.all(b1[..., 3] > b1[..., 1])
     p, _ = synthetic.batch_3d(4, 1, 128)
     assert p.shape == (1, 128, 7)
+
+
+def test_bench_gpus_flag_launches_or_refuses():
+    """bench.py --gpus N is a launcher of its own: without N visible GPUs it exits non-zero with a message (here: no GPU at all),
+    and a launcher-provided WORLD_SIZE that disagrees with --gpus is an error too -- it never silently times fewer GPUs."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
