@@ -102,7 +102,7 @@ extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float t
     const size_t lds = leaders_lds_size(L.NB);
     if (lds > 64 * 1024)
         GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L);
+    leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L, 0);
     GNMS_CHECK_LAUNCH();
     classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);
     GNMS_CHECK_LAUNCH();

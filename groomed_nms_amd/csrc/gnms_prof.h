@@ -1,19 +1,23 @@
-// gnms_prof.h -- per-launch HIP-event timing of the library's HBM-bound launches (gnms_profile_events / gnms_profile_collect).
-// Disarmed (the default) a scope costs one relaxed atomic load.  State lives in nms_layer.hip.
+// gnms_prof.h -- per-launch timing of the library's HBM-bound launches (gnms_profile_events / gnms_profile_collect).
+// Armed, such a launch goes through hipExtLaunchKernel with a start and a stop event: the events then carry the dispatch's own
+// begin / end timestamps -- the interval a kernel trace (rocprofv3 --kernel-trace) reports for it -- without any marker packet in
+// the stream.  Disarmed (the default) a launch costs one relaxed atomic load more than a plain <<<>>>.  State: nms_layer.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 enum { kProfMatrixWrite = 0, kProfMatrixRead = 1, kProfSlots = 2 };
 
 bool gnms_prof_armed();
-void gnms_prof_begin(int slot, hipStream_t st);
-void gnms_prof_end(int slot, hipStream_t st);
+// a fresh (start, stop) event pair registered under `slot`; false if events could not be created (the launch then goes unprofiled)
+bool gnms_prof_pair(int slot, hipEvent_t* start, hipEvent_t* stop);
 
-// brackets the launches issued on `st` during its lifetime with one event pair of slot `slot`
-struct GnmsProfScope {
-    int slot;
-    hipStream_t st;
-    bool on;
-    GnmsProfScope(int s, hipStream_t stream) : slot(s), st(stream), on(gnms_prof_armed()) { if (on) gnms_prof_begin(slot, st); }
-    ~GnmsProfScope() { if (on) gnms_prof_end(slot, st); }
-};
+template <typename... KArgs, typename... Args>
+inline void gnms_launch_prof(int slot, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st, Args... args) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (gnms_prof_armed() && gnms_prof_pair(slot, &e0, &e1)) {
+        hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)lds, st, e0, e1, 0u, static_cast<KArgs>(args)...);
+        return;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, static_cast<KArgs>(args)...);
+}

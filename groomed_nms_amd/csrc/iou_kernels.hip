@@ -265,8 +265,8 @@ template <bool VEC, int METHOD>
 void launch_iou3d(const float* ra, const float* rb, int B, int M, int N, float* bev, float* o3, long ld, hipStream_t st) {
     const int tr = tile_rows_for(B, M, N);
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);
-    if (bev) iou3d_kernel<VEC, METHOD, true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, bev, o3, ld, tr);
-    else iou3d_kernel<VEC, METHOD, false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, nullptr, o3, ld, tr);
+    if (bev) gnms_launch_prof(kProfMatrixWrite, iou3d_kernel<VEC, METHOD, true>, grid, dim3(kWavesPerWG * 64), 0, st, ra, rb, M, N, bev, o3, ld, tr);
+    else gnms_launch_prof(kProfMatrixWrite, iou3d_kernel<VEC, METHOD, false>, grid, dim3(kWavesPerWG * 64), 0, st, ra, rb, M, N, (float*)nullptr, o3, ld, tr);
 }
 
 int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, int method, float* bev, float* o3, int64_t ld,
@@ -277,13 +277,11 @@ int iou3d_from_records(const float* ra, const float* rb, int B, int M, int N, in
         if (row_end > M) row_end = M;
         if (row0 >= row_end) return GNMS_OK;
         dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(row_end - row0, tr), B);
-        GnmsProfScope prof(kProfMatrixWrite, st);
-        if (vec) iou3d_nms_fast_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr, row0, row_end, guard_thr);
-        else iou3d_nms_fast_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(ra, rb, M, N, o3, ld, tr, row0, row_end, guard_thr);
+        if (vec) gnms_launch_prof(kProfMatrixWrite, iou3d_nms_fast_kernel<true>, grid, dim3(kWavesPerWG * 64), 0, st, ra, rb, M, N, o3, (long)ld, tr, row0, row_end, guard_thr);
+        else gnms_launch_prof(kProfMatrixWrite, iou3d_nms_fast_kernel<false>, grid, dim3(kWavesPerWG * 64), 0, st, ra, rb, M, N, o3, (long)ld, tr, row0, row_end, guard_thr);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
-    GnmsProfScope prof(kProfMatrixWrite, st);
     if (vec) {
         if (method == 0) launch_iou3d<true, 0>(ra, rb, B, M, N, bev, o3, ld, st);
         else if (method == 1) launch_iou3d<true, 1>(ra, rb, B, M, N, bev, o3, ld, st);
@@ -323,9 +321,8 @@ int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64
     if (row0 >= row_end) return GNMS_OK;
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(row_end - row0, tr), B);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
-    GnmsProfScope prof(kProfMatrixWrite, st);
-    if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes, boxes, N, N, out, (long)ld, tr, row0, row_end);
-    else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes, boxes, N, N, out, (long)ld, tr, row0, row_end);
+    if (vec) gnms_launch_prof(kProfMatrixWrite, iou2d_kernel<true>, grid, dim3(kWavesPerWG * 64), 0, st, boxes, boxes, N, N, out, (long)ld, tr, row0, row_end);
+    else gnms_launch_prof(kProfMatrixWrite, iou2d_kernel<false>, grid, dim3(kWavesPerWG * 64), 0, st, boxes, boxes, N, N, out, (long)ld, tr, row0, row_end);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -341,9 +338,8 @@ extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int
     const int tr = tile_rows_for(B, M, N);
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
-    GnmsProfScope prof(kProfMatrixWrite, st);
-    if (vec) iou2d_kernel<true><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr, 0, M);
-    else iou2d_kernel<false><<<grid, kWavesPerWG * 64, 0, st>>>(boxes_a, boxes_b, M, N, out, (long)ld, tr, 0, M);
+    if (vec) gnms_launch_prof(kProfMatrixWrite, iou2d_kernel<true>, grid, dim3(kWavesPerWG * 64), 0, st, boxes_a, boxes_b, M, N, out, (long)ld, tr, 0, M);
+    else gnms_launch_prof(kProfMatrixWrite, iou2d_kernel<false>, grid, dim3(kWavesPerWG * 64), 0, st, boxes_a, boxes_b, M, N, out, (long)ld, tr, 0, M);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

@@ -39,7 +39,6 @@ struct ProfState {
     std::mutex mu;
     std::vector<hipEvent_t> pool;                                  // recycled events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs[kProfSlots];
-    hipEvent_t open_start[kProfSlots] = {nullptr, nullptr};
     hipEvent_t take() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
@@ -51,23 +50,15 @@ ProfState& prof() { static ProfState P; return P; }
 }  // namespace
 
 bool gnms_prof_armed() { return prof().armed.load(std::memory_order_relaxed); }
-void gnms_prof_begin(int slot, hipStream_t st) {
+bool gnms_prof_pair(int slot, hipEvent_t* start, hipEvent_t* stop) {
     ProfState& P = prof();
     std::lock_guard<std::mutex> lock(P.mu);
-    hipEvent_t e = P.take();
-    if (!e) return;
-    if (hipEventRecord(e, st) != hipSuccess) { P.pool.push_back(e); return; }
-    P.open_start[slot] = e;
-}
-void gnms_prof_end(int slot, hipStream_t st) {
-    ProfState& P = prof();
-    std::lock_guard<std::mutex> lock(P.mu);
-    hipEvent_t s0 = P.open_start[slot];
-    P.open_start[slot] = nullptr;
-    if (!s0) return;
-    hipEvent_t e = P.take();
-    if (!e || hipEventRecord(e, st) != hipSuccess) { if (e) P.pool.push_back(e); P.pool.push_back(s0); return; }
-    P.pairs[slot].emplace_back(s0, e);
+    hipEvent_t a = P.take(), b = P.take();
+    if (!a || !b) { if (a) P.pool.push_back(a); if (b) P.pool.push_back(b); return false; }
+    P.pairs[slot].emplace_back(a, b);
+    *start = a;
+    *stop = b;
+    return true;
 }
 
 extern "C" int gnms_profile_events(int enable) {
@@ -219,16 +210,13 @@ int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* coun
                  hipStream_t st) {
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
     dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
-    {
-        GnmsProfScope prof(kProfMatrixRead, st);
-        if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
-        else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, thr, ws, L);
-    }
+    if (vec) gnms_launch_prof(kProfMatrixRead, bitmask_kernel<true>, gm, dim3(kMaskWaves * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L);
+    else gnms_launch_prof(kProfMatrixRead, bitmask_kernel<false>, gm, dim3(kMaskWaves * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L);
     GNMS_CHECK_LAUNCH();
     const size_t lds = leaders_lds_bytes(N);
     int rc = allow_lds(leaders_kernel, lds);
     if (rc) return rc;
-    leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L);
+    leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L, 0);
     GNMS_CHECK_LAUNCH();
     attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, thr, ws, L);
     GNMS_CHECK_LAUNCH();
@@ -299,6 +287,65 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
     iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, blockIdx.z, blockIdx.y * tile_rows, blockIdx.x * kWGCols + wave * kWaveCols, lane, tile_rows);
 }
 
+// The per-image chain K3..K6 (leaders -> attribution -> groups + rescoring -> finalize: one workgroup per image, 8 of 256 CUs at
+// B = 8) and the N x N matrix write in ONE launch.  Nothing in the masked from-boxes layer reads the matrix, so the two are
+// independent; as separate launches the chain ran strictly after the write, as two streams the fork and join cost more than the
+// overlap bought.  Here the first `nimg` workgroups ARE tail_kernel (same device functions, 1024 threads) and the
+// rest (one per CU) write the matrix.  The launch asks for the chain's LDS (> 80 KiB), so a CU holds ONE workgroup: the chain
+// workgroups are dispatched first, get a CU each to themselves and run at their stand-alone speed while the other CUs stream the
+// matrix; when a chain workgroup retires, a writer workgroup still waiting in the grid takes its CU.
+template <bool VEC, int E>
+__global__ __launch_bounds__(1024) void tail_iou2d_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts, gnms_params P,
+                                                          char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob,
+                                                          long long* __restrict__ valid, long long* __restrict__ invalid,
+                                                          int* __restrict__ nvalid, int* __restrict__ ninvalid, int nimg,
+                                                          float* __restrict__ out, long ld, int tile_rows, int row0, int row_end, int skip_tail) {
+    if ((int)blockIdx.x < nimg) {
+        if (skip_tail & 1) return;                                  // (developer timing experiment: the writers alone)
+        const int b = blockIdx.x;
+        leaders_body(N, counts, ws, L, b, 1);
+        __syncthreads();
+        for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<kFromBoxes>(boxes, (long)N, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63);
+        __syncthreads();
+        groups_body<E, kFromBoxes>(boxes, N, (long)N, counts, P, ws, L, Ppow2, b);
+        __syncthreads();
+        finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+        return;
+    }
+    using namespace gnms_iou;
+    // PERSISTENT writers: one workgroup per CU for the whole launch (a workgroup that ends leaves its CU empty until the next one has
+    // been placed, and with one workgroup per CU nothing covers that gap).  A workgroup claims CHUNKS of 16 wave tiles (tile_rows x
+    // 256 entries each: tile_rows full rows at N = 4096) from a counter in global memory, one chunk ahead so that the atomic's round
+    // trip hides behind the chunk in progress.  (One claim per WAVE tile serialises on the counter: 16384 device-scope atomics on one
+    // address took 430 us.)  The counter (misc[4] of image 0) was zeroed by the sort kernels of this call.
+    __shared__ int s_next[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncc = (N + kWaveCols - 1) / kWaveCols;
+    const int nrt = (row_end - row0 + tile_rows - 1) / tile_rows;
+    const int per_img = ncc * nrt;
+    const int ntiles = per_img * nimg;
+    const int nchunks = (ntiles + 15) >> 4;
+    int* counter = img_ptrs(ws, L, 0).misc + 4;
+    if (threadIdx.x == 0) s_next[0] = skip_tail < 2 ? atomicAdd(counter, 1) : (int)blockIdx.x - nimg;
+    __syncthreads();
+    int cur = s_next[0], ph = 0;
+    while (cur < nchunks) {
+        int nx = 0;
+        if (threadIdx.x == 0) nx = skip_tail < 2 ? atomicAdd(counter, 1) : cur + (int)gridDim.x - nimg;   // the claim after this one, in flight during the tile
+        const int t = cur * 16 + wave;
+        if (t < ntiles) {
+            const int img = t / per_img;
+            const int r = t - img * per_img;
+            const int rt = r / ncc, cc = r - rt * ncc;
+            iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, img, row0 + rt * tile_rows, cc * kWaveCols, lane, tile_rows, row_end);
+        }
+        if (threadIdx.x == 0) s_next[ph ^ 1] = nx;
+        __syncthreads();
+        ph ^= 1;
+        cur = s_next[ph];
+    }
+}
+
 // bitmask_boxes_kernel: workgroups of 4 wave tiles, (row blocks) x (column chunks) tiles per image; 4 columns per lane
 // (64 x 256 tiles) when that already gives every SIMD a couple of waves, else 1 column per lane (64 x 64 tiles)
 int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
@@ -360,7 +407,7 @@ bool use_tail_kernel(int N) {
 // K3..K6 in one launch (masked groups); SRC/src: kFromMatrix (the matrix), kFromBoxes (the boxes), kFromRecords (src unused)
 template <int BOXES>
 int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* counts, const gnms_params& P, char* ws, const gnms_ws_layout& L,
-                float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, hipStream_t st) {
+                float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, hipStream_t st, int sym) {
     int P2 = next_pow2(N);
     if (P2 < 1024) P2 = 1024;                                   // the fused kernel always runs 1024 threads
     const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
@@ -369,7 +416,54 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(tail_kernel<E, BOXES>, lds))) return rc;
         tail_kernel<E, BOXES><<<B, 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
-                                                    ninvalid);
+                                                    ninvalid, sym);
+    });
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+int device_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    int& c = cus[dev];
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return c;
+}
+
+// K3..K6 of every image + the whole matrix write in one launch (tail_iou2d_kernel)
+int launch_tail_iou2d(const float* boxes, int B, int N, const int32_t* counts, const gnms_params& P, char* ws, const gnms_ws_layout& L,
+                      float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, float* out, int64_t ld, hipStream_t st) {
+    int P2 = next_pow2(N);
+    if (P2 < 1024) P2 = 1024;
+    const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
+    const size_t lds = llds > glds ? llds : glds;
+    static const int forced_rows = [] { const char* e = getenv("GNMS_FUSED_TILE_ROWS"); return e ? atoi(e) : 0; }();
+    static const int skip_tail = [] { const char* e = getenv("GNMS_DEBUG_SKIP_TAIL"); return e ? atoi(e) : 0; }();   // 1: writers only; 2: static chunk striding
+    int tr = forced_rows > 0 ? forced_rows : 16;
+    if (tr > 64) tr = 64;
+    const long tiles = (long)B * gnms_div_up(N, tr) * gnms_div_up(N, gnms_iou::kWaveCols);
+    long writers = (tiles + 15) / 16;                                // persistent writers: at most one per CU
+    const int cus = device_cu_count();
+    if (writers > cus) writers = cus;
+    const dim3 grid((unsigned)(B + writers));
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    int rc;
+    GNMS_DISPATCH_SORT(P2, {
+        if (vec) {
+            if ((rc = allow_lds(tail_iou2d_kernel<true, E>, lds))) return rc;
+            gnms_launch_prof(kProfMatrixWrite, tail_iou2d_kernel<true, E>, grid, dim3(1024), lds, st, boxes, N, counts, P, ws, L, P2, prob,
+                             (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, skip_tail);
+        } else {
+            if ((rc = allow_lds(tail_iou2d_kernel<false, E>, lds))) return rc;
+            gnms_launch_prof(kProfMatrixWrite, tail_iou2d_kernel<false, E>, grid, dim3(1024), lds, st, boxes, N, counts, P, ws, L, P2, prob,
+                             (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, skip_tail);
+        }
     });
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
@@ -400,13 +494,10 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N)) {
         const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
         dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
-        {
-            GnmsProfScope prof(kProfMatrixRead, st);
-            if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, P.nms_threshold, ws, L);
-            else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, st>>>(iou, N, (long)ld, counts, P.nms_threshold, ws, L);
-        }
+        if (vec) gnms_launch_prof(kProfMatrixRead, bitmask_kernel<true>, gm, dim3(kMaskWaves * 64), 0, st, iou, N, (long)ld, counts, P.nms_threshold, ws, L);
+        else gnms_launch_prof(kProfMatrixRead, bitmask_kernel<false>, gm, dim3(kMaskWaves * 64), 0, st, iou, N, (long)ld, counts, P.nms_threshold, ws, L);
         GNMS_CHECK_LAUNCH();
-        return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
+        return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 0);
     }
     if (P.group_boxes) {
         if ((rc = run_grouping(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;
@@ -496,7 +587,7 @@ int side_fork(hipStream_t st, hipStream_t* side, int which = 0) {
     return GNMS_OK;
 }
 // the matrix write that gnms_forward_with_iou2d hands to the from-boxes layer for the side stream
-struct MatrixWrite { float* out; int64_t ld; };
+struct MatrixWrite { float* out; int64_t ld; bool one_launch; };   // one_launch: inside the chain's launch (tail_iou2d_kernel), else on the side stream
 // The write in two launches: rows [0, r) beside the bit-matrix kernel (a VALU-bound kernel of small workgroups, which interleaves
 // with the write's), the rest beside the tail.  r as a percentage of N (GNMS_SPLIT_PCT overrides), rounded down to whole 64-row
 // tiles.  Measured B=8: 2D N=8192 0.625 / 0.575 / 0.568 / 0.595 ms at 0 / 20 / 40 / 50 %, N=16384 2.10 / 2.03 / 2.08 / 2.08;
@@ -543,10 +634,20 @@ bool sorts_ride_in_iou_launch(int B, int N) {
 }
 }  // namespace
 
+namespace {
+// masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_iou2d_kernel).  GNMS_FUSE_TAIL=0/1 forces.
+bool chain_rides_in_write_launch(int B, int N) {
+    static const int forced = [] { const char* e = getenv("GNMS_FUSE_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return forced >= 0 ? forced == 1 : true;
+}
+}  // namespace
+
 // name, as a kernel trace lists it, of the launch that writes the matrix inside gnms_forward_with_iou2d (default parameters, aligned boxes)
 extern "C" const char* gnms_profile_write_kernel_name(int B, int N) {
     if (B <= 0 || N <= 0) return "";
-    if (!use_side_stream(B, N, N) && sorts_ride_in_iou_launch(B, N)) return "iou2d_sort_kernel";
+    if (use_side_stream(B, N, N)) return "iou2d_kernel";
+    if (chain_rides_in_write_launch(B, N)) return "tail_iou2d_kernel";
+    if (sorts_ride_in_iou_launch(B, N)) return "iou2d_sort_kernel";
     return "iou2d_kernel";
 }
 
@@ -564,10 +665,16 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     const int P2 = next_pow2(N);
     const bool from_boxes = params->group_boxes && !params->presorted && ((uintptr_t)boxes % 16 == 0);
     const bool beside = B > 0 && N > 0 && from_boxes && params->mask_group_boxes && use_side_stream(B, N, ld);
-    const bool fuse = ((uintptr_t)boxes % 16 == 0) && !beside && sorts_ride_in_iou_launch(B, N);
+    const bool chain_in_write = B > 0 && N > 0 && from_boxes && params->mask_group_boxes && !beside && chain_rides_in_write_launch(B, N);
+    const bool fuse = ((uintptr_t)boxes % 16 == 0) && !beside && !chain_in_write && sorts_ride_in_iou_launch(B, N);
+    if (chain_in_write) {
+        const MatrixWrite mw = {iou_out, ld, true};
+        return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
+                                  workspace_bytes, stream, false, &mw);
+    }
     if (!fuse) {
         if (beside) {
-            const MatrixWrite mw = {iou_out, ld};
+            const MatrixWrite mw = {iou_out, ld, false};
             return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
                                       workspace_bytes, stream, false, &mw);
         }
@@ -588,19 +695,16 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     const int xs = from_boxes ? 1 : 0;
 #define GNMS_LAUNCH_FUSED(EE)                                                                                                           \
     do {                                                                                                                                \
-        if (vec) iou2d_sort_kernel<true, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,               \
-                                                                            (char*)workspace, L, P2, (long long*)order, xs, tr);       \
-        else iou2d_sort_kernel<false, EE><<<grid, threads, sort_lds, st>>>(boxes, scores, N, counts, iou_out, (long)ld,                  \
-                                                                         (char*)workspace, L, P2, (long long*)order, xs, tr);          \
+        if (vec) gnms_launch_prof(kProfMatrixWrite, iou2d_sort_kernel<true, EE>, grid, dim3(threads), sort_lds, st, boxes, scores, N, counts,   \
+                                  iou_out, (long)ld, (char*)workspace, L, P2, (long long*)order, xs, tr);                              \
+        else gnms_launch_prof(kProfMatrixWrite, iou2d_sort_kernel<false, EE>, grid, dim3(threads), sort_lds, st, boxes, scores, N, counts,      \
+                              iou_out, (long)ld, (char*)workspace, L, P2, (long long*)order, xs, tr);                                  \
     } while (0)
-    {
-        GnmsProfScope prof(kProfMatrixWrite, st);
-        switch (P2 / threads) {
-            case 1: GNMS_LAUNCH_FUSED(1); break;
-            case 2: GNMS_LAUNCH_FUSED(2); break;
-            case 4: GNMS_LAUNCH_FUSED(4); break;
-            default: GNMS_LAUNCH_FUSED(8); break;
-        }
+    switch (P2 / threads) {
+        case 1: GNMS_LAUNCH_FUSED(1); break;
+        case 2: GNMS_LAUNCH_FUSED(2); break;
+        case 4: GNMS_LAUNCH_FUSED(4); break;
+        default: GNMS_LAUNCH_FUSED(8); break;
     }
 #undef GNMS_LAUNCH_FUSED
     GNMS_CHECK_LAUNCH();
@@ -642,7 +746,8 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         if ((rc = scope.fork(&side, 0))) return rc;
         if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, r1))) return rc;
     }
-    if (!(P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY)) {
+    const int sym = (P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY) ? 1 : 0;   // the culled kernel writes full symmetric rows of W
+    if (!sym) {
         // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
         bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
     } else {
@@ -656,14 +761,14 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     if (beside) {                                                 // see forward_boxes_impl for why the fork sits exactly here
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 1))) return rc;
-        if ((rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st))) return rc;
+        if ((rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym))) return rc;
         if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, r1, N))) return rc;
         return scope.join();
     }
-    if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
+    if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);
     const size_t llds = leaders_lds_bytes(N);
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
-    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
+    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, sym);
     GNMS_CHECK_LAUNCH();
     attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L);
     GNMS_CHECK_LAUNCH();
@@ -797,6 +902,10 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
     if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
+    if (mw && mw->one_launch) {
+        if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
+        return launch_tail_iou2d(boxes, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, mw->out, mw->ld, st);
+    }
     SideScope beside(st);
     const int r1 = mw ? split_rows(N, 20) : 0;
     if (r1 > 0) {                        // first part of the write beside the bit-matrix kernel (small workgroups: they interleave)
@@ -813,15 +922,15 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
         // the event (same-queue successor ~2 us, cross-queue event ~25 us), and then keep their CUs until the layer is done.
         hipStream_t side = nullptr;
         if ((rc = beside.fork(&side, 1))) return rc;
-        if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st))) return rc;
+        if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1))) return rc;
         if ((rc = gnms_internal_iou2d_rows(boxes, B, N, mw->out, mw->ld, side, r1, N))) return rc;
         return beside.join();
     }
     if (P.mask_group_boxes && use_tail_kernel(N))
-        return launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st);
+        return launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1);
     const size_t llds = leaders_lds_bytes(N);
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
-    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L);
+    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, 1);      // bitmask_boxes_kernel wrote full symmetric rows
     GNMS_CHECK_LAUNCH();
     attribute_kernel<true><<<dim3(L.NB, B), 64, 0, st>>>(boxes, (long)N, N, counts, P.nms_threshold, ws, L);
     GNMS_CHECK_LAUNCH();
@@ -891,8 +1000,8 @@ extern "C" int gnms_profile_bitmask(const float* iou, int B, int N, int64_t ld, 
     const gnms_ws_layout L = gnms_make_layout(N);
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
     dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
-    if (vec) bitmask_kernel<true><<<gm, kMaskWaves * 64, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
-    else bitmask_kernel<false><<<gm, kMaskWaves * 64, 0, (hipStream_t)stream>>>(iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
+    if (vec) gnms_launch_prof(kProfMatrixRead, bitmask_kernel<true>, gm, dim3(kMaskWaves * 64), 0, (hipStream_t)stream, iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
+    else gnms_launch_prof(kProfMatrixRead, bitmask_kernel<false>, gm, dim3(kMaskWaves * 64), 0, (hipStream_t)stream, iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

@@ -1,0 +1,48 @@
+"""Developer tool: phase breakdown (s_memtime ticks of thread 0 of image 0) of the per-image kernels.  Needs a build with
+GNMS_EXTRA_FLAGS=-DGNMS_TIMING (python -m groomed_nms_amd.build --force); slots are the GNMS_TACC(n) markers in nms_kernels.h."""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from groomed_nms_amd import _lib, synthetic          # noqa: E402
+from groomed_nms_amd._lib import GnmsParams, ptr, check  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--boxes", type=int, default=4096)
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--kind", default="clustered")
+ap.add_argument("--reps", type=int, default=20)
+a = ap.parse_args()
+lib = _lib.load()
+B, N = a.batch, a.boxes
+P = GnmsParams()
+lib.gnms_default_params(ctypes.byref(P))
+boxes_np, scores_np = synthetic.batch_2d(1000, B, N, a.kind)
+boxes, scores = torch.from_numpy(boxes_np).cuda(), torch.from_numpy(scores_np).cuda()
+nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(P))
+ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+prob = torch.empty((B, N), device="cuda")
+iou = torch.empty((B, N, N), device="cuda")
+n4 = (4 * N + 255) // 256 * 256
+off_gx = 15 * n4
+names = {0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store",
+         4: "leaders barrier B", 8: "groups keys", 9: "groups radix", 10: "groups runs", 11: "groups rescoring", 12: "finalize classify", 13: "finalize sort",
+         14: "finalize output"}
+tot = np.zeros(16, np.int64)
+for rep in range(a.reps + 2):
+    ws[off_gx:off_gx + 128].zero_()
+    check(lib.gnms_forward_with_iou2d(ptr(boxes), ptr(scores), B, N, N, None, ctypes.byref(P), ptr(iou), ptr(prob), None, None, None, None, None,
+                                      ptr(ws), nbytes, None), "fwd")
+    torch.cuda.synchronize()
+    t = ws[off_gx:off_gx + 128].cpu().numpy().view(np.int64)
+    if rep >= 2:
+        tot += t
+for k in range(16):
+    if tot[k]:
+        print("slot %2d %-40s %9.0f ticks" % (k, names.get(k, ""), tot[k] / a.reps))
