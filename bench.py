@@ -260,10 +260,10 @@ def main():
                     "measured": "HIP events around the launch inside %d repetitions of the timed step sequence, %d rotating %d-MiB matrix buffers"
                                 % (k_roof, n_buf, mat_bytes >> 20)}
 
-        if args.dim == 2:
-            wname = "iou2d_kernel" if (args.two_calls or not one_call) else lib_write_kernel_name(B, N)
+        if one_call:
+            wname = lib.gnms_profile_write_kernel_name(args.dim, B, N).decode()
         else:
-            wname = "iou3d_nms_fast_kernel"
+            wname = "iou2d_kernel" if args.dim == 2 else "iou3d_nms_fast_kernel"
         r_write = roof(ms_write, n_write, alg_write, wname, fill_gbs, "plain non-temporal float4 store stream (gnms_profile_fill)")
         r_read = roof(ms_read, n_read, alg_read, "bitmask_kernel", read_gbs, "plain non-temporal float4 load stream (gnms_profile_read)")
 
@@ -353,14 +353,6 @@ def main():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
-
-
-def lib_write_kernel_name(B, N):
-    """Name (as rocprofv3 lists it) of the launch that writes the matrix inside gnms_forward_with_iou2d for this problem size."""
-    from groomed_nms_amd import _lib
-    lib = _lib.load()
-    name = lib.gnms_profile_write_kernel_name(B, N)
-    return name.decode() if name else "iou2d_kernel"
 
 
 if __name__ == "__main__":

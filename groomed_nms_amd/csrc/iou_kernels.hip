@@ -13,6 +13,7 @@
 #include "gnms_prof.h"
 #include "iou_tile.h"
 #include "iou3d_pair.h"
+#include "iou3d_tile.h"
 
 namespace {
 
@@ -220,45 +221,8 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const 
                                                                           int row_end, float thr) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int img = blockIdx.z;
-    const int i0 = row0 + blockIdx.y * tile_rows;                 // a launch may cover the rows [row0, row_end) only
-    const int c0 = blockIdx.x * kWGCols + wave * kWaveCols;
-    if (row_end > M) row_end = M;
-    if (c0 >= N || i0 >= row_end) return;
-    const float* ra = RA + (size_t)img * M * kRec;
-    const float* rb = RB + (size_t)img * N * kRec;
-    float* o3 = out + (size_t)img * M * ld;
-
-    gnms_iou3d::Cols2 cols[2];
-    int col[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
-        const int cc = col[j] < N ? col[j] : (N - 1);
-        const float4* p = reinterpret_cast<const float4*>(rb + (size_t)cc * kRec);
-        gnms_iou3d::cols2_set(cols[j >> 1], j & 1, p[0], p[1], p[2]);
-    }
-    const int nrows = min(tile_rows, row_end - i0);
-    for (int r = 0; r < nrows; ++r) {
-        // the row record is wave-uniform and read-only: scalar loads (s_load_dwordx4 x 3), no VALU, no LDS.  (Broadcasting it
-        // from a lane with 10 v_readlane per row measured 111 instead of 99 us at B=8, N=4096.)
-        const float* rr = ra + (size_t)(i0 + r) * kRec;
-        gnms_iou3d::Row a;
-        a.vol = rr[0]; a.y0 = rr[1]; a.y1 = rr[2]; a.x0 = rr[3]; a.x1 = rr[4]; a.z0 = rr[5]; a.z1 = rr[6]; a.lx = rr[8]; a.ly = rr[9]; a.lz = rr[10];
-        float res[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f2 q = gnms_iou3d::nms_overlap3d_guarded(a, cols[h], thr);   // entries near `thr`: the reference's exact order
-            res[2 * h] = q.x; res[2 * h + 1] = q.y;
-        }
-        const size_t roff = (size_t)(i0 + r) * ld;
-        if (VEC && col[3] < N) {
-            store_nt_f4(o3 + roff + col[0], res[0], res[1], res[2], res[3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (col[j] < N) o3[roff + col[j]] = res[j];
-        }
-    }
+    gnms_iou3d::nms_overlap3d_tile<VEC>(RA, RB, M, N, out, ld, blockIdx.z, row0 + blockIdx.y * tile_rows, blockIdx.x * kWGCols + wave * kWaveCols,
+                                        lane, tile_rows, row_end, thr);
 }
 
 template <bool VEC, int METHOD>

@@ -385,10 +385,11 @@ __device__ __forceinline__ u64 sort_key_of(int role, const float* __restrict__ s
     return ((u64)(~gnms_desc_key(v.x + v.z)) << 32) | (unsigned)i;
 }
 
-__global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
-                                                         const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P) {
+// (run r of image b, role) -- also called from the launch that carries a slice of the matrix write (nms_layer.hip)
+__device__ __forceinline__ void sort_runs_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                               const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P, const int r, const int b,
+                                               const int role) {
     __shared__ u64 keys[1024];
-    const int r = blockIdx.x, b = blockIdx.y, role = blockIdx.z;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int i = r * 1024 + (int)threadIdx.x;
@@ -399,13 +400,17 @@ __global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict
     if (r == 0 && role == 0 && threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;   // [2] = "already sorted", cleared below
 }
 
+__global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                         const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P) {
+    sort_runs_body(scores, boxes, N, counts, ws, L, P, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 template <int R>
-__global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
-                                                          const int* __restrict__ counts, char* ws, gnms_ws_layout L,
-                                                          long long* __restrict__ order_out) {
+__device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                const int* __restrict__ counts, char* ws, gnms_ws_layout L, long long* __restrict__ order_out,
+                                                const int r, const int b, const int role) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* all = reinterpret_cast<u64*>(smem);                          // [R][1024]
-    const int r = blockIdx.x, b = blockIdx.y, role = blockIdx.z;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int t = threadIdx.x;
@@ -447,6 +452,13 @@ __global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restric
         }
         if (!__syncthreads_and(same) && t == 0) I.misc[2] = 0;        // (every writer stores 0)
     }
+}
+
+template <int R>
+__global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                          const int* __restrict__ counts, char* ws, gnms_ws_layout L,
+                                                          long long* __restrict__ order_out) {
+    sort_merge_body<R>(scores, boxes, N, counts, ws, L, order_out, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,11 +586,10 @@ __device__ __forceinline__ float wave_max_f(float v) { return gnms_wave_max_f(v)
 // row W[kb][.] (indexed by column rank) and leave as one coalesced write of the 64 (kb+1) words a leader scan can read.  Without it
 // every lane scatters its 8-byte words to global memory: 1 M scattered stores per launch at B=8, N=4096 = ~15 us of store
 // throughput, about a third of it exposed.
-template <int CPL, int KBW, bool ROWBUF = false>
-__global__ __launch_bounds__(ROWBUF ? 1024 : 256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
-                                                            float thr, char* ws, gnms_ws_layout L) {
+template <int CPL, int KBW, bool ROWBUF>
+__device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ boxes, int N, const int* __restrict__ counts, float thr, char* ws,
+                                                   gnms_ws_layout L, const int b, const int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.z;
     const int n = gnms_count(counts, b, N);
     constexpr int kCols = 64 * CPL;
     const int nchunk = (N + kCols - 1) / kCols;
@@ -586,13 +597,13 @@ __global__ __launch_bounds__(ROWBUF ? 1024 : 256) void bitmask_boxes_kernel(cons
     u64* rowbuf = reinterpret_cast<u64*>(smem);                       // ROWBUF: [NC] words of row kb, by column rank
     ImgPtrs I = img_ptrs(ws, L, b);
     if (ROWBUF) {
-        const int kbr = blockIdx.x;                                   // one rank block per workgroup, wave w = column chunk w
+        const int kbr = bx;                                   // one rank block per workgroup, wave w = column chunk w
         if (kbr * 64 >= n) return;
         for (int i = threadIdx.x; i < L.NC; i += blockDim.x) rowbuf[i] = 0ull;
         __syncthreads();
     }
-    const int tile = ROWBUF ? (int)blockIdx.x * nchunk + wave : (int)blockIdx.x * 4 + wave;
-    const int kbg = ROWBUF ? (int)blockIdx.x : tile / nchunk;        // kbg = group of KBW consecutive rank blocks
+    const int tile = ROWBUF ? bx * nchunk + wave : bx * 4 + wave;
+    const int kbg = ROWBUF ? bx : tile / nchunk;        // kbg = group of KBW consecutive rank blocks
     const int chunk = ROWBUF ? wave : tile - kbg * nchunk;           // ROWBUF: <= 16 chunks, one per wave
     const int c0 = chunk * kCols;
     const bool idle = (kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n || chunk >= nchunk);   // (ragged images)
@@ -688,9 +699,15 @@ __global__ __launch_bounds__(ROWBUF ? 1024 : 256) void bitmask_boxes_kernel(cons
     }   // !idle
     if (ROWBUF) {
         __syncthreads();
-        u64* Wk = I.W + (size_t)blockIdx.x * L.NC;
+        u64* Wk = I.W + (size_t)bx * L.NC;
         for (int i = threadIdx.x; i < L.NC; i += blockDim.x) Wk[i] = rowbuf[i];      // the whole row, coalesced
     }
+}
+
+template <int CPL, int KBW, bool ROWBUF = false>
+__global__ __launch_bounds__(ROWBUF ? 1024 : 256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
+                                                            float thr, char* ws, gnms_ws_layout L) {
+    bitmask_boxes_body<CPL, KBW, ROWBUF>(boxes, N, counts, thr, ws, L, (int)blockIdx.z, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include <vector>
 #include "gnms_prof.h"
 #include "iou_tile.h"
+#include "iou3d_tile.h"
 #include "nms_solve_kernels.h"
 
 // defined in iou_kernels.hip
@@ -287,63 +288,94 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
     iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, blockIdx.z, blockIdx.y * tile_rows, blockIdx.x * kWGCols + wave * kWaveCols, lane, tile_rows);
 }
 
-// The per-image chain K3..K6 (leaders -> attribution -> groups + rescoring -> finalize: one workgroup per image, 8 of 256 CUs at
-// B = 8) and the N x N matrix write in ONE launch.  Nothing in the masked from-boxes layer reads the matrix, so the two are
-// independent; as separate launches the chain ran strictly after the write, as two streams the fork and join cost more than the
-// overlap bought.  Here the first `nimg` workgroups ARE tail_kernel (same device functions, 1024 threads) and the
-// rest (one per CU) write the matrix.  The launch asks for the chain's LDS (> 80 KiB), so a CU holds ONE workgroup: the chain
-// workgroups are dispatched first, get a CU each to themselves and run at their stand-alone speed while the other CUs stream the
-// matrix; when a chain workgroup retires, a writer workgroup still waiting in the grid takes its CU.
-template <bool VEC, int E>
-__global__ __launch_bounds__(1024) void tail_iou2d_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts, gnms_params P,
-                                                          char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob,
-                                                          long long* __restrict__ valid, long long* __restrict__ invalid,
-                                                          int* __restrict__ nvalid, int* __restrict__ ninvalid, int nimg,
-                                                          float* __restrict__ out, long ld, int tile_rows, int row0, int row_end, int skip_tail) {
-    if ((int)blockIdx.x < nimg) {
-        if (skip_tail & 1) return;                                  // (developer timing experiment: the writers alone)
-        const int b = blockIdx.x;
-        leaders_body(N, counts, ws, L, b, 1);
-        __syncthreads();
-        for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<kFromBoxes>(boxes, (long)N, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63);
-        __syncthreads();
-        groups_body<E, kFromBoxes>(boxes, N, (long)N, counts, P, ws, L, Ppow2, b);
-        __syncthreads();
-        finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
-        return;
-    }
+// ------------------------------------------------------------------------------------------------
+// The matrix write as a ROLE inside the launch of the per-image chain (masked from-boxes layer, gnms_forward_with_iou2d).
+// Nothing in that layer reads the matrix, so the write is independent of the chain sorts -> threshold bits -> K3..K6.  As launches of
+// their own the chain K3..K6 (one workgroup per image: 8 of 256 CUs at B = 8) ran strictly behind the write; as two streams the fork
+// and join cost more than the overlap bought.  tail_iou2d_kernel is both in ONE launch: the first B workgroups ARE
+// the chain (the device functions of tail_kernel), the others write the matrix.  The launch asks for the chain's LDS (> 80 KiB), so a
+// CU holds ONE workgroup: the chain workgroups are dispatched first and have a CU each to themselves (beside the write they run
+// within 10 % of their stand-alone time; sharing a CU with streaming waves they ran 1.5-3x slower), the other CUs stream the matrix;
+// when a chain workgroup retires, a writer still waiting in the grid takes its CU.
+// A chunk = 16 wave tiles of tile_rows x 256 entries (tile_rows full rows of one image at N = 4096), written by the 16 waves of a
+// workgroup with iou2d_tile -- the tile code of gnms_iou2d, so the matrix is the same bit for bit.
+// Measured and dropped: slices of the write ALSO inside the sort launches and the bit-matrix launch (7 % / 5 % / 10-20 % of the rows,
+// behind those kernels' own workgroups in the grid).  The sort and bit-matrix workgroups then share their CUs with streaming waves
+// and slow down by more than the slices save: sort runs 7.8 -> 15.6 us, merges 5.9 -> 15.0, bit matrix 24 -> 46, chain + rest of the
+// write 114 -> 98 (B = 8, N = 4096: 0.172 -> 0.173-0.184 ms per step for every split tried).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline int write_chunk_count(int N, int nimg, int tile_rows, int row0, int row_end) {
+    if (row_end <= row0) return 0;
+    const long tiles = (long)nimg * ((N + gnms_iou::kWaveCols - 1) / gnms_iou::kWaveCols) * ((row_end - row0 + tile_rows - 1) / tile_rows);
+    return (int)((tiles + 15) >> 4);
+}
+
+// what the writers compute: SRC = kFromBoxes: `in` = boxes [B][N][4], lib/core.py iou (iou2d_tile);
+// SRC = kFromRecords: `in` = corner-AABB records [B][N][12], 0.5 * (1 + GIoU3D) with the guard band around `thr` (nms_overlap3d_tile)
+template <bool VEC, int SRC>
+__device__ __forceinline__ void write_chunk(const float* __restrict__ in, int N, float* __restrict__ out, long ld, int nimg, int tile_rows,
+                                            int row0, int row_end, float thr, int chunk) {
     using namespace gnms_iou;
-    // PERSISTENT writers: one workgroup per CU for the whole launch (a workgroup that ends leaves its CU empty until the next one has
-    // been placed, and with one workgroup per CU nothing covers that gap).  A workgroup claims CHUNKS of 16 wave tiles (tile_rows x
-    // 256 entries each: tile_rows full rows at N = 4096) from a counter in global memory, one chunk ahead so that the atomic's round
-    // trip hides behind the chunk in progress.  (One claim per WAVE tile serialises on the counter: 16384 device-scope atomics on one
-    // address took 430 us.)  The counter (misc[4] of image 0) was zeroed by the sort kernels of this call.
-    __shared__ int s_next[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ncc = (N + kWaveCols - 1) / kWaveCols;
     const int nrt = (row_end - row0 + tile_rows - 1) / tile_rows;
     const int per_img = ncc * nrt;
-    const int ntiles = per_img * nimg;
-    const int nchunks = (ntiles + 15) >> 4;
-    int* counter = img_ptrs(ws, L, 0).misc + 4;
-    if (threadIdx.x == 0) s_next[0] = skip_tail < 2 ? atomicAdd(counter, 1) : (int)blockIdx.x - nimg;
+    const int t = chunk * 16 + wave;                               // tiles numbered image-major, column chunk fastest
+    if (t >= per_img * nimg) return;
+    const int img = t / per_img;
+    const int r = t - img * per_img;
+    const int rt = r / ncc, cc = r - rt * ncc;
+    if (SRC == kFromRecords)
+        gnms_iou3d::nms_overlap3d_tile<VEC>(in, in, N, N, out, ld, img, row0 + rt * tile_rows, cc * kWaveCols, lane, tile_rows, row_end, thr);
+    else
+        iou2d_tile<VEC>(in, in, N, N, out, ld, img, row0 + rt * tile_rows, cc * kWaveCols, lane, tile_rows, row_end);
+}
+
+// PERSISTENT writers: one workgroup stays on its CU and claims chunk after chunk from `counter` (zeroed by the sort kernels of this
+// call), one claim ahead so that the atomic's round trip hides behind the chunk in progress.  (Ordinary workgroups of one chunk each
+// leave the CU empty between a workgroup's last wave and the next workgroup's start, and with one workgroup per CU nothing covers
+// that gap: 116 against 107 us.  One claim per WAVE tile serialises on the counter: 16384 device-scope atomics on one address took
+// 430 us.)
+template <bool VEC, int SRC>
+__device__ __forceinline__ void writers_persistent(const float* __restrict__ in, int N, float* __restrict__ out, long ld, int nimg,
+                                                   int tile_rows, int row0, int row_end, float thr, int* counter) {
+    __shared__ int s_next[2];
+    const int nchunks = write_chunk_count(N, nimg, tile_rows, row0, row_end);
+    if (threadIdx.x == 0) s_next[0] = atomicAdd(counter, 1);
     __syncthreads();
     int cur = s_next[0], ph = 0;
     while (cur < nchunks) {
         int nx = 0;
-        if (threadIdx.x == 0) nx = skip_tail < 2 ? atomicAdd(counter, 1) : cur + (int)gridDim.x - nimg;   // the claim after this one, in flight during the tile
-        const int t = cur * 16 + wave;
-        if (t < ntiles) {
-            const int img = t / per_img;
-            const int r = t - img * per_img;
-            const int rt = r / ncc, cc = r - rt * ncc;
-            iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, img, row0 + rt * tile_rows, cc * kWaveCols, lane, tile_rows, row_end);
-        }
+        if (threadIdx.x == 0) nx = atomicAdd(counter, 1);          // the claim after this one, in flight during the chunk
+        write_chunk<VEC, SRC>(in, N, out, ld, nimg, tile_rows, row0, row_end, thr, cur);
         if (threadIdx.x == 0) s_next[ph ^ 1] = nx;
         __syncthreads();
         ph ^= 1;
         cur = s_next[ph];
     }
+}
+
+// chain_src: what the chain's single overlaps come from (the boxes for SRC = kFromBoxes; unused for kFromRecords: the workspace copy
+// of the records); write_src: the writers' input (the boxes / the batch's contiguous records)
+template <bool VEC, int E, int SRC>
+__global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restrict__ chain_src, const float* __restrict__ write_src, int N,
+                                                          const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L, int Ppow2,
+                                                          float* __restrict__ prob, long long* __restrict__ valid,
+                                                          long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
+                                                          int nimg, float* __restrict__ out, long ld, int tile_rows, int row0, int row_end) {
+    if ((int)blockIdx.x < nimg) {
+        const int b = blockIdx.x;
+        leaders_body(N, counts, ws, L, b, 1);
+        __syncthreads();
+        for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16)
+            attribute_body<SRC>(chain_src, (long)N, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63);
+        __syncthreads();
+        groups_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
+        __syncthreads();
+        finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+        return;
+    }
+    writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
 }
 
 // bitmask_boxes_kernel: workgroups of 4 wave tiles, (row blocks) x (column chunks) tiles per image; 4 columns per lane
@@ -436,19 +468,25 @@ int device_cu_count() {
     return c;
 }
 
-// K3..K6 of every image + the whole matrix write in one launch (tail_iou2d_kernel)
-int launch_tail_iou2d(const float* boxes, int B, int N, const int32_t* counts, const gnms_params& P, char* ws, const gnms_ws_layout& L,
-                      float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, float* out, int64_t ld, hipStream_t st) {
+// rows per wave tile of the write role (GNMS_FUSED_TILE_ROWS overrides): 16 measured best at B = 8, N = 4096 (0.168 ms per step; 8: 0.174,
+// 32: 0.175, 64: 0.193 -- the last chunks of a launch end together only if chunks are short)
+int fused_tile_rows() {
+    static const int forced = [] { const char* e = getenv("GNMS_FUSED_TILE_ROWS"); return e ? atoi(e) : 0; }();
+    int tr = forced > 0 ? forced : 16;
+    return tr > 64 ? 64 : tr;
+}
+
+// K3..K6 of every image + the matrix in one launch (tail_write_kernel)
+template <int SRC>
+int launch_tail_write(const float* chain_src, const float* write_src, int B, int N, const int32_t* counts, const gnms_params& P, char* ws,
+                      const gnms_ws_layout& L, float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, float* out,
+                      int64_t ld, hipStream_t st) {
     int P2 = next_pow2(N);
     if (P2 < 1024) P2 = 1024;
     const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
     const size_t lds = llds > glds ? llds : glds;
-    static const int forced_rows = [] { const char* e = getenv("GNMS_FUSED_TILE_ROWS"); return e ? atoi(e) : 0; }();
-    static const int skip_tail = [] { const char* e = getenv("GNMS_DEBUG_SKIP_TAIL"); return e ? atoi(e) : 0; }();   // 1: writers only; 2: static chunk striding
-    int tr = forced_rows > 0 ? forced_rows : 16;
-    if (tr > 64) tr = 64;
-    const long tiles = (long)B * gnms_div_up(N, tr) * gnms_div_up(N, gnms_iou::kWaveCols);
-    long writers = (tiles + 15) / 16;                                // persistent writers: at most one per CU
+    const int tr = fused_tile_rows();
+    long writers = write_chunk_count(N, B, tr, 0, N);                // persistent writers: at most one per CU
     const int cus = device_cu_count();
     if (writers > cus) writers = cus;
     const dim3 grid((unsigned)(B + writers));
@@ -456,13 +494,13 @@ int launch_tail_iou2d(const float* boxes, int B, int N, const int32_t* counts, c
     int rc;
     GNMS_DISPATCH_SORT(P2, {
         if (vec) {
-            if ((rc = allow_lds(tail_iou2d_kernel<true, E>, lds))) return rc;
-            gnms_launch_prof(kProfMatrixWrite, tail_iou2d_kernel<true, E>, grid, dim3(1024), lds, st, boxes, N, counts, P, ws, L, P2, prob,
-                             (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, skip_tail);
+            if ((rc = allow_lds(tail_write_kernel<true, E, SRC>, lds))) return rc;
+            gnms_launch_prof(kProfMatrixWrite, tail_write_kernel<true, E, SRC>, grid, dim3(1024), lds, st, chain_src, write_src, N, counts, P, ws,
+                             L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N);
         } else {
-            if ((rc = allow_lds(tail_iou2d_kernel<false, E>, lds))) return rc;
-            gnms_launch_prof(kProfMatrixWrite, tail_iou2d_kernel<false, E>, grid, dim3(1024), lds, st, boxes, N, counts, P, ws, L, P2, prob,
-                             (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, skip_tail);
+            if ((rc = allow_lds(tail_write_kernel<false, E, SRC>, lds))) return rc;
+            gnms_launch_prof(kProfMatrixWrite, tail_write_kernel<false, E, SRC>, grid, dim3(1024), lds, st, chain_src, write_src, N, counts, P,
+                             ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N);
         }
     });
     GNMS_CHECK_LAUNCH();
@@ -638,15 +676,17 @@ namespace {
 // masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_iou2d_kernel).  GNMS_FUSE_TAIL=0/1 forces.
 bool chain_rides_in_write_launch(int B, int N) {
     static const int forced = [] { const char* e = getenv("GNMS_FUSE_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced == 1 : true;
+    return forced >= 0 ? forced == 1 : N > 1024;          // smaller images: the launch-bound regime, where the round-1 sequence measures the same or better
 }
 }  // namespace
 
-// name, as a kernel trace lists it, of the launch that writes the matrix inside gnms_forward_with_iou2d (default parameters, aligned boxes)
-extern "C" const char* gnms_profile_write_kernel_name(int B, int N) {
+// name, as a kernel trace lists it, of the launch that writes the matrix inside gnms_forward_with_iou2d (dim 2) / _iou3d (dim 3)
+// (default parameters, aligned inputs)
+extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (B <= 0 || N <= 0) return "";
-    if (use_side_stream(B, N, N)) return "iou2d_kernel";
-    if (chain_rides_in_write_launch(B, N)) return "tail_iou2d_kernel";
+    if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : "iou2d_kernel";
+    if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
+    if (dim == 3) return "iou3d_nms_fast_kernel";
     if (sorts_ride_in_iou_launch(B, N)) return "iou2d_sort_kernel";
     return "iou2d_kernel";
 }
@@ -736,7 +776,12 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     float* xkeys = rec + (size_t)B * N * gnms_iou3d::kRec;         // [B][N] pseudo boxes
     if ((rc = gnms_internal_records_for_layer(params3d, B, N, rec, ws, L, xkeys, st))) return rc;
     const bool beside = use_side_stream(B, N, ld);
-    if (!beside && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st, P.nms_threshold))) return rc;
+    const int sym = (P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY) ? 1 : 0;   // the culled kernel writes full symmetric rows of W
+    // K3..K6 inside the write launch like the 2D entry -- up to N = 2048 only: the 3D writers are VALU-bound (23 slots per pair) and
+    // at the one workgroup per CU that launch runs at they lose more than the overlap buys (B = 8, N = 4096: launch 166 us against a
+    // 107-us write + 55-us chain, step 0.264 against 0.248 ms; N = 2048: 0.117 against 0.163 ms)
+    const bool chain_in_write = !beside && sym && N <= 2048 && chain_rides_in_write_launch(B, N);
+    if (!beside && !chain_in_write && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st, P.nms_threshold))) return rc;
     const int P2 = next_pow2(N);
     if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
     SideScope scope(st);
@@ -746,7 +791,6 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         if ((rc = scope.fork(&side, 0))) return rc;
         if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, r1))) return rc;
     }
-    const int sym = (P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY) ? 1 : 0;   // the culled kernel writes full symmetric rows of W
     if (!sym) {
         // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
         bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
@@ -758,6 +802,8 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
             bitmask_rec3d_culled_kernel<1><<<dim3(gnms_div_up(L.NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
     }
     GNMS_CHECK_LAUNCH();
+    if (chain_in_write)                                           // K3..K6 and the matrix in one launch, like the 2D entry
+        return launch_tail_write<kFromRecords>(nullptr, rec, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, iou_out, ld, st);
     if (beside) {                                                 // see forward_boxes_impl for why the fork sits exactly here
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 1))) return rc;
@@ -904,7 +950,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
     if (mw && mw->one_launch) {
         if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
-        return launch_tail_iou2d(boxes, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, mw->out, mw->ld, st);
+        return launch_tail_write<kFromBoxes>(boxes, boxes, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, mw->out, mw->ld, st);
     }
     SideScope beside(st);
     const int r1 = mw ? split_rows(N, 20) : 0;

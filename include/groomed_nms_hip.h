@@ -194,7 +194,7 @@ int gnms_profile_bitmask_boxes(const float* boxes, int B, int N, const int32_t* 
 #define GNMS_PROF_MATRIX_READ 1
 int gnms_profile_events(int enable);
 int gnms_profile_collect(int slot, double* ms_sum, int* launches);
-const char* gnms_profile_write_kernel_name(int B, int N); /* the launch that writes the matrix in gnms_forward_with_iou2d, as a kernel trace names it */
+const char* gnms_profile_write_kernel_name(int dim, int B, int N); /* the launch that writes the matrix in gnms_forward_with_iou2d (dim 2) / _iou3d (dim 3), as a kernel trace names it */
 int gnms_profile_fill(float* dst, size_t count, void* stream);
 int gnms_profile_read(const float* src, size_t count, float* sink, void* stream);
 
