@@ -66,6 +66,9 @@ _SIGNATURES = {
     "gnms_pruning_function_backward": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_vp, c_vp]),
     "gnms_soft_sort": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
                                       ctypes.c_size_t, c_vp]),
+    "gnms_soft_sort_backward_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "gnms_soft_sort_backward": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                               c_vp, c_vp, ctypes.c_size_t, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_sgemm": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                   ctypes.c_int64, c_vp]),
     "_nms": (None, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),

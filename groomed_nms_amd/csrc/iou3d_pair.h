@@ -28,8 +28,18 @@ __device__ __forceinline__ void cols2_set(Cols2& c, int k, const float4 u, const
     c.lx[k] = e.x; c.ly[k] = e.y; c.lz[k] = e.z;
 }
 struct Row {               // one row box, every field wave-uniform
-    float x0, x1, y0, y1, z0, z1, vol, lx, ly, lz;
+    float x0, x1, y0, y1, z0, z1, vol, lx, ly, lz, bad;
 };
+
+// record[11]: 0 for a SANE box -- extents in (1e-4, 1e5), coordinates below 1e5 in magnitude, hence a positive finite volume -- and 1
+// otherwise (NaN anywhere included).  For two sane boxes every intermediate of the overlap expressions is a normal finite number
+// (u3 >= max volume > 1e-12, hull volume in (1e-12, 1e17), their product far inside the fp32 range), so the re-associated expression
+// yields a finite value in [0, 1] within 1e-6 of the reference order.  Pairs with a box that is not sane always take the reference order.
+__device__ __forceinline__ float record_bad_flag(float x0, float x1, float y0, float y1, float z0, float z1, float lx, float ly, float lz) {
+    const bool ok = (lx > 1e-4f) && (lx < 1e5f) && (ly > 1e-4f) && (ly < 1e5f) && (lz > 1e-4f) && (lz < 1e5f) &&
+                    (fabsf(x0) < 1e5f) && (fabsf(x1) < 1e5f) && (fabsf(y0) < 1e5f) && (fabsf(y1) < 1e5f) && (fabsf(z0) < 1e5f) && (fabsf(z1) < 1e5f);
+    return ok ? 0.0f : 1.0f;
+}
 
 // 0.5 * (1 + i3/u3 - (vh - u3)/vh) re-associated to 0.5 * (i3*vh + u3*u3) / (u3*vh): one v_rcp_f32, hull extents from the
 // overlap's own d, everything two columns wide.  Symmetric in (row, column) bit for bit.
@@ -71,27 +81,35 @@ __device__ __forceinline__ f2 nms_overlap3d_exact(const Row& a, const Cols2& b) 
 }
 
 // GUARD BAND.  The layer decides `overlap > nms_threshold` (lib/groomed_nms.py:249-250) on the matrix entries, and the re-associated
-// expression above differs from the reference's order by up to ~2e-6 (both are a handful of fp32 roundings of a value in [0, 1]).
-// Entries within kGuard3D = 8e-6 of the threshold (4x that bound) -- and anything that is not a finite value of sane magnitude --
-// are therefore REPLACED by the exact-order value: outside the band both expressions lie on the same side of the threshold, inside
-// it the entry IS the reference's fp32 value, so thresholding the written matrix takes exactly the reference's decisions.  The
-// matrix kernel, the bit-matrix kernels and the single-pair lookups all go through these two functions, hence agree bit for bit.
-// A few dozen pairs per image fall into the band (N = 4096 .. 16384): one wave-uniform branch per row.
+// expression above differs from the reference's order by a few fp32 roundings of a value in [0, 1] (measured <= 3e-7, bound 2e-6).
+// The value of a pair is therefore DEFINED as
+//     both boxes sane and |fast - thr| > kGuard3D = 8e-6 :  the re-associated expression
+//     otherwise                                          :  the reference's exact operation order
+// -- outside the band both expressions lie on the same side of the threshold, inside it the entry IS the reference's fp32 value, so
+// thresholding takes exactly the reference's decision for every pair.  The definition is per pair (it does not depend on which other
+// boxes share a wave tile), and the matrix kernel, the bit-matrix kernels and the single-pair lookups all evaluate it through the
+// functions below, hence agree bit for bit.  A few dozen pairs per image fall into the band (N = 4096 .. 16384): the exact order runs
+// behind ONE wave-uniform branch per row; the test itself is a packed subtract and a min3 per four pairs.
 constexpr float kGuard3D = 8e-6f;
-__device__ __forceinline__ bool in_guard3d(float q, float thr) { return !(fabsf(q - thr) > kGuard3D) || !(fabsf(q) <= 2.0f); }
 
-__device__ __forceinline__ f2 nms_overlap3d_guarded(const Row& a, const Cols2& b, float thr) {
-    f2 q = nms_overlap3d(a, b);
-    const bool gx = in_guard3d(q.x, thr), gy = in_guard3d(q.y, thr);
-    if (__any(gx || gy)) {
-        const f2 e = nms_overlap3d_exact(a, b);
-        q.x = gx ? e.x : q.x;
-        q.y = gy ? e.y : q.y;
+// four columns of one row.  colbad: bit j set iff the lane's column j is not sane (record[11] != 0); cols_sane: no lane of the wave has
+// such a column (wave-uniform, computed once per tile).
+__device__ __forceinline__ void nms_overlap3d_guarded4(const Row& a, const Cols2 (&b)[2], unsigned colbad, bool cols_sane, float thr, float (&q)[4]) {
+    const f2 q0 = nms_overlap3d(a, b[0]), q1 = nms_overlap3d(a, b[1]);
+    const f2 d0 = q0 - splat(thr), d1 = q1 - splat(thr);
+    const float m = fminf(fminf(fminf(fabsf(d0.x), fabsf(d0.y)), fabsf(d1.x)), fabsf(d1.y));
+    q[0] = q0.x; q[1] = q0.y; q[2] = q1.x; q[3] = q1.y;
+    if (__any(!(m > kGuard3D)) || !cols_sane || a.bad != 0.0f) {              // rare
+        const f2 e0 = nms_overlap3d_exact(a, b[0]), e1 = nms_overlap3d_exact(a, b[1]);
+        const bool rb = a.bad != 0.0f;
+        if (rb || (colbad & 1u) || !(fabsf(d0.x) > kGuard3D)) q[0] = e0.x;
+        if (rb || (colbad & 2u) || !(fabsf(d0.y) > kGuard3D)) q[1] = e0.y;
+        if (rb || (colbad & 4u) || !(fabsf(d1.x) > kGuard3D)) q[2] = e1.x;
+        if (rb || (colbad & 8u) || !(fabsf(d1.y) > kGuard3D)) q[3] = e1.y;
     }
-    return q;
 }
 
-// The same overlap for ONE pair of records with per-lane operands (the layer's O(N) single-entry lookups when it runs beside the
+// The same value for ONE pair of records with per-lane operands (the layer's O(N) single-entry lookups when it runs beside the
 // matrix write instead of after it).  Same operations in the same order as nms_overlap3d / nms_overlap3d_exact, one column wide:
 // with -ffp-contract=off every product, sum, division and the v_rcp_f32 round exactly as there, and v_min/v_max do not depend on
 // which operand sits in an SGPR, so the result equals the matrix entry bit for bit (tests/test_gpu_parity.py compares the paths).
@@ -110,7 +128,7 @@ __device__ __forceinline__ float nms_overlap3d_pair(const float* __restrict__ ra
     const float num = __builtin_fmaf(u3, u3, i3 * vh);
     const float den = u3 * vh;
     float q = (num * __builtin_amdgcn_rcpf(den)) * 0.5f;
-    if (in_guard3d(q, thr)) {                                                // exact order (nms_overlap3d_exact, one column wide)
+    if (ae.w != 0.0f || be.w != 0.0f || !(fabsf(q - thr) > kGuard3D)) {      // exact order (nms_overlap3d_exact, one column wide)
         const float xh = fmaxf(fmaxf(av.x, bv.x) - fminf(au.w, bu.w), 0.0f);
         const float yh = fmaxf(fmaxf(au.z, bu.z) - fminf(au.y, bu.y), 0.0f);
         const float zh = fmaxf(fmaxf(av.z, bv.z) - fminf(av.y, bv.y), 0.0f);

@@ -54,7 +54,8 @@ __device__ __forceinline__ void aabb_record(const float (&cx)[8], const float (&
     float z0 = fminf(fminf(cz[2], cz[3]), fminf(cz[6], cz[7])), z1 = fmaxf(fmaxf(cz[2], cz[3]), fmaxf(cz[6], cz[7]));
     rec[0] = vol; rec[1] = mny; rec[2] = mxy; rec[3] = x0; rec[4] = x1; rec[5] = z0; rec[6] = z1;
     rec[7] = (x1 - x0) * (z1 - z0);
-    rec[8] = x1 - x0; rec[9] = mxy - mny; rec[10] = z1 - z0; rec[11] = 0.0f;      // extents, used by the fast NMS-overlap kernel
+    rec[8] = x1 - x0; rec[9] = mxy - mny; rec[10] = z1 - z0;                      // extents, used by the fast NMS-overlap kernel
+    rec[11] = gnms_iou3d::record_bad_flag(x0, x1, mny, mxy, z0, z1, rec[8], rec[9], rec[10]);   // 0 = sane (iou3d_pair.h)
 }
 
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __
 using gnms_iou3d::f2;
 
 template <bool VEC>
-__global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_nms_fast_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M,
+__global__ __launch_bounds__(kWavesPerWG * 64) __attribute__((amdgpu_waves_per_eu(7))) void iou3d_nms_fast_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M,
                                                                           int N, float* __restrict__ out, long ld, int tile_rows, int row0,
                                                                           int row_end, float thr) {
     const int lane = threadIdx.x & 63;

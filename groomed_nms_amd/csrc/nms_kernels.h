@@ -746,15 +746,19 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_kernel(int N, const int* __
     ImgPtrs I = img_ptrs(ws, L, b);
     Cols2 cols[2];
     int col[4];
+    unsigned colbad = 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         col[j] = c0 + 4 * lane + j;
         const float4* p = reinterpret_cast<const float4*>(I.rec + (size_t)I.order[col[j] < n ? col[j] : n - 1] * kRec);
-        cols2_set(cols[j >> 1], j & 1, p[0], p[1], p[2]);
+        const float4 e = p[2];
+        cols2_set(cols[j >> 1], j & 1, p[0], p[1], e);
+        colbad |= (e.w != 0.0f) ? (1u << j) : 0u;
     }
     const float4* rp = reinterpret_cast<const float4*>(I.rec + (size_t)I.order[min(k0 + lane, n - 1)] * kRec);
     const float4 ru = rp[0], rv = rp[1], re = rp[2];
     const int nrows = min(64, n - k0);
+    const bool cols_sane = __all(colbad == 0u);
     unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -764,14 +768,12 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_kernel(int N, const int* __
             auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r)); };
             Row a;
             a.vol = bc(ru.x); a.y0 = bc(ru.y); a.y1 = bc(ru.z); a.x0 = bc(ru.w); a.x1 = bc(rv.x); a.z0 = bc(rv.y); a.z1 = bc(rv.z);
-            a.lx = bc(re.x); a.ly = bc(re.y); a.lz = bc(re.z);
+            a.lx = bc(re.x); a.ly = bc(re.y); a.lz = bc(re.z); a.bad = bc(re.w);
             const unsigned bit = 1u << rr;
+            float q[4];
+            nms_overlap3d_guarded4(a, cols, colbad, cols_sane, thr, q);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f2 q = nms_overlap3d_guarded(a, cols[h], thr);
-                wd[half][2 * h] |= !(q.x <= thr) ? bit : 0u;
-                wd[half][2 * h + 1] |= !(q.y <= thr) ? bit : 0u;
-            }
+            for (int j = 0; j < 4; ++j) wd[half][j] |= !(q[j] <= thr) ? bit : 0u;
         }
     }
     u64* Wk = I.W + (size_t)kb * L.NC;
@@ -802,6 +804,7 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
     ImgPtrs I = img_ptrs(ws, L, b);
     Cols2 cols[2];
     int crank[4];
+    unsigned colbad = 0u;
     float hx0 = INFINITY, hx1 = -INFINITY, maxlx = 0.0f;
     float hz0 = INFINITY, hz1 = -INFINITY, maxlz = 0.0f;          // the same bound holds along z (it culls another 5 % of the rows)
     bool cok = true;
@@ -813,6 +816,7 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
         const float4* rp = reinterpret_cast<const float4*>(I.rec + (size_t)idx * kRec);
         const float4 u = rp[0], v = rp[1], e = rp[2];
         cols2_set(cols[j >> 1], j & 1, u, v, e);
+        colbad |= (e.w != 0.0f) ? (1u << j) : 0u;
         crank[j] = (p < n) ? I.rankof[idx] : 0x7fffffff;
         hx0 = fminf(hx0, u.w); hx1 = fmaxf(hx1, v.x); maxlx = fmaxf(maxlx, e.x);
         hz0 = fminf(hz0, v.y); hz1 = fmaxf(hz1, v.z); maxlz = fmaxf(maxlz, e.z);
@@ -821,6 +825,7 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
     hx0 = wave_min_f(hx0); hx1 = wave_max_f(hx1); maxlx = wave_max_f(maxlx);
     hz0 = wave_min_f(hz0); hz1 = wave_max_f(hz1); maxlz = wave_max_f(maxlz);
     const bool cull = __all(cok) && (thr >= 0.01f) && (thr < INFINITY);
+    const bool cols_sane = __all(colbad == 0u);
     const float kappa = fmaxf(1.0f / (2.0f * thr) - 1.0f, 0.0f) + 1e-3f;
 #pragma unroll 1
     for (int kw = 0; kw < KBW; ++kw) {
@@ -847,14 +852,12 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
                 auto bc = [&](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), r)); };
                 Row a;
                 a.vol = bc(ru.x); a.y0 = bc(ru.y); a.y1 = bc(ru.z); a.x0 = bc(ru.w); a.x1 = bc(rv.x); a.z0 = bc(rv.y); a.z1 = bc(rv.z);
-                a.lx = bc(re.x); a.ly = bc(re.y); a.lz = bc(re.z);
+                a.lx = bc(re.x); a.ly = bc(re.y); a.lz = bc(re.z); a.bad = bc(re.w);
                 const unsigned bit = 1u << rr;
+                float q[4];
+                nms_overlap3d_guarded4(a, cols, colbad, cols_sane, thr, q);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const f2 q = nms_overlap3d_guarded(a, cols[h], thr);
-                    wd[half][2 * h] |= !(q.x <= thr) ? bit : 0u;
-                    wd[half][2 * h + 1] |= !(q.y <= thr) ? bit : 0u;
-                }
+                for (int j = 0; j < 4; ++j) wd[half][j] |= !(q[j] <= thr) ? bit : 0u;
             }
         }
         u64* Wk = I.W + (size_t)kb * L.NC;                             // full rows (symmetric overlap): see bitmask_boxes_kernel

@@ -73,7 +73,7 @@ constexpr int BM = 128, BN = 128, BK = 32, LDP = 132;   // LDS row pitch (floats
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D,
-                                                         int M, int Nn, int K, long lda, long ldb, long ldd) {
+                                                         int M, int Nn, int K, long lda, long ldb, long ldd, int accumulate) {
     __shared__ __attribute__((aligned(16))) float As[BK][LDP];   // As[k][m]
     __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];   // Bs[k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,8 +151,152 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int col = n0 + wn + tb * 32 + (lane & 31);
-                if (row < M && col < Nn) D[(size_t)row * ldd + col] = acc[ta][tb][r];
+                if (row < M && col < Nn) {
+                    float* d = D + (size_t)row * ldd + col;
+                    *d = accumulate ? (*d + acc[ta][tb][r]) : acc[ta][tb][r];         // D += A B (the adjoint's dC accumulation) or D = A B
+                }
             }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adjoint of soft_sort (the reference differentiates lib/groomed_nms.py:145-164 with autograd).  With
+//   A[i][j] = -|s_j - shat_i|,  E = exp((A - rowmax A) / T),  Z[i] = sum_j E[i][j] + 1e-3,  C[i][j] = E[i][j] / Z[j]  (:155),
+//   soft_scores = C s,  soft_matrix = C M
+// and upstream gradients g_soft, g_C, g_mat:
+//   dC      = g_C + g_soft s^T + g_mat M^T                       (MFMA GEMM, accumulating)
+//   dM      = C^T g_mat                                          (MFMA GEMM)
+//   dZ[j]   = -(sum_i dC[i][j] C[i][j]) / Z[j]                   (column pass; the same pass yields (C^T g_soft)[j])
+//   dE[i][j]= dC[i][j] / Z[j] + dZ[i];   dArg = dE E / T          (row pass: E recomputed with the forward's own expression, bit for bit)
+//   dA      = dArg, minus the row sum of dArg at the row's arg max (the rowmax term)
+//   ds[j]   = (C^T g_soft)[j] - sum_i dA[i][j] sign(s_j - shat_i) + dshat[rank of j],   dshat[i] = sum_j dA[i][j] sign(s_j - shat_i)
+// Deterministic: column sums walk the rows in order, no atomics.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int rows, int cols, long ld_in, float* __restrict__ out,
+                                                        long ld_out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads, 4 passes
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + ty + 8 * p, c = c0 + tx;
+        tile[ty + 8 * p][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = c0 + ty + 8 * p, r = r0 + tx;                  // out[c][r] = in[r][c]
+        if (c < cols && r < rows) out[(size_t)c * ld_out + r] = tile[tx][ty + 8 * p];
+    }
+}
+
+// dC[i][j] = g_C[i][j] + g_soft[i] * s[j]   (either gradient may be absent)
+__global__ __launch_bounds__(256) void softsort_bwd_dc_kernel(const float* __restrict__ g_C, const float* __restrict__ g_soft,
+                                                              const float* __restrict__ scores, int N, float* __restrict__ dC) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const float gs = g_soft ? g_soft[i] : 0.0f;
+    dC[(size_t)i * N + j] = (g_C ? g_C[(size_t)i * N + j] : 0.0f) + gs * scores[j];
+}
+
+// per column j (one thread each, rows walked in order: coalesced and deterministic):
+//   dZ[j] = -(sum_i dC[i][j] C[i][j]) / Z[j],   base[j] = sum_i C[i][j] g_soft[i]
+__global__ __launch_bounds__(256) void softsort_bwd_cols1_kernel(const float* __restrict__ dC, const float* __restrict__ C,
+                                                                 const float* __restrict__ g_soft, const float* __restrict__ Z, int N,
+                                                                 float* __restrict__ dZ, float* __restrict__ base) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int i = 0; i < N; ++i) {
+        const float c = C[(size_t)i * N + j];
+        s1 += dC[(size_t)i * N + j] * c;
+        if (g_soft) s2 += c * g_soft[i];
+    }
+    dZ[j] = -(s1 / Z[j]);
+    base[j] = s2;
+}
+
+// one workgroup per row i: dA row; writes  -dA[i][j] * sign(s_j - shat_i)  over dC[i][j] and dshat[i]
+__global__ __launch_bounds__(256) void softsort_bwd_rows_kernel(const float* __restrict__ scores, int N, float T, char* ws, gnms_ws_layout L,
+                                                                const float* __restrict__ Z, const float* __restrict__ dZ,
+                                                                float* __restrict__ dC, float* __restrict__ dshat) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    const int i = blockIdx.x;
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    const float shat = I.sscore[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // row maximum of A and its first position (the forward's softsort_rows_kernel expression)
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const float a = -fabsf(scores[j] - shat);
+        if (a > mx) { mx = a; am = j; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float om = __shfl_xor(mx, off, 64);
+        const int oa = __shfl_xor(am, off, 64);
+        if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
+    if (lane == 0) { red[wave] = mx; redi[wave] = am; }
+    __syncthreads();
+    mx = red[0]; am = redi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (red[w] > mx || (red[w] == mx && redi[w] < am)) { mx = red[w]; am = redi[w]; }
+    __syncthreads();
+    const float dz = dZ[i];
+    float* row = dC + (size_t)i * N;
+    float rs = 0.0f;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const float e = expf((-fabsf(scores[j] - shat) - mx) / T);
+        const float darg = ((row[j] / Z[j] + dz) * e) / T;
+        row[j] = darg;
+        rs += darg;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) rs += __shfl_xor(rs, off, 64);
+    if (lane == 0) red[wave] = rs;
+    __syncthreads();
+    rs = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    float dsh = 0.0f;
+    for (int j = threadIdx.x; j < N; j += 256) {
+        const float da = row[j] - ((j == am) ? rs : 0.0f);
+        const float d = scores[j] - shat;
+        const float sg = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);
+        dsh += da * sg;
+        row[j] = -(da * sg);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dsh += __shfl_xor(dsh, off, 64);
+    if (lane == 0) red[wave] = dsh;
+    __syncthreads();
+    if (threadIdx.x == 0) dshat[i] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ds[j] = base[j] + sum_i M2[i][j] + dshat[rank of j]
+__global__ __launch_bounds__(256) void softsort_bwd_cols2_kernel(const float* __restrict__ M2, const float* __restrict__ base,
+                                                                 const float* __restrict__ dshat, int N, char* ws, gnms_ws_layout L,
+                                                                 float* __restrict__ d_scores) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    float acc = 0.0f;
+    for (int i = 0; i < N; ++i) acc += M2[(size_t)i * N + j];
+    d_scores[j] = (base[j] + acc) + dshat[I.rankof[j]];
+}
+
+int launch_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd, int accumulate,
+                 hipStream_t st) {
+    if (M == 0 || N == 0) return GNMS_OK;
+    dim3 grid(gnms_div_up(N, BN), gnms_div_up(M, BM));
+    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
+    if (aligned) sgemm_mfma_kernel<true><<<grid, 256, 0, st>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd, accumulate);
+    else sgemm_mfma_kernel<false><<<grid, 256, 0, st>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd, accumulate);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
 }
 
 }  // namespace
@@ -162,10 +306,60 @@ extern "C" int gnms_sgemm(const float* A, const float* B, float* D, int M, int N
     GNMS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gnms_sgemm: negative size");
     if (M == 0 || N == 0) return GNMS_OK;
     GNMS_CHECK_ARG(A && B && D, "gnms_sgemm: null pointer");
-    dim3 grid(gnms_div_up(N, BN), gnms_div_up(M, BM));
-    const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
-    if (aligned) sgemm_mfma_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd);
-    else sgemm_mfma_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd);
+    return launch_sgemm(A, B, D, M, N, K, lda, ldb, ldd, 0, (hipStream_t)stream);
+}
+
+extern "C" size_t gnms_soft_sort_backward_scratch_bytes(int N, int K) {
+    if (N <= 0) return 0;
+    const size_t n = (size_t)N, k = (size_t)(K > 0 ? K : 0);
+    return (2 * n * n + k * n + 3 * n) * sizeof(float) + 256;
+}
+
+extern "C" int gnms_soft_sort_backward(const float* scores, const float* matrix, int N, int K, int64_t ld, float temperature, const float* C,
+                                       const float* g_soft, const float* g_C, const float* g_mat, float* d_scores, float* d_matrix,
+                                       void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream) {
+    GNMS_CHECK_ARG(N >= 0 && K >= 0, "gnms_soft_sort_backward: negative size");
+    if (N == 0) return GNMS_OK;
+    if (N > GNMS_MAX_BOXES) { gnms_set_error("gnms_soft_sort_backward: N=%d exceeds GNMS_MAX_BOXES", N); return GNMS_ERR_UNSUPPORTED; }
+    GNMS_CHECK_ARG(scores && C && d_scores && workspace && scratch, "gnms_soft_sort_backward: null pointer");
+    const bool with_matrix = matrix && g_mat && K > 0;
+    GNMS_CHECK_ARG(!with_matrix || ld >= K, "gnms_soft_sort_backward: ld < K");
+    GNMS_CHECK_ARG(!d_matrix || with_matrix, "gnms_soft_sort_backward: d_matrix needs matrix and g_mat");
+    const gnms_ws_layout L = gnms_make_layout(N);
+    if (workspace_bytes < L.per_image) { gnms_set_error("gnms_soft_sort_backward: workspace too small"); return GNMS_ERR_WORKSPACE; }
+    if (scratch_bytes < gnms_soft_sort_backward_scratch_bytes(N, with_matrix ? K : 0)) {
+        gnms_set_error("gnms_soft_sort_backward: scratch too small");
+        return GNMS_ERR_WORKSPACE;
+    }
+    GNMS_CHECK_ARG((uintptr_t)scratch % 16 == 0, "gnms_soft_sort_backward: scratch must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    const float* Z = img_ptrs(ws, L, 0).xsol;                       // row sums left by gnms_soft_sort
+    const size_t n2 = (size_t)N * N;
+    float* dC = (float*)scratch;                                    // [N][N]
+    float* T1 = dC + n2;                                            // [N][N]: C^T; before that (first K*N floats) matrix^T... kept apart below
+    float* MT = T1 + n2;                                            // [K][N]: matrix^T
+    float* dZ = MT + (with_matrix ? (size_t)K * N : 0);
+    float* base = dZ + N;
+    float* dshat = base + N;
+    int rc;
+    softsort_bwd_dc_kernel<<<dim3(gnms_div_up(N, 256), N), 256, 0, st>>>(g_C, g_soft, scores, N, dC);
+    GNMS_CHECK_LAUNCH();
+    if (with_matrix) {
+        transpose_kernel<<<dim3(gnms_div_up(K, 32), gnms_div_up(N, 32)), 256, 0, st>>>(matrix, N, K, (long)ld, MT, (long)N);   // MT [K][N]
+        GNMS_CHECK_LAUNCH();
+        if ((rc = launch_sgemm(g_mat, MT, dC, N, N, K, K, N, N, 1, st))) return rc;                 // dC += g_mat M^T
+        if (d_matrix) {
+            transpose_kernel<<<dim3(gnms_div_up(N, 32), gnms_div_up(N, 32)), 256, 0, st>>>(C, N, N, (long)N, T1, (long)N);      // C^T
+            GNMS_CHECK_LAUNCH();
+            if ((rc = launch_sgemm(T1, g_mat, d_matrix, N, K, N, N, K, ld, 0, st))) return rc;      // dM = C^T g_mat
+        }
+    }
+    softsort_bwd_cols1_kernel<<<gnms_div_up(N, 256), 256, 0, st>>>(dC, C, g_soft, Z, N, dZ, base);
+    GNMS_CHECK_LAUNCH();
+    softsort_bwd_rows_kernel<<<N, 256, 0, st>>>(scores, N, temperature, ws, L, Z, dZ, dC, dshat);
+    GNMS_CHECK_LAUNCH();
+    softsort_bwd_cols2_kernel<<<gnms_div_up(N, 256), 256, 0, st>>>(dC, base, dshat, N, ws, L, d_scores);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -207,6 +401,6 @@ extern "C" int gnms_soft_sort(const float* scores, const float* iou, int N, int6
     GNMS_CHECK_LAUNCH();
     softsort_normalize_kernel<<<N, 256, 0, st>>>(scores, N, Z, C, soft_scores);
     GNMS_CHECK_LAUNCH();
-    if (iou) return gnms_sgemm(C, iou, soft_matrix, N, N, N, N, ld, N, stream);
+    if (iou) return launch_sgemm(C, iou, soft_matrix, N, N, N, N, ld, N, 0, st);
     return GNMS_OK;
 }

@@ -212,9 +212,9 @@ class _GroomedNMSFromBoxesFunction(torch.autograd.Function):
 
 
 class _SoftSortFunction(torch.autograd.Function):
-    """soft_sort (lib/groomed_nms.py:131-165) for one image: HIP forward (row kernels + fp32 MFMA GEMM);
-    backward = the hand-derived adjoint of the same expressions (including the reference's last-axis
-    broadcast of the row sums, :155), its two GEMMs on the MFMA kernel as well."""
+    """soft_sort (lib/groomed_nms.py:131-165) for one image: HIP forward (row kernels + fp32 MFMA GEMM) and HIP backward
+    (gnms_soft_sort_backward: the hand-derived adjoint of the same expressions, including the reference's last-axis
+    broadcast of the row sums, :155; its two GEMMs on the MFMA kernel as well)."""
 
     @staticmethod
     def forward(ctx, scores, matrix, temperature):
@@ -247,38 +247,35 @@ class _SoftSortFunction(torch.autograd.Function):
         ctx.temperature = float(temperature)
         ctx.set_materialize_grads(False)
         ctx.has_matrix = matrix is not None
-        ctx.save_for_backward(scores_c, m_c if m_c is not None else scores_c, C)
+        ctx.save_for_backward(scores_c, m_c if m_c is not None else scores_c, C, ws)
         if matrix is None:
             return soft_scores, C
         return soft_scores, C, soft_matrix
 
     @staticmethod
     def backward(ctx, g_soft, g_C, g_mat=None):
-        scores, matrix, C = ctx.saved_tensors
-        T = ctx.temperature
+        """gnms_soft_sort_backward: the hand-derived adjoint as HIP kernels (row / column passes + the two MFMA GEMMs)."""
+        lib = _lib.load()
+        scores, matrix, C, ws = ctx.saved_tensors
         n = scores.shape[0]
-        shat, order = torch.sort(scores, descending=True, stable=True)
-        A = -(scores.unsqueeze(0) - shat.unsqueeze(1)).abs()
-        mx, amax = A.max(dim=1)
-        E = torch.exp((A - mx.unsqueeze(1)) / T)
-        Z = E.sum(dim=1) + 1e-3
-        dC = torch.zeros_like(C) if g_C is None else g_C.clone()
-        d_s = torch.zeros_like(scores)
-        d_m = None
-        if g_soft is not None:
-            dC = dC + torch.outer(g_soft, scores)
-            d_s = d_s + _sgemm(C.t().contiguous(), g_soft.unsqueeze(1).contiguous()).squeeze(1)
-        if ctx.has_matrix and g_mat is not None:
-            dC = dC + _sgemm(g_mat.contiguous(), matrix.t().contiguous())
-            d_m = _sgemm(C.t().contiguous(), g_mat.contiguous())
-        dZ = -((dC * C).sum(dim=0) / Z)                   # C[i][j] = E[i][j] / Z[j]
-        dE = dC / Z.unsqueeze(0) + dZ.unsqueeze(1)
-        dArg = dE * E / T
-        dA = dArg.clone()
-        dA[torch.arange(n, device=scores.device), amax] += -dArg.sum(dim=1)
-        sg = torch.sign(scores.unsqueeze(0) - shat.unsqueeze(1))
-        d_s = d_s + (dA * (-sg)).sum(dim=0)
-        d_s = d_s.index_add(0, order, (dA * sg).sum(dim=1))
+        dev = scores.device
+        has_m = ctx.has_matrix and g_mat is not None
+        K = matrix.shape[1] if has_m else 0
+        d_s = torch.empty_like(scores)
+        if n == 0:
+            return d_s, (torch.zeros_like(matrix) if ctx.has_matrix else None), None
+        g_soft_c = g_soft.contiguous().float() if g_soft is not None else None
+        g_C_c = g_C.contiguous().float() if g_C is not None else None
+        g_mat_c = g_mat.contiguous().float() if has_m else None
+        d_m = torch.empty_like(matrix) if has_m else None
+        nb = lib.gnms_soft_sort_backward_scratch_bytes(n, K)
+        scratch = torch.empty((nb,), dtype=torch.uint8, device=dev)
+        with on_device(dev):
+            check(lib.gnms_soft_sort_backward(ptr(scores), ptr(matrix) if has_m else None, n, K, max(K, 1), ctx.temperature, ptr(C),
+                                              ptr(g_soft_c), ptr(g_C_c), ptr(g_mat_c), ptr(d_s), ptr(d_m), ptr(ws), ws.numel(),
+                                              ptr(scratch), scratch.numel(), stream_ptr(dev)), "gnms_soft_sort_backward")
+        if ctx.has_matrix and d_m is None:
+            d_m = torch.zeros_like(matrix)
         return d_s, (d_m if ctx.has_matrix else None), None
 
 

@@ -219,6 +219,17 @@ int gnms_pruning_function_backward(const float* iou, const float* grad_out, int6
 int gnms_soft_sort(const float* scores, const float* iou, int N, int64_t ld, float temperature, float* C,
                    float* soft_scores, float* soft_matrix, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Adjoint of gnms_soft_sort (the reference differentiates lib/groomed_nms.py:145-164 with autograd).  scores, temperature, C and
+ * `workspace` are what the forward call saw / produced (the workspace still holds the sorted scores, their order and the row sums);
+ * matrix [N][ld] with K columns is the matrix that was multiplied (NULL: none).  Upstream gradients, each may be NULL: g_soft [N]
+ * (of soft_scores), g_C [N][N] (of C), g_mat [N][K] (of soft_matrix).  Outputs: d_scores [N]; d_matrix [N][ld] or NULL.
+ * scratch: gnms_soft_sort_backward_scratch_bytes(N, K) bytes, 16-byte aligned.  The two products (g_mat M^T, C^T g_mat) run on
+ * the MFMA GEMM; row and column passes are deterministic (no atomics). */
+size_t gnms_soft_sort_backward_scratch_bytes(int N, int K);
+int gnms_soft_sort_backward(const float* scores, const float* matrix, int N, int K, int64_t ld, float temperature, const float* C,
+                            const float* g_soft, const float* g_C, const float* g_mat, float* d_scores, float* d_matrix,
+                            void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream);
+
 /* D[M x N] = A[M x K] B[K x N], fp32 row-major with leading dimensions lda/ldb/ldd, on the matrix cores
  * (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf chain over k).  The GEMM behind soft_sort's C @ iou (:163). */
 int gnms_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd,

@@ -6,8 +6,9 @@ run() { echo "== $* $EXTRA" >> $O; env "$@" python bench.py --steps 100 --warmup
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline'] or {}
 print(d['config']['workload'][:40], 'ms/step', d['ms_per_step'], 'boxes/s %.3e' % d['value'], '|', (r.get('kernel') or '')[-20:], r.get('kernel_ms'), 'frac', r.get('frac'))" >> $O; }
-for k in clustered uniform; do for f in 0 1; do EXTRA="--dim 3 --kind $k" run GNMS_FUSE_TAIL=$f; done; done
-for n in 2048 8192; do for f in 0 1; do EXTRA="--dim 3 --boxes $n" run GNMS_FUSE_TAIL=$f; done; done
-EXTRA="--dim 3 --boxes 16384 --steps 30" run GNMS_FUSE_TAIL=0
-EXTRA="--dim 3 --boxes 16384 --steps 30 --kind uniform" run GNMS_FUSE_TAIL=0
+EXTRA="" run A=1
+EXTRA="--dim 3" run A=1
+EXTRA="--dim 3 --kind uniform" run A=1
+EXTRA="--dim 3 --boxes 16384 --steps 30" run A=1
+EXTRA="--boxes 16384 --steps 30" run A=1
 cat $O
