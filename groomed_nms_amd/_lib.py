@@ -74,6 +74,11 @@ _SIGNATURES = {
     "_nms": (None, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),
     "gnms_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "gnms_nms_sorted": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "gnms_nms_sorted_shift": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_vp, c_vp, c_vp,
+                                             ctypes.c_size_t, c_vp]),
+    "gnms_soft_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "gnms_soft_nms": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                     ctypes.c_double, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_bbox_transform_inv": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, c_vp]),
     "gnms_select_topk": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int, c_vp, ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                          c_vp]),

@@ -22,8 +22,10 @@ __device__ __forceinline__ float bcastf(float v, int lane) {
 }
 
 // boxes [n][dim] sorted by score; W[kb][c] bit r = devIoU(box[64 kb + r], box[c]) > thresh
-__global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restrict__ boxes, int n, int dim, float thresh, char* ws,
-                                                           gnms_ws_layout L) {
+// shift: the pixel convention (x2 - x1 + shift): 1 in nms_kernel.cu:24-32, a parameter of lib/nms_others.py:119 girshick_nms.
+// keep_le: 0 = suppress when IoU > thresh (nms_kernel.cu:71); 1 = keep only IoU <= thresh (nms_others.py:146: a NaN overlap suppresses)
+__global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restrict__ boxes, int n, int dim, float thresh, float shift, int keep_le,
+                                                           char* ws, gnms_ws_layout L) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kb = blockIdx.y;
     const int k0 = kb * 64;
@@ -37,12 +39,12 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
         col[j] = c0 + 4 * lane + j;
         const float* p = boxes + (size_t)(col[j] < n ? col[j] : n - 1) * dim;
         bx1[j] = p[0]; by1[j] = p[1]; bx2[j] = p[2]; by2[j] = p[3];
-        bs[j] = (bx2[j] - bx1[j] + 1) * (by2[j] - by1[j] + 1);                 // nms_kernel.cu:30
+        bs[j] = (bx2[j] - bx1[j] + shift) * (by2[j] - by1[j] + shift);         // nms_kernel.cu:30
     }
     const int myr = min(k0 + lane, n - 1);
     const float* q = boxes + (size_t)myr * dim;
     const float rx1 = q[0], ry1 = q[1], rx2 = q[2], ry2 = q[3];
-    const float rs = (rx2 - rx1 + 1) * (ry2 - ry1 + 1);                        // :29
+    const float rs = (rx2 - rx1 + shift) * (ry2 - ry1 + shift);                // :29
     const int nrows = min(64, n - k0);
     unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
 #pragma unroll 8
@@ -52,9 +54,10 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
         for (int j = 0; j < 4; ++j) {
             const float left = fmaxf(ax1, bx1[j]), right = fminf(ax2, bx2[j]);   // :25
             const float top = fmaxf(ay1, by1[j]), bottom = fminf(ay2, by2[j]);   // :26
-            const float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);   // :27
+            const float width = fmaxf(right - left + shift, 0.f), height = fmaxf(bottom - top + shift, 0.f);   // :27
             const float inter = width * height;                                  // :28
-            const bool sup = (inter / (as + bs[j] - inter)) > thresh;            // :31, :71
+            const float ov = inter / (as + bs[j] - inter);                       // :31
+            const bool sup = keep_le ? !(ov <= thresh) : (ov > thresh);           // :71 / nms_others.py:146
             if (r < 32) lo[j] |= sup ? (1u << r) : 0u; else hi[j] |= sup ? (1u << (r - 32)) : 0u;
         }
     }
@@ -84,9 +87,9 @@ __global__ void classic_export_kernel(int n, char* ws, gnms_ws_layout L, int* __
 
 extern "C" size_t gnms_nms_workspace_bytes(int n) { return n > 0 ? gnms_make_layout(n).per_image : 0; }
 
-extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int32_t* keep, int32_t* num_out,
-                               void* workspace, size_t workspace_bytes, void* stream) {
-    GNMS_CHECK_ARG(n >= 0 && boxes_dim >= 4, "gnms_nms_sorted: bad shape (n=%d dim=%d)", n, boxes_dim);
+extern "C" int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, float thresh, float shift, int keep_le, int32_t* keep,
+                                     int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream) {
+    GNMS_CHECK_ARG(n >= 0 && boxes_dim >= 4, "gnms_nms_sorted_shift: bad shape (n=%d dim=%d)", n, boxes_dim);
     GNMS_CHECK_ARG(num_out != nullptr, "gnms_nms_sorted: num_out is NULL");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) { GNMS_CHECK_HIP(hipMemsetAsync(num_out, 0, sizeof(int32_t), st)); return GNMS_OK; }
@@ -97,7 +100,7 @@ extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float t
     char* ws = (char*)workspace;
     classic_init_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L);
     GNMS_CHECK_LAUNCH();
-    classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, ws, L);
+    classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, shift, keep_le, ws, L);
     GNMS_CHECK_LAUNCH();
     const size_t lds = leaders_lds_size(L.NB);
     if (lds > 64 * 1024)
@@ -107,6 +110,11 @@ extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float t
     classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
+}
+
+extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int32_t* keep, int32_t* num_out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    return gnms_nms_sorted_shift(boxes, n, boxes_dim, thresh, 1.0f, 0, keep, num_out, workspace, workspace_bytes, stream);
 }
 
 // The reference's exact symbol (lib/nms/gpu_nms.hpp:1-2): host pointers, blocking, allocates per call

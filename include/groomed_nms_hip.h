@@ -255,6 +255,21 @@ size_t gnms_nms_workspace_bytes(int n);
 int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int32_t* keep, int32_t* num_out,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* the same scan with the pixel convention and the comparison as parameters: areas and overlaps use (x2 - x1 + shift); keep_le = 0
+ * suppresses when IoU > thresh (`_nms`), keep_le = 1 keeps only IoU <= thresh -- lib/nms_others.py:119-150 girshick_nms(dets, thresh,
+ * shift) on score-sorted boxes (a NaN overlap then suppresses, as `np.where(ovr <= thresh)` does). */
+int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, float thresh, float shift, int keep_le, int32_t* keep,
+                          int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* lib/nms_others.py:6-116 navneeth_soft_nms(boxes, sigma, Nt, threshold, method, shift): Soft-NMS with the reference's slot
+ * bookkeeping.  boxes [n][boxes_dim] (x1 y1 x2 y2 score ...), fp64 when is_fp64 else fp32, NOT modified (the reference decays the
+ * scores and swaps the rows of its argument in place).  method 0 hard, 1 linear, 2 gaussian.  keep [n] int64: the kept ORIGINAL
+ * indices in the reference's slot order (`keep_orig[:N]`), *num_out (device int32) of them.  One workgroup; n <= GNMS_MAX_BOXES.
+ * workspace: gnms_soft_nms_workspace_bytes(n), 256-byte aligned. */
+size_t gnms_soft_nms_workspace_bytes(int n);
+int gnms_soft_nms(const void* boxes, int n, int boxes_dim, int is_fp64, double sigma, double Nt, double threshold, int method, double shift,
+                  int64_t* keep, int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * After-NMS AP loss (lib/loss/aploss.py:14-87 backpropAPLoss.forward, called per image on the rescored
  * scores at lib/loss/rpn_3d.py:1117-1131): the immediate consumer of gnms_forward's `prob`.

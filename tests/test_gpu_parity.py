@@ -1421,3 +1421,36 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env2,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_nms_others_on_the_gpu(golden_misc):
+    """lib/nms_others.py on the device (gnms_soft_nms, gnms_nms_sorted_shift): the reference's vectors (Soft-NMS methods 0/1/2 with its
+    slot order, Girshick NMS with shift 1 and 0) and the pure-Python oracle on seeded inputs, float64 and float32, odd sizes; the
+    caller's array stays untouched."""
+    from groomed_nms_amd.nms_others import navneeth_soft_nms, girshick_nms
+    from groomed_nms_amd import synthetic
+    from oracle import nms_others_oracle as NO
+    g = golden_misc
+    for tag in ("dets40", "dets300", "dets_uni200"):
+        d = g[f"{tag}/dets"]
+        for thr in (0.4, 0.7):
+            assert [int(i) for i in girshick_nms(d, thr)] == list(g[f"{tag}/girshick_nms_{thr}"]), (tag, thr)
+            assert [int(i) for i in girshick_nms(d, thr, shift=0)] == list(g[f"{tag}/girshick_nms_shift0_{thr}"]), (tag, thr)
+        for m in (0, 1, 2):
+            d64 = d.astype(np.float64).copy()
+            keep = navneeth_soft_nms(d64, method=m)
+            assert list(keep) == list(g[f"{tag}/soft_nms_m{m}"]), (tag, m)
+            assert np.array_equal(d64, d.astype(np.float64))                     # not modified (the reference rewrites its argument)
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 63, 64, 65, 257, 1000, 2500):
+        per = max(2, n // 12)
+        dets = np.concatenate([np.round(synthetic.clustered_boxes_2d(rng, n, per)), synthetic.tie_free_scores(rng, n)[:, None]], 1)
+        for m, kw in ((0, {}), (1, {}), (2, dict(sigma=0.3)), (1, dict(Nt=0.2, threshold=0.05, shift=0)), (2, dict(threshold=0.2))):
+            want = list(NO.soft_nms(dets.astype(np.float64), method=m, **kw))
+            assert list(navneeth_soft_nms(dets.astype(np.float64), method=m, **kw)) == want, (n, m, kw)
+        # float32 input: fp32 geometry and stored scores; same kept SET as the fp64 oracle on these pixel-rounded boxes for hard NMS
+        assert sorted(navneeth_soft_nms(dets.astype(np.float32), method=0)) == sorted(NO.soft_nms(dets.astype(np.float64), method=0)), n
+        for thr, sh in ((0.5, 1), (0.3, 0), (0.7, 2)):
+            d32 = dets.astype(np.float32)
+            assert [int(i) for i in girshick_nms(d32, thr, shift=sh)] == [int(i) for i in NO.girshick_nms(d32, thr, shift=sh)], (n, thr, sh)
+    assert list(navneeth_soft_nms(np.zeros((0, 5)))) == [] and girshick_nms(np.zeros((0, 5), np.float32), 0.5) == []
