@@ -3,8 +3,9 @@
 `APLoss` / `backpropAPLoss` keep the reference's names, arguments, defaults and return shapes
 (lib/loss/aploss.py:12-97; used at lib/loss/rpn_3d.py:189 and :1117-1131 on the scores GrooMeD-NMS
 rescored).  The ranking itself -- the reference's Python loop over the positives, O(N) tensor ops per
-trip (:50-68) -- is one HIP kernel launch behind `gnms_aploss` (include/groomed_nms_hip.h), one workgroup
-per image.  No CPU implementation lives here: without the library or a GPU the calls raise.
+trip (:50-68) -- runs behind `gnms_aploss` (include/groomed_nms_hip.h): one workgroup per image up to 2047 boxes,
+four launches that spread the positives over the machine above that (up to 16384 boxes per image).
+No CPU implementation lives here: without the library or a GPU the calls raise.
 """
 import torch
 
@@ -13,7 +14,7 @@ from ._lib import check, ptr, stream_ptr, on_device
 
 __all__ = ["APLoss", "backpropAPLoss", "ap_loss_batched"]
 
-MAX_BOXES = 4096                                       # GNMS_APLOSS_MAX_BOXES
+MAX_BOXES = 16384                                      # GNMS_APLOSS_MAX_BOXES = GNMS_MAX_BOXES
 
 
 def _device():

@@ -15,6 +15,7 @@
 //      reference's order (ascending positives, :61-67)
 //   6. grad[positives] = -(1 - prec)/F, grad[negatives] = grad_j/F, loss = 1 - mean(prec)  (:70-78)
 // delta is 1.0 whatever the caller asks for, as in the reference (:16).
+#include <cstdlib>
 #include "nms_kernels.h"
 
 namespace {
@@ -225,6 +226,239 @@ __global__ __launch_bounds__(kApThreads) void aploss_kernel(const float* __restr
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Large images (N > 4096, up to GNMS_MAX_BOXES) and many positives: the same computation spread over the machine.
+//   ap_prepare_kernel  one workgroup per image: classify, compact, sort the positive values (passes 1-2 above) into global scratch
+//   ap_rank_kernel     one WAVE per positive, 16 per workgroup, all positives of all images at once: a_p, b_p (pass 3) -- the
+//                      O(F (F + G)) part that took 0.9 ms on one CU at F = 1024, N = 4096
+//   ap_scan_kernel     one workgroup per image: running maximum, rescale factors, loss, gradient of the positives (passes 4, 6)
+//   ap_neg_grad_kernel 256 valid negatives per workgroup: their gradients, positives walked in ascending order through LDS tiles
+//                      (pass 5: the reference's order of additions)
+// Scratch per image (stream-ordered temporary): 8 N words + 4.
+// ------------------------------------------------------------------------------------------------
+struct ApScratch {
+    unsigned* keys;      // [N] sorted positive logits (as keys)
+    unsigned* poskey;    // [N] key of the k-th positive in index order
+    int* posidx;         // [N] box index of the k-th positive in index order
+    float* bgv;          // [N] valid negative logits in index order
+    int* negidx;         // [N] their box indices
+    float* denom;        // [N] a_p + b_p
+    float* mprec;        // [N] current_prec, then the running maximum
+    float* scale;        // [N]
+    int* meta;           // [4] F, G, has positives
+};
+__host__ __device__ inline size_t ap_scratch_words(int N) { return (size_t)8 * N + 4; }
+__device__ __forceinline__ ApScratch ap_scratch(float* base, int N, int b) {
+    unsigned* p = reinterpret_cast<unsigned*>(base) + (size_t)b * ap_scratch_words(N);
+    ApScratch S;
+    S.keys = p; S.poskey = p + N; S.posidx = reinterpret_cast<int*>(p + 2 * (size_t)N); S.bgv = reinterpret_cast<float*>(p + 3 * (size_t)N);
+    S.negidx = reinterpret_cast<int*>(p + 4 * (size_t)N); S.denom = reinterpret_cast<float*>(p + 5 * (size_t)N);
+    S.mprec = reinterpret_cast<float*>(p + 6 * (size_t)N); S.scale = reinterpret_cast<float*>(p + 7 * (size_t)N);
+    S.meta = reinterpret_cast<int*>(p + 8 * (size_t)N);
+    return S;
+}
+
+template <int kApE>
+__global__ __launch_bounds__(kApThreads) void ap_prepare_kernel(const float* __restrict__ logits, const float* __restrict__ targets, int N,
+                                                                const int* __restrict__ counts, float positive_label, float negative_label,
+                                                                float* __restrict__ loss, float* __restrict__ grad, float* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int P = kApThreads * kApE;
+    unsigned* keys = reinterpret_cast<unsigned*>(smem);               // [P]
+    __shared__ float red_f[16];
+    __shared__ unsigned long long red_u[16];
+    __shared__ double red_d[16];
+    const int b = blockIdx.x;
+    const int n = gnms_count(counts, b, N);
+    const float* lg = logits + (size_t)b * N;
+    const float* tg = targets + (size_t)b * N;
+    float* gr = grad + (size_t)b * N;
+    ApScratch S = ap_scratch(scratch, N, b);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float v[kApE], tv[kApE];
+    float tmax = -INFINITY, fmin = INFINITY;
+#pragma unroll
+    for (int e = 0; e < kApE; ++e) {
+        const int i = t * kApE + e;
+        v[e] = 0.0f; tv[e] = 0.0f;
+        if (i < n) {
+            v[e] = lg[i]; tv[e] = tg[i];
+            tmax = fmaxf(tmax, tv[e]);
+            if (tv[e] == positive_label) fmin = fminf(fmin, v[e]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64)); fmin = fminf(fmin, __shfl_xor(fmin, off, 64)); }
+    if (lane == 0) { red_f[wave] = tmax; red_d[wave] = (double)fmin; }
+    for (int i = t; i < N; i += blockDim.x) gr[i] = 0.0f;
+    __syncthreads();
+    tmax = red_f[0]; fmin = (float)red_d[0];
+    for (int w = 1; w < 16; ++w) { tmax = fmaxf(tmax, red_f[w]); fmin = fminf(fmin, (float)red_d[w]); }
+    __syncthreads();
+    if (n == 0 || !(tmax > 0.0f) || fmin == INFINITY) {              // no positives (:26-28)
+        if (t == 0) { loss[b] = 0.0f; S.meta[0] = 0; S.meta[1] = 0; S.meta[2] = 0; }
+        return;
+    }
+    const float threshold_logit = fmin - 1.0f;
+    int cls[kApE];
+    unsigned long long packed = 0;
+#pragma unroll
+    for (int e = 0; e < kApE; ++e) {
+        const int i = t * kApE + e;
+        cls[e] = 0;
+        if (i < n) {
+            if (tv[e] == positive_label) cls[e] = 1;
+            else if (tv[e] == negative_label && v[e] >= threshold_logit) cls[e] = 2;
+        }
+        packed += (cls[e] == 1) ? 1ull : (cls[e] == 2 ? (1ull << 32) : 0ull);
+    }
+    unsigned long long inc = packed;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long u = shfl_up_u64(inc, off);
+        if (lane >= off) inc += u;
+    }
+    if (lane == 63) red_u[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { const unsigned long long u = red_u[w]; if (w < wave) base += u; total += u; }
+    const int F = (int)(total & 0xffffffffu), G = (int)(total >> 32);
+    unsigned long long run = base + inc - packed;
+    for (int i = t; i < P; i += blockDim.x) keys[i] = ~0u;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kApE; ++e) {
+        const int i = t * kApE + e;
+        if (cls[e] == 1) {
+            const int k = (int)(run & 0xffffffffu);
+            const unsigned key = asc_key(v[e]);
+            keys[k] = key; S.poskey[k] = key; S.posidx[k] = i;
+            run += 1ull;
+        } else if (cls[e] == 2) {
+            const int j = (int)(run >> 32);
+            S.bgv[j] = v[e]; S.negidx[j] = i;
+            run += 1ull << 32;
+        }
+    }
+    __syncthreads();
+    unsigned r[kApE];
+#pragma unroll
+    for (int e = 0; e < kApE; ++e) r[e] = keys[t * kApE + e];
+    __syncthreads();
+    block_sort<kApE, unsigned>(r, keys, P);
+    for (int k = t; k < F; k += blockDim.x) S.keys[k] = keys[k];
+    if (t == 0) { S.meta[0] = F; S.meta[1] = G; S.meta[2] = 1; }
+}
+
+__global__ __launch_bounds__(1024) void ap_rank_kernel(int N, float* __restrict__ scratch) {
+    const int b = blockIdx.y;
+    ApScratch S = ap_scratch(scratch, N, b);
+    const int F = S.meta[0], G = S.meta[1];
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (p >= F) return;
+    const float x = asc_key_decode(S.keys[p]);
+    double sa = 0.0, sb = 0.0;
+    for (int k = lane; k < F; k += 64) sa += (double)rank_term(asc_key_decode(S.keys[k]), x, 2.0f);
+    for (int j = lane; j < G; j += 64) sb += (double)rank_term(S.bgv[j], x, 2.0f);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
+    if (lane == 0) {
+        const float a = (float)sa + 0.5f;
+        const float bsum = (float)sb;
+        S.denom[p] = a + bsum;
+        S.mprec[p] = a / (a + bsum);
+    }
+}
+
+template <int kApE>
+__global__ __launch_bounds__(kApThreads) void ap_scan_kernel(int N, float* __restrict__ scratch, float* __restrict__ loss, float* __restrict__ grad) {
+    __shared__ float red_f[16];
+    __shared__ double red_d[16];
+    const int b = blockIdx.x;
+    ApScratch S = ap_scratch(scratch, N, b);
+    if (!S.meta[2]) return;
+    const int F = S.meta[0];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float cur[kApE];
+    float m = 0.0f;
+#pragma unroll
+    for (int e = 0; e < kApE; ++e) {
+        const int p = t * kApE + e;
+        cur[e] = (p < F) ? S.mprec[p] : 0.0f;
+        m = (m <= cur[e]) ? cur[e] : m;
+    }
+    float incm = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float u = __shfl_up(incm, off, 64);
+        if (lane >= off) incm = fmaxf(incm, u);
+    }
+    float before = __shfl_up(incm, 1, 64);
+    if (lane == 0) before = 0.0f;
+    if (lane == 63) red_f[wave] = incm;
+    __syncthreads();
+    float carry = 0.0f;
+    for (int w = 0; w < wave; ++w) carry = fmaxf(carry, red_f[w]);
+    float prev = fmaxf(before, carry);
+    double sp = 0.0;
+#pragma unroll
+    for (int e = 0; e < kApE; ++e) {
+        const int p = t * kApE + e;
+        if (p < F) {
+            const bool rises = prev <= cur[e];
+            S.scale[p] = rises ? 1.0f : (1.0f - prev) / (1.0f - cur[e]);
+            prev = rises ? cur[e] : prev;
+            S.mprec[p] = prev;
+            sp += (double)prev;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sp += __shfl_xor(sp, off, 64);
+    if (lane == 0) red_d[wave] = sp;
+    __syncthreads();                                                   // mprec[] complete (global, same workgroup)
+    const float fnum = (float)(F > 1 ? F : 1);
+    float* gr = grad + (size_t)b * N;
+    for (int k = t; k < F; k += blockDim.x) {                          // gradient of the positives: any position with this logit carries its prec
+        const unsigned key = S.poskey[k];
+        int lo = 0, hi = F;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (S.keys[mid] < key) lo = mid + 1; else hi = mid; }
+        gr[S.posidx[k]] = (-(1.0f - S.mprec[lo])) / fnum;
+    }
+    if (t == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 16; ++w) s += red_d[w];
+        loss[b] = 1.0f - (float)s / fnum;
+    }
+}
+
+__global__ __launch_bounds__(256) void ap_neg_grad_kernel(int N, float* __restrict__ scratch, float* __restrict__ grad) {
+    __shared__ float tx[256], td[256], tsc[256];
+    const int b = blockIdx.y;
+    ApScratch S = ap_scratch(scratch, N, b);
+    const int F = S.meta[0], G = S.meta[1];
+    if ((int)blockIdx.x * 256 >= G) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const float vj = (j < G) ? S.bgv[j] : 0.0f;
+    float g = 0.0f;
+    for (int p0 = 0; p0 < F; p0 += 256) {
+        const int p = p0 + threadIdx.x;
+        if (p < F) { tx[threadIdx.x] = asc_key_decode(S.keys[p]); td[threadIdx.x] = S.denom[p]; tsc[threadIdx.x] = S.scale[p]; }
+        __syncthreads();
+        const int np = min(256, F - p0);
+        for (int q = 0; q < np; ++q) {                                 // ascending positives: the reference's order of additions (:61-67)
+            float term = rank_term(vj, tx[q], 2.0f) / td[q];
+            const float sc = tsc[q];
+            if (sc != 1.0f) term *= sc;
+            g += term;
+        }
+        __syncthreads();
+    }
+    const float fnum = (float)(F > 1 ? F : 1);
+    if (j < G) grad[(size_t)b * N + S.negidx[j]] = g / fnum;
+}
+
 }  // namespace
 
 extern "C" int gnms_aploss(const float* logits, const float* targets, int B, int N, const int32_t* counts, float positive_label,
@@ -234,11 +468,44 @@ extern "C" int gnms_aploss(const float* logits, const float* targets, int B, int
     GNMS_CHECK_ARG(loss != nullptr, "gnms_aploss: loss is NULL");
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) { GNMS_CHECK_HIP(hipMemsetAsync(loss, 0, sizeof(float) * B, st)); return GNMS_OK; }
-    if (N > kApMaxN) {
-        gnms_set_error("gnms_aploss: N=%d exceeds %d (the reference ranks at most 500 boxes per image, lib/loss/rpn_3d.py:732)", N, kApMaxN);
+    if (N > GNMS_MAX_BOXES) {
+        gnms_set_error("gnms_aploss: N=%d exceeds GNMS_MAX_BOXES=%d", N, GNMS_MAX_BOXES);
         return GNMS_ERR_UNSUPPORTED;
     }
     GNMS_CHECK_ARG(logits && targets && grad, "gnms_aploss: null pointer");
+    // One workgroup per image ranks up to 4096 boxes entirely in LDS; larger images -- and, by request (GNMS_APLOSS_SPREAD=1), any
+    // image whose F x N product makes the one-CU version slow -- run the four-kernel version that spreads the positives over the machine.
+    static const int spread = [] { const char* e = getenv("GNMS_APLOSS_SPREAD"); return e ? atoi(e) : 0; }();
+    if (N > kApMaxN || spread == 1 || (spread == 0 && N >= 2048 && B <= 64)) {
+        float* scratch = nullptr;
+        GNMS_CHECK_HIP(hipMallocAsync((void**)&scratch, (size_t)B * ap_scratch_words(N) * sizeof(float), st));
+        int P2 = 1024;
+        while (P2 < N) P2 <<= 1;
+        const int E = P2 / kApThreads;
+        const size_t lds = (size_t)P2 * 4;
+#define GNMS_AP_PREP(EE)                                                                                                              \
+    do {                                                                                                                              \
+        if (lds > 64 * 1024)                                                                                                          \
+            GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ap_prepare_kernel<EE>),                                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                \
+        ap_prepare_kernel<EE><<<B, kApThreads, lds, st>>>(logits, targets, N, counts, positive_label, negative_label, loss, grad, scratch); \
+    } while (0)
+        switch (E) { case 1: GNMS_AP_PREP(1); break; case 2: GNMS_AP_PREP(2); break; case 4: GNMS_AP_PREP(4); break; case 8: GNMS_AP_PREP(8); break;
+                     default: GNMS_AP_PREP(16); break; }
+#undef GNMS_AP_PREP
+        ap_rank_kernel<<<dim3(gnms_div_up(N, 16), B), 1024, 0, st>>>(N, scratch);
+        switch (E) { case 1: ap_scan_kernel<1><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
+                     case 2: ap_scan_kernel<2><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
+                     case 4: ap_scan_kernel<4><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
+                     case 8: ap_scan_kernel<8><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
+                     default: ap_scan_kernel<16><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break; }
+        ap_neg_grad_kernel<<<dim3(gnms_div_up(N, 256), B), 256, 0, st>>>(N, scratch, grad);
+        const hipError_t le = hipGetLastError();
+        const hipError_t fe = hipFreeAsync(scratch, st);
+        if (le != hipSuccess) { gnms_set_error("gnms_aploss: kernel launch failed: %s", hipGetErrorString(le)); return GNMS_ERR_HIP; }
+        if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }
+        return GNMS_OK;
+    }
     if (N > 2 * kApThreads)      // > 64 KiB of dynamic LDS; set per call: the attribute is per device and the call is cheap
         GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aploss_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            kApThreads * 4 * 4 * 6));

@@ -277,9 +277,11 @@ int gnms_soft_nms(const void* boxes, int n, int boxes_dim, int is_fp64, double s
  *   loss: [B] = 1 - mean precision of the positives; grad: [B][N] = d loss / d logits, both produced by the
  *   forward pass as in the reference (:69-78; its backward only scales grad by the incoming gradient, :80-85).
  *   An image without a positive (max(targets) <= 0, :26-28) gets loss 0 and a zero gradient.
- *   delta is 1.0 whatever the caller of the reference passes (:16).  N <= 4096 (GNMS_ERR_UNSUPPORTED above).
+ *   delta is 1.0 whatever the caller of the reference passes (:16).  N <= GNMS_MAX_BOXES.  Up to 2047 boxes per image one workgroup per
+ *   image does everything in LDS (no scratch); larger images take a stream-ordered temporary of 8 N words per image and spread the
+ *   positives over the machine (four launches).
  * ------------------------------------------------------------------------------------------------ */
-#define GNMS_APLOSS_MAX_BOXES 4096
+#define GNMS_APLOSS_MAX_BOXES GNMS_MAX_BOXES
 int gnms_aploss(const float* logits, const float* targets, int B, int N, const int32_t* counts, float positive_label,
                 float negative_label, float* loss, float* grad, void* stream);
 

@@ -710,7 +710,43 @@ def test_aploss_properties_and_limits():
     # positives are pushed up, negatives down
     assert (lg.grad[1, :F] < 0).all() and (lg.grad[1, F:] >= 0).all()
     with pytest.raises(_lib.GnmsError):
-        ap_loss_batched(torch.zeros((1, 5000), device="cuda"), torch.zeros((1, 5000), device="cuda"))
+        ap_loss_batched(torch.zeros((1, 20000), device="cuda"), torch.zeros((1, 20000), device="cuda"))
+
+
+def test_aploss_large_images_and_many_positives():
+    """N up to GNMS_MAX_BOXES and F in the thousands (the spread version: positives over the machine) against the oracle; the
+    one-workgroup version (N < 2048) and the spread version (same boxes padded to N = 2048 with a count) give the same numbers."""
+    from groomed_nms_amd.aploss import ap_loss_batched
+    from oracle import oracle as O
+    rng = np.random.default_rng(23)
+    for N, F in ((6000, 300), (16384, 2500), (4096, 1024), (2048, 1)):
+        B = 2
+        lg = rng.normal(0, 2.0, size=(B, N)).astype(np.float32)
+        tg = np.zeros((B, N), np.float32)
+        for b in range(B):
+            tg[b, rng.choice(N, F, replace=False)] = 1
+        tg[1, rng.choice(N, 50, replace=False)] = -1                 # ignored label
+        lt = torch.from_numpy(lg).cuda().requires_grad_(True)
+        loss = ap_loss_batched(lt, torch.from_numpy(tg).cuda())
+        loss.sum().backward()
+        for b in range(B):
+            rl, rg = O.aploss(lg[b], tg[b])
+            assert abs(float(loss[b]) - rl) <= APLOSS_TOL, (N, F, b)
+            np.testing.assert_allclose(lt.grad[b].cpu().numpy(), rg, atol=APLOSS_TOL, rtol=1e-4, err_msg=str((N, F, b)))
+    n = 2047
+    lg = rng.normal(0, 2.0, size=(1, n)).astype(np.float32)
+    tg = (rng.uniform(size=(1, n)) < 0.1).astype(np.float32)
+    a = torch.from_numpy(lg).cuda().requires_grad_(True)
+    la = ap_loss_batched(a, torch.from_numpy(tg).cuda())
+    la.sum().backward()
+    pad = torch.zeros((1, 2048), device="cuda"); pad[:, :n] = torch.from_numpy(lg).cuda()
+    padt = torch.zeros((1, 2048), device="cuda"); padt[:, :n] = torch.from_numpy(tg).cuda()
+    pb = pad.clone().requires_grad_(True)
+    lb = ap_loss_batched(pb, padt, counts=torch.tensor([n], dtype=torch.int32))
+    lb.sum().backward()
+    assert abs(float(la) - float(lb)) <= 1e-6
+    np.testing.assert_allclose(a.grad.cpu().numpy()[0], pb.grad.cpu().numpy()[0, :n], atol=1e-7, rtol=1e-6)
+    assert float(pb.grad[0, n:].abs().max()) == 0.0
 
 
 def test_from_boxes_decisions_on_adversarial_boxes(G):

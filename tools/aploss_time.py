@@ -13,7 +13,7 @@ from groomed_nms_amd.aploss import ap_loss_batched  # noqa: E402
 
 def main():
     rng = np.random.default_rng(0)
-    for B, N, F in ((8, 500, 20), (8, 500, 100), (64, 500, 20), (8, 4096, 64), (8, 4096, 1024), (256, 512, 32)):
+    for B, N, F in ((8, 500, 20), (8, 500, 100), (64, 500, 20), (8, 2047, 64), (8, 2048, 64), (8, 4096, 64), (8, 4096, 1024), (8, 16384, 256), (8, 16384, 4096), (256, 512, 32)):
         lg = torch.from_numpy(rng.uniform(0, 1, (B, N)).astype(np.float32)).cuda().requires_grad_(True)
         tg = np.zeros((B, N), np.float32)
         for b in range(B):
