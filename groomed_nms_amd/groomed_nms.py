@@ -17,7 +17,7 @@ from ._lib import GnmsParams, check, ptr, stream_ptr, on_device
 
 __all__ = ["differentiable_nms", "differentiable_nms_batched", "differentiable_nms_from_boxes_batched",
            "differentiable_nms_with_iou2d_batched", "differentiable_nms_with_iou3d_batched", "soft_sort", "pruning_function", "sigmoid_numpy",
-           "cast_to_cpu_cuda_tensor", "get_groups", "indices_copy", "GroomedNMS"]
+           "cast_to_cpu_cuda_tensor", "get_groups", "indices_copy", "GroomedNMS", "LazyIndexList"]
 
 _PRUNE = {"linear": 0, "sigmoidal": 1, "soft_nms": 2}
 
@@ -391,6 +391,7 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
         :param iou_unsorted:             Overlap matrix of the boxes, Tensor or ndarray (N, N)
         :return: valid_boxes_index   (K,)   original indices, by descending re-score
                  invalid_boxes_index (N-K,) original indices
+                 (GPU tensors in: both are LazyIndexList objects -- tensors whose length is fetched from the GPU on first use)
                  non_suppression_prob (N,)  re-scores in descending-input-score order (the reference's order)
         NumPy in -> CPU tensors out (lib/rpn_util.py:1319-1320 calls .numpy() on the result); tensors
         come back on the device of `iou_unsorted` (:60-62).  Computation always runs on the GPU.
@@ -421,21 +422,92 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
     else:
         prob, order, valid, invalid, nvalid, ninvalid = differentiable_nms_batched(scores.unsqueeze(0), iou.unsqueeze(0), **kw)
         indices = None
+    non_suppression_prob = prob[0]
+    if debug:
+        print("\nInside diff NMS... After sorting")
+        print(non_suppression_prob)
+    if out_device == dev and LAZY_INDEX_LISTS and n > 0:
+        # GPU tensors in: the two index lists have a data-dependent length K, which only the host can turn into a tensor shape.  They
+        # come back as LazyIndexList objects that hold the padded device list and its device-side count and become real tensors on
+        # first use -- training reads only the probabilities (lib/loss/rpn_3d.py:791 takes `[2]`), so its step never waits for the GPU.
+        both = torch.stack([nvalid[0], ninvalid[0]])
+        return (LazyIndexList(valid[0], both, 0, indices), LazyIndexList(invalid[0], both, 1, indices), non_suppression_prob)
     counts = torch.stack([nvalid[0], ninvalid[0]]).tolist() if n > 0 else [0, 0]   # the one host sync: K is data dependent
     valid_boxes_index = valid[0, :counts[0]]
     invalid_boxes_index = invalid[0, :counts[1]]
     if indices is not None:
         valid_boxes_index = indices[valid_boxes_index]
         invalid_boxes_index = indices[invalid_boxes_index]
-    non_suppression_prob = prob[0]
-    if debug:
-        print("\nInside diff NMS... After sorting")
-        print(non_suppression_prob)
     if out_device != dev:
         valid_boxes_index = valid_boxes_index.to(out_device)
         invalid_boxes_index = invalid_boxes_index.to(out_device)
         non_suppression_prob = non_suppression_prob.to(out_device)
     return valid_boxes_index, invalid_boxes_index, non_suppression_prob
+
+
+LAZY_INDEX_LISTS = True     # module switch: False makes differentiable_nms return plain tensors (one host sync per call)
+
+
+class LazyIndexList:
+    """A 1-D int64 index tensor whose LENGTH is still on the GPU.  Holds the padded list and the device-side counts; the first use
+    (any attribute, method, torch function, indexing, len(), iteration, NumPy conversion) copies the count to the host -- the one
+    synchronisation the reference's return convention needs -- and from then on the object forwards to the real tensor `t`."""
+
+    __slots__ = ("_padded", "_counts", "_which", "_map", "_t")
+
+    def __init__(self, padded, counts, which, index_map=None):
+        self._padded, self._counts, self._which, self._map, self._t = padded, counts, which, index_map, None
+
+    @property
+    def t(self):
+        if self._t is None:
+            k = int(self._counts[self._which].item())
+            t = self._padded[:k]
+            if self._map is not None:
+                t = self._map[t]
+            self._t = t
+            self._padded = self._counts = self._map = None
+        return self._t
+
+    def __getattr__(self, name):                       # everything a tensor has: shape, device, cpu(), numpy(), tolist(), ...
+        return getattr(self.t, name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def unwrap(x):
+            if isinstance(x, LazyIndexList):
+                return x.t
+            if isinstance(x, (list, tuple)):
+                return type(x)(unwrap(y) for y in x)
+            return x
+        return func(*unwrap(args), **{k: unwrap(v) for k, v in (kwargs or {}).items()})
+
+    def __len__(self):
+        return len(self.t)
+
+    def __iter__(self):
+        return iter(self.t)
+
+    def __getitem__(self, i):
+        return self.t[i]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.t.cpu().numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __index__(self):
+        return self.t.__index__()
+
+    def __repr__(self):
+        return "LazyIndexList(%r)" % (self.t,) if self._t is not None else "LazyIndexList(<length still on the GPU>)"
+
+    def __eq__(self, other):
+        return self.t == (other.t if isinstance(other, LazyIndexList) else other)
+
+    def __ne__(self, other):
+        return self.t != (other.t if isinstance(other, LazyIndexList) else other)
+
+    __hash__ = None
 
 
 class GroomedNMS(torch.nn.Module):

@@ -1490,3 +1490,28 @@ def test_nms_others_on_the_gpu(golden_misc):
             d32 = dets.astype(np.float32)
             assert [int(i) for i in girshick_nms(d32, thr, shift=sh)] == [int(i) for i in NO.girshick_nms(d32, thr, shift=sh)], (n, thr, sh)
     assert list(navneeth_soft_nms(np.zeros((0, 5)))) == [] and girshick_nms(np.zeros((0, 5), np.float32), 0.5) == []
+
+
+def test_lazy_index_lists(G, O):
+    """GPU tensors in: the two index lists come back as LazyIndexList objects (no host sync inside differentiable_nms); on first use
+    they are the tensors the eager convention returns, through every access path the reference's callers and tests use."""
+    from groomed_nms_amd import synthetic, groomed_nms as GN
+    b, s = synthetic.batch_2d(5, 1, 300, "clustered", per=20)
+    m = torch.from_numpy(O.iou2d(b[0], b[0])).cuda()
+    st = torch.from_numpy(s[0]).cuda()
+    v, iv, p = G.differentiable_nms(st, m)
+    assert type(v) is GN.LazyIndexList and type(iv) is GN.LazyIndexList and isinstance(p, torch.Tensor)
+    ref = O.differentiable_nms(s[0], O.iou2d(b[0], b[0]))
+    assert v.tolist() == list(ref["valid"]) and len(v) == len(ref["valid"]) and v.shape == (len(ref["valid"]),)
+    assert v.device.type == "cuda" and v.dtype == torch.int64
+    assert np.array_equal(np.asarray(iv), iv.cpu().numpy()) and sorted(iv.tolist()) == sorted(ref["invalid"].tolist())
+    assert torch.equal(torch.sort(v)[0], torch.sort(v.t)[0]) and torch.equal(st[v.t], torch.index_select(st, 0, v))
+    old = GN.LAZY_INDEX_LISTS
+    try:
+        GN.LAZY_INDEX_LISTS = False
+        v2, iv2, p2 = G.differentiable_nms(st, m)
+        assert isinstance(v2, torch.Tensor) and torch.equal(v2, v.t) and torch.equal(iv2, iv.t) and torch.equal(p2, p)
+    finally:
+        GN.LAZY_INDEX_LISTS = old
+    vs, ivs, _ = G.differentiable_nms(torch.sort(st, descending=True)[0], m, sorting_method="soft", sorting_temperature=0.01)
+    assert len(vs) + len(ivs) <= 300 and int(vs.max()) < 300                # soft sort: mapped through the hard-sort indices lazily as well
