@@ -1,0 +1,41 @@
+#!/bin/bash
+# usage: tools/profile_round.sh <round tag, e.g. r02>   -- the evidence set kept under profiles/ (run on the GPU box, then copy):
+#   <tag>_bench.json + <tag>_bench_kernel_stats.csv      the default bench line and the rocprofv3 --kernel-trace --stats of the same command
+#   <tag>_pmc_summary.json                               HBM traffic per launch (tools/pmc.sh), fed back into the bench line's roofline.traffic
+#   <tag>_grid.jsonl                                     N in {256,1024,4096,16384} x {clustered,uniform} (+ 3D at 4096/16384)
+#   <tag>_uniform4096_kernel_stats.csv                   kernel stats of the uniform N=4096 run
+export TMPDIR=/tmp
+T=$1
+O=gpurun_out/profiles_$T
+mkdir -p $O
+bash tools/pmc.sh $T > $O/pmc_stdout.txt 2>&1
+cp gpurun_out/pmc_${T}_summary.json $O/${T}_pmc_summary.json
+python bench.py --steps 200 --warmup 20 --pmc-summary $O/${T}_pmc_summary.json > $O/${T}_bench.json 2> $O/bench.err
+bash tools/prof.sh ${T}_main --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind > $O/prof_main.txt 2>&1
+cp gpurun_out/prof_${T}_main/bench_kernel_stats.csv $O/${T}_bench_kernel_stats.csv
+tail -1 gpurun_out/prof_${T}_main/bench_stdout.txt > $O/${T}_bench_under_rocprof.json
+bash tools/prof.sh ${T}_uni --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind --kind uniform > $O/prof_uni.txt 2>&1
+cp gpurun_out/prof_${T}_uni/bench_kernel_stats.csv $O/${T}_uniform4096_kernel_stats.csv
+tail -1 gpurun_out/prof_${T}_uni/bench_stdout.txt > $O/${T}_uniform4096_bench_under_rocprof.json
+: > $O/${T}_grid.jsonl
+for n in 256 1024 4096 16384; do for k in clustered uniform; do
+  st=100; [ $n -ge 16384 ] && st=30
+  python bench.py --boxes $n --kind $k --steps $st --warmup 10 --no-cpu-baseline --no-other-kind 2>/dev/null | tail -1 >> $O/${T}_grid.jsonl
+done; done
+for n in 4096 16384; do for k in clustered uniform; do
+  st=100; [ $n -ge 16384 ] && st=30
+  python bench.py --dim 3 --boxes $n --kind $k --steps $st --warmup 10 --no-cpu-baseline --no-other-kind 2>/dev/null | tail -1 >> $O/${T}_grid.jsonl
+done; done
+python bench.py --two-calls --steps 100 --warmup 10 --no-other-kind --cpu-seconds 3 2>/dev/null | tail -1 > $O/${T}_two_calls_bench.json
+for n in 512 1024 2048; do python bench.py --graph --boxes $n --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/${T}_graph.jsonl; done
+python tools/kernel_times.py > $O/${T}_kernel_times.txt 2>/dev/null
+python tools/kernel_times.py --boxes 16384 --reps 10 >> $O/${T}_kernel_times.txt 2>/dev/null
+python tools/aploss_time.py > $O/${T}_aploss_times.jsonl 2>/dev/null
+python tools/e2e_bench.py --mode infer --steps 10 2>/dev/null | tail -1 > $O/${T}_e2e.jsonl
+python tools/e2e_bench.py --mode train --steps 10 2>/dev/null | tail -1 >> $O/${T}_e2e.jsonl
+cat $O/${T}_bench.json; echo; cat $O/${T}_grid.jsonl | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.strip():
+        d=json.loads(l); r=d['roofline'] or {}
+        print(d['config']['workload'][:46], d['ms_per_step'], '%.3e'%d['value'], r.get('kernel'), r.get('kernel_ms'), r.get('frac'))"
