@@ -332,7 +332,10 @@ __device__ __forceinline__ void write_chunk(const float* __restrict__ in, int N,
 }
 
 // PERSISTENT writers: one workgroup stays on its CU and claims chunk after chunk from `counter` (zeroed by the sort kernels of this
-// call), one claim ahead so that the atomic's round trip hides behind the chunk in progress.  (Ordinary workgroups of one chunk each
+// call), one claim ahead so that the atomic's round trip hides behind the chunk in progress.  Claims are the ONLY cross-workgroup
+// traffic of the launch: anything that needs a release/acquire fence between workgroups (the whole chain sorts -> bits -> K3..K6 as
+// tasks of one persistent launch was the plan) is out of the question beside the write stream -- one __threadfence() per chunk
+// (buffer_wbl2 + buffer_inv at agent scope) took this launch from 0.115 to 1.13 ms.  (Ordinary workgroups of one chunk each
 // leave the CU empty between a workgroup's last wave and the next workgroup's start, and with one workgroup per CU nothing covers
 // that gap: 116 against 107 us.  One claim per WAVE tile serialises on the counter: 16384 device-scope atomics on one address took
 // 430 us.)
@@ -673,6 +676,15 @@ bool sorts_ride_in_iou_launch(int B, int N) {
 }  // namespace
 
 namespace {
+// 3D one-call entry: the matrix-write kernel also produces the threshold bits (iou3d_bits_kernel).  GNMS_3D_BITS_IN_WRITE=0 keeps the
+// separate from-records bit-matrix kernel.
+// Measured at B = 8 (ms per step, separate kernel -> bits in the write): N = 4096 0.248 -> 0.210, 8192 0.686 -> 0.619, 16384 2.51 -> 2.21
+// (its launch then runs at the 4.6 TB/s store ceiling); N <= 2048 loses (0.133 -> 0.182 at 2048: 64-row tiles leave too few
+// workgroups, and there the chain rides in the write launch instead).
+bool bits_in_write_3d(int N) {
+    static const int forced = [] { const char* e = getenv("GNMS_3D_BITS_IN_WRITE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    return forced >= 0 ? forced == 1 : N > 2048;
+}
 // masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_iou2d_kernel).  GNMS_FUSE_TAIL=0/1 forces.
 bool chain_rides_in_write_launch(int B, int N) {
     static const int forced = [] { const char* e = getenv("GNMS_FUSE_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
@@ -684,6 +696,7 @@ bool chain_rides_in_write_launch(int B, int N) {
 // (default parameters, aligned inputs)
 extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (B <= 0 || N <= 0) return "";
+    if (dim == 3 && bits_in_write_3d(N)) return "iou3d_bits_kernel";
     if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : "iou2d_kernel";
     if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
     if (dim == 3) return "iou3d_nms_fast_kernel";
@@ -761,6 +774,93 @@ int gnms_internal_records_for_layer(const float* params, int B, int N, float* re
 int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int row0 = 0, int row_end = 0x7fffffff);
 
 namespace {
+// ------------------------------------------------------------------------------------------------
+// 3D one-call entry: the matrix write ALSO yields the threshold bits.
+// The write kernel evaluates every pair anyway; thresholding costs two more VALU instructions per pair on a kernel that is bound by
+// its stores at large N, where the separate from-records bit-matrix kernel (29 slots per pair on the rows its cull keeps: 45 us at
+// B = 8, N = 4096, 0.5-0.6 ms at N = 16384) and the x sort that feeds it were serial work in front of the chain.  For the words to
+// come out in rank space the rows are walked in RANK order: a tile is rank block kb x 256 input columns, row r of the tile is the box
+// of rank 64 kb + r -- its record is read from a rank-ordered copy (records_by_rank_kernel; slot 7 carries the row's input index)
+// and its matrix row is written where it belongs (rows are contiguous 4 N-byte streams whatever the permutation); the column words
+// go to W[kb][rank of the column], full rows, so the leader scan can pull (leaders_body, sym).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void records_by_rank_kernel(const float* __restrict__ rec, int N, char* ws, gnms_ws_layout L,
+                                                              float* __restrict__ recs) {
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    const int idx = img_ptrs(ws, L, b).order[k];
+    const float4* src = reinterpret_cast<const float4*>(rec + ((size_t)b * N + idx) * gnms_iou3d::kRec);
+    float4* dst = reinterpret_cast<float4*>(recs + ((size_t)b * N + k) * gnms_iou3d::kRec);
+    float4 v = src[1];
+    v.w = __int_as_float(idx);                                       // slot 7 (area_bev, unused by the NMS overlap): the row's input index
+    dst[0] = src[0]; dst[1] = v; dst[2] = src[2];
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64) void iou3d_bits_kernel(const float* __restrict__ recs, const float* __restrict__ rec, int N,
+                                                                                const int* __restrict__ counts, float thr, float* __restrict__ out,
+                                                                                long ld, char* ws, gnms_ws_layout L) {
+    using namespace gnms_iou3d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z, kb = blockIdx.y;
+    const int c0 = (blockIdx.x * gnms_iou::kWavesPerWG + wave) * gnms_iou::kWaveCols;
+    const int k0 = kb * 64;
+    if (c0 >= N || k0 >= N) return;
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const float* ra = recs + (size_t)b * N * kRec;                   // rows: rank order
+    const float* rb = rec + (size_t)b * N * kRec;                    // columns: input order
+    float* o3 = out + (size_t)b * N * ld;
+    Cols2 cols[2];
+    int col[4];
+    unsigned colbad = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
+        const int cc = col[j] < N ? col[j] : (N - 1);
+        const float4* p = reinterpret_cast<const float4*>(rb + (size_t)cc * kRec);
+        const float4 e = p[2];
+        cols2_set(cols[j >> 1], j & 1, p[0], p[1], e);
+        colbad |= (e.w != 0.0f) ? (1u << j) : 0u;
+    }
+    const bool cols_sane = __all(colbad == 0u);
+    const int nrows = min(64, N - k0);                                // every row of the matrix is written (padding ranks map to themselves)
+    const int nbits = max(0, min(64, n - k0));                        // ... but only the image's own ranks enter the bit matrix
+    unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int rend = min(32, nrows - half * 32);
+        for (int rr_ = 0; rr_ < rend; ++rr_) {
+            const int r = half * 32 + rr_;
+            const float* rr = ra + (size_t)(k0 + r) * kRec;         // wave-uniform: scalar loads
+            Row a;
+            a.vol = rr[0]; a.y0 = rr[1]; a.y1 = rr[2]; a.x0 = rr[3]; a.x1 = rr[4]; a.z0 = rr[5]; a.z1 = rr[6]; a.lx = rr[8]; a.ly = rr[9]; a.lz = rr[10];
+            a.bad = rr[11];
+            const int orow = __float_as_int(rr[7]);
+            float res[4];
+            nms_overlap3d_guarded4(a, cols, colbad, cols_sane, thr, res);
+            const unsigned bit = (r < nbits) ? (1u << rr_) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wd[half][j] |= !(res[j] <= thr) ? bit : 0u;     // lib/groomed_nms.py:250 (NaN -> removed)
+            const size_t roff = (size_t)orow * ld;
+            if (VEC && col[3] < N) {
+                gnms_iou::store_nt_f4(o3 + roff + col[0], res[0], res[1], res[2], res[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (col[j] < N) o3[roff + col[j]] = res[j];
+            }
+        }
+    }
+    if (k0 >= n) return;
+    u64* Wk = I.W + (size_t)kb * L.NC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (col[j] < n) Wk[I.rankof[col[j]]] = ((u64)wd[1][j] << 32) | wd[0][j];
+}
+
+}  // namespace
+
+namespace {
 // everything of gnms_forward_with_iou3d that uses the temporary `rec` ([B][N] records, then [B][N] pseudo boxes for the x sort).
 // Masked hard-sorted groups: the whole layer runs from the records (threshold bits AND the O(N) single overlaps, same arithmetic
 // as the matrix kernel), so nothing waits for the matrix; large images write it on the side stream beside the one-launch tail.
@@ -773,8 +873,42 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         if ((rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st))) return rc;
         return gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st, P.nms_threshold);
     }
-    float* xkeys = rec + (size_t)B * N * gnms_iou3d::kRec;         // [B][N] pseudo boxes
+    float* xkeys = rec + (size_t)B * N * gnms_iou3d::kRec;         // [B][N] pseudo boxes; later the rank-ordered records
     if ((rc = gnms_internal_records_for_layer(params3d, B, N, rec, ws, L, xkeys, st))) return rc;
+    if (bits_in_write_3d(N)) {
+        // score sort -> records in rank order -> ONE pass over all pairs writes the matrix and the bit matrix -> K3..K6
+        float* recs = xkeys;
+        const int P2s = next_pow2(N);
+        if ((rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2s, order, st))) return rc;
+        records_by_rank_kernel<<<dim3(gnms_div_up(N, 256), B), 256, 0, st>>>(rec, N, ws, L, recs);
+        GNMS_CHECK_LAUNCH();
+        const bool vec = (ld % 4 == 0) && ((uintptr_t)iou_out % 16 == 0);
+        const dim3 grid(gnms_div_up(N, gnms_iou::kWGCols), L.NB, B);
+        if (vec) gnms_launch_prof(kProfMatrixWrite, iou3d_bits_kernel<true>, grid, dim3(gnms_iou::kWavesPerWG * 64), 0, st, recs, rec, N, counts, P.nms_threshold, iou_out, (long)ld, ws, L);
+        else gnms_launch_prof(kProfMatrixWrite, iou3d_bits_kernel<false>, grid, dim3(gnms_iou::kWavesPerWG * 64), 0, st, recs, rec, N, counts, P.nms_threshold, iou_out, (long)ld, ws, L);
+        GNMS_CHECK_LAUNCH();
+        if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1);
+        const size_t llds = leaders_lds_bytes(N);
+        if ((rc = allow_lds(leaders_kernel, llds))) return rc;
+        leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, 1);
+        GNMS_CHECK_LAUNCH();
+        attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L);
+        GNMS_CHECK_LAUNCH();
+        const size_t sort_lds = (size_t)P2s * 8;
+        const int sort_threads = P2s <= 1024 ? P2s : 1024;
+        GNMS_DISPATCH_SORT(P2s, {
+            if ((rc = allow_lds(groups_kernel<E, kFromRecords>, sort_lds))) return rc;
+            groups_kernel<E, kFromRecords><<<B, sort_threads, sort_lds, st>>>(nullptr, N, (long)ld, counts, P, ws, L, P2s);
+        });
+        GNMS_CHECK_LAUNCH();
+        GNMS_DISPATCH_SORT(P2s, {
+            if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
+            finalize_kernel<E><<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2s, prob, (long long*)valid, (long long*)invalid, nvalid,
+                                                                   ninvalid);
+        });
+        GNMS_CHECK_LAUNCH();
+        return GNMS_OK;
+    }
     const bool beside = use_side_stream(B, N, ld);
     const int sym = (P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY) ? 1 : 0;   // the culled kernel writes full symmetric rows of W
     // K3..K6 inside the write launch like the 2D entry -- up to N = 2048 only: the 3D writers are VALU-bound (23 slots per pair) and
@@ -856,7 +990,7 @@ extern "C" int gnms_forward_with_iou3d(const float* params3d, const float* score
     // records of the whole batch in one stream-ordered temporary (the overlap kernel wants them contiguous); the layer's copy goes
     // into the per-image workspace regions
     float* rec = nullptr;
-    GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * (gnms_iou3d::kRec + 4) * sizeof(float), st));
+    GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * (2 * gnms_iou3d::kRec) * sizeof(float), st));
     rc = forward_with_iou3d_on(rec, params3d, scores, B, N, ld, counts, P, iou_out, prob, order, valid, invalid, nvalid, ninvalid, ws, L, st);
     const hipError_t fe = hipFreeAsync(rec, st);                  // after the side stream, if any, has joined `st`
     if (rc) return rc;
