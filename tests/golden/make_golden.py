@@ -16,6 +16,8 @@ Reference entry points exercised (file:line under /root/reference):
   lib/nms/py_cpu_nms.py:10 py_cpu_nms             lib/nms_others.py:6,119 navneeth_soft_nms, girshick_nms
   lib/loss/aploss.py:14   backpropAPLoss / APLoss (the consumer of the rescored scores)
   lib/rpn_util.py:872     bbox_transform_inv      lib/math_3d.py:47       project_3d_points_in_4D_format   
+  lib/rpn_util.py:1489,1571,2013  convert_image_predictions_to_correct_entries, get_text_to_write_in_kitti_format,
+                                  parse_kitti_result
 Known-answer vectors KAT-1/KAT-2 come from test/test_differentiable_nms_forward.py:127-140.
 
 Inputs are stored next to outputs: RNG streams differ across library versions, so nothing is ever
@@ -508,7 +510,47 @@ def main():
         pg[f"best/{tag}/targets"] = tg
     np.savez_compressed(os.path.join(OUT, "proposals.npz"), **pg)
 
-    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz", "aploss.npz", "proposals.npz"):
+    # ------------------------------------------------------------------ KITTI result writer / evaluation hand-off
+    # lib/rpn_util.py:1489-1545 convert_image_predictions_to_correct_entries, :1571-1631 get_text_to_write_in_kitti_format,
+    # :2013-2040 parse_kitti_result.  The text is stored as bytes; the devkit's stats-file format is exercised on a synthetic file.
+    import tempfile
+    rng = np.random.default_rng(777)
+    kg = {}
+
+    class Conf(dict):
+        __getattr__ = dict.__getitem__
+    p2d = p2.astype(np.float64)
+    for tag, n, has_un in (("k12", 12, False), ("k40_un", 40, True), ("k0", 0, False)):
+        ctr = np.stack([rng.uniform(100, 1600, n), rng.uniform(100, 400, n)], 1)
+        wh = rng.uniform(20, 200, size=(n, 2))
+        bx = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1)
+        boxes = np.concatenate([bx, rng.uniform(0.05, 1, (n, 1)), rng.integers(1, 4, (n, 1)).astype(np.float64),
+                                ctr + rng.normal(0, 5, (n, 2)), rng.uniform(4, 70, (n, 1)),                 # projected 3D centre + depth
+                                rng.uniform(1.4, 2.0, (n, 1)), rng.uniform(1.3, 2.0, (n, 1)), rng.uniform(3, 5, (n, 1)),
+                                rng.uniform(-3 * np.pi, 3 * np.pi, (n, 1)), rng.uniform(0.2, 1, (n, 1))], 1)   # alpha (un-wrapped), un
+        conf = Conf(lbls=["Car", "Pedestrian", "Cyclist"], has_un=has_un, use_un_for_score=has_un)
+        kg[f"{tag}/boxes"] = boxes
+        kg[f"{tag}/p2"] = p2d
+        kg[f"{tag}/has_un"] = np.array(has_un)
+        if n > 0:
+            conv = rpn_util.convert_image_predictions_to_correct_entries(boxes.copy(), conf, p2d)
+        else:
+            conv = np.zeros((0, 17))
+        kg[f"{tag}/converted"] = conv
+        text = rpn_util.get_text_to_write_in_kitti_format(conv, conf)
+        kg[f"{tag}/text"] = np.frombuffer(text.encode(), dtype=np.uint8)
+    stats = rng.uniform(0, 1, size=(3, 41))
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for row in stats:
+            f.write(" ".join("%.6f" % v for v in row) + "\n")
+        stats_path = f.name
+    kg["stats/text"] = np.frombuffer(open(stats_path).read().encode(), dtype=np.uint8)
+    kg["stats/r11"] = np.array(rpn_util.parse_kitti_result(stats_path, use_40=False))
+    kg["stats/r40"] = np.array(rpn_util.parse_kitti_result(stats_path, use_40=True))
+    os.unlink(stats_path)
+    np.savez_compressed(os.path.join(OUT, "kitti_io.npz"), **kg)
+
+    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz", "aploss.npz", "proposals.npz", "kitti_io.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 

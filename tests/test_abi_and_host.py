@@ -157,3 +157,36 @@ def test_bench_gpus_flag_launches_or_refuses():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_kitti_result_writer_against_reference_vectors(tmp_path):
+    """the inference tail behind the NMS (lib/rpn_util.py:1489-1631, :2013-2076) -- converted entries, the 16-column
+    result text byte for byte, the file writer, the devkit stats parser and the subprocess hand-off (a stand-in evaluator script)."""
+    from conftest import Golden
+    from groomed_nms_amd import kitti_io as K
+    g = Golden("kitti_io.npz")
+
+    class Conf(dict):
+        __getattr__ = dict.__getitem__
+    for tag in ("k12", "k40_un", "k0"):
+        conf = Conf(lbls=["Car", "Pedestrian", "Cyclist"], has_un=bool(g[f"{tag}/has_un"]), use_un_for_score=bool(g[f"{tag}/has_un"]))
+        boxes = g[f"{tag}/boxes"]
+        keep = boxes.copy()
+        conv = K.convert_image_predictions_to_correct_entries(boxes, conf, g[f"{tag}/p2"]) if len(boxes) else np.zeros((0, 17))
+        assert np.array_equal(boxes, keep)                                                  # input untouched (deepcopy, :1490)
+        np.testing.assert_allclose(conv, g[f"{tag}/converted"], rtol=1e-12, atol=1e-12)
+        text = K.get_text_to_write_in_kitti_format(conv, conf)
+        assert text.encode() == g[f"{tag}/text"].tobytes(), tag
+        assert K.write_image_boxes_to_txt_file(conv, {"lbls": conf.lbls}, str(tmp_path), "000042") == text
+        assert open(tmp_path / "000042.txt").read() == text
+    stats = tmp_path / "stats_car_detection.txt"
+    stats.write_bytes(g["stats/text"].tobytes())
+    np.testing.assert_allclose(K.parse_kitti_result(str(stats), use_40=False), g["stats/r11"], rtol=1e-12)
+    np.testing.assert_allclose(K.parse_kitti_result(str(stats), use_40=True), g["stats/r40"], rtol=1e-12)
+    # the hand-off: any executable taking (results, gt) that leaves stats_<class>_*.txt files behind
+    ev = tmp_path / "evaluate_object"
+    ev.write_text("#!/bin/sh\ncp \"$1/stats_car_detection.txt\" \"$1/stats_car_detection_3d.txt\"\n")
+    ev.chmod(0o755)
+    res = K.run_kitti_eval_script(str(ev), str(tmp_path), str(tmp_path), ["Car", "Pedestrian"])
+    assert set(res) == {"det_2d_car", "det_3d_car"} and np.allclose(res["det_3d_car"], g["stats/r40"])
+    assert abs(K.convertAlpha2Rot(0.3, 10.0, 2.0) - (0.3 + np.arctan2(2.0, 10.0))) < 1e-12
