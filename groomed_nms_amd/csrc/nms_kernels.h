@@ -1004,6 +1004,8 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
     auto push = [&](int src, int first, int last, int w, int nw) {
         const int* list = llist + (src & 1) * (kSB * 64);
         const int nl = lcount[src & 1];
+        // (Pulling full rows instead -- 16 coalesced 512-byte reads per target block, AND with the leader masks, ballot -- was measured
+        // for the many-leaders case, ~470 leaders per super-block on uniform boxes: near push 28k -> 49k ticks, slower.)
         for (int base = first + w; base < last; base += 4 * nw) {
             u64 a[4] = {0ull, 0ull, 0ull, 0ull};
             for (int j0 = 0; j0 < nl; j0 += 64) {
@@ -1169,12 +1171,14 @@ __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
     return gnms_or_scan64(up);                                      // DPP inclusive OR-scan (gnms_common.h)
 }
 
+__device__ __forceinline__ u64 slab_col(const ImgPtrs& I, const gnms_ws_layout& L, int bb, int k) { return I.W[(size_t)bb * L.NC + k]; }
+
 // one wave: rank block kb of image b.  Besides the attribution it evaluates, in parallel over all rank blocks, the overlap of
 // every rank with the leader that removed it (plead[k], groups_kernel's membership test) -- as a prologue of groups_kernel these
 // N dependent gathers ran on ONE CU (50 us of its 180 at N=16384).  `src`: see kFromMatrix / kFromBoxes / kFromRecords.
 template <int SRC>
 __device__ __forceinline__ void attribute_body(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, float thr, char* ws,
-                                               gnms_ws_layout L, const int b, const int kb, const int lane) {
+                                               gnms_ws_layout L, const int b, const int kb, const int lane, const int sym = 0) {
     __shared__ int att_lead[16][64];                   // per wave: ordinal of the leader that claimed rank k0 + i
     int* my_lead = att_lead[(threadIdx.x >> 6) & 15];
     const int n = gnms_count(counts, b, N);
@@ -1188,6 +1192,40 @@ __device__ __forceinline__ void attribute_body(const float* __restrict__ src, lo
     my_lead[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     u64 acc = 0;
+    // measured, uniform boxes, B = 8: N = 4096 step 0.202 -> 0.192 ms; N = 16384 (up to 256 row blocks to scan) 2.91 -> 3.10: small images only
+    if (sym && L.NB <= 64 && nl > 8 * (kb + 1) + 64) {
+        // MANY leaders (uniform boxes): walking them 64 at a time costs two dependent gathers per step and ~0.5 (kb + 1) steps.  With
+        // the full symmetric rows the first claimer of rank k is the lowest-ranked leader among the ranks that overlap k:
+        // scan the row blocks bb <= kb, W[bb][k] & leaders of bb -- coalesced, independent loads, 8 in flight.
+        const u64 lw_own = I.leadw[kb];
+        const bool self = ((lw_own >> lane) & 1ull) != 0ull;           // a leader claims itself
+        int lr = self ? k0 + lane : -1;
+        for (int bb0 = 0; bb0 <= kb; bb0 += 8) {
+            u64 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = (bb0 + u <= kb && lane < nrows) ? slab_col(I, L, bb0 + u, k0 + lane) : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int bb = bb0 + u;
+                if (bb <= kb) {
+                    u64 m = t[u] & I.leadw[bb];
+                    if (bb == kb) m &= (1ull << lane) - 1ull;             // only earlier ranks of the own block
+                    if (lr < 0 && m != 0ull) lr = (bb << 6) + __builtin_ctzll(m);
+                }
+            }
+            if (__all(lr >= 0 || lane >= nrows)) break;
+        }
+        if (lane < nrows) {
+            const int k = k0 + lane;
+            if (lr < 0) lr = k;                                          // (cannot happen: a non-leader has an earlier overlapping leader)
+            const int g = I.leadpfx[lr >> 6] + __builtin_popcountll(I.leadw[lr >> 6] & ((1ull << (lr & 63)) - 1ull));
+            I.rem[k] = lr;
+            I.gpos[k] = g;
+            const float* m = overlap_src<SRC>(src, I, b, N, ld);
+            I.plead[k] = overlap_at<SRC>(m, ld, I.order[k], I.leadc[g], thr);
+        }
+        return;
+    }
     for (int base = 0; base < nl && (acc & want) != want; base += 64) {
         const int t = base + lane;
         u64 w = 0;
@@ -1220,8 +1258,8 @@ __device__ __forceinline__ void attribute_body(const float* __restrict__ src, lo
 
 template <int SRC>
 __global__ __launch_bounds__(64) void attribute_kernel(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, float thr,
-                                                       char* ws, gnms_ws_layout L) {
-    attribute_body<SRC>(src, ld, N, counts, thr, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x);
+                                                       char* ws, gnms_ws_layout L, int sym) {
+    attribute_body<SRC>(src, ld, N, counts, thr, ws, L, (int)blockIdx.y, (int)blockIdx.x, (int)threadIdx.x, sym);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1585,7 +1623,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     const int b = blockIdx.x;
     leaders_body(N, counts, ws, L, b, sym);
     __syncthreads();
-    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63);
+    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63, sym);
     __syncthreads();
     groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
     __syncthreads();

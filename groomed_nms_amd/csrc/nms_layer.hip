@@ -219,7 +219,7 @@ int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* coun
     if (rc) return rc;
     leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L, 0);
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, thr, ws, L);
+    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, thr, ws, L, 0);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         leaders_body(N, counts, ws, L, b, 1);
         __syncthreads();
         for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16)
-            attribute_body<SRC>(chain_src, (long)N, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63);
+            attribute_body<SRC>(chain_src, (long)N, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63, 1);
         __syncthreads();
         groups_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
         __syncthreads();
@@ -892,7 +892,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         if ((rc = allow_lds(leaders_kernel, llds))) return rc;
         leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, 1);
         GNMS_CHECK_LAUNCH();
-        attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L);
+        attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L, 1);
         GNMS_CHECK_LAUNCH();
         const size_t sort_lds = (size_t)P2s * 8;
         const int sort_threads = P2s <= 1024 ? P2s : 1024;
@@ -950,7 +950,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
     leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, sym);
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L);
+    attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L, sym);
     GNMS_CHECK_LAUNCH();
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
@@ -1112,7 +1112,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
     leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, 1);      // bitmask_boxes_kernel wrote full symmetric rows
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<true><<<dim3(L.NB, B), 64, 0, st>>>(boxes, (long)N, N, counts, P.nms_threshold, ws, L);
+    attribute_kernel<true><<<dim3(L.NB, B), 64, 0, st>>>(boxes, (long)N, N, counts, P.nms_threshold, ws, L, 1);
     GNMS_CHECK_LAUNCH();
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(groups_kernel<E, true>, sort_lds))) return rc;
