@@ -1515,3 +1515,64 @@ def test_lazy_index_lists(G, O):
         GN.LAZY_INDEX_LISTS = old
     vs, ivs, _ = G.differentiable_nms(torch.sort(st, descending=True)[0], m, sorting_method="soft", sorting_temperature=0.01)
     assert len(vs) + len(ivs) <= 300 and int(vs.max()) < 300                # soft sort: mapped through the hard-sort indices lazily as well
+
+
+def test_bench_line_contract_on_a_small_problem():
+    """bench.py end to end on a small problem (2 images x 512 boxes, a few steps): one JSON line with the driver's fields, the
+    roofline object measured from the library's launch events, parity 0 against the oracle, the CPU baseline -- 2D, 3D and the
+    matrix-in variant."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for extra in ([], ["--dim", "3"], ["--two-calls"], ["--graph", "--no-cpu-baseline"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--boxes", "512", "--batch", "2", "--steps", "4", "--warmup", "1",
+                            "--cpu-seconds", "0.3"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                    "data", "config", "roofline"):
+            assert key in d, (extra, key)
+        assert d["n_gpus"] == 1 and d["steps"] == 4 and d["unit"] == "boxes/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+        assert d["value"] > 0 and "workload" in d["config"]
+        rf = d["roofline"]
+        assert rf and rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["kernel_ms"] > 0 and rf["kernel"]
+        if "--graph" not in extra:
+            assert d["parity"]["valid_index_sets_equal"] and d["parity"]["max_abs_dscore"] <= 1e-4 and d["parity"]["max_abs_dgrad_scores"] <= 1e-4
+            if "--dim" not in extra:
+                assert d["parity"]["max_abs_dscore"] == 0.0 and d["parity"]["max_abs_dgrad_scores"] == 0.0
+            assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+
+
+def test_profile_hooks(G):
+    """gnms_profile_events / _collect: armed, every matrix-writing launch is timed (start/stop events of hipExtLaunchKernel);
+    disarmed nothing is recorded; the fill / read streams run."""
+    import ctypes
+    from groomed_nms_amd import _lib, overlaps, synthetic
+    from groomed_nms_amd._lib import ptr, check, stream_ptr
+    lib = _lib.load()
+    b, _ = synthetic.batch_2d(1, 2, 1024, "clustered")
+    bt = torch.from_numpy(b).cuda()
+
+    def collect(slot):
+        ms, n = ctypes.c_double(-1), ctypes.c_int(-1)
+        check(lib.gnms_profile_collect(slot, ctypes.byref(ms), ctypes.byref(n)), "collect")
+        return ms.value, n.value
+    collect(0); collect(1)
+    overlaps.iou_batched(bt)
+    assert collect(0) == (0.0, 0)
+    check(lib.gnms_profile_events(1), "arm")
+    m = overlaps.iou_batched(bt)
+    overlaps.iou_batched(bt)
+    G.differentiable_nms_batched(torch.rand((2, 1024), device="cuda"), m)
+    check(lib.gnms_profile_events(0), "disarm")
+    ms, n = collect(0)
+    assert n == 2 and 0 < ms < 50
+    ms, n = collect(1)
+    assert n == 1 and 0 < ms < 50
+    assert lib.gnms_profile_write_kernel_name(2, 8, 4096).decode() == "tail_write_kernel"
+    buf = torch.empty(1 << 20, device="cuda")
+    sink = torch.zeros(4, device="cuda")
+    check(lib.gnms_profile_fill(ptr(buf), buf.numel(), stream_ptr()), "fill")
+    check(lib.gnms_profile_read(ptr(buf), buf.numel(), ptr(sink), stream_ptr()), "read")
+    torch.cuda.synchronize()
+    assert float(buf.min()) == 0.5 and float(buf.max()) == 0.5
