@@ -224,18 +224,18 @@ def main():
 
         # achievable ceilings: a plain non-temporal store / load stream over the same rotating buffers
         def stream_rate(fn, nbytes):
-            stream = torch.cuda.current_stream(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # timed like the kernel it is the ceiling of: the dispatch's own begin / end timestamps (slot 2), launch gaps excluded
             for _ in range(2):
                 fn(next_buf())
             torch.cuda.synchronize()
-            e0.record(stream)
-            reps = max(6, 2 * n_buf)
-            for _ in range(reps):
+            collect(2)
+            check(lib.gnms_profile_events(1), "gnms_profile_events")
+            for _ in range(max(6, 2 * n_buf)):
                 fn(next_buf())
-            e1.record(stream)
-            e1.synchronize()
-            return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            torch.cuda.synchronize()
+            check(lib.gnms_profile_events(0), "gnms_profile_events")
+            ms, n = collect(2)
+            return nbytes * n / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         sink = torch.zeros(4, dtype=torch.float32, device=dev)
         n_fl = B * N * N // 4 * 4
         fill_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill(ptr(b), n_fl, stream_ptr(dev)), "fill"), 4.0 * n_fl) if n_fl else 0.0

@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
-enum { kProfMatrixWrite = 0, kProfMatrixRead = 1, kProfSlots = 2 };
+enum { kProfMatrixWrite = 0, kProfMatrixRead = 1, kProfPlainStream = 2, kProfSlots = 3 };
 
 bool gnms_prof_armed();
 // a fresh (start, stop) event pair registered under `slot`; false if events could not be created (the launch then goes unprofiled)

@@ -36,6 +36,49 @@ __device__ __forceinline__ void store_nt_f4(float* p, float a, float b, float c,
     __builtin_nontemporal_store(d, p + 3);
 }
 
+// The row loop of a wave tile: the column boxes (bx1 .. barea, 4 per lane) against the rows held one per lane in `ra` (lane r = row
+// i0 + r, broadcast with v_readlane), one 16-byte (VEC) or four 4-byte stores per row.  `o` = the image's matrix.  ROWS_CT > 0: exactly
+// that many rows, unrolled; 0: `rows` at run time.  ALLCOLS (with VEC): every column of the tile exists -- with ROWS_CT > 0 the body is
+// then ONE basic block of ROWS_CT stores, so the compiler can count the stores in flight behind an earlier memory operation and wait
+// for that one alone (writers_staged_2d).
+template <bool VEC, int ROWS_CT, bool ALLCOLS = false>
+__device__ __forceinline__ void iou2d_rows(const float (&bx1)[4], const float (&by1)[4], const float (&bx2)[4], const float (&by2)[4],
+                                           const float (&barea)[4], const int (&col)[4], float4 ra, int rows, float* __restrict__ o, int i0,
+                                           long ld, int N) {
+    const float rarea = (ra.z - ra.x) * (ra.w - ra.y);               // lib/core.py:500-501
+    auto one_row = [&](int r) {
+        const float ax1 = bcast(ra.x, r), ay1 = bcast(ra.y, r), ax2 = bcast(ra.z, r), ay2 = bcast(ra.w, r);
+        const float aarea = bcast(rarea, r);
+        float res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float w = relu0(hw_min_s(ax2, bx2[j]) - hw_max_s(ax1, bx1[j]));   // lib/core.py:210-212
+            float h = relu0(hw_min_s(ay2, by2[j]) - hw_max_s(ay1, by1[j]));
+            float inter = w * h;                                        // :218
+            float uni = (aarea + barea[j]) - inter;                     // :507
+            res[j] = inter / uni;                                       // :508
+        }
+        float* orow = o + (size_t)(i0 + r) * ld;
+        if (VEC) {
+            if (ALLCOLS || col[3] < N) {
+                store_nt_f4(orow + col[0], res[0], res[1], res[2], res[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
+        }
+    };
+    if (ROWS_CT > 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS_CT; ++r) one_row(r);
+    } else {
+        for (int r = 0; r < rows; ++r) one_row(r);
+    }
+}
+
 // One wave: rows i0..i0+63 of image `img` against the 256 columns starting at c0.  a [B][M][4], b [B][N][4], out [B][M][ld].
 // VEC: ld % 4 == 0 and out 16-byte aligned -> lane owns columns c0+4*lane+{0..3}, one 16-B store per row; otherwise lane
 // owns columns c0+lane+64*{0..3} and stores dwords (still coalesced).
@@ -67,31 +110,39 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
     const int myrow = i0 + lane;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
     if (myrow < M) ra = *reinterpret_cast<const float4*>(a + (size_t)myrow * 4);
-    const float rarea = (ra.z - ra.x) * (ra.w - ra.y);               // lib/core.py:500-501
-    for (int r = 0; r < rows; ++r) {
-        const float ax1 = bcast(ra.x, r), ay1 = bcast(ra.y, r), ax2 = bcast(ra.z, r), ay2 = bcast(ra.w, r);
-        const float aarea = bcast(rarea, r);
-        float res[4];
+    iou2d_rows<VEC, 0>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
+}
+
+// The same wave tile with the image's boxes already in LDS (`sbox` [N], M == N): no vector-memory load anywhere, so nothing in the
+// wave waits for its own earlier stores and consecutive tiles stream back to back.  issue() runs after the LDS reads and before the
+// first store, consume() after the last: a full tile (ROWS_CT rows x 256 existing columns, VEC) is one basic block in between.
+template <bool VEC, int ROWS_CT, typename Issue, typename Consume>
+__device__ __forceinline__ void iou2d_tile_staged(const float4* sbox, int N, float* __restrict__ o, long ld, int i0, int c0, int lane,
+                                                  Issue issue, Consume consume) {
+    float bx1[4], by1[4], bx2[4], by2[4], barea[4];
+    int col[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float w = relu0(hw_min_s(ax2, bx2[j]) - hw_max_s(ax1, bx1[j]));   // lib/core.py:210-212
-            float h = relu0(hw_min_s(ay2, by2[j]) - hw_max_s(ay1, by1[j]));
-            float inter = w * h;                                        // :218
-            float uni = (aarea + barea[j]) - inter;                     // :507
-            res[j] = inter / uni;                                       // :508
+    for (int j = 0; j < 4; ++j) {
+        col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
+        const int cc = col[j] < N ? col[j] : (N - 1);
+        const float4 v = sbox[cc];
+        bx1[j] = v.x; by1[j] = v.y; bx2[j] = v.z; by2[j] = v.w;
+        barea[j] = (v.z - v.x) * (v.w - v.y);
+    }
+    const int myrow = i0 + lane;
+    const float4 ra = sbox[myrow < N ? myrow : (N - 1)];
+    const int rows = min(ROWS_CT, N - i0);
+    if (VEC && rows == ROWS_CT && (N & 3) == 0) {
+        // (N % 4 == 0: a lane's four columns exist together; the lanes past the last column of a ragged tile just sit the block out)
+        if (col[0] < N) {
+            issue();
+            iou2d_rows<VEC, ROWS_CT, true>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
+            consume();
         }
-        float* orow = o + (size_t)(i0 + r) * ld;
-        if (VEC) {
-            if (col[3] < N) {
-                store_nt_f4(orow + col[0], res[0], res[1], res[2], res[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
-        }
+    } else {
+        issue();
+        iou2d_rows<VEC, 0>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
+        consume();
     }
 }
 

@@ -915,6 +915,13 @@ __device__ __forceinline__ void static_for_until(F&& f) {
     }
 }
 
+// exclusive OR-scan across the lanes of a wave
+__device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
+    u64 up = shfl_up_u64(v, 1);                                     // lane i <- lane i-1
+    if (lane == 0) up = 0ull;
+    return gnms_or_scan64(up);                                      // DPP inclusive OR-scan (gnms_common.h)
+}
+
 __host__ __device__ __forceinline__ size_t leaders_lds_layout(int NB, size_t* off_acc, size_t* off_lm, size_t* off_cand, size_t* off_pair) {
     size_t o = (size_t)kSBPairs * 64 * 8;                       // Xs
     *off_acc = o; o += (size_t)((NB + 1) & ~1) * 8;             // accAll[NB]
@@ -960,6 +967,12 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
     if (tid == 0) I.leadpfx[0] = 0;
     if (tid < kSB) for (int bp = tid; bp < kSB; ++bp) { pair_b[tri_index(tid, bp)] = tid; pair_bp[tri_index(tid, bp)] = bp; }
     for (int i = tid; i < nb; i += 1024) { accAll[i] = 0ull; lmask[i] = 0ull; }
+    // sym: the scan also ATTRIBUTES -- rem[k] = rank of the first (lowest-ranked) leader that overlaps rank k, k itself for a leader.
+    // Every word that decides it passes through this kernel anyway: the pushes gather W[target block][leader] for the leaders in
+    // rank order (the first of them to set a bit claims that rank), the resolve's table holds the pairs inside a super-block.  As a
+    // pass of its own (K4) the attribution read W a second time, and beside the matrix write the chain workgroup gets a CU's share
+    // of the memory system and no more: 1 MiB more per image = 103-126k of the chain's 295k ticks on uniform boxes at N = 4096.
+    if (sym) for (int k = tid; k < n; k += 1024) I.rem[k] = k;
     __syncthreads();
 
     // table prefetch of super-block `sb` into registers, by the threads [first, 1024)
@@ -1006,19 +1019,79 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
         const int nl = lcount[src & 1];
         // (Pulling full rows instead -- 16 coalesced 512-byte reads per target block, AND with the leader masks, ballot -- was measured
         // for the many-leaders case, ~470 leaders per super-block on uniform boxes: near push 28k -> 49k ticks, slower.)
-        for (int base = first + w; base < last; base += 4 * nw) {
-            u64 a[4] = {0ull, 0ull, 0ull, 0ull};
-            for (int j0 = 0; j0 < nl; j0 += 64) {
-                const int j = j0 + lane;
-                const int lr = (j < nl) ? list[j] : -1;
+        if (!sym) {
+            for (int base = first + w; base < last; base += 4 * nw) {
+                u64 a[4] = {0ull, 0ull, 0ull, 0ull};
+                for (int j0 = 0; j0 < nl; j0 += 64) {
+                    const int j = j0 + lane;
+                    const int lr = (j < nl) ? list[j] : -1;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int kbp = base + u * nw;
+                        if (lr >= 0 && kbp < last) a[u] |= I.W[(size_t)kbp * L.NC + lr];
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int kbp = base + u * nw;
-                    if (lr >= 0 && kbp < last) a[u] |= I.W[(size_t)kbp * L.NC + lr];
+                    if (kbp < last) {                                  // wave-uniform
+                        const u64 acc = gnms_wave_or(a[u]);
+                        if (lane == 0 && acc != 0ull) atomicOr(reinterpret_cast<unsigned long long*>(&accAll[kbp]), (unsigned long long)acc);
+                    }
+                }
+            }
+            return;
+        }
+        // sym: the push also attributes.  Lane order inside a batch of 64 leaders = rank order, batches ascend: the first lane of the
+        // first batch that has bit r is the claimer of rank r of the target block -- unless an earlier source took it (accAll).
+        // Two target blocks x eight batches (512 leaders) per round, every load of the round issued before the first use (consuming
+        // batch by batch cost one memory round trip per batch: near push 28k -> 71k ticks on uniform boxes).  An exclusive OR-scan
+        // over the lanes tells each leader which bits it is the first to set; it stores those itself (a wave-uniform loop over the new
+        // bits with a ballot per bit was tried: one trip per claimed rank, 3900 per clustered image -- leaders 62k -> 134k ticks).
+        constexpr int PB = 2, PJ = 8;
+        for (int base = first + w; base < last; base += PB * nw) {
+            u64 a[PB], claimed[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                a[u] = 0ull;
+                claimed[u] = (base + u * nw < last) ? accAll[base + u * nw] : ~0ull;
+            }
+            for (int j0 = 0; j0 < nl; j0 += 64 * PJ) {
+                int lr[PJ];
+                u64 wv[PJ][PB];
+#pragma unroll
+                for (int q = 0; q < PJ; ++q) {
+                    const int j = j0 + q * 64 + lane;
+                    lr[q] = (j < nl) ? list[j] : -1;
+                }
+#pragma unroll
+                for (int q = 0; q < PJ; ++q)
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) {
+                        const int kbp = base + u * nw;
+                        wv[q][u] = (lr[q] >= 0 && kbp < last) ? I.W[(size_t)kbp * L.NC + lr[q]] : 0ull;
+                    }
+#pragma unroll
+                for (int q = 0; q < PJ; ++q) {
+                    if (j0 + q * 64 >= nl) break;                      // wave-uniform
+#pragma unroll
+                    for (int u = 0; u < PB; ++u) {
+                        a[u] |= wv[q][u];
+                        if (~claimed[u] == 0ull) continue;             // (wave-uniform) nothing left to claim in this block
+                        const u64 wo = gnms_wave_or(wv[q][u]);
+                        if ((wo & ~claimed[u]) != 0ull) {              // (wave-uniform) the first lane with a free bit claims it
+                            u64 got = wv[q][u] & ~(claimed[u] | wave_or_exclusive_scan(wv[q][u], lane));
+                            while (got != 0ull) {                      // a leader's own claims in this block, lanes in parallel
+                                I.rem[((base + u * nw) << 6) + __builtin_ctzll(got)] = lr[q];
+                                got &= got - 1;
+                            }
+                        }
+                        claimed[u] |= wo;
+                    }
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < PB; ++u) {
                 const int kbp = base + u * nw;
                 if (kbp < last) {                                      // wave-uniform
                     const u64 acc = gnms_wave_or(a[u]);
@@ -1026,6 +1099,28 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
                 }
             }
         }
+    };
+    // sym: the ranks of super-block sb that no earlier super-block's leader took and that are not leaders: their first claimer is a
+    // leader of the super-block itself -- the lowest earlier block of it with a leader in the table word, else the own block.
+    // One wave per block, off the sequential path (between barrier A and the table store that overwrites Xs).
+    auto claim_inside = [&](int sb) {
+        const int kb0 = sb * kSB;
+        const int nblk = min(kSB, nb - kb0);
+        const int tb = wave;
+        if (tb >= nblk) return;
+        const int k = ((kb0 + tb) << 6) + lane;
+        const u64 lead_tb = lmask[kb0 + tb], taken = accAll[kb0 + tb];
+        if (k >= n || (((lead_tb | taken) >> lane) & 1ull)) return;
+        int cl = -1;
+        for (int bb = 0; bb < tb && cl < 0; ++bb) {
+            const u64 m = Xs[(size_t)tri_index(bb, tb) * 64 + lane] & lmask[kb0 + bb];
+            if (m != 0ull) cl = ((kb0 + bb) << 6) + __builtin_ctzll(m);
+        }
+        if (cl < 0) {
+            const u64 m = Xs[(size_t)tri_index(tb, tb) * 64 + lane] & lead_tb & ((1ull << lane) - 1ull);
+            if (m != 0ull) cl = ((kb0 + tb) << 6) + __builtin_ctzll(m);
+        }
+        if (cl >= 0) I.rem[k] = cl;
     };
 
     // Per super-block sb:  wave 0 resolves it (registers and LDS only) WHILE waves 1..15 prefetch the table of sb+1 and push the
@@ -1119,7 +1214,9 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
         GNMS_TACC(1);
         __syncthreads();                                               // (A) wave 0 is done with Xs; the far pushes have landed
         GNMS_TACC(2);
+        if (sym) claim_inside(sb);
         push(sb, kb0 + nblk, min(kb0 + nblk + kSB, nb), wave, 16);
+        if (sym && sb + 1 < nsb) __syncthreads();                      // claim_inside has read Xs
         if (sb + 1 < nsb) table_store(64, 960);                        // land the prefetched table for the next super-block
         GNMS_TACC(3);
         __syncthreads();                                               // (B)
@@ -1165,12 +1262,6 @@ __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restr
 // an exclusive OR-scan across lanes tells each leader which bits it is the FIRST to claim.
 //   rem[k] = rank of the leader that removed rank k (k itself for a leader), gpos[k] = that leader's ordinal.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
-    u64 up = shfl_up_u64(v, 1);                                     // lane i <- lane i-1
-    if (lane == 0) up = 0ull;
-    return gnms_or_scan64(up);                                      // DPP inclusive OR-scan (gnms_common.h)
-}
-
 __device__ __forceinline__ u64 slab_col(const ImgPtrs& I, const gnms_ws_layout& L, int bb, int k) { return I.W[(size_t)bb * L.NC + k]; }
 
 // one wave: rank block kb of image b.  Besides the attribution it evaluates, in parallel over all rank blocks, the overlap of
@@ -1192,34 +1283,13 @@ __device__ __forceinline__ void attribute_body(const float* __restrict__ src, lo
     my_lead[lane] = 0;
     __builtin_amdgcn_wave_barrier();
     u64 acc = 0;
-    // measured, uniform boxes, B = 8: N = 4096 step 0.202 -> 0.192 ms; N = 16384 (up to 256 row blocks to scan) 2.91 -> 3.10: small images only
-    if (sym && L.NB <= 64 && nl > 8 * (kb + 1) + 64) {
-        // MANY leaders (uniform boxes): walking them 64 at a time costs two dependent gathers per step and ~0.5 (kb + 1) steps.  With
-        // the full symmetric rows the first claimer of rank k is the lowest-ranked leader among the ranks that overlap k:
-        // scan the row blocks bb <= kb, W[bb][k] & leaders of bb -- coalesced, independent loads, 8 in flight.
-        const u64 lw_own = I.leadw[kb];
-        const bool self = ((lw_own >> lane) & 1ull) != 0ull;           // a leader claims itself
-        int lr = self ? k0 + lane : -1;
-        for (int bb0 = 0; bb0 <= kb; bb0 += 8) {
-            u64 t[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = (bb0 + u <= kb && lane < nrows) ? slab_col(I, L, bb0 + u, k0 + lane) : 0ull;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int bb = bb0 + u;
-                if (bb <= kb) {
-                    u64 m = t[u] & I.leadw[bb];
-                    if (bb == kb) m &= (1ull << lane) - 1ull;             // only earlier ranks of the own block
-                    if (lr < 0 && m != 0ull) lr = (bb << 6) + __builtin_ctzll(m);
-                }
-            }
-            if (__all(lr >= 0 || lane >= nrows)) break;
-        }
+    if (sym) {
+        // the leader scan has attributed already (leaders_body, sym): rem[k] is final, what is left is the leader's ordinal and the
+        // overlap with it
         if (lane < nrows) {
             const int k = k0 + lane;
-            if (lr < 0) lr = k;                                          // (cannot happen: a non-leader has an earlier overlapping leader)
+            const int lr = I.rem[k];
             const int g = I.leadpfx[lr >> 6] + __builtin_popcountll(I.leadw[lr >> 6] & ((1ull << (lr & 63)) - 1ull));
-            I.rem[k] = lr;
             I.gpos[k] = g;
             const float* m = overlap_src<SRC>(src, I, b, N, ld);
             I.plead[k] = overlap_at<SRC>(m, ld, I.order[k], I.leadc[g], thr);
@@ -1253,6 +1323,43 @@ __device__ __forceinline__ void attribute_body(const float* __restrict__ src, lo
         I.gpos[k] = g;                                // ordinal of the leader (groups_kernel's sort key; it overwrites gpos afterwards)
         const float* m = overlap_src<SRC>(src, I, b, N, ld);
         I.plead[k] = overlap_at<SRC>(m, ld, I.order[k], I.leadc[g], thr);    // likewise overwritten by groups_kernel's own plead
+    }
+}
+
+// K4 for one image by its WHOLE workgroup (1024 threads; the chain kernels below).  sym: the scan has attributed (rem[] final); what
+// is left per rank is three levels of dependent gathers (leader ordinal, order / leadc, the two boxes) whose latency beside the write
+// stream is microseconds each: four ranks of a thread side by side, every load of a level issued before the first use, stores last.
+template <int SRC>
+__device__ __forceinline__ void attribute_image(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, float thr, char* ws,
+                                                gnms_ws_layout L, const int b, const int sym) {
+    const int tid = threadIdx.x;
+    if (!sym) {
+        for (int kb = tid >> 6; kb < L.NB; kb += 16) attribute_body<SRC>(src, ld, N, counts, thr, ws, L, b, kb, tid & 63, 0);
+        return;
+    }
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const float* m = overlap_src<SRC>(src, I, b, N, ld);
+    for (int k0 = 0; k0 < n; k0 += 4096) {
+        int g4[4], ca[4], cb[4];
+        float pl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + tid + e * 1024;
+            const bool ok = k < n;
+            const int lr = ok ? I.rem[k] : 0;
+            g4[e] = I.leadpfx[lr >> 6] + __builtin_popcountll(I.leadw[lr >> 6] & ((1ull << (lr & 63)) - 1ull));
+            ca[e] = ok ? I.order[k] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cb[e] = (k0 + tid + e * 1024 < n) ? I.leadc[g4[e]] : 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pl[e] = (k0 + tid + e * 1024 < n) ? overlap_at<SRC>(m, ld, ca[e], cb[e], thr) : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + tid + e * 1024;
+            if (k < n) { I.gpos[k] = g4[e]; I.plead[k] = pl[e]; }
+        }
     }
 }
 
@@ -1623,7 +1730,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     const int b = blockIdx.x;
     leaders_body(N, counts, ws, L, b, sym);
     __syncthreads();
-    for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16) attribute_body<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63, sym);
+    attribute_image<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, sym);
     __syncthreads();
     groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
     __syncthreads();

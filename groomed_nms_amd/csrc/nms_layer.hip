@@ -111,14 +111,14 @@ __global__ __launch_bounds__(512) void prof_read_kernel(const float4* __restrict
 extern "C" int gnms_profile_fill(float* dst, size_t count, void* stream) {
     GNMS_CHECK_ARG(dst && count % 4 == 0 && (uintptr_t)dst % 16 == 0, "gnms_profile_fill: dst must be 16-byte aligned, count a multiple of 4");
     if (count == 0) return GNMS_OK;
-    prof_fill_kernel<<<256 * 16, 512, 0, (hipStream_t)stream>>>(reinterpret_cast<float4*>(dst), count / 4, 0.5f);
+    gnms_launch_prof(kProfPlainStream, prof_fill_kernel, dim3(256 * 16), dim3(512), 0, (hipStream_t)stream, reinterpret_cast<float4*>(dst), count / 4, 0.5f);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
 extern "C" int gnms_profile_read(const float* src, size_t count, float* sink, void* stream) {
     GNMS_CHECK_ARG(src && sink && count % 4 == 0 && (uintptr_t)src % 16 == 0, "gnms_profile_read: src must be 16-byte aligned, count a multiple of 4");
     if (count == 0) return GNMS_OK;
-    prof_read_kernel<<<256 * 16, 512, 0, (hipStream_t)stream>>>(reinterpret_cast<const float4*>(src), count / 4, sink);
+    gnms_launch_prof(kProfPlainStream, prof_read_kernel, dim3(256 * 16), dim3(512), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src), count / 4, sink);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -358,6 +358,79 @@ __device__ __forceinline__ void writers_persistent(const float* __restrict__ in,
     }
 }
 
+// STAGED writers (2D, N <= 4096): what keeps the persistent writers above from the rate of a plain store stream is vmcnt.  On gfx9
+// loads, stores and returning atomics retire through ONE in-order counter, so the wave that waits for its next tile's boxes (5 loads)
+// first waits for the 16 stores of the tile before, and thread 0, waiting for its claim, drains wave 0's stores while 15 waves sit at
+// the barrier -- at 16 waves per CU nothing covers those gaps (tail_write_kernel 0.115 ms where gnms_iou2d's many small workgroups
+// take 0.100).  Here the steady state has no vector load at all:
+//   * the image's boxes are staged in LDS once per (workgroup, image) -- the chain's dynamic LDS, unused by writer workgroups -- and a
+//     tile reads its column and row boxes from there (lgkmcnt);
+//   * every image has its own claim counter (misc[5] of its workspace, zeroed by its sort) and a workgroup starts on image
+//     (index mod B), moving on when that image is exhausted: 1-2 stagings per workgroup instead of B;
+//   * the claim for the unit after next is issued BEFORE the tile's stores and consumed after them, the 16 rows unrolled so that the
+//     compiler counts the stores behind it and waits with vmcnt(16), not vmcnt(0).  (The atomic's address is made lane-dependent on
+//     purpose: with a wave-uniform address the compiler's atomic optimizer wraps it in a readfirstlane that needs the result at once.)
+// A unit = 16 wave tiles of 16 rows x 256 columns, numbered row band major inside an image.
+constexpr int kStagedRows = 16;
+template <bool VEC>
+__device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxes, int N, float* __restrict__ out, long ld, int nimg, char* ws,
+                                                  gnms_ws_layout L) {
+    using namespace gnms_iou;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* sbox = reinterpret_cast<float4*>(smem);                  // [N] boxes of the staged image
+    __shared__ int s_claim[2];                                       // (image << 16 | unit) or -1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncc = (N + kWaveCols - 1) / kWaveCols;
+    const int nrt = (N + kStagedRows - 1) / kStagedRows;
+    const int units = (ncc * nrt + 15) >> 4;
+    // thread 0 only: the image it claims from and how many images it has not yet seen exhausted
+    int cur_img = ((int)blockIdx.x - nimg) % nimg, left = nimg;
+    // never 1 at run time, but not provably 0 either: keeps the claim's address lane-dependent in the compiler's eyes
+    const int lane_dep = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 6);
+    auto counter = [&](int img) { return reinterpret_cast<int*>(ws + (size_t)img * L.per_image + L.off_misc) + 5 + lane_dep; };
+    auto claim_now = [&]() -> int {                                  // the next unit of cur_img, or of the next image that has one
+        while (left > 0) {
+            const int u = atomicAdd(counter(cur_img), 1);
+            if (u < units) return (cur_img << 16) | u;
+            cur_img = cur_img + 1 == nimg ? 0 : cur_img + 1;
+            --left;
+        }
+        return -1;
+    };
+    if (tid == 0) s_claim[0] = claim_now();
+    __syncthreads();
+    int cur = s_claim[0], ph = 0, staged = -1;
+    while (cur >= 0) {
+        const int img = cur >> 16, u = cur & 0xffff;
+        if (img != staged) {                                         // (every wave finished reading the old image before the last barrier)
+            const float4* b4 = reinterpret_cast<const float4*>(boxes) + (size_t)img * N;
+            for (int i = tid; i < N; i += 1024) sbox[i] = b4[i];
+            staged = img;
+            __syncthreads();
+        }
+        int pre = 0;
+        const bool claims = tid == 0 && left > 0;
+        const int t = u * 16 + wave;                                 // (wave 0's tile always exists: it carries the claim)
+        if (t < ncc * nrt) {
+            const int rt = t / ncc, cc = t - rt * ncc;
+            iou2d_tile_staged<VEC, kStagedRows>(sbox, N, out + (size_t)img * N * ld, ld, rt * kStagedRows, cc * kWaveCols, lane,
+                [&] { if (claims) pre = atomicAdd(counter(cur_img), 1); },       // in flight ahead of this tile's stores
+                [&] { asm volatile("" :: "v"(pre)); });                          // every path waits for it here: vmcnt(16) on a full tile
+        }
+        if (tid == 0) {
+            int nx = -1;
+            if (left > 0) {
+                if (pre < units) nx = (cur_img << 16) | pre;
+                else { cur_img = cur_img + 1 == nimg ? 0 : cur_img + 1; --left; nx = claim_now(); }
+            }
+            s_claim[ph ^ 1] = nx;
+        }
+        __syncthreads();
+        ph ^= 1;
+        cur = s_claim[ph];
+    }
+}
+
 // chain_src: what the chain's single overlaps come from (the boxes for SRC = kFromBoxes; unused for kFromRecords: the workspace copy
 // of the records); write_src: the writers' input (the boxes / the batch's contiguous records)
 template <bool VEC, int E, int SRC>
@@ -365,19 +438,30 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
                                                           const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L, int Ppow2,
                                                           float* __restrict__ prob, long long* __restrict__ valid,
                                                           long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
-                                                          int nimg, float* __restrict__ out, long ld, int tile_rows, int row0, int row_end) {
+                                                          int nimg, float* __restrict__ out, long ld, int tile_rows, int row0, int row_end,
+                                                          int staged) {
     if ((int)blockIdx.x < nimg) {
         const int b = blockIdx.x;
+#ifdef GNMS_TIMING
+        long long tt__ = (long long)__builtin_amdgcn_s_memtime();
+#define GNMS_TW_ACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && b == 0) ((long long*)img_ptrs(ws, L, 0).gx)[slot] += n__ - tt__; tt__ = n__; } while (0)
+#else
+#define GNMS_TW_ACC(slot) do {} while (0)
+#endif
         leaders_body(N, counts, ws, L, b, 1);
         __syncthreads();
-        for (int kb = threadIdx.x >> 6; kb < L.NB; kb += 16)
-            attribute_body<SRC>(chain_src, (long)N, N, counts, P.nms_threshold, ws, L, b, kb, threadIdx.x & 63, 1);
+        GNMS_TW_ACC(5);
+        attribute_image<SRC>(chain_src, (long)N, N, counts, P.nms_threshold, ws, L, b, 1);
         __syncthreads();
+        GNMS_TW_ACC(6);
         groups_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
         __syncthreads();
+        GNMS_TW_ACC(7);
         finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+        GNMS_TW_ACC(15);
         return;
     }
+    if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, ws, L); return; }
     writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
 }
 
@@ -473,6 +557,11 @@ int device_cu_count() {
 
 // rows per wave tile of the write role (GNMS_FUSED_TILE_ROWS overrides): 16 measured best at B = 8, N = 4096 (0.168 ms per step; 8: 0.174,
 // 32: 0.175, 64: 0.193 -- the last chunks of a launch end together only if chunks are short)
+bool writers_staged() {
+    static const bool on = [] { const char* e = getenv("GNMS_WRITERS_STAGED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 int fused_tile_rows() {
     static const int forced = [] { const char* e = getenv("GNMS_FUSED_TILE_ROWS"); return e ? atoi(e) : 0; }();
     int tr = forced > 0 ? forced : 16;
@@ -487,8 +576,10 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     int P2 = next_pow2(N);
     if (P2 < 1024) P2 = 1024;
     const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
-    const size_t lds = llds > glds ? llds : glds;
+    size_t lds = llds > glds ? llds : glds;
     const int tr = fused_tile_rows();
+    const int staged = (SRC == kFromBoxes && N <= 4096 && writers_staged()) ? 1 : 0;   // writers_staged_2d: the image's boxes in LDS
+    if (staged && lds < (size_t)N * 16) lds = (size_t)N * 16;
     long writers = write_chunk_count(N, B, tr, 0, N);                // persistent writers: at most one per CU
     const int cus = device_cu_count();
     if (writers > cus) writers = cus;
@@ -499,11 +590,11 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
         if (vec) {
             if ((rc = allow_lds(tail_write_kernel<true, E, SRC>, lds))) return rc;
             gnms_launch_prof(kProfMatrixWrite, tail_write_kernel<true, E, SRC>, grid, dim3(1024), lds, st, chain_src, write_src, N, counts, P, ws,
-                             L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N);
+                             L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, staged);
         } else {
             if ((rc = allow_lds(tail_write_kernel<false, E, SRC>, lds))) return rc;
             gnms_launch_prof(kProfMatrixWrite, tail_write_kernel<false, E, SRC>, grid, dim3(1024), lds, st, chain_src, write_src, N, counts, P,
-                             ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N);
+                             ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, staged);
         }
     });
     GNMS_CHECK_LAUNCH();

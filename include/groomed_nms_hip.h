@@ -183,15 +183,17 @@ int gnms_profile_bitmask_boxes(const float* boxes, int B, int N, const int32_t* 
                                size_t workspace_bytes, void* stream);
 
 /* Per-launch timing of the two HBM-bound launches inside whatever call sequence the caller runs (bench.py's roofline line).
- * gnms_profile_events(1) arms it: from then on the library records a HIP event on the launch stream before and after every launch
- * that writes an N x N overlap matrix (slot GNMS_PROF_MATRIX_WRITE: gnms_iou2d, gnms_iou3d_*, gnms_forward_with_iou2d / _iou3d) and
- * every launch of the kernel that reads one (slot GNMS_PROF_MATRIX_READ: gnms_forward's bit-matrix kernel).  Two in-stream markers
- * per launch; not capturable in a HIP graph; one profiling thread at a time.  gnms_profile_collect waits for the recorded events
+ * gnms_profile_events(1) arms it: from then on every launch that writes an N x N overlap matrix (slot GNMS_PROF_MATRIX_WRITE:
+ * gnms_iou2d, gnms_iou3d_*, gnms_forward_with_iou2d / _iou3d), every launch of the kernel that reads one (slot GNMS_PROF_MATRIX_READ:
+ * gnms_forward's bit-matrix kernel) and the plain streams below (slot GNMS_PROF_PLAIN_STREAM) go through hipExtLaunchKernel with a
+ * start and a stop event -- the dispatch's own begin / end timestamps, what a kernel trace reports, no marker packet in the stream.
+ * Not capturable in a HIP graph; one profiling thread at a time.  gnms_profile_collect waits for the recorded events
  * and returns the SUM of the launch durations (ms) and their number since the last collect.  gnms_profile_events(0) disarms.
  * gnms_profile_fill / gnms_profile_read: a plain non-temporal float4 store / load stream over `count` floats -- the HBM write /
  * read rate a kernel that does nothing else reaches on this device (the ceiling the roofline fraction is quoted beside). */
 #define GNMS_PROF_MATRIX_WRITE 0
 #define GNMS_PROF_MATRIX_READ 1
+#define GNMS_PROF_PLAIN_STREAM 2
 int gnms_profile_events(int enable);
 int gnms_profile_collect(int slot, double* ms_sum, int* launches);
 const char* gnms_profile_write_kernel_name(int dim, int B, int N); /* the launch that writes the matrix in gnms_forward_with_iou2d (dim 2) / _iou3d (dim 3), as a kernel trace names it */

@@ -31,7 +31,7 @@ prob = torch.empty((B, N), device="cuda")
 iou = torch.empty((B, N, N), device="cuda")
 n4 = (4 * N + 255) // 256 * 256
 off_gx = 15 * n4
-names = {0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store",
+names = {5: "CHAIN leaders total", 6: "CHAIN attribute total", 7: "CHAIN groups total", 15: "CHAIN finalize total", 0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store",
          4: "leaders barrier B", 8: "groups keys", 9: "groups radix", 10: "groups runs", 11: "groups rescoring", 12: "finalize classify", 13: "finalize sort",
          14: "finalize output"}
 tot = np.zeros(16, np.int64)
