@@ -36,29 +36,76 @@ __device__ __forceinline__ void store_nt_f4(float* p, float a, float b, float c,
     __builtin_nontemporal_store(d, p + 3);
 }
 
+// ---- the division of the tile kernels --------------------------------------------------------------------------------------------
+// `inter / uni` must be the correctly rounded quotient (the reference divides in IEEE fp32).  The compiler's expansion of a / b is
+//     v_div_scale x2, v_rcp, six fma-type steps, v_div_fmas, v_div_fixup               (10 VALU slots per quotient)
+// and of the ~92 VALU instructions the tile spends per row of four entries 40 are these -- on a kernel that is as much VALU- as
+// store-bound (134M pairs x 23 lane-slots = 79 us of VALU at B = 8, N = 4096, beside a ~96 us store stream).  The scale / fixup
+// steps only act on zero, infinite, NaN or denormal operands and on quotients near the ends of the exponent range (ISA: V_DIV_SCALE
+// scales when an operand or 1/b or a/b is denormal, when exp(a) - exp(b) >= 96, or when exp(a) <= 23); everywhere else the quotient
+// is exactly the bare sequence rcp + 6 fma, which this header issues PACKED (v_pk_fma_f32, two quotients per instruction):
+// 4 rcp + 14 packed = 18 slots per row instead of 40, bit for bit the same result.
+// "Everywhere else" is decided per tile from the boxes (box_divides_plainly): every coordinate finite and 0 or 2^-13 <= |c| < 2^20,
+// x2 >= x1, y2 >= y1.  Then widths, heights and areas are 0 or in [2^-72, 2^42] (differences of multiples of 2^-36), inter <= both
+// areas (fp subtraction and multiplication are monotone), uni = 0 only for 0 / 0 (NaN either way) and otherwise >= the larger area,
+// so 0 <= inter / uni <~ 1 with inter = 0 or >= 2^-72 and uni <= 2^43: no operand, reciprocal or quotient anywhere near a case
+// V_DIV_SCALE acts on.  A tile with any other box (pixel boxes never are) takes the compiler's full division.
+typedef float gnms_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ bool box_divides_plainly(const float4 v) {
+    auto coord_ok = [](float c) {
+        const unsigned u = __float_as_uint(c) & 0x7fffffffu;
+        return u == 0u || (u - 0x39000000u) < (0x49800000u - 0x39000000u);   // 0, or 2^-13 <= |c| < 2^20 (NaN / Inf fail)
+    };
+    return coord_ok(v.x) && coord_ok(v.y) && coord_ok(v.z) && coord_ok(v.w) && v.z >= v.x && v.w >= v.y;
+}
+
+// q[j] = n[j] / d[j], correctly rounded, for operands box_divides_plainly vouches for: the steps of the compiler's fp32 division
+// (LLVM AMDGPU LowerFDIV32) without scale and fixup, two quotients per packed instruction
+__device__ __forceinline__ void div4_plain(const float (&n)[4], const float (&d)[4], float (&q)[4]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const gnms_f2 a = {n[2 * p], n[2 * p + 1]}, b = {d[2 * p], d[2 * p + 1]}, one = {1.0f, 1.0f};
+        gnms_f2 r = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+        const gnms_f2 e = __builtin_elementwise_fma(-b, r, one);
+        r = __builtin_elementwise_fma(e, r, r);
+        gnms_f2 qq = a * r;
+        gnms_f2 t = __builtin_elementwise_fma(-b, qq, a);
+        qq = __builtin_elementwise_fma(t, r, qq);
+        t = __builtin_elementwise_fma(-b, qq, a);
+        qq = __builtin_elementwise_fma(t, r, qq);
+        q[2 * p] = qq.x; q[2 * p + 1] = qq.y;
+    }
+}
+
 // The row loop of a wave tile: the column boxes (bx1 .. barea, 4 per lane) against the rows held one per lane in `ra` (lane r = row
 // i0 + r, broadcast with v_readlane), one 16-byte (VEC) or four 4-byte stores per row.  `o` = the image's matrix.  ROWS_CT > 0: exactly
 // that many rows, unrolled; 0: `rows` at run time.  ALLCOLS (with VEC): every column of the tile exists -- with ROWS_CT > 0 the body is
 // then ONE basic block of ROWS_CT stores, so the compiler can count the stores in flight behind an earlier memory operation and wait
 // for that one alone (writers_staged_2d).
-template <bool VEC, int ROWS_CT, bool ALLCOLS = false>
+template <bool VEC, int ROWS_CT, bool ALLCOLS = false, bool PLAINDIV = false>
 __device__ __forceinline__ void iou2d_rows(const float (&bx1)[4], const float (&by1)[4], const float (&bx2)[4], const float (&by2)[4],
                                            const float (&barea)[4], const int (&col)[4], float4 ra, int rows, float* __restrict__ o, int i0,
                                            long ld, int N) {
     const float rarea = (ra.z - ra.x) * (ra.w - ra.y);               // lib/core.py:500-501
+    float* orow = o + (size_t)i0 * ld;                               // advanced by one row per trip (not (i0 + r) * ld: two quarter-rate multiplies)
     auto one_row = [&](int r) {
         const float ax1 = bcast(ra.x, r), ay1 = bcast(ra.y, r), ax2 = bcast(ra.z, r), ay2 = bcast(ra.w, r);
         const float aarea = bcast(rarea, r);
-        float res[4];
+        float res[4], inter[4], uni[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float w = relu0(hw_min_s(ax2, bx2[j]) - hw_max_s(ax1, bx1[j]));   // lib/core.py:210-212
             float h = relu0(hw_min_s(ay2, by2[j]) - hw_max_s(ay1, by1[j]));
-            float inter = w * h;                                        // :218
-            float uni = (aarea + barea[j]) - inter;                     // :507
-            res[j] = inter / uni;                                       // :508
+            inter[j] = w * h;                                           // :218
+            uni[j] = (aarea + barea[j]) - inter[j];                     // :507
         }
-        float* orow = o + (size_t)(i0 + r) * ld;
+        if (PLAINDIV) {
+            div4_plain(inter, uni, res);                                // :508, see above
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) res[j] = inter[j] / uni[j];     // :508
+        }
         if (VEC) {
             if (ALLCOLS || col[3] < N) {
                 store_nt_f4(orow + col[0], res[0], res[1], res[2], res[3]);
@@ -70,6 +117,7 @@ __device__ __forceinline__ void iou2d_rows(const float (&bx1)[4], const float (&
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (col[j] < N) orow[col[j]] = res[j];
         }
+        orow += ld;
     };
     if (ROWS_CT > 0) {
 #pragma unroll
@@ -95,6 +143,7 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
     // column boxes -> registers
     float bx1[4], by1[4], bx2[4], by2[4], barea[4];
     int col[4];
+    bool plain = true;                                            // every box of the tile divides without scale / fixup (div4_plain)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
@@ -102,6 +151,7 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
         float4 v = *reinterpret_cast<const float4*>(b + (size_t)cc * 4);
         bx1[j] = v.x; by1[j] = v.y; bx2[j] = v.z; by2[j] = v.w;
         barea[j] = (v.z - v.x) * (v.w - v.y);                        // lib/core.py:502-503
+        plain = plain && box_divides_plainly(v);
     }
     const int rows = min(tile_rows, row_end - i0);                // tile_rows <= 64: lane r holds row i0 + r
 
@@ -110,7 +160,9 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
     const int myrow = i0 + lane;
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
     if (myrow < M) ra = *reinterpret_cast<const float4*>(a + (size_t)myrow * 4);
-    iou2d_rows<VEC, 0>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
+    plain = plain && box_divides_plainly(ra);                     // (the zero box of a lane past the last row passes)
+    if (__all(plain)) iou2d_rows<VEC, 0, false, true>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
+    else iou2d_rows<VEC, 0>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
 }
 
 // The same wave tile with the image's boxes already in LDS (`sbox` [N], M == N): no vector-memory load anywhere, so nothing in the
@@ -121,6 +173,7 @@ __device__ __forceinline__ void iou2d_tile_staged(const float4* sbox, int N, flo
                                                   Issue issue, Consume consume) {
     float bx1[4], by1[4], bx2[4], by2[4], barea[4];
     int col[4];
+    bool plain = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
@@ -128,15 +181,17 @@ __device__ __forceinline__ void iou2d_tile_staged(const float4* sbox, int N, flo
         const float4 v = sbox[cc];
         bx1[j] = v.x; by1[j] = v.y; bx2[j] = v.z; by2[j] = v.w;
         barea[j] = (v.z - v.x) * (v.w - v.y);
+        plain = plain && box_divides_plainly(v);
     }
     const int myrow = i0 + lane;
     const float4 ra = sbox[myrow < N ? myrow : (N - 1)];
+    plain = plain && box_divides_plainly(ra);
     const int rows = min(ROWS_CT, N - i0);
-    if (VEC && rows == ROWS_CT && (N & 3) == 0) {
+    if (VEC && rows == ROWS_CT && (N & 3) == 0 && __all(plain)) {
         // (N % 4 == 0: a lane's four columns exist together; the lanes past the last column of a ragged tile just sit the block out)
         if (col[0] < N) {
             issue();
-            iou2d_rows<VEC, ROWS_CT, true>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
+            iou2d_rows<VEC, ROWS_CT, true, true>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
             consume();
         }
     } else {
