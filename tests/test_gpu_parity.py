@@ -1576,3 +1576,59 @@ def test_profile_hooks(G):
     check(lib.gnms_profile_read(ptr(buf), buf.numel(), ptr(sink), stream_ptr()), "read")
     torch.cuda.synchronize()
     assert float(buf.min()) == 0.5 and float(buf.max()) == 0.5
+
+
+def test_iou2d_division_paths_bit_exact(G, O):
+    """The 2D tile divides without the scale / fixup steps (packed v_pk_fma_f32) where every box of the tile is in the range that
+    makes them no-ops, and with the compiler's full IEEE division elsewhere (iou_tile.h).  Boxes chosen to sit on both sides of that
+    predicate -- tiny and huge coordinates, coordinates just inside / outside 2^-13 and 2^20, zero-area, inverted, NaN and Inf boxes,
+    denormal extents -- mixed into ordinary pixel boxes: every entry must equal the oracle's IEEE division bit for bit, through
+    gnms_iou2d AND through the matrix the fused launch writes (staged persistent writers, N = 2048), whose layer output must also
+    match the oracle run on that matrix."""
+    from groomed_nms_amd import overlaps, synthetic
+    rng = np.random.default_rng(77)
+
+    def adversarial(n):
+        b = synthetic.clustered_boxes_2d(rng, n, 16)
+        specials = [
+            (0.0, 0.0, 0.0, 0.0), (5.0, 5.0, 5.0, 9.0), (9.0, 3.0, 2.0, 8.0),                       # zero-area, degenerate, inverted
+            (1e-6, 1e-6, 3e-6, 4e-6), (1e-20, 1e-20, 2e-20, 3e-20), (1e-39, 0.0, 3e-39, 2e-39),        # tiny / denormal
+            (2.0 ** -13, 2.0 ** -13, 2.0 ** -12, 2.0 ** -12), (2.0 ** -14, 0.0, 2.0 ** -12, 1.0),      # the predicate's lower edge
+            (0.0, 0.0, 2.0 ** 20 - 1.0, 2.0 ** 19), (0.0, 0.0, 2.0 ** 20, 2.0 ** 20),                  # ... and upper edge
+            (1e7, 1e7, 3e7, 2e7), (1e18, 1e18, 3e18, 3e18), (-1e30, -1e30, 1e30, 1e30),                # huge (areas overflow towards inf)
+            (float("nan"), 0.0, 1.0, 1.0), (0.0, 0.0, float("inf"), 1.0), (-float("inf"), 0.0, 0.0, 1.0),
+            (100.0, 100.0, 100.00001, 100.00001), (-50.0, -50.0, 50.0, 50.0),
+        ]
+        where = rng.choice(n, size=min(n // 3, 8 * len(specials)), replace=False)
+        for i, k in enumerate(where):
+            b[k] = specials[i % len(specials)]
+        return b.astype(np.float32)
+
+    for n in (64, 300, 1024):
+        a, b = adversarial(n), adversarial(n + 13)
+        got = overlaps.iou(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
+        assert np.array_equal(got, O.iou2d(a, b), equal_nan=True), n
+    # boxes at the edges of what the predicate admits (so the tiles DO take the plain division): zero-area boxes (0 / 0 -> NaN),
+    # coordinates of exactly 2^-13 and just under 2^20, sub-ulp extents next to large coordinates, a box covering everything
+    edge = [(0.0, 0.0, 0.0, 0.0), (5.0, 5.0, 5.0, 9.0), (2.0 ** -13, 2.0 ** -13, 2.0 ** -12, 2.0 ** -12), (0.0, 0.0, 2.0 ** -13, 2.0 ** -13),
+            (0.0, 0.0, 2.0 ** 20 - 1.0, 2.0 ** 19), (-(2.0 ** 20 - 1.0), -(2.0 ** 20 - 1.0), 2.0 ** 20 - 1.0, 2.0 ** 20 - 1.0),
+            (100.0, 100.0, 100.00001, 100.00001), (1000000.0, 1000000.0, 1000000.0625, 1000000.0625), (2.0 ** -13, 0.0, 2.0 ** 19, 2.0 ** -13)]
+    for n in (256, 777):
+        a = synthetic.clustered_boxes_2d(rng, n, 16).astype(np.float32)
+        for i, k in enumerate(rng.choice(n, size=n // 4, replace=False)):
+            a[k] = edge[i % len(edge)]
+        got = overlaps.iou(torch.from_numpy(a).cuda(), torch.from_numpy(a).cuda()).cpu().numpy()
+        assert np.array_equal(got, O.iou2d(a, a), equal_nan=True), n
+    # through the fused launch: two images, one ordinary (every tile plain), one adversarial (tiles on both paths)
+    N = 2048
+    boxes = np.stack([synthetic.clustered_boxes_2d(rng, N, 24).astype(np.float32), adversarial(N)])
+    boxes[1, ::2] = np.where(np.isfinite(boxes[1, ::2]), boxes[1, ::2], 1.0)                        # keep half of the weird boxes finite
+    scores = rng.random((2, N), dtype=np.float32)
+    st = torch.from_numpy(scores).cuda().requires_grad_(True)
+    out = G.differentiable_nms_with_iou2d_batched(st, torch.from_numpy(boxes).cuda())
+    for i in range(2):
+        want = O.iou2d(boxes[i], boxes[i])
+        got = out[6][i].cpu().numpy()
+        assert np.array_equal(got, want, equal_nan=True), i
+    ref = O.differentiable_nms(scores[0], O.iou2d(boxes[0], boxes[0]))
+    assert np.array_equal(out[0][0].detach().cpu().numpy(), ref["prob"])
