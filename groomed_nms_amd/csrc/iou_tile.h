@@ -165,12 +165,13 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
     else iou2d_rows<VEC, 0>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
 }
 
-// The same wave tile with the image's boxes already in LDS (`sbox` [N], M == N): no vector-memory load anywhere, so nothing in the
-// wave waits for its own earlier stores and consecutive tiles stream back to back.  issue() runs after the LDS reads and before the
-// first store, consume() after the last: a full tile (ROWS_CT rows x 256 existing columns, VEC) is one basic block in between.
+// The same wave tile with its boxes already in LDS: column box of column c at scol[c - colbase], the ROWS_CT row boxes at srow[0 ..]
+// (M == N) -- no vector-memory load anywhere, so nothing in the wave waits for its own earlier stores and consecutive tiles stream back
+// to back.  issue() runs after the LDS reads and before the first store, consume() after the last: a full tile (ROWS_CT rows, VEC,
+// N % 4 == 0) is one basic block in between.
 template <bool VEC, int ROWS_CT, typename Issue, typename Consume>
-__device__ __forceinline__ void iou2d_tile_staged(const float4* sbox, int N, float* __restrict__ o, long ld, int i0, int c0, int lane,
-                                                  Issue issue, Consume consume) {
+__device__ __forceinline__ void iou2d_tile_staged(const float4* scol, int colbase, const float4* srow, int N, float* __restrict__ o, long ld,
+                                                  int i0, int c0, int lane, Issue issue, Consume consume) {
     float bx1[4], by1[4], bx2[4], by2[4], barea[4];
     int col[4];
     bool plain = true;
@@ -178,15 +179,14 @@ __device__ __forceinline__ void iou2d_tile_staged(const float4* sbox, int N, flo
     for (int j = 0; j < 4; ++j) {
         col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
         const int cc = col[j] < N ? col[j] : (N - 1);
-        const float4 v = sbox[cc];
+        const float4 v = scol[cc - colbase];
         bx1[j] = v.x; by1[j] = v.y; bx2[j] = v.z; by2[j] = v.w;
         barea[j] = (v.z - v.x) * (v.w - v.y);
         plain = plain && box_divides_plainly(v);
     }
-    const int myrow = i0 + lane;
-    const float4 ra = sbox[myrow < N ? myrow : (N - 1)];
-    plain = plain && box_divides_plainly(ra);
     const int rows = min(ROWS_CT, N - i0);
+    const float4 ra = srow[lane < rows ? lane : rows - 1];
+    plain = plain && box_divides_plainly(ra);
     if (VEC && rows == ROWS_CT && (N & 3) == 0 && __all(plain)) {
         // (N % 4 == 0: a lane's four columns exist together; the lanes past the last column of a ragged tile just sit the block out)
         if (col[0] < N) {

@@ -106,8 +106,68 @@ __global__ __launch_bounds__(512) void prof_read_kernel(const float4* __restrict
     }
     if (acc == 123456.789f) *sink = acc;                          // never true for the data it is run on; keeps the loads alive
 }
-}  // namespace
+int device_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lock(mu);
+    int& c = cus[dev];
+    if (c == 0) {
+        hipDeviceProp_t prop;
+        c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return c;
+}
 
+
+// the same bytes in the geometry of the matrix writers: a wave stores 16 rows x 1 KiB (rows `ld` floats apart), 16 waves side by side,
+// one workgroup per CU walking the row bands -- no loads, no arithmetic
+template <int ROWS>
+__global__ __launch_bounds__(1024) void prof_fill_tiles_kernel(float* __restrict__ dst, int N, long ld, long bands, float v, int order) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ncc = (N + 255) >> 8;
+    const int ncg = (ncc + 15) >> 4;                              // column groups of 16 wave tiles (4096 columns)
+    const long units = bands * ncg;
+    const long bands_img = N / ROWS;
+    for (long u = blockIdx.x; u < units; u += gridDim.x) {
+        long band;
+        int g;
+        if (order == 0) { band = u / ncg; g = (int)(u - band * ncg); }           // row band major: a band's column groups side by side
+        else {                                                                    // (image, column group) major: bands of one group in a row
+            const long pair = u / bands_img, bi = u - pair * bands_img;
+            const long img = pair / ncg;
+            g = (int)(pair - img * ncg);
+            band = img * bands_img + bi;
+        }
+        const int col = (g * 16 + wave) * 256 + 4 * lane;
+        if (col + 3 >= N) continue;
+        float* p = dst + band * ROWS * ld + col;
+#pragma unroll 16
+        for (int r = 0; r < ROWS; ++r) {
+            __builtin_nontemporal_store(v, p); __builtin_nontemporal_store(v, p + 1);
+            __builtin_nontemporal_store(v, p + 2); __builtin_nontemporal_store(v, p + 3);
+            p += ld;
+        }
+    }
+}
+}  // namespace
+extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, void* stream) {
+    GNMS_CHECK_ARG(dst && B > 0 && N > 0 && N % 16 == 0 && ld >= N && ld % 4 == 0 && (uintptr_t)dst % 16 == 0,
+                   "gnms_profile_fill_tiles: dst 16-byte aligned, N a multiple of 16, ld >= N a multiple of 4");
+    static const int order = [] { const char* e = getenv("GNMS_FILL_ORDER"); return e ? atoi(e) : 0; }();
+    static const int fewer = [] { const char* e = getenv("GNMS_FILL_FEWER"); return e ? atoi(e) : 0; }();
+    static const int rows = [] { const char* e = getenv("GNMS_FILL_ROWS"); return e ? atoi(e) : 16; }();
+    const dim3 grid((unsigned)(device_cu_count() - fewer));
+    if (rows == 64 && N % 64 == 0)
+        gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<64>, grid, dim3(1024), 0, (hipStream_t)stream, dst, N, (long)ld, (long)B * N / 64, 0.5f, order);
+    else if (rows == 32 && N % 32 == 0)
+        gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<32>, grid, dim3(1024), 0, (hipStream_t)stream, dst, N, (long)ld, (long)B * N / 32, 0.5f, order);
+    else
+        gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<16>, grid, dim3(1024), 0, (hipStream_t)stream, dst, N, (long)ld, (long)B * N / 16, 0.5f, order);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
 extern "C" int gnms_profile_fill(float* dst, size_t count, void* stream) {
     GNMS_CHECK_ARG(dst && count % 4 == 0 && (uintptr_t)dst % 16 == 0, "gnms_profile_fill: dst must be 16-byte aligned, count a multiple of 4");
     if (count == 0) return GNMS_OK;
@@ -413,7 +473,7 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
         const int t = u * 16 + wave;                                 // (wave 0's tile always exists: it carries the claim)
         if (t < ncc * nrt) {
             const int rt = t / ncc, cc = t - rt * ncc;
-            iou2d_tile_staged<VEC, kStagedRows>(sbox, N, out + (size_t)img * N * ld, ld, rt * kStagedRows, cc * kWaveCols, lane,
+            iou2d_tile_staged<VEC, kStagedRows>(sbox, 0, sbox + rt * kStagedRows, N, out + (size_t)img * N * ld, ld, rt * kStagedRows, cc * kWaveCols, lane,
                 [&] { if (claims) pre = atomicAdd(counter(cur_img), 1); },       // in flight ahead of this tile's stores
                 [&] { asm volatile("" :: "v"(pre)); });                          // every path waits for it here: vmcnt(16) on a full tile
         }
@@ -429,6 +489,69 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
         ph ^= 1;
         cur = s_claim[ph];
     }
+}
+
+// LARGE images (N > 4096): the matrix write as a launch of its own on the side stream (3.2d), in the same geometry -- persistent
+// workgroups of 16 waves, 16 rows x 256 columns per wave -- because that geometry is what the store stream likes: a plain fill written
+// this way reaches 5.7-5.8 TB/s at N = 4096 ... 16384 where a linear grid-stride fill and gnms_iou2d's 64-row tiles reach 4.6-4.8
+// (tools/kernel_times.py).  A unit = one row band (16 rows) of one column group (4096 columns) of one image, numbered
+// (image, column group) major; the workgroups take them round robin (no chain workgroup in this launch and nothing to balance, so no
+// claims).  The column group's boxes are staged in LDS when the (image, group) changes; the 16 row boxes of a workgroup's NEXT unit
+// are loaded by wave 0 before the stores of the current one and parked in LDS after them (vmcnt(16), as the claim above).
+template <bool VEC>
+__global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restrict__ boxes, int N, int nimg, float* __restrict__ out, long ld) {
+    using namespace gnms_iou;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* sbox = reinterpret_cast<float4*>(smem);                  // [4096] column boxes of the staged (image, column group)
+    float4* srow = sbox + 4096;                                      // [2][16] row boxes of the current / the next unit
+    const float4* b4 = reinterpret_cast<const float4*>(boxes);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncg = (N + 4095) >> 12;
+    const int nb = (N + kStagedRows - 1) / kStagedRows;
+    const long units = (long)nimg * ncg * nb;
+    auto row_box = [&](long u, int r) {
+        const long pair = u / nb;
+        const int band = (int)(u - pair * nb), img = (int)(pair / ncg);
+        return b4[(size_t)img * N + min(band * kStagedRows + r, N - 1)];
+    };
+    long u = blockIdx.x;
+    if (u < units && tid < kStagedRows) srow[tid] = row_box(u, tid);
+    int ph = 0;
+    long staged = -1;
+    for (; u < units; u += gridDim.x) {
+        const long pair = u / nb;
+        const int band = (int)(u - pair * nb), img = (int)(pair / ncg), g = (int)(pair - (long)img * ncg);
+        if (pair != staged) {                                        // (the barrier that ended the last unit covers the old contents)
+            const int c0g = g << 12, ncol = min(4096, N - c0g);
+            for (int i = tid; i < ncol; i += 1024) sbox[i] = b4[(size_t)img * N + c0g + i];
+            staged = pair;
+            __syncthreads();
+        }
+        const long un = u + gridDim.x;
+        const bool fetch = tid < kStagedRows && un < units;
+        float4 nrow = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c0 = (g << 12) + wave * kWaveCols;
+        if (c0 < N)
+            iou2d_tile_staged<VEC, kStagedRows>(sbox, g << 12, srow + ph * kStagedRows, N, out + (size_t)img * N * ld, ld, band * kStagedRows, c0, lane,
+                [&] { if (fetch) nrow = row_box(un, tid); },
+                [&] { asm volatile("" :: "v"(nrow.x), "v"(nrow.y), "v"(nrow.z), "v"(nrow.w)); });
+        if (fetch) srow[(ph ^ 1) * kStagedRows + tid] = nrow;
+        __syncthreads();
+        ph ^= 1;
+    }
+}
+
+// the launch; reserve: CUs left without a writer workgroup for the layer's one-workgroup-per-image kernels on the caller's stream
+int launch_write_staged(const float* boxes, int B, int N, float* out, int64_t ld, int reserve, hipStream_t st) {
+    const int cus = device_cu_count();
+    int grid = cus - reserve;
+    if (grid < cus / 2) grid = cus / 2;
+    const size_t lds = 96 * 1024;                                    // > 80 KiB: one writer workgroup per CU (it uses 4096 + 32 boxes = 64.5 KiB)
+    int rc;
+    if ((rc = allow_lds(write_staged_kernel<true>, lds))) return rc;
+    gnms_launch_prof(kProfMatrixWrite, write_staged_kernel<true>, dim3((unsigned)grid), dim3(1024), lds, st, boxes, N, B, out, (long)ld);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
 }
 
 // chain_src: what the chain's single overlaps come from (the boxes for SRC = kFromBoxes; unused for kFromRecords: the workspace copy
@@ -539,20 +662,6 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     });
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
-}
-
-int device_cu_count() {
-    static std::mutex mu;
-    static std::map<int, int> cus;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    std::lock_guard<std::mutex> lock(mu);
-    int& c = cus[dev];
-    if (c == 0) {
-        hipDeviceProp_t prop;
-        c = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    }
-    return c;
 }
 
 // rows per wave tile of the write role (GNMS_FUSED_TILE_ROWS overrides): 16 measured best at B = 8, N = 4096 (0.168 ms per step; 8: 0.174,
@@ -788,7 +897,7 @@ bool chain_rides_in_write_launch(int B, int N) {
 extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (B <= 0 || N <= 0) return "";
     if (dim == 3 && bits_in_write_3d(N)) return "iou3d_bits_kernel";
-    if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : "iou2d_kernel";
+    if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : (writers_staged() && N % 4 == 0 ? "write_staged_kernel" : "iou2d_kernel");
     if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
     if (dim == 3) return "iou3d_nms_fast_kernel";
     if (sorts_ride_in_iou_launch(B, N)) return "iou2d_sort_kernel";
@@ -1172,7 +1281,23 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     const int P2 = next_pow2(N);
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
+    // Large images: the matrix write is ONE persistent launch (write_staged_kernel) on the side stream that leaves B CUs without a
+    // writer workgroup; forked behind the bit-matrix kernel, so that what runs beside it on the caller's stream is the one-workgroup-
+    // per-image tail, which finds those CUs free (B = 8, N = 16384: write 1.60 ms = 5.4 TB/s, the tail 1.03 ms beside it, step 2.04 ms;
+    // with gnms_iou2d's kernel in two launches beside bit matrix and tail: 2.13).  Forked in front of the bit-matrix kernel the two
+    // VALU-heavy kernels share the SIMDs and the sum stays the same (write 1.97 ms, step 2.01); forked in front of the sorts as well,
+    // those crawl (step 2.35).
+    const bool persistent_write = mw && !mw->one_launch && writers_staged() && (mw->ld % 4 == 0) && ((uintptr_t)mw->out % 16 == 0) && (N % 4 == 0);
     if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
+    if (persistent_write) {
+        SideScope whole(st);
+        hipStream_t side = nullptr;
+        if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
+        if ((rc = whole.fork(&side, 0))) return rc;
+        if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1))) return rc;
+        if ((rc = launch_write_staged(boxes, B, N, mw->out, mw->ld, B, side))) return rc;
+        return whole.join();
+    }
     if (mw && mw->one_launch) {
         if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
         return launch_tail_write<kFromBoxes>(boxes, boxes, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, mw->out, mw->ld, st);
