@@ -130,7 +130,8 @@ __global__ __launch_bounds__(1024) void prof_fill_tiles_kernel(float* __restrict
     const int ncg = (ncc + 15) >> 4;                              // column groups of 16 wave tiles (4096 columns)
     const long units = bands * ncg;
     const long bands_img = N / ROWS;
-    for (long u = blockIdx.x; u < units; u += gridDim.x) {
+    const long per = (units + gridDim.x - 1) / gridDim.x;
+    for (long u = order == 2 ? blockIdx.x * per : blockIdx.x; u < (order == 2 ? min(units, (blockIdx.x + 1) * per) : units); u += order == 2 ? 1 : gridDim.x) {
         long band;
         int g;
         if (order == 0) { band = u / ncg; g = (int)(u - band * ncg); }           // row band major: a band's column groups side by side
@@ -494,9 +495,9 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
 // LARGE images (N > 4096): the matrix write as a launch of its own on the side stream (3.2d), in the same geometry -- persistent
 // workgroups of 16 waves, 16 rows x 256 columns per wave -- because that geometry is what the store stream likes: a plain fill written
 // this way reaches 5.7-5.8 TB/s at N = 4096 ... 16384 where a linear grid-stride fill and gnms_iou2d's 64-row tiles reach 4.6-4.8
-// (tools/kernel_times.py).  A unit = one row band (16 rows) of one column group (4096 columns) of one image, numbered
-// (image, column group) major; the workgroups take them round robin (no chain workgroup in this launch and nothing to balance, so no
-// claims).  The column group's boxes are staged in LDS when the (image, group) changes; the 16 row boxes of a workgroup's NEXT unit
+// (tools/kernel_times.py).  A unit = one row band (16 rows) of one column group (<= 16 wave tiles; the groups of an image are balanced) of one image, numbered
+// (image, column group) major; every workgroup takes a contiguous range of them (no chain workgroup in this launch and nothing to
+// balance, so no claims).  The column group's boxes are staged in LDS when the (image, group) changes; the 16 row boxes of a workgroup's NEXT unit
 // are loaded by wave 0 before the stores of the current one and parked in LDS after them (vmcnt(16), as the claim above).
 template <bool VEC>
 __global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restrict__ boxes, int N, int nimg, float* __restrict__ out, long ld) {
@@ -506,7 +507,9 @@ __global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restr
     float4* srow = sbox + 4096;                                      // [2][16] row boxes of the current / the next unit
     const float4* b4 = reinterpret_cast<const float4*>(boxes);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ncg = (N + 4095) >> 12;
+    const int ncc = (N + kWaveCols - 1) / kWaveCols;                 // wave tiles per row band
+    const int ncg = (ncc + 15) >> 4;                                 // column groups ...
+    const int tg = (ncc + ncg - 1) / ncg;                            // ... of tg <= 16 wave tiles each, balanced (17 tiles: 9 + 8, not 16 + 1)
     const int nb = (N + kStagedRows - 1) / kStagedRows;
     const long units = (long)nimg * ncg * nb;
     auto row_box = [&](long u, int r) {
@@ -514,25 +517,38 @@ __global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restr
         const int band = (int)(u - pair * nb), img = (int)(pair / ncg);
         return b4[(size_t)img * N + min(band * kStagedRows + r, N - 1)];
     };
-    long u = blockIdx.x;
-    if (u < units && tid < kStagedRows) srow[tid] = row_box(u, tid);
+    // a contiguous range of units per workgroup: at most a couple of stagings each, and 248 sequential store streams are what the
+    // memory likes best (plain fill in this order: 5.5 / 6.0 / 5.9 TB/s at N = 4096 / 8192 / 16384)
+    // (ranges of equal WORK, not of equal length: a unit of a ragged last column group keeps fewer than 16 waves busy and ends sooner)
+    const int tlast = ncc - tg * (ncg - 1);                          // wave tiles in the last group
+    const long wimg = (long)nb * ncc, wfull = (long)nb * tg;
+    auto unit_of_work = [&](long s) {                                // the unit that holds tile-work offset s (units in (image, group) major order)
+        const long img = s / wimg, rem = s - img * wimg;
+        const long g = min((long)(ncg - 1), rem / wfull);
+        const long band = (rem - g * wfull) / (g == ncg - 1 ? tlast : tg);
+        return (img * ncg + g) * nb + band;
+    };
+    const long wtot = wimg * nimg;
+    long u = unit_of_work(wtot * blockIdx.x / gridDim.x);
+    const long uend = blockIdx.x + 1 == gridDim.x ? units : unit_of_work(wtot * (blockIdx.x + 1) / gridDim.x);
+    if (u < uend && tid < kStagedRows) srow[tid] = row_box(u, tid);
     int ph = 0;
     long staged = -1;
-    for (; u < units; u += gridDim.x) {
+    for (; u < uend; ++u) {
         const long pair = u / nb;
         const int band = (int)(u - pair * nb), img = (int)(pair / ncg), g = (int)(pair - (long)img * ncg);
         if (pair != staged) {                                        // (the barrier that ended the last unit covers the old contents)
-            const int c0g = g << 12, ncol = min(4096, N - c0g);
+            const int c0g = g * tg * kWaveCols, ncol = min(tg * kWaveCols, N - c0g);
             for (int i = tid; i < ncol; i += 1024) sbox[i] = b4[(size_t)img * N + c0g + i];
             staged = pair;
             __syncthreads();
         }
-        const long un = u + gridDim.x;
-        const bool fetch = tid < kStagedRows && un < units;
+        const long un = u + 1;
+        const bool fetch = tid < kStagedRows && un < uend;
         float4 nrow = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int c0 = (g << 12) + wave * kWaveCols;
-        if (c0 < N)
-            iou2d_tile_staged<VEC, kStagedRows>(sbox, g << 12, srow + ph * kStagedRows, N, out + (size_t)img * N * ld, ld, band * kStagedRows, c0, lane,
+        const int c0 = (g * tg + wave) * kWaveCols;
+        if (wave < tg && c0 < N)
+            iou2d_tile_staged<VEC, kStagedRows>(sbox, g * tg * kWaveCols, srow + ph * kStagedRows, N, out + (size_t)img * N * ld, ld, band * kStagedRows, c0, lane,
                 [&] { if (fetch) nrow = row_box(un, tid); },
                 [&] { asm volatile("" :: "v"(nrow.x), "v"(nrow.y), "v"(nrow.z), "v"(nrow.w)); });
         if (fetch) srow[(ph ^ 1) * kStagedRows + tid] = nrow;
