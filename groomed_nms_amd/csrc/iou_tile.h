@@ -166,12 +166,12 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
 }
 
 // The same wave tile with its boxes already in LDS: column box of column c at scol[c - colbase], the ROWS_CT row boxes at srow[0 ..]
-// (M == N) -- no vector-memory load anywhere, so nothing in the wave waits for its own earlier stores and consecutive tiles stream back
+// -- no vector-memory load anywhere, so nothing in the wave waits for its own earlier stores and consecutive tiles stream back
 // to back.  issue() runs after the LDS reads and before the first store, consume() after the last: a full tile (ROWS_CT rows, VEC,
 // N % 4 == 0) is one basic block in between.
 template <bool VEC, int ROWS_CT, typename Issue, typename Consume>
-__device__ __forceinline__ void iou2d_tile_staged(const float4* scol, int colbase, const float4* srow, int N, float* __restrict__ o, long ld,
-                                                  int i0, int c0, int lane, Issue issue, Consume consume) {
+__device__ __forceinline__ void iou2d_tile_staged(const float4* scol, int colbase, const float4* srow, int M, int N, float* __restrict__ o,
+                                                  long ld, int i0, int c0, int lane, Issue issue, Consume consume) {
     float bx1[4], by1[4], bx2[4], by2[4], barea[4];
     int col[4];
     bool plain = true;
@@ -184,7 +184,7 @@ __device__ __forceinline__ void iou2d_tile_staged(const float4* scol, int colbas
         barea[j] = (v.z - v.x) * (v.w - v.y);
         plain = plain && box_divides_plainly(v);
     }
-    const int rows = min(ROWS_CT, N - i0);
+    const int rows = min(ROWS_CT, M - i0);
     const float4 ra = srow[lane < rows ? lane : rows - 1];
     plain = plain && box_divides_plainly(ra);
     if (VEC && rows == ROWS_CT && (N & 3) == 0 && __all(plain)) {

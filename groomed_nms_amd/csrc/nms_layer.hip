@@ -433,6 +433,11 @@ __device__ __forceinline__ void writers_persistent(const float* __restrict__ in,
 //     purpose: with a wave-uniform address the compiler's atomic optimizer wraps it in a readfirstlane that needs the result at once.)
 // A unit = 16 wave tiles of 16 rows x 256 columns, numbered row band major inside an image.
 constexpr int kStagedRows = 16;
+bool writers_staged() {
+    static const bool on = [] { const char* e = getenv("GNMS_WRITERS_STAGED"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <bool VEC>
 __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxes, int N, float* __restrict__ out, long ld, int nimg, char* ws,
                                                   gnms_ws_layout L) {
@@ -474,7 +479,7 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
         const int t = u * 16 + wave;                                 // (wave 0's tile always exists: it carries the claim)
         if (t < ncc * nrt) {
             const int rt = t / ncc, cc = t - rt * ncc;
-            iou2d_tile_staged<VEC, kStagedRows>(sbox, 0, sbox + rt * kStagedRows, N, out + (size_t)img * N * ld, ld, rt * kStagedRows, cc * kWaveCols, lane,
+            iou2d_tile_staged<VEC, kStagedRows>(sbox, 0, sbox + rt * kStagedRows, N, N, out + (size_t)img * N * ld, ld, rt * kStagedRows, cc * kWaveCols, lane,
                 [&] { if (claims) pre = atomicAdd(counter(cur_img), 1); },       // in flight ahead of this tile's stores
                 [&] { asm volatile("" :: "v"(pre)); });                          // every path waits for it here: vmcnt(16) on a full tile
         }
@@ -500,22 +505,24 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
 // balance, so no claims).  The column group's boxes are staged in LDS when the (image, group) changes; the 16 row boxes of a workgroup's NEXT unit
 // are loaded by wave 0 before the stores of the current one and parked in LDS after them (vmcnt(16), as the claim above).
 template <bool VEC>
-__global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restrict__ boxes, int N, int nimg, float* __restrict__ out, long ld) {
+__global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restrict__ A, const float* __restrict__ boxes, int M, int N, int nimg,
+                                                            float* __restrict__ out, long ld) {
     using namespace gnms_iou;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sbox = reinterpret_cast<float4*>(smem);                  // [4096] column boxes of the staged (image, column group)
     float4* srow = sbox + 4096;                                      // [2][16] row boxes of the current / the next unit
-    const float4* b4 = reinterpret_cast<const float4*>(boxes);
+    const float4* b4 = reinterpret_cast<const float4*>(boxes);        // columns: boxes [nimg][N][4]
+    const float4* a4 = reinterpret_cast<const float4*>(A);            // rows: A [nimg][M][4] (the layer: the same boxes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ncc = (N + kWaveCols - 1) / kWaveCols;                 // wave tiles per row band
     const int ncg = (ncc + 15) >> 4;                                 // column groups ...
     const int tg = (ncc + ncg - 1) / ncg;                            // ... of tg <= 16 wave tiles each, balanced (17 tiles: 9 + 8, not 16 + 1)
-    const int nb = (N + kStagedRows - 1) / kStagedRows;
+    const int nb = (M + kStagedRows - 1) / kStagedRows;
     const long units = (long)nimg * ncg * nb;
     auto row_box = [&](long u, int r) {
         const long pair = u / nb;
         const int band = (int)(u - pair * nb), img = (int)(pair / ncg);
-        return b4[(size_t)img * N + min(band * kStagedRows + r, N - 1)];
+        return a4[(size_t)img * M + min(band * kStagedRows + r, M - 1)];
     };
     // a contiguous range of units per workgroup: at most a couple of stagings each, and 248 sequential store streams are what the
     // memory likes best (plain fill in this order: 5.5 / 6.0 / 5.9 TB/s at N = 4096 / 8192 / 16384)
@@ -548,7 +555,7 @@ __global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restr
         float4 nrow = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c0 = (g * tg + wave) * kWaveCols;
         if (wave < tg && c0 < N)
-            iou2d_tile_staged<VEC, kStagedRows>(sbox, g * tg * kWaveCols, srow + ph * kStagedRows, N, out + (size_t)img * N * ld, ld, band * kStagedRows, c0, lane,
+            iou2d_tile_staged<VEC, kStagedRows>(sbox, g * tg * kWaveCols, srow + ph * kStagedRows, M, N, out + (size_t)img * M * ld, ld, band * kStagedRows, c0, lane,
                 [&] { if (fetch) nrow = row_box(un, tid); },
                 [&] { asm volatile("" :: "v"(nrow.x), "v"(nrow.y), "v"(nrow.z), "v"(nrow.w)); });
         if (fetch) srow[(ph ^ 1) * kStagedRows + tid] = nrow;
@@ -558,17 +565,28 @@ __global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restr
 }
 
 // the launch; reserve: CUs left without a writer workgroup for the layer's one-workgroup-per-image kernels on the caller's stream
-int launch_write_staged(const float* boxes, int B, int N, float* out, int64_t ld, int reserve, hipStream_t st) {
+int launch_write_staged(const float* a, const float* b, int B, int M, int N, float* out, int64_t ld, int reserve, hipStream_t st) {
     const int cus = device_cu_count();
     int grid = cus - reserve;
     if (grid < cus / 2) grid = cus / 2;
     const size_t lds = 96 * 1024;                                    // > 80 KiB: one writer workgroup per CU (it uses 4096 + 32 boxes = 64.5 KiB)
     int rc;
     if ((rc = allow_lds(write_staged_kernel<true>, lds))) return rc;
-    gnms_launch_prof(kProfMatrixWrite, write_staged_kernel<true>, dim3((unsigned)grid), dim3(1024), lds, st, boxes, N, B, out, (long)ld);
+    gnms_launch_prof(kProfMatrixWrite, write_staged_kernel<true>, dim3((unsigned)grid), dim3(1024), lds, st, a, b, M, N, B, out, (long)ld);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
+}  // namespace
+// gnms_iou2d's large-matrix path (iou_kernels.hip): the persistent writers' geometry reaches 5.5-5.6 TB/s where its 64-row tiles reach 4.6-5.2
+bool gnms_internal_iou2d_wants_staged(int B, int M, int N, int64_t ld, const float* out) {
+    if (!writers_staged() || (ld % 4) != 0 || (N % 4) != 0 || ((uintptr_t)out % 16) != 0) return false;
+    const long units = (long)B * ((M + kStagedRows - 1) / kStagedRows) * ((N + 4095) / 4096);
+    return N >= 1024 && units >= 4L * device_cu_count();
+}
+int gnms_internal_iou2d_staged(const float* a, const float* b, int B, int M, int N, float* out, int64_t ld, hipStream_t st) {
+    return launch_write_staged(a, b, B, M, N, out, ld, 0, st);
+}
+namespace {
 
 // chain_src: what the chain's single overlaps come from (the boxes for SRC = kFromBoxes; unused for kFromRecords: the workspace copy
 // of the records); write_src: the writers' input (the boxes / the batch's contiguous records)
@@ -682,11 +700,6 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
 
 // rows per wave tile of the write role (GNMS_FUSED_TILE_ROWS overrides): 16 measured best at B = 8, N = 4096 (0.168 ms per step; 8: 0.174,
 // 32: 0.175, 64: 0.193 -- the last chunks of a launch end together only if chunks are short)
-bool writers_staged() {
-    static const bool on = [] { const char* e = getenv("GNMS_WRITERS_STAGED"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 int fused_tile_rows() {
     static const int forced = [] { const char* e = getenv("GNMS_FUSED_TILE_ROWS"); return e ? atoi(e) : 0; }();
     int tr = forced > 0 ? forced : 16;
@@ -1311,7 +1324,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
         if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
         if ((rc = whole.fork(&side, 0))) return rc;
         if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1))) return rc;
-        if ((rc = launch_write_staged(boxes, B, N, mw->out, mw->ld, B, side))) return rc;
+        if ((rc = launch_write_staged(boxes, boxes, B, N, N, mw->out, mw->ld, B, side))) return rc;
         return whole.join();
     }
     if (mw && mw->one_launch) {
