@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   parity              max |d prob| and max |d grad_scores| of the timed entry against that oracle on every image of rank 0's batch,
                       and whether the valid-index sets agree -- the "max-|dscore| vs ref" half of BASELINE.json's metric
   other_kind          the same step on the other box generator (uniform <-> clustered), 1 GPU only
+  hip_graph_replay    the same step as a replayed HIP graph of the C-ABI calls (no host cost per step), 1 GPU only
 """
 import argparse
 import ctypes
@@ -152,7 +153,9 @@ def main():
     step, build_overlaps = make_step(boxes, scores)
     eager_step = step
 
-    if args.graph:
+    def graph_steps():
+        """The step as the C-ABI call sequence (forward entry + gnms_backward on fixed buffers), eagerly and captured into HIP graphs:
+        returns (replay_step, eager_raw_step)."""
         ws_g = torch.empty((lib.gnms_workspace_bytes(B, N, ctypes.byref(P)),), dtype=torch.uint8, device=dev)
         prob_g = torch.empty((B, N), dtype=torch.float32, device=dev)
         grad_g = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -184,13 +187,15 @@ def main():
             with torch.cuda.graph(g):
                 raw_step(buf)
             graphs.append(g)
+        gstate = {"i": 0}
 
-        def step():   # noqa: F811  one replay = one full step
-            state["i"] = (state["i"] + 1) % len(graphs)
-            graphs[state["i"]].replay()
+        def replay():                                 # one replay = one full step
+            gstate["i"] = (gstate["i"] + 1) % len(graphs)
+            graphs[gstate["i"]].replay()
+        return replay, (lambda: raw_step(next_buf()))
 
-        def eager_step():   # noqa: F811  the same C-ABI sequence, launched eagerly (events cannot be recorded under replay)
-            raw_step(next_buf())
+    if args.graph:
+        step, eager_step = graph_steps()              # (eager: the same C-ABI sequence; events cannot be recorded under replay)
 
     heartbeat = gdist.StepHeartbeat(dev)
     dt = gdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, heartbeat)
@@ -240,10 +245,11 @@ def main():
         n_fl = B * N * N // 4 * 4
         fill_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill(ptr(b), n_fl, stream_ptr(dev)), "fill"), 4.0 * n_fl) if n_fl else 0.0
         fill_what = "plain non-temporal float4 store stream (gnms_profile_fill)"
-        if N % 16 == 0 and N >= 256:                          # the same stream in the writers' geometry; the better of the two is the ceiling
-            tiles_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill_tiles(ptr(b), B, N, N, stream_ptr(dev)), "fill_tiles"), 4.0 * B * N * N)
-            if tiles_gbs > fill_gbs:
-                fill_gbs, fill_what = tiles_gbs, "plain non-temporal store stream, 16 rows x 1 KiB per wave (gnms_profile_fill_tiles)"
+        for rows_ in (8, 16):                                 # the same stream in the writers' geometry; the best of the three is the ceiling
+            if N % rows_ == 0 and N >= 256:
+                tiles_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill_tiles(ptr(b), B, N, N, rows_, stream_ptr(dev)), "fill_tiles"), 4.0 * B * N * N)
+                if tiles_gbs > fill_gbs:
+                    fill_gbs, fill_what = tiles_gbs, "plain non-temporal store stream, persistent 16-wave workgroups, %d rows x 1 KiB per wave (gnms_profile_fill_tiles)" % rows_
         for b_ in iou_bufs:
             b_.fill_(0.25)
         read_gbs = stream_rate(lambda b: check(lib.gnms_profile_read(ptr(b), n_fl, ptr(sink), stream_ptr(dev)), "read"), 4.0 * n_fl) if n_fl else 0.0
@@ -302,6 +308,14 @@ def main():
         else:
             out["roofline"], out["roofline_iou"] = r_read, r_write
 
+        if world == 1 and not args.no_other_kind and not args.graph:
+            # the same step as a replayed HIP graph of the C-ABI calls: what the GPU alone takes -- the eager line above includes the host's
+            # cost of issuing a step through torch.autograd (85-150 us, box dependent), which the GPU time is now within 1.5x of
+            replay, _ = graph_steps()
+            k_g = max(10, args.steps // 2)
+            dtg = gdist.timed_steps(replay, k_g, max(3, args.warmup // 2), torch.cuda.synchronize)
+            out["hip_graph_replay"] = {"value": round(B * N * k_g / dtg, 1), "unit": "boxes/s", "ms_per_step": round(dtg / k_g * 1e3, 4), "steps": k_g,
+                                       "what": "forward entry + gnms_backward captured once per rotating buffer, replayed"}
         if world == 1 and not args.no_other_kind and not args.graph:
             other = "uniform" if args.kind == "clustered" else "clustered"
             ob_np, os_np = make_inputs(other)

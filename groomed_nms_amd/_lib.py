@@ -59,7 +59,7 @@ _SIGNATURES = {
     "gnms_profile_collect": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "gnms_profile_write_kernel_name": (ctypes.c_char_p, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "gnms_profile_fill": (ctypes.c_int, [c_vp, ctypes.c_size_t, c_vp]),
-    "gnms_profile_fill_tiles": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_vp]),
+    "gnms_profile_fill_tiles": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_vp]),
     "gnms_profile_read": (ctypes.c_int, [c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "gnms_get_groups": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_int, c_vp, c_vp, c_vp,
                                        c_vp, ctypes.c_size_t, c_vp]),
@@ -126,7 +126,9 @@ def check(rc, what):
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """Device address of a tensor as a plain int (None -> NULL): every entry declares c_void_p argtypes, which take ints as they are;
+    wrapping each in a c_void_p object cost ~0.3 us a piece, a dozen per call on a path that is host-bound below N = 4096."""
+    return t.data_ptr() if t is not None else None
 
 
 class _Noop:
@@ -153,7 +155,7 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream_ptr(device=None):
-    """hipStream_t of torch's current stream on `device` (default: the current device) as a void*."""
+    """hipStream_t of torch's current stream on `device` (default: the current device) as an int (0 = the null stream)."""
     if _raw_stream is not None:           # ~0.3 us; torch.cuda.current_stream() builds a Stream object (~10 us)
         if device is None:
             idx = torch.cuda.current_device()
@@ -163,5 +165,5 @@ def stream_ptr(device=None):
             idx = torch.device(device).index
             if idx is None:
                 idx = torch.cuda.current_device()
-        return ctypes.c_void_p(_raw_stream(idx))
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(device).cuda_stream

@@ -121,7 +121,7 @@ int device_cu_count() {
 }
 
 
-// the same bytes in the geometry of the matrix writers: a wave stores 16 rows x 1 KiB (rows `ld` floats apart), 16 waves side by side,
+// the same bytes in the geometry of the matrix writers: a wave stores ROWS rows x 1 KiB (rows `ld` floats apart), 16 waves side by side,
 // one workgroup per CU walking the row bands -- no loads, no arithmetic
 template <int ROWS>
 __global__ __launch_bounds__(1024) void prof_fill_tiles_kernel(float* __restrict__ dst, int N, long ld, long bands, float v, int order) {
@@ -153,19 +153,24 @@ __global__ __launch_bounds__(1024) void prof_fill_tiles_kernel(float* __restrict
     }
 }
 }  // namespace
-extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, void* stream) {
-    GNMS_CHECK_ARG(dst && B > 0 && N > 0 && N % 16 == 0 && ld >= N && ld % 4 == 0 && (uintptr_t)dst % 16 == 0,
-                   "gnms_profile_fill_tiles: dst 16-byte aligned, N a multiple of 16, ld >= N a multiple of 4");
+extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int rows, void* stream) {
+    GNMS_CHECK_ARG(dst && B > 0 && N > 0 && ld >= N && ld % 4 == 0 && (uintptr_t)dst % 16 == 0,
+                   "gnms_profile_fill_tiles: dst 16-byte aligned, ld >= N a multiple of 4");
+    GNMS_CHECK_ARG((rows == 4 || rows == 8 || rows == 16 || rows == 32 || rows == 64) && N % rows == 0,
+                   "gnms_profile_fill_tiles: rows per wave tile must be 4, 8, 16, 32 or 64 and divide N (rows=%d N=%d)", rows, N);
     static const int order = [] { const char* e = getenv("GNMS_FILL_ORDER"); return e ? atoi(e) : 0; }();
-    static const int fewer = [] { const char* e = getenv("GNMS_FILL_FEWER"); return e ? atoi(e) : 0; }();
-    static const int rows = [] { const char* e = getenv("GNMS_FILL_ROWS"); return e ? atoi(e) : 16; }();
-    const dim3 grid((unsigned)(device_cu_count() - fewer));
-    if (rows == 64 && N % 64 == 0)
-        gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<64>, grid, dim3(1024), 0, (hipStream_t)stream, dst, N, (long)ld, (long)B * N / 64, 0.5f, order);
-    else if (rows == 32 && N % 32 == 0)
-        gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<32>, grid, dim3(1024), 0, (hipStream_t)stream, dst, N, (long)ld, (long)B * N / 32, 0.5f, order);
-    else
-        gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<16>, grid, dim3(1024), 0, (hipStream_t)stream, dst, N, (long)ld, (long)B * N / 16, 0.5f, order);
+    const dim3 grid((unsigned)device_cu_count());
+    hipStream_t st = (hipStream_t)stream;
+    const long bands = (long)B * N / rows;
+#define GNMS_FILL_TILES(R) gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<R>, grid, dim3(1024), 0, st, dst, N, (long)ld, bands, 0.5f, order)
+    switch (rows) {
+        case 4: GNMS_FILL_TILES(4); break;
+        case 8: GNMS_FILL_TILES(8); break;
+        case 16: GNMS_FILL_TILES(16); break;
+        case 32: GNMS_FILL_TILES(32); break;
+        default: GNMS_FILL_TILES(64); break;
+    }
+#undef GNMS_FILL_TILES
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -428,11 +433,13 @@ __device__ __forceinline__ void writers_persistent(const float* __restrict__ in,
 //     tile reads its column and row boxes from there (lgkmcnt);
 //   * every image has its own claim counter (misc[5] of its workspace, zeroed by its sort) and a workgroup starts on image
 //     (index mod B), moving on when that image is exhausted: 1-2 stagings per workgroup instead of B;
-//   * the claim for the unit after next is issued BEFORE the tile's stores and consumed after them, the 16 rows unrolled so that the
-//     compiler counts the stores behind it and waits with vmcnt(16), not vmcnt(0).  (The atomic's address is made lane-dependent on
+//   * the claim for the unit after next is issued BEFORE the tile's stores and consumed after them, the rows unrolled so that the
+//     compiler counts the stores behind it and waits with vmcnt(8), not vmcnt(0).  (The atomic's address is made lane-dependent on
 //     purpose: with a wave-uniform address the compiler's atomic optimizer wraps it in a readfirstlane that needs the result at once.)
-// A unit = 16 wave tiles of 16 rows x 256 columns, numbered row band major inside an image.
-constexpr int kStagedRows = 16;
+// A unit = 16 wave tiles of 8 rows x 256 columns, numbered row band major inside an image.  (Rows per tile, B = 8: 16 -> 8 took the
+// launch at N = 4096 from 102.5 to 93.0 us and the large-image launch at N = 16384 from 1.57 to 1.45 ms -- twice as many, shorter units
+// even out what 2048 units on 248 workgroups leave uneven; 4 rows lose again, 111 us / 1.77 ms.)
+constexpr int kStagedRows = 8;
 bool writers_staged() {
     static const bool on = [] { const char* e = getenv("GNMS_WRITERS_STAGED"); return !(e && e[0] == '0'); }();
     return on;
@@ -481,7 +488,7 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
             const int rt = t / ncc, cc = t - rt * ncc;
             iou2d_tile_staged<VEC, kStagedRows>(sbox, 0, sbox + rt * kStagedRows, N, N, out + (size_t)img * N * ld, ld, rt * kStagedRows, cc * kWaveCols, lane,
                 [&] { if (claims) pre = atomicAdd(counter(cur_img), 1); },       // in flight ahead of this tile's stores
-                [&] { asm volatile("" :: "v"(pre)); });                          // every path waits for it here: vmcnt(16) on a full tile
+                [&] { asm volatile("" :: "v"(pre)); });                          // every path waits for it here: vmcnt(8) on a full tile
         }
         if (tid == 0) {
             int nx = -1;
@@ -498,12 +505,12 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
 }
 
 // LARGE images (N > 4096): the matrix write as a launch of its own on the side stream (3.2d), in the same geometry -- persistent
-// workgroups of 16 waves, 16 rows x 256 columns per wave -- because that geometry is what the store stream likes: a plain fill written
+// workgroups of 16 waves, 8 rows x 256 columns per wave -- because that geometry is what the store stream likes: a plain fill written
 // this way reaches 5.7-5.8 TB/s at N = 4096 ... 16384 where a linear grid-stride fill and gnms_iou2d's 64-row tiles reach 4.6-4.8
-// (tools/kernel_times.py).  A unit = one row band (16 rows) of one column group (<= 16 wave tiles; the groups of an image are balanced) of one image, numbered
+// (tools/kernel_times.py).  A unit = one row band (8 rows) of one column group (<= 16 wave tiles; the groups of an image are balanced) of one image, numbered
 // (image, column group) major; every workgroup takes a contiguous range of them (no chain workgroup in this launch and nothing to
-// balance, so no claims).  The column group's boxes are staged in LDS when the (image, group) changes; the 16 row boxes of a workgroup's NEXT unit
-// are loaded by wave 0 before the stores of the current one and parked in LDS after them (vmcnt(16), as the claim above).
+// balance, so no claims).  The column group's boxes are staged in LDS when the (image, group) changes; the row boxes of a workgroup's NEXT unit
+// are loaded by wave 0 before the stores of the current one and parked in LDS after them (vmcnt(8), as the claim above).
 template <bool VEC>
 __global__ __launch_bounds__(1024) void write_staged_kernel(const float* __restrict__ A, const float* __restrict__ boxes, int M, int N, int nimg,
                                                             float* __restrict__ out, long ld) {

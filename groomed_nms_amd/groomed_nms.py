@@ -28,13 +28,29 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+_PARAMS = {}
+
+
 def _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
-            mask_group_boxes, group_size, presorted=False):
-    if pruning_method not in _PRUNE:
-        raise NotImplementedError("Pruning method not implemented!")          # lib/groomed_nms.py:177-178
-    return GnmsParams(float(nms_threshold), float(temperature), float(valid_box_prob_threshold), _PRUNE[pruning_method],
-                      int(bool(return_sorted_prob)), int(bool(group_boxes)), int(bool(mask_group_boxes)),
-                      int(min(int(group_size), 2 ** 31 - 2)), int(bool(presorted)))
+            mask_group_boxes, group_size, presorted=False, index_lists=True):
+    """struct gnms_params for these keyword arguments; one object per distinct argument tuple (treated as immutable by every user:
+    building the ctypes structure anew cost ~3 us per call)."""
+    key = (nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes, mask_group_boxes, group_size,
+           presorted, index_lists)
+    try:
+        p = _PARAMS.get(key)
+    except TypeError:                                                             # an unhashable argument (a tensor threshold, say)
+        p, key = None, None
+    if p is None:
+        if pruning_method not in _PRUNE:
+            raise NotImplementedError("Pruning method not implemented!")          # lib/groomed_nms.py:177-178
+        p = GnmsParams(float(nms_threshold), float(temperature), float(valid_box_prob_threshold), _PRUNE[pruning_method],
+                       int(bool(return_sorted_prob)), int(bool(group_boxes)), int(bool(mask_group_boxes)),
+                       int(min(int(group_size), 2 ** 31 - 2)), int(bool(presorted)))
+        p.index_lists = bool(index_lists)
+        if key is not None and len(_PARAMS) < 256:
+            _PARAMS[key] = p
+    return p
 
 
 _WS_BYTES = {}
@@ -329,8 +345,7 @@ def differentiable_nms_batched(scores, iou, counts=None, nms_threshold=0.4, prun
     index_lists=False (all batched entries): valid / invalid come back as None and the layer skips their compaction and sort --
     the training call site reads only the probabilities (lib/loss/rpn_3d.py:791 uses `[2]`)."""
     params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
-                     mask_group_boxes, group_size, presorted)
-    params.index_lists = bool(index_lists)
+                     mask_group_boxes, group_size, presorted, bool(index_lists))
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSFunction.apply(scores.float(), iou.float(), counts, params)
@@ -343,8 +358,7 @@ def differentiable_nms_with_iou2d_batched(scores, boxes, counts=None, iou_out=No
     layer on it in one call -- what lib/loss/rpn_3d.py:772-791 does in two steps; identical results, and the matrix is
     returned for the caller's later use.  `iou_out` lets the caller provide the matrix buffer."""
     params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
-                     mask_group_boxes, group_size, False)
-    params.index_lists = bool(index_lists)
+                     mask_group_boxes, group_size, False, bool(index_lists))
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSWithIouFunction.apply(scores.float(), boxes.float(), counts, params, iou_out)
@@ -357,8 +371,7 @@ def differentiable_nms_with_iou3d_batched(scores, params3d, counts=None, iou_out
     overlap [B,N,N]): the 3D NMS overlap 0.5*(1+GIoU3D) of lib/loss/rpn_3d.py:778-784 AND the layer on it in one call; identical
     to overlaps.iou3d_batched(from_params=True, nms_overlap=True) + differentiable_nms_batched."""
     params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
-                     mask_group_boxes, group_size, False)
-    params.index_lists = bool(index_lists)
+                     mask_group_boxes, group_size, False, bool(index_lists))
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     if params3d.shape[-1] != 7:
@@ -373,8 +386,7 @@ def differentiable_nms_from_boxes_batched(scores, boxes, counts=None, nms_thresh
     bit-identical to building the 2D IoU matrix (overlaps.iou_batched) and running the layer on it, but the N x N matrix is
     never written to or read from HBM.  Grouped modes only (the defaults of scripts/config/groumd_nms.py)."""
     params = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, True,
-                     mask_group_boxes, group_size, False)
-    params.index_lists = bool(index_lists)
+                     mask_group_boxes, group_size, False, bool(index_lists))
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     return _GroomedNMSFromBoxesFunction.apply(scores.float(), boxes.float(), counts, params)
