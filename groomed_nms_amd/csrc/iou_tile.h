@@ -187,8 +187,11 @@ __device__ __forceinline__ void iou2d_tile_staged(const float4* scol, int colbas
     const int rows = min(ROWS_CT, M - i0);
     const float4 ra = srow[lane < rows ? lane : rows - 1];
     plain = plain && box_divides_plainly(ra);
-    if (VEC && rows == ROWS_CT && (N & 3) == 0 && __all(plain)) {
-        // (N % 4 == 0: a lane's four columns exist together; the lanes past the last column of a ragged tile just sit the block out)
+    if (VEC && rows == ROWS_CT && (N & 3) == 0 && c0 + 4 * ROWS_CT <= N && __all(plain)) {
+        // (N % 4 == 0: a lane's four columns exist together; the lanes past the last column of a ragged tile just sit the block out.
+        // The first ROWS_CT lanes must NOT: the rows are broadcast out of their registers with v_readlane, and what a lane that sits a
+        // branch out holds there is undefined -- the compiler sinks the LDS read of the row box into the branch.  A tile with fewer
+        // than 4 * ROWS_CT columns takes the general path below.)
         if (col[0] < N) {
             issue();
             iou2d_rows<VEC, ROWS_CT, true, true>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);

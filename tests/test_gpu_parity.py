@@ -1632,3 +1632,44 @@ def test_iou2d_division_paths_bit_exact(G, O):
         assert np.array_equal(got, want, equal_nan=True), i
     ref = O.differentiable_nms(scores[0], O.iou2d(boxes[0], boxes[0]))
     assert np.array_equal(out[0][0].detach().cpu().numpy(), ref["prob"])
+
+
+def test_iou2d_large_rectangular_through_the_persistent_writers(G, O):
+    """gnms_iou2d routes large matrices (N % 4 == 0, enough 8-row units) through write_staged_kernel: persistent workgroups, column
+    groups staged in LDS, rows and columns from DIFFERENT box sets, M != N, ragged last column tile, balanced column groups (N = 4100:
+    17 wave tiles = 9 + 8), a leading dimension wider than N.  Every entry equals the oracle's; the rows past M and the padding
+    columns of a wider `ld` stay untouched."""
+    from groomed_nms_amd import _lib, synthetic
+    from groomed_nms_amd._lib import ptr, check, stream_ptr
+    lib = _lib.load()
+    rng = np.random.default_rng(123)
+    for B, M, N, ld in ((8, 1100, 2052, 2052), (3, 3000, 4100, 4100), (2, 4500, 1024, 1040), (1, 9000, 8200, 8200)):
+        a = np.stack([synthetic.clustered_boxes_2d(rng, M, 16) for _ in range(B)]).astype(np.float32)
+        b = np.stack([synthetic.uniform_boxes_2d(rng, N) for _ in range(B)]).astype(np.float32)
+        out = torch.full((B, M + 3, ld), -7.0, device="cuda")
+        # (image stride M * ld: the entry's layout; the 3 spare rows sit behind the last image)
+        flat = out.view(-1)[: B * M * ld].view(B, M, ld)
+        at, bt = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        check(lib.gnms_iou2d(ptr(at), ptr(bt), B, M, N, ptr(flat), ld, stream_ptr()), "gnms_iou2d")
+        torch.cuda.synchronize()
+        got = flat.cpu().numpy()
+        for i in range(B if M * N < 3e7 else 1):
+            assert np.array_equal(got[i, :, :N], O.iou2d(a[i], b[i]), equal_nan=True), (B, M, N, i)
+        if ld > N:
+            assert float(got[:, :, N:].min()) == -7.0 and float(got[:, :, N:].max()) == -7.0
+        assert float(out.view(-1)[B * M * ld:].min()) == -7.0
+
+
+def test_one_call_matrix_with_a_sliver_of_a_last_column_tile(G, O):
+    """N = 256 k + 4: the last wave tile of a row band has ONE valid lane.  The staged writers broadcast a tile's rows out of the first
+    lanes' registers, so such a tile must not take the path on which the other lanes sit the stores out (iou_tile.h); the matrix of the
+    one-call entry equals the oracle's everywhere, through the fused launch (N = 1284, 2052) and the large-image launch (N = 4100)."""
+    from groomed_nms_amd import synthetic
+    for B, N in ((2, 1284), (2, 2052), (1, 4100)):
+        boxes, scores = synthetic.batch_2d(31, B, N, "clustered")
+        out = G.differentiable_nms_with_iou2d_batched(torch.from_numpy(scores).cuda(), torch.from_numpy(boxes).cuda())
+        for i in range(B):
+            want = O.iou2d(boxes[i], boxes[i])
+            assert np.array_equal(out[6][i].cpu().numpy(), want, equal_nan=True), (N, i)
+            ref = O.differentiable_nms(scores[i], want)
+            assert np.array_equal(out[0][i].cpu().numpy(), ref["prob"]), (N, i)
