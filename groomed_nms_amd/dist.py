@@ -67,8 +67,8 @@ def sum_over_ranks(value, device=None):
 
 class StepHeartbeat:
     """The one collective of the pure-NMS scaling runs: a 4-byte all-reduce after every step, so that the 1 -> 8 GPU
-    curve contains a real RCCL round trip per iteration.  Enqueued on the compute stream like DDP's gradient all-reduce would be; no
-    host synchronisation and nothing else on the host path -- ONE collective call per step on a persistent buffer (MAX over the
+    curve contains a real RCCL round trip per iteration.  Issued asynchronously like DDP's gradient all-reduce (ordered behind the step
+    by an event, overlapping the next step); no host synchronisation and nothing else on the host path -- ONE collective call per step on a persistent buffer (MAX over the
     ranks' step counters, which every rank advances by the same amount, so the buffer needs no refill between steps; the copy / add
     pair a SUM needed cost three more launches per step on a loop that is within 1.5x of being host-bound).  A no-op when
     torch.distributed is not initialised.  `check()` (after the timed region) verifies that the collective ran every step and that
@@ -86,11 +86,15 @@ class StepHeartbeat:
     def beat(self):
         self.steps += 1
         if self.on:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.MAX)          # 4 bytes over RCCL / xGMI
+            # asynchronous, as DDP issues its bucket all-reduces: the collective runs on the process group's own stream behind an event
+            # of the compute stream, so its cross-GPU round trip overlaps the next step's kernels instead of stalling them
+            self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.MAX, async_op=True)     # 4 bytes over RCCL / xGMI
 
     def check(self):
         if not self.on:
             return
+        if getattr(self, "work", None) is not None:
+            self.work.wait()
         total = torch.tensor([self.steps], dtype=torch.int32, device=self.device)
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
         if int(self.buf.item()) != 1 or int(total.item()) != self.steps * dist.get_world_size():
