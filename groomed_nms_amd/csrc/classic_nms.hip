@@ -83,6 +83,57 @@ __global__ void classic_export_kernel(int n, char* ws, gnms_ws_layout L, int* __
     if (t < nl) keep[t] = I.leadr[t];                      // :131 keep_out[num_to_keep++] = i
 }
 
+// LARGE inputs (n > GNMS_MAX_BOXES; the reference's `use_nms and synced` inference path hands gpu_nms every anchor, > 100k boxes,
+// lib/rpn_util.py:1268): the leader machinery of the layer keeps per-image state for <= 16384 boxes, so these take the reference's own
+// scan (nms_kernel.cu:118-135) on the device instead -- one workgroup, `remv` (one word per 64 boxes) in LDS:
+//   for every block of 64 boxes, in order: wave 0 settles the block (the lowest box not yet removed is kept and removes what its word of
+//   the diagonal tile says; <= 64 trips on registers), then all threads OR the kept boxes' words into the later blocks' `remv`
+//   (thread j owns block j: the kept columns of the 512 bytes W[j][64 b .. 64 b + 63]).
+// The mask is read once (its upper block triangle: n^2/16 bytes -- the reference copies all n^2/8 to the HOST and scans there).
+constexpr int kClassicLargeMax = 262144;            // remv: 4096 words of LDS; W: 8.6 GB
+__global__ __launch_bounds__(1024) void classic_scan_large_kernel(int n, const u64* __restrict__ W, long NC, int* __restrict__ keep,
+                                                                  int* __restrict__ num_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* remv = reinterpret_cast<u64*>(smem);
+    __shared__ u64 s_kept;
+    __shared__ int s_num;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = (n + 63) >> 6;
+    for (int j = tid; j < nb; j += 1024) remv[j] = 0ull;
+    if (tid == 0) s_num = 0;
+    __syncthreads();
+    for (int b = 0; b < nb; ++b) {
+        if (wave == 0) {
+            const int k0 = b << 6;
+            const int nrows = min(64, n - k0);
+            u64 cur = remv[b];
+            if (nrows < 64) cur |= ~((1ull << nrows) - 1ull);
+            const u64 d = (lane < nrows) ? W[(size_t)b * NC + k0 + lane] : 0ull;     // whom box k0 + lane removes inside the block
+            u64 kept = 0ull;
+            while (~cur != 0ull) {                                                   // wave-uniform: one trip per kept box
+                const int p = __builtin_ctzll(~cur);
+                kept |= 1ull << p;
+                cur |= readlane64(d, p) | (1ull << p);
+            }
+            const int base = s_num;
+            if ((kept >> lane) & 1ull) keep[base + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = k0 + lane;   // :131
+            if (lane == 0) { s_kept = kept; s_num = base + __builtin_popcountll(kept); }
+        }
+        __syncthreads();
+        const u64 kept = s_kept;
+        if (kept != 0ull) {
+            for (int j = b + 1 + tid; j < nb; j += 1024) {
+                const u64* row = W + (size_t)j * NC + ((size_t)b << 6);
+                u64 acc = 0ull, m = kept;
+                while (m) { acc |= row[__builtin_ctzll(m)]; m &= m - 1; }
+                remv[j] |= acc;                                                      // :133-134
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *num_out = s_num;
+}
+
 }  // namespace
 
 extern "C" size_t gnms_nms_workspace_bytes(int n) { return n > 0 ? gnms_make_layout(n).per_image : 0; }
@@ -93,11 +144,19 @@ extern "C" int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, f
     GNMS_CHECK_ARG(num_out != nullptr, "gnms_nms_sorted: num_out is NULL");
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) { GNMS_CHECK_HIP(hipMemsetAsync(num_out, 0, sizeof(int32_t), st)); return GNMS_OK; }
-    if (n > GNMS_MAX_BOXES) { gnms_set_error("gnms_nms_sorted: n=%d exceeds GNMS_MAX_BOXES=%d", n, GNMS_MAX_BOXES); return GNMS_ERR_UNSUPPORTED; }
+    if (n > kClassicLargeMax) { gnms_set_error("gnms_nms_sorted: n=%d exceeds %d", n, kClassicLargeMax); return GNMS_ERR_UNSUPPORTED; }
     GNMS_CHECK_ARG(boxes && keep && workspace, "gnms_nms_sorted: null pointer");
     const gnms_ws_layout L = gnms_make_layout(n);
     if (workspace_bytes < L.per_image) { gnms_set_error("gnms_nms_sorted: workspace too small"); return GNMS_ERR_WORKSPACE; }
     char* ws = (char*)workspace;
+    if (n > GNMS_MAX_BOXES) {                                     // the reference's scan on the device (classic_scan_large_kernel)
+        GNMS_CHECK_ARG(L.NB <= 65535, "gnms_nms_sorted: too many row blocks");
+        classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, shift, keep_le, ws, L);
+        GNMS_CHECK_LAUNCH();
+        classic_scan_large_kernel<<<1, 1024, (size_t)L.NB * 8, st>>>(n, img_ptrs(ws, L, 0).W, (long)L.NC, keep, num_out);
+        GNMS_CHECK_LAUNCH();
+        return GNMS_OK;
+    }
     classic_init_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L);
     GNMS_CHECK_LAUNCH();
     classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, shift, keep_le, ws, L);

@@ -245,10 +245,10 @@ int gnms_sgemm(const float* A, const float* B, float* D, int M, int N, int K, in
 /* EXACT reference symbol and contract (lib/nms/gpu_nms.hpp:1-2, lib/nms/nms_kernel.cu:91-144):
  * host pointers, boxes_host is boxes_num x boxes_dim fp32 pre-sorted by descending score,
  * keep_out holds boxes_num ints, blocking.  +1-pixel IoU (:24-32), strict '>' (:71).
- * Limit: boxes_num <= GNMS_MAX_BOXES (the device-side scan keeps one image's leader state in LDS); above it *num_out = 0 and
- * gnms_last_error() says so (the Python wrapper gpu_nms raises).  The reference's `use_nms and synced` inference branch
- * (lib/rpn_util.py:1268) feeds every anchor (> 100 k): pre-select the top-K scores first (gnms_select_topk), as its own
- * GrooMeD branch does (:1258-1266). */
+ * boxes_num <= GNMS_MAX_BOXES runs the layer's leader scan; larger inputs -- the reference's `use_nms and synced` inference branch
+ * (lib/rpn_util.py:1268) feeds every anchor, > 100 k -- run the reference's own block scan on the device (one workgroup; the n^2/8-byte
+ * mask stays in HBM, 2 GB at 126 720 boxes as in the reference).  Limit: boxes_num <= 262144; above it *num_out = 0 and
+ * gnms_last_error() says so (the Python wrapper gpu_nms raises). */
 void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
           float nms_overlap_thresh, int device_id);
 

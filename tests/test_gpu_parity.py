@@ -1673,3 +1673,18 @@ def test_one_call_matrix_with_a_sliver_of_a_last_column_tile(G, O):
             assert np.array_equal(out[6][i].cpu().numpy(), want, equal_nan=True), (N, i)
             ref = O.differentiable_nms(scores[i], want)
             assert np.array_equal(out[0][i].cpu().numpy(), ref["prob"]), (N, i)
+
+
+def test_classic_nms_beyond_the_layer_limit(G, O):
+    """`_nms` on more boxes than the layer's 16384 (the reference's inference path hands gpu_nms every anchor, lib/rpn_util.py:1268):
+    the reference's block scan on the device (classic_scan_large_kernel), kept indices identical to the oracle's; sizes around the
+    64-box block edge; beyond 262144 boxes it refuses."""
+    from groomed_nms_amd import synthetic, _lib
+    from groomed_nms_amd.nms import gpu_nms
+    rng = np.random.default_rng(17)
+    for n, per in ((16385, 8), (20000, 24), (33000, 3)):
+        dets = np.concatenate([synthetic.clustered_boxes_2d(rng, n, per), synthetic.tie_free_scores(rng, n)[:, None]], 1).astype(np.float32)
+        got = [int(i) for i in gpu_nms(dets, 0.5)]
+        assert got == O.classic_nms(dets, 0.5, rule="gpu"), n
+    with pytest.raises(_lib.GnmsError):
+        gpu_nms(np.zeros((262145, 5), np.float32), 0.5)
