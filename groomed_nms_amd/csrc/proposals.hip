@@ -79,6 +79,73 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(const float* __restri
     }
 }
 
+// MORE candidates than one workgroup sorts in LDS (> GNMS_MAX_BOXES; the reference's inference path selects among ALL anchors,
+// lib/rpn_util.py:1258-1266: ~127k per image): a pre-selection that leaves exactly the K candidates the stable descending sort would put
+// first, in their original order, for select_topk_kernel to sort.  One workgroup per image:
+//   1. radix select on the 32-bit descending key, 8 bits per pass from the top (LDS histogram of the keys that match the prefix so far):
+//      T = the K-th smallest key, need_eq = how many keys equal to T still belong to the first K;
+//   2. compaction in candidate order: keys < T, and the first need_eq keys == T (ties: the earlier candidate, as a stable sort has it) --
+//      every thread owns a contiguous chunk, two block scans (smaller / equal) give its output offsets.
+__global__ __launch_bounds__(1024) void topk_preselect_kernel(const float* __restrict__ scores, int A, const int* __restrict__ cand, int F,
+                                                              const int* __restrict__ cand_counts, int K, int* __restrict__ out_cand,
+                                                              int* __restrict__ out_count) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need;
+    __shared__ int wsum_lt[16], wsum_eq[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = gnms_count(cand_counts, b, F);
+    const float* s = scores + (size_t)b * A;
+    const int* cd = cand ? cand + (size_t)b * F : nullptr;
+    auto key_of = [&](int i) {
+        int a = cd ? cd[i] : i;
+        a = a < 0 ? 0 : (a >= A ? A - 1 : a);
+        return gnms_desc_key(s[a]);
+    };
+    int* oc = out_cand + (size_t)b * K;
+    if (f <= K) {                                                    // everything is selected
+        for (int i = tid; i < f; i += 1024) oc[i] = cd ? cd[i] : i;
+        if (tid == 0) out_count[b] = f;
+        return;
+    }
+    if (tid == 0) { s_prefix = 0u; s_need = (unsigned)K; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 256; i += 1024) hist[i] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+        for (int i = tid; i < f; i += 1024) {
+            const unsigned k = key_of(i);
+            if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {                                              // the digit that holds the need-th smallest key with this prefix
+            unsigned need = s_need, d = 0;
+            while (d < 255u && hist[d] < need) { need -= hist[d]; ++d; }
+            s_prefix = prefix | (d << shift);
+            s_need = need;
+        }
+        __syncthreads();
+    }
+    const unsigned T = s_prefix, need_eq = s_need;                   // keys < T all belong; of the keys == T the first need_eq
+    const int chunk = (f + 1023) / 1024;
+    const int i0 = tid * chunk, i1 = min(f, i0 + chunk);
+    int nlt = 0, neq = 0;
+    for (int i = i0; i < i1; ++i) { const unsigned k = key_of(i); nlt += k < T; neq += k == T; }
+    const int inc_lt = (int)gnms_add_scan32((unsigned)nlt), inc_eq = (int)gnms_add_scan32((unsigned)neq);
+    if (lane == 63) { wsum_lt[wave] = inc_lt; wsum_eq[wave] = inc_eq; }
+    __syncthreads();
+    int lt_before = inc_lt - nlt, eq_before = inc_eq - neq;
+    for (int w = 0; w < wave; ++w) { lt_before += wsum_lt[w]; eq_before += wsum_eq[w]; }
+    // output position of a selected candidate = (# smaller before it) + (# selected equal before it), both in candidate order
+    int lt = lt_before, eq = eq_before;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned k = key_of(i);
+        if (k < T) { oc[lt + min(eq, (int)need_eq)] = cd ? cd[i] : i; ++lt; }
+        else if (k == T) { if (eq < (int)need_eq) oc[lt + eq] = cd ? cd[i] : i; ++eq; }
+    }
+    if (tid == 0) out_count[b] = K;
+}
+
 int next_pow2(int n) {
     int p = 64;
     while (p < n) p <<= 1;
@@ -119,9 +186,18 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
         return GNMS_OK;
     }
     GNMS_CHECK_ARG(scores != nullptr, "gnms_select_topk: scores is NULL");
+    int* pre = nullptr;                                               // [B][K] pre-selected candidates + [B] counts (large F only)
     if (F > GNMS_MAX_BOXES) {
-        gnms_set_error("gnms_select_topk: %d candidates per image exceed GNMS_MAX_BOXES=%d", F, GNMS_MAX_BOXES);
-        return GNMS_ERR_UNSUPPORTED;
+        if (K > GNMS_MAX_BOXES) {
+            gnms_set_error("gnms_select_topk: K=%d exceeds GNMS_MAX_BOXES=%d", K, GNMS_MAX_BOXES);
+            return GNMS_ERR_UNSUPPORTED;
+        }
+        GNMS_CHECK_HIP(hipMallocAsync((void**)&pre, ((size_t)B * K + B) * sizeof(int), st));
+        topk_preselect_kernel<<<B, 1024, 0, st>>>(scores, A, candidates, F, candidate_counts, K, pre, pre + (size_t)B * K);
+        if (hipGetLastError() != hipSuccess) { (void)hipFreeAsync(pre, st); gnms_set_error("gnms_select_topk: launch failed"); return GNMS_ERR_HIP; }
+        candidates = pre;
+        candidate_counts = pre + (size_t)B * K;
+        F = K;
     }
     GNMS_CHECK_ARG(!boxes || ((uintptr_t)boxes % 16 == 0), "gnms_select_topk: boxes must be 16-byte aligned");
     GNMS_CHECK_ARG(!sel_boxes || ((uintptr_t)sel_boxes % 16 == 0), "gnms_select_topk: sel_boxes must be 16-byte aligned");
@@ -146,6 +222,8 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
         default: GNMS_TOPK(16); break;
     }
 #undef GNMS_TOPK
-    GNMS_CHECK_LAUNCH();
+    const hipError_t le = hipGetLastError();
+    if (pre) (void)hipFreeAsync(pre, st);
+    if (le != hipSuccess) { gnms_set_error("gnms_select_topk: launch failed: %s", hipGetErrorString(le)); return GNMS_ERR_HIP; }
     return GNMS_OK;
 }

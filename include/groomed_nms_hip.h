@@ -297,7 +297,9 @@ int gnms_bbox_transform_inv(const float* anchors, const float* deltas, int B, in
                             float* out, void* stream);
 /* lib/loss/rpn_3d.py:731-737 (and lib/rpn_util.py:1258-1266): per image the candidates' scores sorted descending (stable: ties
  * keep candidate order), the first min(K, #candidates) selected.  scores [B][A]; candidates [B][F] int32 indices into [0, A)
- * with candidate_counts [B] (NULL: all F), or candidates == NULL: every one of the A boxes is a candidate; F <= GNMS_MAX_BOXES.
+ * with candidate_counts [B] (NULL: all F), or candidates == NULL: every one of the A boxes is a candidate.  More than GNMS_MAX_BOXES
+ * candidates (all ~127k anchors of an image at inference): a radix pre-selection first leaves exactly the K the stable sort would put
+ * first (then K <= GNMS_MAX_BOXES; a stream-ordered temporary of B * (K + 1) ints).
  * Outputs (any may be NULL), padded behind sel_count[b]: sel_index [B][K] int64 (-1), sel_scores [B][K] (0),
  * sel_boxes [B][K][4] gathered from boxes [B][A][4] (0) -- the padded layout gnms_forward_with_iou2d takes with counts. */
 int gnms_select_topk(const float* scores, int B, int A, const int32_t* candidates, int F, const int32_t* candidate_counts, int K,

@@ -1688,3 +1688,35 @@ def test_classic_nms_beyond_the_layer_limit(G, O):
         assert got == O.classic_nms(dets, 0.5, rule="gpu"), n
     with pytest.raises(_lib.GnmsError):
         gpu_nms(np.zeros((262145, 5), np.float32), 0.5)
+
+
+def test_select_topk_among_all_anchors(G):
+    """gnms_select_topk with more candidates than one workgroup sorts (the reference's inference path selects among ALL anchors,
+    lib/rpn_util.py:1258-1266): the radix pre-selection leaves exactly what the stable descending sort would -- scores with many exact
+    ties and NaNs, with and without a candidate list and ragged candidate counts, K at and around the number of distinct maxima."""
+    from groomed_nms_amd import proposals as PR
+    from oracle import proposals_oracle as PO
+    rng = np.random.default_rng(91)
+    B, A = 3, 126720
+    sc = rng.random((B, A), dtype=np.float32)
+    sc[1] = np.round(sc[1] * 50) / 50                                     # 51 distinct values: thousands of ties at every threshold
+    sc[2, rng.choice(A, 1000, replace=False)] = np.nan
+    boxes = rng.random((B, A, 4), dtype=np.float32)
+    st, bt = torch.from_numpy(sc).cuda(), torch.from_numpy(boxes).cuda()
+    for K in (1, 500, 4096, 16384):
+        idx, num, ssel, bsel = PR.select_topk(st, K, boxes=bt)
+        for b in range(B):
+            want = PO.select_topk(sc[b], None, K)
+            assert int(num[b]) == len(want) and idx[b, :len(want)].cpu().tolist() == want.tolist(), (K, b)
+            assert np.array_equal(ssel[b, :len(want)].cpu().numpy(), sc[b][want], equal_nan=True)
+            assert np.array_equal(bsel[b, :len(want)].cpu().numpy(), boxes[b][want])
+    # a candidate list longer than the in-LDS sort takes, ragged counts (one image below K, one below the limit)
+    F = 40000
+    cand = np.stack([rng.permutation(A)[:F] for _ in range(B)]).astype(np.int32)
+    counts = np.array([F, 300, 17000], np.int32)
+    K = 1000
+    idx, num, ssel, _ = PR.select_topk(st, K, torch.from_numpy(cand).cuda(), torch.from_numpy(counts).cuda())
+    for b in range(B):
+        want = PO.select_topk(sc[b], cand[b, :counts[b]], K)
+        assert int(num[b]) == len(want) and idx[b, :len(want)].cpu().tolist() == want.tolist(), b
+        assert (idx[b, len(want):] == -1).all()
