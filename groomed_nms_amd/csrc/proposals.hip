@@ -113,35 +113,65 @@ __global__ __launch_bounds__(1024) void topk_preselect_kernel(const float* __res
         __syncthreads();
         const unsigned prefix = s_prefix;
         const unsigned himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
-        for (int i = tid; i < f; i += 1024) {
-            const unsigned k = key_of(i);
-            if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        // (a thread adds a run of equal digits at once: scores of one sign share their top byte, and 127k single increments of ONE
+        // LDS word serialise)
+        unsigned run_d = 0u, run_n = 0u;
+        for (int i0 = tid; i0 < f; i0 += 8 * 1024) {                  // eight loads in flight per thread: the pass is latency-bound
+            unsigned k8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) k8[u] = (i0 + u * 1024 < f) ? key_of(i0 + u * 1024) : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u * 1024 < f && (k8[u] & himask) == prefix) {
+                    const unsigned d = (k8[u] >> shift) & 255u;
+                    if (d == run_d) ++run_n;
+                    else { if (run_n) atomicAdd(&hist[run_d], run_n); run_d = d; run_n = 1u; }
+                }
+            }
         }
+        if (run_n) atomicAdd(&hist[run_d], run_n);
         __syncthreads();
-        if (tid == 0) {                                              // the digit that holds the need-th smallest key with this prefix
-            unsigned need = s_need, d = 0;
-            while (d < 255u && hist[d] < need) { need -= hist[d]; ++d; }
-            s_prefix = prefix | (d << shift);
-            s_need = need;
+        if (wave == 0) {                                             // the digit that holds the need-th smallest key with this prefix
+            const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const unsigned mine = h0 + h1 + h2 + h3;
+            const unsigned inc = gnms_add_scan32(mine);               // bins 0 .. 4 lane + 3
+            const unsigned need = s_need;
+            const u64 reach = __ballot(inc >= need);                  // (the last lane always reaches: need <= #keys with this prefix)
+            const int l = __builtin_ctzll(reach);
+            if (lane == l) {
+                unsigned rest = need - (inc - mine), d = 4u * lane;
+                if (rest > h0) { rest -= h0; ++d; if (rest > h1) { rest -= h1; ++d; if (rest > h2) { rest -= h2; ++d; } } }
+                s_prefix = prefix | (d << shift);
+                s_need = rest;
+            }
         }
         __syncthreads();
     }
     const unsigned T = s_prefix, need_eq = s_need;                   // keys < T all belong; of the keys == T the first need_eq
-    const int chunk = (f + 1023) / 1024;
-    const int i0 = tid * chunk, i1 = min(f, i0 + chunk);
+    // compaction in candidate order, coalesced: wave w owns the contiguous range [w * per, (w + 1) * per), 64 candidates per trip
+    const int per = ((f + 15) / 16 + 63) & ~63;
+    const int w0 = wave * per, w1 = min(f, w0 + per);
     int nlt = 0, neq = 0;
-    for (int i = i0; i < i1; ++i) { const unsigned k = key_of(i); nlt += k < T; neq += k == T; }
-    const int inc_lt = (int)gnms_add_scan32((unsigned)nlt), inc_eq = (int)gnms_add_scan32((unsigned)neq);
-    if (lane == 63) { wsum_lt[wave] = inc_lt; wsum_eq[wave] = inc_eq; }
+    for (int i = w0 + lane; i - lane < w1; i += 64) {
+        const unsigned k = i < w1 ? key_of(i) : 0xffffffffu;
+        nlt += __builtin_popcountll(__ballot(i < w1 && k < T));
+        neq += __builtin_popcountll(__ballot(i < w1 && k == T));
+    }
+    if (lane == 0) { wsum_lt[wave] = nlt; wsum_eq[wave] = neq; }
     __syncthreads();
-    int lt_before = inc_lt - nlt, eq_before = inc_eq - neq;
-    for (int w = 0; w < wave; ++w) { lt_before += wsum_lt[w]; eq_before += wsum_eq[w]; }
+    int lt = 0, eq = 0;
+    for (int w = 0; w < wave; ++w) { lt += wsum_lt[w]; eq += wsum_eq[w]; }
     // output position of a selected candidate = (# smaller before it) + (# selected equal before it), both in candidate order
-    int lt = lt_before, eq = eq_before;
-    for (int i = i0; i < i1; ++i) {
-        const unsigned k = key_of(i);
-        if (k < T) { oc[lt + min(eq, (int)need_eq)] = cd ? cd[i] : i; ++lt; }
-        else if (k == T) { if (eq < (int)need_eq) oc[lt + eq] = cd ? cd[i] : i; ++eq; }
+    const u64 below = (1ull << lane) - 1ull;
+    for (int i = w0 + lane; i - lane < w1; i += 64) {
+        const unsigned k = i < w1 ? key_of(i) : 0xffffffffu;
+        const bool is_lt = i < w1 && k < T, is_eq = i < w1 && k == T;
+        const u64 b_lt = __ballot(is_lt), b_eq = __ballot(is_eq);
+        const int lt_me = lt + __builtin_popcountll(b_lt & below), eq_me = eq + __builtin_popcountll(b_eq & below);
+        if (is_lt) oc[lt_me + min(eq_me, (int)need_eq)] = cd ? cd[i] : i;
+        else if (is_eq && eq_me < (int)need_eq) oc[lt_me + eq_me] = cd ? cd[i] : i;
+        lt += __builtin_popcountll(b_lt);
+        eq += __builtin_popcountll(b_eq);
     }
     if (tid == 0) out_count[b] = K;
 }

@@ -155,9 +155,8 @@ def main():
         scores = 1.0 - prob[:, :, 0]                                                    # foreground probability (lib/loss/rpn_3d.py:722-730)
         boxes = PR.bbox_transform_inv(anchors, d2.detach(), means=[0, 0, 0, 0], stds=[0.1, 0.1, 0.2, 0.2])
         A = scores.shape[1]
-        # foreground candidates: the reference ranks the anchors labelled foreground; here the 4 K best-scoring ones stand in
-        cand = torch.topk(scores.detach(), min(4 * K, A), dim=1)[1].to(torch.int32).contiguous()
-        idx, num, s_sel, b_sel = PR.select_topk(scores.detach(), K, cand, None, boxes)
+        # the K best-scoring of ALL anchors (lib/rpn_util.py:1258-1266; the loss ranks the anchors labelled foreground, rpn_3d.py:731)
+        idx, num, s_sel, b_sel = PR.select_topk(scores.detach(), K, None, None, boxes)
         s_sel = torch.gather(scores, 1, idx.clamp(min=0)) * (idx >= 0)                   # differentiable gather of the same boxes
         out = G.differentiable_nms_with_iou2d_batched(s_sel, b_sel, counts=num, index_lists=not train)
         if not train:
@@ -197,8 +196,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             boxes = PR.bbox_transform_inv(anchors, d2, means=[0, 0, 0, 0], stds=[0.1, 0.1, 0.2, 0.2])
-            cand = torch.topk(scores.detach(), min(4 * K, scores.shape[1]), dim=1)[1].to(torch.int32).contiguous()
-            idx, num, s_sel, b_sel = PR.select_topk(scores.detach(), K, cand, None, boxes)
+            idx, num, s_sel, b_sel = PR.select_topk(scores.detach(), K, None, None, boxes)
             s_sel = torch.gather(scores, 1, idx.clamp(min=0)) * (idx >= 0)
             out = G.differentiable_nms_with_iou2d_batched(s_sel, b_sel, counts=num, index_lists=not train)
             if train:

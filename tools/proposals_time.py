@@ -38,6 +38,9 @@ def main():
         cand = torch.from_numpy(np.stack([rng.choice(A, F, replace=False) for _ in range(B)]).astype(np.int32)).cuda()
         t = timed(lambda: PR.select_topk(scores, K, cand, None, boxes))
         print(json.dumps({"kernel": "select_topk (+ gather of scores and boxes)", "B": B, "candidates": F, "K": K, "us": round(t, 1)}))
+    for K in (500, 4096):                               # among ALL anchors: radix pre-selection + the sort of the K survivors
+        t = timed(lambda: PR.select_topk(scores, K, None, None, boxes))
+        print(json.dumps({"kernel": "select_topk among all anchors (+ gathers)", "B": B, "candidates": A, "K": K, "us": round(t, 1)}))
     N = 4096
     par = torch.from_numpy(np.stack([rng.uniform(-20, 20, (B, N)), rng.uniform(0.5, 2.5, (B, N)), rng.uniform(4, 60, (B, N)),
                                      rng.uniform(1.4, 2, (B, N)), rng.uniform(1.3, 2, (B, N)), rng.uniform(3, 5, (B, N)),
