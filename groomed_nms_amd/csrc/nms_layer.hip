@@ -587,8 +587,10 @@ int launch_write_staged(const float* a, const float* b, int B, int M, int N, flo
 // gnms_iou2d's large-matrix path (iou_kernels.hip): the persistent writers' geometry reaches 5.5-5.6 TB/s where its 64-row tiles reach 4.6-5.2
 bool gnms_internal_iou2d_wants_staged(int B, int M, int N, int64_t ld, const float* out) {
     if (!writers_staged() || (ld % 4) != 0 || (N % 4) != 0 || ((uintptr_t)out % 16) != 0) return false;
+    // (N <= 4096: the per-unit row fetch and barrier cost more than the geometry gains -- B = 8, M = N = 4096: 108-114 us against the
+    // 64-row tiles' 102; N = 16384: 1.61 ms against 1.85)
     const long units = (long)B * ((M + kStagedRows - 1) / kStagedRows) * ((N + 4095) / 4096);
-    return N >= 1024 && units >= 4L * device_cu_count();
+    return N > 4096 && units >= 4L * device_cu_count();
 }
 int gnms_internal_iou2d_staged(const float* a, const float* b, int B, int M, int N, float* out, int64_t ld, hipStream_t st) {
     return launch_write_staged(a, b, B, M, N, out, ld, 0, st);

@@ -1635,7 +1635,8 @@ def test_iou2d_division_paths_bit_exact(G, O):
 
 
 def test_iou2d_large_rectangular_through_the_persistent_writers(G, O):
-    """gnms_iou2d routes large matrices (N % 4 == 0, enough 8-row units) through write_staged_kernel: persistent workgroups, column
+    """gnms_iou2d routes large matrices (N > 4096, N % 4 == 0, enough 8-row units) through write_staged_kernel (the smaller ones here
+    take the 64-row tiles): persistent workgroups, column
     groups staged in LDS, rows and columns from DIFFERENT box sets, M != N, ragged last column tile, balanced column groups (N = 4100:
     17 wave tiles = 9 + 8), a leading dimension wider than N.  Every entry equals the oracle's; the rows past M and the padding
     columns of a wider `ld` stay untouched."""
@@ -1643,7 +1644,7 @@ def test_iou2d_large_rectangular_through_the_persistent_writers(G, O):
     from groomed_nms_amd._lib import ptr, check, stream_ptr
     lib = _lib.load()
     rng = np.random.default_rng(123)
-    for B, M, N, ld in ((8, 1100, 2052, 2052), (3, 3000, 4100, 4100), (2, 4500, 1024, 1040), (1, 9000, 8200, 8200)):
+    for B, M, N, ld in ((8, 1100, 2052, 2052), (3, 3000, 4100, 4100), (2, 4500, 1024, 1040), (2, 4000, 4104, 4112), (1, 9000, 8200, 8200)):
         a = np.stack([synthetic.clustered_boxes_2d(rng, M, 16) for _ in range(B)]).astype(np.float32)
         b = np.stack([synthetic.uniform_boxes_2d(rng, N) for _ in range(B)]).astype(np.float32)
         out = torch.full((B, M + 3, ld), -7.0, device="cuda")
