@@ -1080,15 +1080,15 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
                     for (int u = 0; u < PB; ++u) {
                         a[u] |= wv[q][u];
                         if (~claimed[u] == 0ull) continue;             // (wave-uniform) nothing left to claim in this block
-                        const u64 wo = gnms_wave_or(wv[q][u]);
-                        if ((wo & ~claimed[u]) != 0ull) {              // (wave-uniform) the first lane with a free bit claims it
-                            u64 got = wv[q][u] & ~(claimed[u] | wave_or_exclusive_scan(wv[q][u], lane));
+                        if (__any((wv[q][u] & ~claimed[u]) != 0ull)) { // a free bit somewhere: the first lane that has it claims it
+                            const u64 ex = wave_or_exclusive_scan(wv[q][u], lane);
+                            u64 got = wv[q][u] & ~(claimed[u] | ex);
                             while (got != 0ull) {                      // a leader's own claims in this block, lanes in parallel
                                 I.rem[((base + u * nw) << 6) + __builtin_ctzll(got)] = lr[q];
                                 got &= got - 1;
                             }
+                            claimed[u] |= readlane64(ex | wv[q][u], 63);   // the OR of all lanes' words comes with the scan
                         }
-                        claimed[u] |= wo;
                     }
                 }
             }
