@@ -926,7 +926,10 @@ bool bits_in_write_3d(int N) {
 // masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_iou2d_kernel).  GNMS_FUSE_TAIL=0/1 forces.
 bool chain_rides_in_write_launch(int B, int N) {
     static const int forced = [] { const char* e = getenv("GNMS_FUSE_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced == 1 : N > 1024;          // smaller images: the launch-bound regime, where the round-1 sequence measures the same or better
+    // (up to N = 1024 the score / x sorts could ride in the IoU launch instead, iou2d_sort_kernel; replayed as a HIP graph -- the GPU's
+    // own time -- this sequence measures the same or better there too: B = 8, N = 128 / 256 / 512 / 1024: 42.4 / 41.0 / 41.5 / 52.1 us
+    // against 38.0 / 36.6 / 40.0 / 47.5)
+    return forced >= 0 ? forced == 1 : true;
 }
 }  // namespace
 
