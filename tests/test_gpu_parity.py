@@ -598,7 +598,7 @@ def test_iou_and_forward_in_one_call(G):
     """gnms_forward_with_iou2d (score sort inside the IoU launch for N <= 4096, two launches above) == iou_batched +
     differentiable_nms_batched: matrix, all six outputs and the gradient bit for bit; ragged counts; repeated calls."""
     from groomed_nms_amd import synthetic, overlaps
-    for B, N in ((3, 500), (8, 4096), (1, 64), (2, 1001), (200, 520), (1, 5000)):
+    for B, N in ((3, 500), (8, 4096), (1, 64), (2, 1001), (200, 520), (300, 1100), (1, 5000)):      # (300 images: more chain workgroups than CUs)
         boxes, scores = synthetic.batch_2d(9, B, N, "clustered", per=32)
         bt = torch.from_numpy(boxes).cuda()
         counts = torch.tensor([N] + [max(1, N // 2)] * (B - 1), dtype=torch.int32).cuda()
