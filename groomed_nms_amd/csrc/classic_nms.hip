@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
         const float ax1 = bcastf(rx1, r), ay1 = bcastf(ry1, r), ax2 = bcastf(rx2, r), ay2 = bcastf(ry2, r), as = bcastf(rs, r);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float left = fmaxf(ax1, bx1[j]), right = fminf(ax2, bx2[j]);   // :25
-            const float top = fmaxf(ay1, by1[j]), bottom = fminf(ay2, by2[j]);   // :26
+            // (v_max / v_min issued directly, the row coordinate from its SGPR: no canonicalising moves; iou3d_pair.h)
+            const float left = gnms_iou3d::vmax_s(ax1, bx1[j]), right = gnms_iou3d::vmin_s(ax2, bx2[j]);   // :25
+            const float top = gnms_iou3d::vmax_s(ay1, by1[j]), bottom = gnms_iou3d::vmin_s(ay2, by2[j]);   // :26
             const float width = fmaxf(right - left + shift, 0.f), height = fmaxf(bottom - top + shift, 0.f);   // :27
             const float inter = width * height;                                  // :28
             const float ov = inter / (as + bs[j] - inter);                       // :31
