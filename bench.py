@@ -251,11 +251,13 @@ def main():
         n_fl = B * N * N // 4 * 4
         fill_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill(ptr(b), n_fl, stream_ptr(dev)), "fill"), 4.0 * n_fl) if n_fl else 0.0
         fill_what = "plain non-temporal float4 store stream (gnms_profile_fill)"
-        for rows_ in (8, 16):                                 # the same stream in the writers' geometry; the best of the three is the ceiling
+        for rows_, nt_ in ((8, 1), (16, 1), (8, 0), (16, 0)):   # the same stream in the writers' geometry; the best of the five is the ceiling
             if N % rows_ == 0 and N >= 256:
-                tiles_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill_tiles(ptr(b), B, N, N, rows_, stream_ptr(dev)), "fill_tiles"), 4.0 * B * N * N)
+                tiles_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill_tiles(ptr(b), B, N, N, rows_, nt_, stream_ptr(dev)), "fill_tiles"), 4.0 * B * N * N)
                 if tiles_gbs > fill_gbs:
-                    fill_gbs, fill_what = tiles_gbs, "plain non-temporal store stream, persistent 16-wave workgroups, %d rows x 1 KiB per wave (gnms_profile_fill_tiles)" % rows_
+                    fill_gbs = tiles_gbs
+                    fill_what = "plain %s store stream, persistent 16-wave workgroups, %d rows x 1 KiB per wave (gnms_profile_fill_tiles)" % (
+                        "non-temporal" if nt_ else "16-byte", rows_)
         for b_ in iou_bufs:
             b_.fill_(0.25)
         read_gbs = stream_rate(lambda b: check(lib.gnms_profile_read(ptr(b), n_fl, ptr(sink), stream_ptr(dev)), "read"), 4.0 * n_fl) if n_fl else 0.0

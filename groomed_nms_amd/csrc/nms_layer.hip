@@ -123,7 +123,7 @@ int device_cu_count() {
 
 // the same bytes in the geometry of the matrix writers: a wave stores ROWS rows x 1 KiB (rows `ld` floats apart), 16 waves side by side,
 // one workgroup per CU walking the row bands -- no loads, no arithmetic
-template <int ROWS>
+template <int ROWS, bool NT>
 __global__ __launch_bounds__(1024) void prof_fill_tiles_kernel(float* __restrict__ dst, int N, long ld, long bands, float v, int order) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ncc = (N + 255) >> 8;
@@ -146,14 +146,18 @@ __global__ __launch_bounds__(1024) void prof_fill_tiles_kernel(float* __restrict
         float* p = dst + band * ROWS * ld + col;
 #pragma unroll 16
         for (int r = 0; r < ROWS; ++r) {
-            __builtin_nontemporal_store(v, p); __builtin_nontemporal_store(v, p + 1);
-            __builtin_nontemporal_store(v, p + 2); __builtin_nontemporal_store(v, p + 3);
+            if (NT) {
+                __builtin_nontemporal_store(v, p); __builtin_nontemporal_store(v, p + 1);
+                __builtin_nontemporal_store(v, p + 2); __builtin_nontemporal_store(v, p + 3);
+            } else {
+                *reinterpret_cast<float4*>(p) = make_float4(v, v, v, v);
+            }
             p += ld;
         }
     }
 }
 }  // namespace
-extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int rows, void* stream) {
+extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int rows, int nontemporal, void* stream) {
     GNMS_CHECK_ARG(dst && B > 0 && N > 0 && ld >= N && ld % 4 == 0 && (uintptr_t)dst % 16 == 0,
                    "gnms_profile_fill_tiles: dst 16-byte aligned, ld >= N a multiple of 4");
     GNMS_CHECK_ARG((rows == 4 || rows == 8 || rows == 16 || rows == 32 || rows == 64) && N % rows == 0,
@@ -162,7 +166,11 @@ extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int
     const dim3 grid((unsigned)device_cu_count());
     hipStream_t st = (hipStream_t)stream;
     const long bands = (long)B * N / rows;
-#define GNMS_FILL_TILES(R) gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<R>, grid, dim3(1024), 0, st, dst, N, (long)ld, bands, 0.5f, order)
+#define GNMS_FILL_TILES(R)                                                                                                                  \
+    do {                                                                                                                                    \
+        if (nontemporal) gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<R, true>, grid, dim3(1024), 0, st, dst, N, (long)ld, bands, 0.5f, order);   \
+        else gnms_launch_prof(kProfPlainStream, prof_fill_tiles_kernel<R, false>, grid, dim3(1024), 0, st, dst, N, (long)ld, bands, 0.5f, order);            \
+    } while (0)
     switch (rows) {
         case 4: GNMS_FILL_TILES(4); break;
         case 8: GNMS_FILL_TILES(8); break;

@@ -198,7 +198,7 @@ int gnms_profile_events(int enable);
 int gnms_profile_collect(int slot, double* ms_sum, int* launches);
 const char* gnms_profile_write_kernel_name(int dim, int B, int N); /* the launch that writes the matrix in gnms_forward_with_iou2d (dim 2) / _iou3d (dim 3), as a kernel trace names it */
 int gnms_profile_fill(float* dst, size_t count, void* stream);
-int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int rows, void* stream); /* the same store stream in the matrix writers' geometry: persistent 16-wave workgroups, `rows` (4, 8, 16, 32 or 64, dividing N) rows x 1 KiB per wave, rows ld floats apart */
+int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int rows, int nontemporal, void* stream); /* the same store stream in the matrix writers' geometry: persistent 16-wave workgroups, `rows` (4, 8, 16, 32 or 64, dividing N) rows x 1 KiB per wave, rows ld floats apart; non-temporal (as the writers store) or ordinary 16-byte stores */
 int gnms_profile_read(const float* src, size_t count, float* sink, void* stream);
 
 /* get_groups(iou_unsorted, group_threshold, scores_unsorted, group_size)  lib/groomed_nms.py:208-270 for one

@@ -63,8 +63,9 @@ rows = [("iou2d_kernel", timed(lambda o: check(lib.gnms_iou2d(ptr(boxes2), ptr(b
         ("iou3d_nms_fast_kernel thr=-100 (no pair in the band)", timed(lambda o: check(lib.gnms_nms_overlap3d_from_params(ptr(par3), B, N, -100.0, ptr(o), N, sp), "o3"))),
         ("iou3d_kernel<METHOD 2> (exact order)", timed(lambda o: check(lib.gnms_iou3d_from_params(ptr(par3), ptr(par3), B, N, N, 2, None, ptr(o), N, sp), "o3e"))),
         ("plain fill (same launch events)", timed(lambda o: check(lib.gnms_profile_fill(ptr(o), B * N * N, sp), "fill"), slot=2)),
-        ("plain fill, writers' geometry (8 rows x 1 KiB per wave)", timed(lambda o: check(lib.gnms_profile_fill_tiles(ptr(o), B, N, N, 8, sp), "fillt"), slot=2)),
-        ("plain fill, writers' geometry (16 rows x 1 KiB per wave)", timed(lambda o: check(lib.gnms_profile_fill_tiles(ptr(o), B, N, N, 16, sp), "fillt"), slot=2)),
+        ("plain fill, writers' geometry (8 rows x 1 KiB per wave)", timed(lambda o: check(lib.gnms_profile_fill_tiles(ptr(o), B, N, N, 8, 1, sp), "fillt"), slot=2)),
+        ("plain fill, writers' geometry (16 rows x 1 KiB per wave)", timed(lambda o: check(lib.gnms_profile_fill_tiles(ptr(o), B, N, N, 16, 1, sp), "fillt"), slot=2)),
+        ("plain fill, writers' geometry, ordinary stores (8 rows)", timed(lambda o: check(lib.gnms_profile_fill_tiles(ptr(o), B, N, N, 8, 0, sp), "fillt"), slot=2)),
         ("plain fill (events around back-to-back launches)", evt(lambda o: check(lib.gnms_profile_fill(ptr(o), B * N * N, sp), "fill")))]
 for name, ms in rows:
     print("%-58s %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s" % (name, ms, bytes_ / ms / 1e6, bytes_ / ms / 1e6 / 8000))
