@@ -80,10 +80,10 @@ def launch_ranks_if_needed(args):
     if args.gpus <= 1:
         return
     import torch
-    have = torch.cuda.device_count()
-    if have < args.gpus:
-        sys.exit("bench.py: --gpus %d requested but this node has %d visible GPU(s); refusing to time fewer GPUs than asked" % (args.gpus, have))
     from groomed_nms_amd import dist as gdist
+    have = torch.cuda.device_count()
+    if have < args.gpus and not gdist.share_gpu():          # (GNMS_SHARE_GPU=1: debug mode, ranks fold onto the visible devices over gloo)
+        sys.exit("bench.py: --gpus %d requested but this node has %d visible GPU(s); refusing to time fewer GPUs than asked" % (args.gpus, have))
     sys.exit(gdist.relaunch_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
 
 
@@ -304,13 +304,18 @@ def main():
             "config": {"workload": "%d images/GPU x %d %s %dD boxes/image, nms_threshold 0.4, linear pruning, grouped+masked, group_size 100"
                                    % (B, N, args.kind, args.dim), "boxes_per_image": N, "images_per_gpu": B,
                        "scores_presorted": bool(args.sorted_scores), "hip_graph_replay": bool(args.graph), "untimed_steps_before_the_warmup": prewarm, "parallelism": "images sharded, dp%d" % world,
-                       "collective": "one 4-byte RCCL all-reduce per step" if world > 1 else "none (1 GPU)",
+                       "collective": ("one 4-byte all-reduce (SUM) per step over %s, issued asynchronously like DDP's gradient all-reduce (it "
+                                      "overlaps the next step; not a blocking round trip); every step's sum verified == world_size after the "
+                                      "timed region" % ("gloo [GNMS_SHARE_GPU debug mode]" if gdist.share_gpu() else "RCCL/xGMI")) if world > 1 else "none (1 GPU)",
                        "matrix_buffers": n_buf},
             "roofline": None,
             "reference_cpu_survey": {"value": REF_CPU_SURVEY, "unit": "boxes/s", "ratio_per_gpu": round(value / world / REF_CPU_SURVEY, 1),
                                      "note": "reference lib/groomed_nms.py + lib/core.py iou on torch CPU, 8 threads, uniform N=4096, measured in the "
                                              "survey container (BASELINE.md section 2); not a published number, hence vs_baseline null"},
         }
+        if gdist.share_gpu() and world > 1:
+            out["debug_shared_gpu"] = "GNMS_SHARE_GPU=1: %d ranks share %d GPU(s), gloo collectives -- launcher-path check, not a scaling number" % (
+                world, torch.cuda.device_count())
         if one_call:
             out["roofline"] = r_write
         else:

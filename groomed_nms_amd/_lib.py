@@ -34,6 +34,8 @@ _SIGNATURES = {
     "gnms_default_params": (None, [ctypes.POINTER(GnmsParams)]),
     "gnms_iou2d": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int64, c_vp]),
     "gnms_corners_of_cuboid": (ctypes.c_int, [c_vp, ctypes.c_int64, c_vp, c_vp]),
+    "gnms_iou2d_f64": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_int64, c_vp]),
+    "gnms_corners_of_cuboid_f64": (ctypes.c_int, [c_vp, ctypes.c_int64, ctypes.c_int, c_vp, c_vp]),
     "gnms_iou3d_approximate": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp,
                                               ctypes.c_int64, c_vp]),
     "gnms_iou3d_from_params": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp,
@@ -77,6 +79,8 @@ _SIGNATURES = {
     "gnms_nms_sorted": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_nms_sorted_shift": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int, c_vp, c_vp, c_vp,
                                              ctypes.c_size_t, c_vp]),
+    "gnms_nms_sorted_shift_f64": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, c_vp, c_vp, c_vp,
+                                                 ctypes.c_size_t, c_vp]),
     "gnms_soft_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "gnms_soft_nms": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                      ctypes.c_double, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),

@@ -477,8 +477,9 @@ extern "C" int gnms_aploss(const float* logits, const float* targets, int B, int
     // image whose F x N product makes the one-CU version slow -- run the four-kernel version that spreads the positives over the machine.
     static const int spread = [] { const char* e = getenv("GNMS_APLOSS_SPREAD"); return e ? atoi(e) : 0; }();
     if (N > kApMaxN || spread == 1 || (spread == 0 && N >= 2048 && B <= 64)) {
-        float* scratch = nullptr;
-        GNMS_CHECK_HIP(hipMallocAsync((void**)&scratch, (size_t)B * ap_scratch_words(N) * sizeof(float), st));
+        gnms_async_buffer scratch_buf;                                // returned to the pool on every exit, the early error returns included
+        GNMS_CHECK_HIP(scratch_buf.alloc((size_t)B * ap_scratch_words(N) * sizeof(float), st));
+        float* scratch = scratch_buf.as<float>();
         int P2 = 1024;
         while (P2 < N) P2 <<= 1;
         const int E = P2 / kApThreads;
@@ -500,10 +501,8 @@ extern "C" int gnms_aploss(const float* logits, const float* targets, int B, int
                      case 8: ap_scan_kernel<8><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
                      default: ap_scan_kernel<16><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break; }
         ap_neg_grad_kernel<<<dim3(gnms_div_up(N, 256), B), 256, 0, st>>>(N, scratch, grad);
-        const hipError_t le = hipGetLastError();
-        const hipError_t fe = hipFreeAsync(scratch, st);
-        if (le != hipSuccess) { gnms_set_error("gnms_aploss: kernel launch failed: %s", hipGetErrorString(le)); return GNMS_ERR_HIP; }
-        if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }
+        GNMS_CHECK_LAUNCH();
+        GNMS_CHECK_HIP(scratch_buf.release());
         return GNMS_OK;
     }
     if (N > 2 * kApThreads)      // > 64 KiB of dynamic LDS; set per call: the attribute is per device and the call is cheap

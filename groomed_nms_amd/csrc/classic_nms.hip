@@ -69,6 +69,45 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
         if (col[j] < L.NC) Wk[col[j]] = ((((u64)hi[j]) << 32) | lo[j]) & rowmask;
 }
 
+// The same bit matrix from float64 boxes, every operation in double: lib/nms_others.py:119-150 girshick_nms computes in the dtype of
+// `dets`, which is float64 for the arrays its own test feeds (test/test_differentiable_nms_forward.py:111-114) -- in fp32 an overlap
+// within a rounding of `thresh` could flip a keep / suppress decision relative to the reference.  fp64 vector rate is ample for a
+// test-only helper; the scan behind it is the same.
+__device__ __forceinline__ double bcastd(double v, int lane) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(b & 0xffffffffll), lane);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__global__ __launch_bounds__(256) void classic_mask_f64_kernel(const double* __restrict__ boxes, int n, int dim, double thresh, double shift, int keep_le,
+                                                               char* ws, gnms_ws_layout L) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kb = blockIdx.y;
+    const int k0 = kb * 64;
+    const int c0 = (blockIdx.x * 4 + wave) * 64;            // one column per lane (64 x 64 tiles): doubles take two registers each
+    if (k0 >= n || c0 >= n || c0 >= k0 + 64) return;
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    const int col = c0 + lane;
+    const double* p = boxes + (size_t)(col < n ? col : n - 1) * dim;
+    const double bx1 = p[0], by1 = p[1], bx2 = p[2], by2 = p[3];
+    const double bs = (bx2 - bx1 + shift) * (by2 - by1 + shift);
+    const double* q = boxes + (size_t)min(k0 + lane, n - 1) * dim;
+    const double rx1 = q[0], ry1 = q[1], rx2 = q[2], ry2 = q[3];
+    const double rs = (rx2 - rx1 + shift) * (ry2 - ry1 + shift);
+    const int nrows = min(64, n - k0);
+    u64 word = 0ull;
+    for (int r = 0; r < nrows; ++r) {
+        const double ax1 = bcastd(rx1, r), ay1 = bcastd(ry1, r), ax2 = bcastd(rx2, r), ay2 = bcastd(ry2, r), as = bcastd(rs, r);
+        const double w = fmax(0.0, fmin(ax2, bx2) - fmax(ax1, bx1) + shift);     // nms_others.py:139-143
+        const double h = fmax(0.0, fmin(ay2, by2) - fmax(ay1, by1) + shift);
+        const double inter = w * h;
+        const double ov = inter / (as + bs - inter);                              // :144
+        const bool sup = keep_le ? !(ov <= thresh) : (ov > thresh);               // :146
+        word |= sup ? (1ull << r) : 0ull;
+    }
+    if (col < L.NC) I.W[(size_t)kb * L.NC + col] = word;
+}
+
 __global__ void classic_init_kernel(int n, char* ws, gnms_ws_layout L) {
     ImgPtrs I = img_ptrs(ws, L, 0);
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,8 +178,10 @@ __global__ __launch_bounds__(1024) void classic_scan_large_kernel(int n, const u
 
 extern "C" size_t gnms_nms_workspace_bytes(int n) { return n > 0 ? gnms_make_layout(n).per_image : 0; }
 
-extern "C" int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, float thresh, float shift, int keep_le, int32_t* keep,
-                                     int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+// boxes: float [n][dim] (is_fp64 = 0) or double [n][dim] (is_fp64 = 1)
+int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double thresh, double shift, int keep_le, int32_t* keep,
+                    int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream) {
     GNMS_CHECK_ARG(n >= 0 && boxes_dim >= 4, "gnms_nms_sorted_shift: bad shape (n=%d dim=%d)", n, boxes_dim);
     GNMS_CHECK_ARG(num_out != nullptr, "gnms_nms_sorted: num_out is NULL");
     hipStream_t st = (hipStream_t)stream;
@@ -150,9 +191,15 @@ extern "C" int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, f
     const gnms_ws_layout L = gnms_make_layout(n);
     if (workspace_bytes < L.per_image) { gnms_set_error("gnms_nms_sorted: workspace too small"); return GNMS_ERR_WORKSPACE; }
     char* ws = (char*)workspace;
+    GNMS_CHECK_ARG(L.NB <= 65535, "gnms_nms_sorted: too many row blocks");
+    auto mask = [&]() {
+        if (is_fp64)
+            classic_mask_f64_kernel<<<dim3(gnms_div_up(n, 256), L.NB), 256, 0, st>>>((const double*)boxes, n, boxes_dim, thresh, shift, keep_le, ws, L);
+        else
+            classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L);
+    };
     if (n > GNMS_MAX_BOXES) {                                     // the reference's scan on the device (classic_scan_large_kernel)
-        GNMS_CHECK_ARG(L.NB <= 65535, "gnms_nms_sorted: too many row blocks");
-        classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, shift, keep_le, ws, L);
+        mask();
         GNMS_CHECK_LAUNCH();
         classic_scan_large_kernel<<<1, 1024, (size_t)L.NB * 8, st>>>(n, img_ptrs(ws, L, 0).W, (long)L.NC, keep, num_out);
         GNMS_CHECK_LAUNCH();
@@ -160,7 +207,7 @@ extern "C" int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, f
     }
     classic_init_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L);
     GNMS_CHECK_LAUNCH();
-    classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>(boxes, n, boxes_dim, thresh, shift, keep_le, ws, L);
+    mask();
     GNMS_CHECK_LAUNCH();
     const size_t lds = leaders_lds_size(L.NB);
     if (lds > 64 * 1024)
@@ -170,6 +217,17 @@ extern "C" int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, f
     classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
+}
+}  // namespace
+
+extern "C" int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, float thresh, float shift, int keep_le, int32_t* keep,
+                                     int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return nms_sorted_impl(boxes, 0, n, boxes_dim, (double)thresh, (double)shift, keep_le, keep, num_out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gnms_nms_sorted_shift_f64(const double* boxes, int n, int boxes_dim, double thresh, double shift, int keep_le, int32_t* keep,
+                                         int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return nms_sorted_impl(boxes, 1, n, boxes_dim, thresh, shift, keep_le, keep, num_out, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int32_t* keep, int32_t* num_out,

@@ -37,6 +37,21 @@ void gnms_set_error(const char* fmt, ...);
         }                                                                                     \
     } while (0)
 
+// A stream-ordered temporary (hipMallocAsync) that is returned to the pool on EVERY exit from the scope, error paths included:
+// the GNMS_CHECK_* macros return early.  `release()` frees explicitly and reports the result.
+struct gnms_async_buffer {
+    void* p = nullptr;
+    hipStream_t st = nullptr;
+    gnms_async_buffer() = default;
+    gnms_async_buffer(const gnms_async_buffer&) = delete;
+    gnms_async_buffer& operator=(const gnms_async_buffer&) = delete;
+    ~gnms_async_buffer() { if (p) (void)hipFreeAsync(p, st); }
+    hipError_t alloc(size_t bytes, hipStream_t stream) { st = stream; return hipMallocAsync(&p, bytes, stream); }
+    hipError_t release() { void* q = p; p = nullptr; return q ? hipFreeAsync(q, st) : hipSuccess; }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+
 static inline int gnms_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
@@ -148,7 +163,7 @@ __device__ __forceinline__ float gnms_desc_key_decode(uint32_t key) {
 }
 
 // wave-wide OR on the VALU: DPP row_shr 1,2,4,8 + row_bcast:15 + row_bcast:31 leave the total in lane 63 (an inclusive
-// OR-scan on the way); 6 dependent DPP ops instead of 6 ds_bpermute round trips (checked on gfx950: tools/scratch/t_dpp2.hip)
+// OR-scan on the way); 6 dependent DPP ops instead of 6 ds_bpermute round trips (checked on gfx950 with a stand-alone kernel in round 1)
 __device__ __forceinline__ unsigned gnms_or_scan32(unsigned v) {
     v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
     v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2

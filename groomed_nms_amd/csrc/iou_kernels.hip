@@ -324,6 +324,75 @@ extern "C" int gnms_corners_of_cuboid(const float* params, int64_t count, float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// The float64 NumPy branches the reference's INFERENCE call site takes (lib/rpn_util.py:1292-1320): `aboxes` is float64 after the
+// hstack at :1258, so lib/core.py:205-207, 512-513 build the IoU matrix in float64 and only lib/groomed_nms.py:36 rounds it to fp32,
+// once; lib/math_3d.py:438-490 builds the corners in float64 (np.einsum) before `.float()`.  An fp32 evaluation differs from that in
+// the last ulp of some entries, under a strict `> nms_threshold`.  These two kernels run the same IEEE double operations in the same
+// order (compiled -ffp-contract=off): the matrix is bit-identical to NumPy's, the corners up to libm's sin / cos (a sub-ulp of double,
+// gone after the caller's rounding to fp32).  Throughput is irrelevant here (N = 500 at that call site).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void iou2d_f64_kernel(const double* __restrict__ A, const double* __restrict__ Bx, int M, int N,
+                                                        double* __restrict__ out, long ld) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+    if (j >= N) return;
+    const double* a = A + ((size_t)b * M + i) * 4;
+    const double* c = Bx + ((size_t)b * N + j) * 4;
+    const double ax1 = a[0], ay1 = a[1], ax2 = a[2], ay2 = a[3];
+    const double bx1 = c[0], by1 = c[1], bx2 = c[2], by2 = c[3];
+    const double area_a = (ax2 - ax1) * (ay2 - ay1);                              // lib/core.py:499-500
+    const double area_b = (bx2 - bx1) * (by2 - by1);                              // :502-503
+    // :205-207.  (np.minimum / np.maximum / np.clip propagate a NaN coordinate where fmin / fmax drop it -- but such a box has a NaN
+    // area, hence a NaN union and a NaN quotient either way, exactly as in the fp32 tile, iou_tile.h)
+    const double w = fmax(fmin(ax2, bx2) - fmax(ax1, bx1), 0.0);
+    const double h = fmax(fmin(ay2, by2) - fmax(ay1, by1), 0.0);
+    const double inter = w * h;                                                   // :218
+    out[((size_t)b * M + i) * ld + j] = inter / ((area_a + area_b) - inter);      // :512-513
+}
+
+__global__ void corners_f64_kernel(const double* __restrict__ params, long count, int trig_f32, double* __restrict__ corners) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double* p = params + i * 7;
+    const double x = p[0], y = p[1], z = p[2], w = p[3], h = p[4], l = p[5], ry = p[6];
+    // lib/math_3d.py:443-447: np.cos / np.sin evaluate in the dtype of `ry3d` -- float32 at the inference call site (coords_3d_raw is the
+    // network's fp32 output, lib/rpn_util.py:1186,1211) -- and the result is widened into the float64 matrix R
+    const double c = trig_f32 ? (double)cosf((float)ry) : cos(ry), s = trig_f32 ? (double)sinf((float)ry) : sin(ry);
+    double* o = corners + i * 24;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool xh = (k == 1) | (k == 3) | (k == 5) | (k == 6);               // :470
+        const bool yh = (k == 2) | (k == 3) | (k == 6) | (k == 7);               // :471
+        const bool zh = k >= 4;                                                  // :472
+        const double bx = (xh ? l : 0.0) - l / 2, by = (yh ? h : 0.0) - h / 2, bz = (zh ? w : 0.0) - w / 2;   // :474-476
+        // np.einsum('ijk,ikl->ijl', R, corners) :480: sum over k in ascending order
+        const double rx = (c * bx + 0.0 * by) + s * bz;
+        const double ryy = (0.0 * bx + 1.0 * by) + 0.0 * bz;
+        const double rz = ((-s) * bx + 0.0 * by) + c * bz;
+        o[k] = rx + x; o[8 + k] = ryy + y; o[16 + k] = rz + z;                   // :483-485
+    }
+}
+
+extern "C" int gnms_iou2d_f64(const double* boxes_a, const double* boxes_b, int B, int M, int N, double* out, int64_t ld, void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && M >= 0 && N >= 0, "gnms_iou2d_f64: negative size (B=%d M=%d N=%d)", B, M, N);
+    if (B == 0 || M == 0 || N == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(boxes_a && boxes_b && out, "gnms_iou2d_f64: null pointer");
+    GNMS_CHECK_ARG(ld >= N, "gnms_iou2d_f64: ld (%lld) < N (%d)", (long long)ld, N);
+    GNMS_CHECK_ARG(M <= 65535 && B <= 65535, "gnms_iou2d_f64: M and B must be <= 65535");
+    iou2d_f64_kernel<<<dim3(gnms_div_up(N, 256), M, B), 256, 0, (hipStream_t)stream>>>(boxes_a, boxes_b, M, N, out, (long)ld);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+extern "C" int gnms_corners_of_cuboid_f64(const double* params, int64_t count, int trig_f32, double* corners, void* stream) {
+    GNMS_CHECK_ARG(count >= 0, "gnms_corners_of_cuboid_f64: negative count");
+    if (count == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(params && corners, "gnms_corners_of_cuboid_f64: null pointer");
+    corners_f64_kernel<<<(unsigned)((count + 255) / 256), 256, 0, (hipStream_t)stream>>>(params, (long)count, trig_f32, corners);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // "projected" 2D boxes of the NMS (lib/loss/rpn_3d.py:746-768, diff_nms_boxes_2d == "projected"): cuboid corners
 // (get_corners_of_cuboid) -> image plane with the 4x4 projection p2 (lib/math_3d.py:47-72: rows 0,1 divided by row 2 where
 // |row 2| > 1e-2) -> min/max over the 8 corners -> times the image's scale factor.  One thread per box.

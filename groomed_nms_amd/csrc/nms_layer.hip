@@ -35,13 +35,15 @@ extern "C" const char* gnms_last_error(void) { return g_err; }
 // profiling: event pairs around the HBM-bound launches (bench.py's roofline is computed from these)
 // ------------------------------------------------------------------------------------------------
 namespace {
+struct ProfPair { int dev; hipEvent_t start, stop; };
 struct ProfState {
     std::atomic<bool> armed{false};
     std::mutex mu;
-    std::vector<hipEvent_t> pool;                                  // recycled events
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs[kProfSlots];
-    hipEvent_t take() {
-        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    std::map<int, std::vector<hipEvent_t>> pool;                   // recycled events, per device (an event belongs to the device it was created on)
+    std::vector<ProfPair> pairs[kProfSlots];
+    hipEvent_t take(int dev) {
+        std::vector<hipEvent_t>& p = pool[dev];
+        if (!p.empty()) { hipEvent_t e = p.back(); p.pop_back(); return e; }
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return nullptr;
         return e;
@@ -53,10 +55,12 @@ ProfState& prof() { static ProfState P; return P; }
 bool gnms_prof_armed() { return prof().armed.load(std::memory_order_relaxed); }
 bool gnms_prof_pair(int slot, hipEvent_t* start, hipEvent_t* stop) {
     ProfState& P = prof();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
     std::lock_guard<std::mutex> lock(P.mu);
-    hipEvent_t a = P.take(), b = P.take();
-    if (!a || !b) { if (a) P.pool.push_back(a); if (b) P.pool.push_back(b); return false; }
-    P.pairs[slot].emplace_back(a, b);
+    hipEvent_t a = P.take(dev), b = P.take(dev);
+    if (!a || !b) { if (a) P.pool[dev].push_back(a); if (b) P.pool[dev].push_back(b); return false; }
+    P.pairs[slot].push_back(ProfPair{dev, a, b});
     *start = a;
     *stop = b;
     return true;
@@ -73,18 +77,25 @@ extern "C" int gnms_profile_collect(int slot, double* ms_sum, int* launches) {
     std::lock_guard<std::mutex> lock(P.mu);
     double sum = 0.0;
     int n = 0;
-    for (auto& pr : P.pairs[slot]) {
+    hipError_t first_err = hipSuccess;
+    // every pair leaves the list and goes back to its device's pool whatever happens: an error on one pair is reported after the
+    // walk, it never strands the others (or leaves recycled events behind in the list)
+    for (const ProfPair& pr : P.pairs[slot]) {
         float ms = 0.0f;
-        GNMS_CHECK_HIP(hipEventSynchronize(pr.second));
-        GNMS_CHECK_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
-        sum += ms;
-        ++n;
-        P.pool.push_back(pr.first);
-        P.pool.push_back(pr.second);
+        hipError_t e = hipEventSynchronize(pr.stop);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.start, pr.stop);
+        if (e == hipSuccess) { sum += ms; ++n; }
+        else if (first_err == hipSuccess) first_err = e;
+        P.pool[pr.dev].push_back(pr.start);
+        P.pool[pr.dev].push_back(pr.stop);
     }
     P.pairs[slot].clear();
     *ms_sum = sum;
     *launches = n;
+    if (first_err != hipSuccess) {
+        gnms_set_error("gnms_profile_collect: %s", hipGetErrorString(first_err));
+        return GNMS_ERR_HIP;
+    }
     return GNMS_OK;
 }
 

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(1024) void soft_nms_kernel(const T* __restrict__ bo
                     else weight = (ov > Nt) ? 0.0 : 1.0;                                         // :87-91
                     const T ns = (T)(weight * (double)ss[p]);                                    // :93
                     ss[p] = ns;
-                    gone = ns < (T)threshold;                                                    // :97
+                    gone = (double)ns < threshold;                                                   // :97
                 }
             }
             if (gone) dead |= 1u << e; else ++nsurv;

@@ -216,22 +216,24 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
         return GNMS_OK;
     }
     GNMS_CHECK_ARG(scores != nullptr, "gnms_select_topk: scores is NULL");
-    int* pre = nullptr;                                               // [B][K] pre-selected candidates + [B] counts (large F only)
+    // (every argument check sits in front of the stream-ordered temporary; the guard returns it to the pool on every later exit)
+    GNMS_CHECK_ARG(!boxes || ((uintptr_t)boxes % 16 == 0), "gnms_select_topk: boxes must be 16-byte aligned");
+    GNMS_CHECK_ARG(!sel_boxes || ((uintptr_t)sel_boxes % 16 == 0), "gnms_select_topk: sel_boxes must be 16-byte aligned");
+    GNMS_CHECK_ARG(!sel_boxes || boxes, "gnms_select_topk: sel_boxes needs boxes");
+    gnms_async_buffer pre_buf;                                        // [B][K] pre-selected candidates + [B] counts (large F only)
     if (F > GNMS_MAX_BOXES) {
         if (K > GNMS_MAX_BOXES) {
             gnms_set_error("gnms_select_topk: K=%d exceeds GNMS_MAX_BOXES=%d", K, GNMS_MAX_BOXES);
             return GNMS_ERR_UNSUPPORTED;
         }
-        GNMS_CHECK_HIP(hipMallocAsync((void**)&pre, ((size_t)B * K + B) * sizeof(int), st));
+        GNMS_CHECK_HIP(pre_buf.alloc(((size_t)B * K + B) * sizeof(int), st));
+        int* pre = pre_buf.as<int>();
         topk_preselect_kernel<<<B, 1024, 0, st>>>(scores, A, candidates, F, candidate_counts, K, pre, pre + (size_t)B * K);
-        if (hipGetLastError() != hipSuccess) { (void)hipFreeAsync(pre, st); gnms_set_error("gnms_select_topk: launch failed"); return GNMS_ERR_HIP; }
+        GNMS_CHECK_LAUNCH();
         candidates = pre;
         candidate_counts = pre + (size_t)B * K;
         F = K;
     }
-    GNMS_CHECK_ARG(!boxes || ((uintptr_t)boxes % 16 == 0), "gnms_select_topk: boxes must be 16-byte aligned");
-    GNMS_CHECK_ARG(!sel_boxes || ((uintptr_t)sel_boxes % 16 == 0), "gnms_select_topk: sel_boxes must be 16-byte aligned");
-    GNMS_CHECK_ARG(!sel_boxes || boxes, "gnms_select_topk: sel_boxes needs boxes");
     const int P2 = next_pow2(F);
     const size_t lds = (size_t)P2 * 8;
     const int threads = P2 <= 1024 ? P2 : 1024;
@@ -252,8 +254,7 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
         default: GNMS_TOPK(16); break;
     }
 #undef GNMS_TOPK
-    const hipError_t le = hipGetLastError();
-    if (pre) (void)hipFreeAsync(pre, st);
-    if (le != hipSuccess) { gnms_set_error("gnms_select_topk: launch failed: %s", hipGetErrorString(le)); return GNMS_ERR_HIP; }
+    GNMS_CHECK_LAUNCH();
+    GNMS_CHECK_HIP(pre_buf.release());
     return GNMS_OK;
 }

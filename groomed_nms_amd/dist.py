@@ -13,8 +13,19 @@ import torch
 import torch.distributed as dist
 
 
+def share_gpu():
+    """GNMS_SHARE_GPU=1 -- a DEBUG mode that proves the N-rank launch path on a box with fewer GPUs than ranks: every rank uses device
+    (local_rank mod visible devices) and the collectives run over gloo (RCCL refuses two ranks on one device).  Timings taken this way
+    say nothing about scaling; bench.py marks its line with "debug_shared_gpu"."""
+    return os.environ.get("GNMS_SHARE_GPU", "0") == "1"
+
+
 def env_world():
-    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    """(world, rank, local_rank) from the launcher's environment; under GNMS_SHARE_GPU local_rank is folded onto the visible devices."""
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if share_gpu() and torch.cuda.is_available():
+        local_rank %= max(1, torch.cuda.device_count())
+    return world, rank, local_rank
 
 
 def init(backend=None):
@@ -24,6 +35,8 @@ def init(backend=None):
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if share_gpu():
+            backend = "gloo"
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank)
@@ -67,37 +80,57 @@ def sum_over_ranks(value, device=None):
 
 class StepHeartbeat:
     """The one collective of the pure-NMS scaling runs: a 4-byte all-reduce after every step, so that the 1 -> 8 GPU
-    curve contains a real RCCL round trip per iteration.  Issued asynchronously like DDP's gradient all-reduce (ordered behind the step
-    by an event, overlapping the next step); no host synchronisation and nothing else on the host path -- ONE collective call per step on a persistent buffer (MAX over the
-    ranks' step counters, which every rank advances by the same amount, so the buffer needs no refill between steps; the copy / add
-    pair a SUM needed cost three more launches per step on a loop that is within 1.5x of being host-bound).  A no-op when
-    torch.distributed is not initialised.  `check()` (after the timed region) verifies that the collective ran every step and that
-    all ranks took part (a SUM over the per-rank step counts)."""
+    curve contains a real RCCL round trip per iteration.  Issued ASYNCHRONOUSLY like DDP's gradient all-reduce (ordered behind the
+    step by an event on the process group's stream, overlapping the next step's kernels; not a blocking round trip) with no host
+    synchronisation and ONE collective call per step: step i SUM-reduces slot i of a persistent vector of ones, in place -- no refill,
+    no copy, no extra launch on a loop that is within 1.5x of being host-bound.
+    `check()` (after the timed region) is a real test of the collectives: every used slot must hold exactly world_size (each rank
+    contributed its 1 exactly once to exactly that step's reduction), the unused ones still 1, and the per-rank step counts must sum
+    to steps x world.  A no-op when torch.distributed is not initialised."""
+
+    CAPACITY = 8192                                   # slots; on wrap-around the used ones are verified and reset
 
     def __init__(self, device=None):
         self.on = dist.is_available() and dist.is_initialized()
         self.steps = 0
+        self.used = 0
+        self.works = []
         if self.on:
             if device is None:
                 device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
             self.device = device
-            self.buf = torch.ones(1, dtype=torch.int32, device=device)
+            self.buf = torch.ones(self.CAPACITY, dtype=torch.int32, device=device)
+            self.slots = [self.buf[i:i + 1] for i in range(self.CAPACITY)]      # views made once: nothing but the collective call per beat
 
     def beat(self):
         self.steps += 1
         if self.on:
+            if self.used == self.CAPACITY:
+                self._verify_slots()
             # asynchronous, as DDP issues its bucket all-reduces: the collective runs on the process group's own stream behind an event
             # of the compute stream, so its cross-GPU round trip overlaps the next step's kernels instead of stalling them
-            self.work = dist.all_reduce(self.buf, op=dist.ReduceOp.MAX, async_op=True)     # 4 bytes over RCCL / xGMI
+            self.works.append(dist.all_reduce(self.slots[self.used], op=dist.ReduceOp.SUM, async_op=True))     # 4 bytes over RCCL / xGMI
+            self.used += 1
+
+    def _verify_slots(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        world = dist.get_world_size()
+        got = self.buf[:self.used]
+        bad = int((got != world).sum().item()) + int((self.buf[self.used:] != 1).sum().item())
+        if bad:
+            raise RuntimeError("step heartbeat: %d of %d per-step all-reduces did not sum to world_size %d" % (bad, self.used, world))
+        self.buf.fill_(1)
+        self.used = 0
 
     def check(self):
         if not self.on:
             return
-        if getattr(self, "work", None) is not None:
-            self.work.wait()
+        self._verify_slots()
         total = torch.tensor([self.steps], dtype=torch.int32, device=self.device)
         dist.all_reduce(total, op=dist.ReduceOp.SUM)
-        if int(self.buf.item()) != 1 or int(total.item()) != self.steps * dist.get_world_size():
+        if int(total.item()) != self.steps * dist.get_world_size():
             raise RuntimeError("step heartbeat: %d steps summed over the ranks, expected %d x %d" % (int(total.item()), self.steps,
                                                                                                         dist.get_world_size()))
 

@@ -33,22 +33,19 @@ _PARAMS = {}
 
 def _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes,
             mask_group_boxes, group_size, presorted=False, index_lists=True):
-    """struct gnms_params for these keyword arguments; one object per distinct argument tuple (treated as immutable by every user:
-    building the ctypes structure anew cost ~3 us per call)."""
-    key = (nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes, mask_group_boxes, group_size,
-           presorted, index_lists)
-    try:
-        p = _PARAMS.get(key)
-    except TypeError:                                                             # an unhashable argument (a tensor threshold, say)
-        p, key = None, None
+    """struct gnms_params for these keyword arguments; one object per distinct VALUE tuple (treated as immutable by every user:
+    building the ctypes structure anew cost ~3 us per call).  The arguments are converted to plain Python numbers first and the
+    cache is keyed on those: a 0-dim tensor threshold or temperature is re-read on every call, as the reference does
+    (lib/groomed_nms.py:10 takes them as plain arguments), and is never pinned by the cache."""
+    if pruning_method not in _PRUNE:
+        raise NotImplementedError("Pruning method not implemented!")              # lib/groomed_nms.py:177-178
+    key = (float(nms_threshold), _PRUNE[pruning_method], float(temperature), float(valid_box_prob_threshold), bool(return_sorted_prob),
+           bool(group_boxes), bool(mask_group_boxes), int(min(int(group_size), 2 ** 31 - 2)), bool(presorted), bool(index_lists))
+    p = _PARAMS.get(key)
     if p is None:
-        if pruning_method not in _PRUNE:
-            raise NotImplementedError("Pruning method not implemented!")          # lib/groomed_nms.py:177-178
-        p = GnmsParams(float(nms_threshold), float(temperature), float(valid_box_prob_threshold), _PRUNE[pruning_method],
-                       int(bool(return_sorted_prob)), int(bool(group_boxes)), int(bool(mask_group_boxes)),
-                       int(min(int(group_size), 2 ** 31 - 2)), int(bool(presorted)))
-        p.index_lists = bool(index_lists)
-        if key is not None and len(_PARAMS) < 256:
+        p = GnmsParams(key[0], key[2], key[3], key[1], int(key[4]), int(key[5]), int(key[6]), key[7], int(key[8]))
+        p.index_lists = key[9]
+        if len(_PARAMS) < 256:
             _PARAMS[key] = p
     return p
 
@@ -403,7 +400,8 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
         :param iou_unsorted:             Overlap matrix of the boxes, Tensor or ndarray (N, N)
         :return: valid_boxes_index   (K,)   original indices, by descending re-score
                  invalid_boxes_index (N-K,) original indices
-                 (GPU tensors in: both are LazyIndexList objects -- tensors whose length is fetched from the GPU on first use)
+                 (plain index tensors, as in the reference; with the module switch LAZY_INDEX_LISTS = True and GPU tensors in they
+                  are LazyIndexList objects instead -- opt-in for training loops that read only the probabilities)
                  non_suppression_prob (N,)  re-scores in descending-input-score order (the reference's order)
         NumPy in -> CPU tensors out (lib/rpn_util.py:1319-1320 calls .numpy() on the result); tensors
         come back on the device of `iou_unsorted` (:60-62).  Computation always runs on the GPU.
@@ -457,13 +455,22 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
     return valid_boxes_index, invalid_boxes_index, non_suppression_prob
 
 
-LAZY_INDEX_LISTS = True     # module switch: False makes differentiable_nms return plain tensors (one host sync per call)
+# Module switch, OFF by default: differentiable_nms returns plain index tensors exactly like the reference (one host sync per call: their
+# length K is data dependent).  A training loop that reads only the probabilities (lib/loss/rpn_3d.py:791 takes `[2]`) may set it to
+# True: with GPU tensors in, the two lists then come back as LazyIndexList objects and the call never waits for the GPU.
+LAZY_INDEX_LISTS = False
 
 
 class LazyIndexList:
-    """A 1-D int64 index tensor whose LENGTH is still on the GPU.  Holds the padded list and the device-side counts; the first use
-    (any attribute, method, torch function, indexing, len(), iteration, NumPy conversion) copies the count to the host -- the one
-    synchronisation the reference's return convention needs -- and from then on the object forwards to the real tensor `t`."""
+    """Opt-in stand-in (LAZY_INDEX_LISTS = True) for a 1-D int64 index tensor whose LENGTH is still on the GPU.  Holds the padded list
+    and the device-side counts; `.t` is the real tensor -- the first access copies the count to the host, the one synchronisation the
+    reference's return convention needs.  Attribute access, torch functions, arithmetic, comparisons, len(), iteration and NumPy
+    conversion forward to `.t`.
+
+    It is deliberately NOT a sequence (no __getitem__): used as an index, `boxes[lazy]` / `mask[lazy] = 1`, torch then hands the
+    operation to __torch_function__, which substitutes `.t` -- with a __getitem__ it walked the object as a sequence of per-dimension
+    indices instead (an IndexError on 1-D data, silently wrong data on tensors with enough dimensions).  Element access: `lazy.t[i]`.
+    `isinstance(lazy, torch.Tensor)` is False; code that needs a real tensor takes `lazy.t`."""
 
     __slots__ = ("_padded", "_counts", "_which", "_map", "_t")
 
@@ -500,26 +507,29 @@ class LazyIndexList:
     def __iter__(self):
         return iter(self.t)
 
-    def __getitem__(self, i):
-        return self.t[i]
-
     def __array__(self, dtype=None, copy=None):
         a = self.t.cpu().numpy()
         return a.astype(dtype) if dtype is not None else a
 
-    def __index__(self):
-        return self.t.__index__()
-
     def __repr__(self):
         return "LazyIndexList(%r)" % (self.t,) if self._t is not None else "LazyIndexList(<length still on the GPU>)"
 
-    def __eq__(self, other):
-        return self.t == (other.t if isinstance(other, LazyIndexList) else other)
-
-    def __ne__(self, other):
-        return self.t != (other.t if isinstance(other, LazyIndexList) else other)
-
     __hash__ = None
+
+
+def _forward_dunder(name):
+    def op(self, *args):
+        return getattr(self.t, name)(*[a.t if isinstance(a, LazyIndexList) else a for a in args])
+    op.__name__ = name
+    return op
+
+
+for _n in ("add", "sub", "mul", "floordiv", "truediv", "mod", "and", "or", "xor", "lshift", "rshift"):
+    setattr(LazyIndexList, "__%s__" % _n, _forward_dunder("__%s__" % _n))
+    setattr(LazyIndexList, "__r%s__" % _n, _forward_dunder("__r%s__" % _n))
+for _n in ("lt", "le", "gt", "ge", "eq", "ne", "neg", "invert", "abs"):
+    setattr(LazyIndexList, "__%s__" % _n, _forward_dunder("__%s__" % _n))
+del _n
 
 
 class GroomedNMS(torch.nn.Module):

@@ -39,11 +39,14 @@ def navneeth_soft_nms(boxes, sigma=0.5, Nt=0.4, threshold=0.001, method=0, shift
 def girshick_nms(dets, thresh, shift=1):
     """lib/nms_others.py:119-150: greedy NMS with a configurable pixel `shift`, boxes with IoU <= thresh survive.  The reference returns
     `keep_orig`, built as kept index + N_dropped where N_dropped is recomputed after every round as len(order) - len(inds) on the ALREADY
-    filtered order (:148) -- which is always 0 -- so the list equals the kept indices; reproduced as such.  fp32 on the device
-    (float32 `dets`, the dtype `gpu_nms` takes as well, give the reference's own arithmetic)."""
+    filtered order (:148) -- which is always 0 -- so the list equals the kept indices; reproduced as such.  The arithmetic runs in the
+    dtype of `dets` like the reference's NumPy expressions: float64 arrays (what its own test feeds) in fp64 on the device
+    (gnms_nms_sorted_shift_f64), anything else in fp32 (the dtype `gpu_nms` takes as well)."""
     lib = _lib.load()
     dev = _device()
-    arr = np.ascontiguousarray(np.asarray(dets), dtype=np.float32)
+    arr = np.asarray(dets)
+    fp64 = arr.dtype == np.float64
+    arr = np.ascontiguousarray(arr, dtype=np.float64 if fp64 else np.float32)
     n, dim = arr.shape
     if n == 0:
         return []
@@ -52,8 +55,8 @@ def girshick_nms(dets, thresh, shift=1):
     keep = torch.empty((n,), dtype=torch.int32, device=dev)
     num = torch.zeros((1,), dtype=torch.int32, device=dev)
     ws = torch.empty((lib.gnms_nms_workspace_bytes(n),), dtype=torch.uint8, device=dev)
+    entry, what = (lib.gnms_nms_sorted_shift_f64, "gnms_nms_sorted_shift_f64") if fp64 else (lib.gnms_nms_sorted_shift, "gnms_nms_sorted_shift")
     with torch.cuda.device(dev):
-        check(lib.gnms_nms_sorted_shift(ptr(d), n, dim, float(thresh), float(shift), 1, ptr(keep), ptr(num), ptr(ws), ws.numel(),
-                                        _lib.stream_ptr(dev)), "gnms_nms_sorted_shift")
+        check(entry(ptr(d), n, dim, float(thresh), float(shift), 1, ptr(keep), ptr(num), ptr(ws), ws.numel(), _lib.stream_ptr(dev)), what)
     k = keep[:int(num.item())].cpu().numpy()
     return [np.int64(i) for i in order[k]]

@@ -5,9 +5,11 @@ lib/math_3d.py that feed the NMS.  Same names and argumen
   iou3d_approximate(c1, c2, mode, method)            lib/core.py:305-421
   get_corners_of_cuboid(x, y, z, w, h, l, ry)        lib/math_3d.py:364-490
 'combinations' mode runs in the HIP kernels (csrc/iou_kernels.hip); 'list' mode is O(N) elementwise
-tensor arithmetic.  ndarray in -> ndarray out, computed in fp32 on the GPU (the reference's NumPy
-branch keeps the input dtype, e.g. float64 at lib/rpn_util.py:1295; the NMS casts to fp32 anyway,
-lib/groomed_nms.py:36).
+tensor arithmetic.  ndarray in -> ndarray out.  float64 ndarrays -- what the inference call site passes
+(lib/rpn_util.py:1295: `aboxes` is float64 after the hstack at :1258) -- keep their dtype like the reference's
+NumPy branches: `iou` (combinations) and `get_corners_of_cuboid` run the same IEEE double operations on the
+GPU (gnms_iou2d_f64, gnms_corners_of_cuboid_f64), so the matrix that lib/groomed_nms.py:36 then rounds to
+fp32 is the reference's bit for bit; other ndarrays are computed in fp32.
 """
 import numpy as np
 import torch
@@ -17,6 +19,10 @@ from ._lib import check, ptr, stream_ptr, on_device
 from .groomed_nms import _device
 
 __all__ = ["iou", "intersect", "iou3d_approximate", "get_corners_of_cuboid", "iou_batched", "iou3d_batched"]
+
+
+def _is_f64_array(x):
+    return isinstance(x, np.ndarray) and x.dtype == np.float64
 
 
 def _to_dev(x):
@@ -91,6 +97,17 @@ def intersect(box_a, box_b, mode='combinations', data_type=None):
 def iou(box_a, box_b, mode='combinations', data_type=None):
     """lib/core.py:480-532.  combinations: M x N matrix from the HIP kernel; list: M values."""
     if mode == 'combinations':
+        if _is_f64_array(box_a) and isinstance(box_b, np.ndarray):
+            # the reference's NumPy branch in float64 (lib/core.py:205-207, 512-513), the dtype its inference call site passes
+            lib = _lib.load()
+            dev = _device()
+            a = torch.from_numpy(np.ascontiguousarray(box_a[:, :4], dtype=np.float64)).to(dev)
+            b = torch.from_numpy(np.ascontiguousarray(box_b[:, :4], dtype=np.float64)).to(dev)
+            M, N = a.shape[0], b.shape[0]
+            out = torch.empty((M, N), dtype=torch.float64, device=dev)
+            with on_device(dev):
+                check(lib.gnms_iou2d_f64(ptr(a), ptr(b), 1, M, N, ptr(out), max(N, 1), stream_ptr(dev)), "gnms_iou2d_f64")
+            return out.cpu().numpy()
         a, kind, dev = _to_dev(box_a)
         b, _, _ = _to_dev(box_b)
         out = iou_batched(a[:, :4].unsqueeze(0), b[:, :4].unsqueeze(0))[0]
@@ -114,6 +131,18 @@ def get_corners_of_cuboid(x3d, y3d, z3d, w3d, h3d, l3d, ry3d, iou_3d_convention=
         raise NotImplementedError("only iou_3d_convention=True is on the NMS path (lib/loss/rpn_3d.py:746-750)")
     lib = _lib.load()
     kind = "numpy" if isinstance(x3d, np.ndarray) else "torch"
+    if kind == "numpy":
+        # lib/math_3d.py:438-490: the NumPy branch builds R and the box-frame corners with .astype(float), i.e. in float64 whatever
+        # the dtype of the arguments -- the corners come back as a float64 array
+        dev = _device()
+        params = torch.from_numpy(np.stack([np.asarray(v, dtype=np.float64).reshape(-1) for v in (x3d, y3d, z3d, w3d, h3d, l3d, ry3d)], 1)).to(dev)
+        n = params.shape[0]
+        corners = torch.empty((n, 3, 8), dtype=torch.float64, device=dev)
+        with on_device(dev):
+            # np.cos / np.sin evaluate in the dtype of ry3d (float32 at lib/rpn_util.py:1303-1309)
+            trig_f32 = int(np.asarray(ry3d).dtype == np.float32)
+            check(lib.gnms_corners_of_cuboid_f64(ptr(params), n, trig_f32, ptr(corners), stream_ptr(dev)), "gnms_corners_of_cuboid_f64")
+        return corners.cpu().numpy()
     cols = [torch.as_tensor(v) for v in (x3d, y3d, z3d, w3d, h3d, l3d, ry3d)]
     out_device = cols[0].device
     dev = out_device if out_device.type == "cuda" else _device()

@@ -85,6 +85,14 @@ int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int M, int N, 
  * params [count][7] = (x3d, y3d, z3d, w3d, h3d, l3d, ry3d) -> corners [count][3][8]. */
 int gnms_corners_of_cuboid(const float* params, int64_t count, float* corners, void* stream);
 
+/* The float64 NumPy branches of the same two helpers -- what the reference's inference call site runs (lib/rpn_util.py:1292-1320:
+ * `aboxes` is float64 after the hstack at :1258): lib/core.py:205-207, 512-513 (iou in float64, rounded to fp32 once by
+ * lib/groomed_nms.py:36) and lib/math_3d.py:438-490 (corners in float64 before `.float()`).  Same layouts as above with double
+ * elements; the IoU matrix is bit-identical to NumPy's IEEE double arithmetic.  trig_f32 != 0: cos / sin of the yaw in fp32, widened
+ * (np.cos on a float32 `ry3d`, the dtype that call site passes). */
+int gnms_iou2d_f64(const double* boxes_a, const double* boxes_b, int B, int M, int N, double* out, int64_t ld, void* stream);
+int gnms_corners_of_cuboid_f64(const double* params, int64_t count, int trig_f32, double* corners, void* stream);
+
 /* iou3d_approximate(corners_b1, corners_b2, mode="combinations", method=...)  lib/core.py:305-421.
  * corners_a [B][M][3][8], corners_b [B][N][3][8].  Inputs are const (the reference overwrites them, :379-380).
  *   method 0 "normal", 1 "generalized", 2 = 0.5*(1+generalized): what both callers feed the NMS
@@ -263,6 +271,10 @@ int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float thresh, int3
  * shift) on score-sorted boxes (a NaN overlap then suppresses, as `np.where(ovr <= thresh)` does). */
 int gnms_nms_sorted_shift(const float* boxes, int n, int boxes_dim, float thresh, float shift, int keep_le, int32_t* keep,
                           int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
+/* the same for float64 boxes, every operation in double: girshick_nms computes in the dtype of `dets` (lib/nms_others.py:119-150),
+ * float64 for the arrays the reference's own test feeds it (test/test_differentiable_nms_forward.py:111-114) */
+int gnms_nms_sorted_shift_f64(const double* boxes, int n, int boxes_dim, double thresh, double shift, int keep_le, int32_t* keep,
+                              int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* lib/nms_others.py:6-116 navneeth_soft_nms(boxes, sigma, Nt, threshold, method, shift): Soft-NMS with the reference's slot
  * bookkeeping.  boxes [n][boxes_dim] (x1 y1 x2 y2 score ...), fp64 when is_fp64 else fp32, NOT modified (the reference decays the

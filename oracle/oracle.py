@@ -75,6 +75,46 @@ def iou2d(a, b):
     return out
 
 
+def iou2d_f64(a, b):
+    """lib/core.py:205-207, 499-513, the NumPy branch on float64 boxes (the inference call site, lib/rpn_util.py:1295):
+    out[i][j] = IoU(a_i, b_j) in IEEE double, operation for operation."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    max_xy = np.minimum(a[:, 2:4], np.expand_dims(b[:, 2:4], axis=1))       # [b][a]
+    min_xy = np.maximum(a[:, 0:2], np.expand_dims(b[:, 0:2], axis=1))
+    inter = np.clip(max_xy - min_xy, a_min=0, a_max=None)
+    inter = inter[:, :, 0] * inter[:, :, 1]
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    union = np.expand_dims(area_a, 0) + np.expand_dims(area_b, 1) - inter
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (inter / union).T
+
+
+def corners_of_cuboid_numpy_branch(params):
+    """lib/math_3d.py:438-490, the NumPy branch: cos / sin in the dtype of the yaw column, everything else in float64
+    (`.astype(float)` matrices, np.einsum over the three rotated axes in order)."""
+    p = np.asarray(params)
+    x, y, z, w, h, l, ry = [p[:, i] for i in range(7)]
+    n = p.shape[0]
+    R = np.zeros((n, 3, 3)).astype(float)
+    R[:, 0, 0] = np.cos(ry); R[:, 0, 2] = np.sin(ry); R[:, 1, 1] = 1.0; R[:, 2, 0] = -np.sin(ry); R[:, 2, 2] = np.cos(ry)
+    c = np.zeros((n, 3, 8)).astype(float)
+    c[:, 0, [1, 3, 5, 6]] = l[:, np.newaxis]
+    c[:, 1, [2, 3, 6, 7]] = h[:, np.newaxis]
+    c[:, 2, [4, 5, 6, 7]] = w[:, np.newaxis]
+    c[:, 0] -= l[:, np.newaxis] / 2
+    c[:, 1] -= h[:, np.newaxis] / 2
+    c[:, 2] -= w[:, np.newaxis] / 2
+    out = np.zeros((n, 3, 8))
+    for j in range(3):
+        out[:, j] = (R[:, j, 0:1] * c[:, 0] + R[:, j, 1:2] * c[:, 1]) + R[:, j, 2:3] * c[:, 2]
+    out[:, 0] += x[:, np.newaxis]
+    out[:, 1] += y[:, np.newaxis]
+    out[:, 2] += z[:, np.newaxis]
+    return out
+
+
 def corners_of_cuboid(params):
     params = _f32(params)
     out = np.empty((len(params), 3, 8), np.float32)

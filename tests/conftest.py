@@ -56,6 +56,18 @@ def golden_misc():
     return Golden("misc.npz")
 
 
+@pytest.fixture(scope="session")
+def golden_f64site():
+    return Golden("f64site.npz")
+
+
+def f64site_aboxes(g, c):
+    """`aboxes` of case c of tests/golden/f64site.npz: float64 proposals defined from the stored fp32 arrays by one IEEE double
+    multiplication (tests/golden/make_golden.py::make_f64_call_site), scores widened as np.hstack does (lib/rpn_util.py:1258)."""
+    b = g["d2/boxes32"][c].astype(np.float64) * float(g["f64_scale"])
+    return np.hstack((b, g["d2/scores32"][c].astype(np.float64)[:, np.newaxis]))
+
+
 # mode tag -> kwargs, mirrors tests/golden/make_golden.py::MODES
 MODES = {
     "gm_lin": dict(group_boxes=True, mask_group_boxes=True, pruning_method="linear"),

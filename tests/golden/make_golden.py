@@ -209,6 +209,73 @@ def pack_case(store, name, scores, iou, modes=MODES, grad_iou=False, rng=None, e
             store[f"{name}/groups_gs{gs}/lens"] = lens
 
 
+def make_f64_call_site():
+    """The reference's INFERENCE call site, lib/rpn_util.py:1292-1320, restated on synthetic proposals: `aboxes` (float64 after the
+    hstack at :1258, sorted by descending score, :1260-1262) -> lib.core.iou NumPy branch in float64 (:1295) -> differentiable_nms with
+    NumPy arguments (:1319, which rounds to fp32 once, lib/groomed_nms.py:36); and, overlap_in_nms == "3d" (:1300-1314):
+    get_corners_of_cuboid NumPy branch on the float32 `coords_3d_raw` (:1303-1309, float64 corners) -> .float() -> iou3d_approximate
+    -> 0.5 * (1 + giou) -> NumPy -> differentiable_nms.  N = 500 (:1293), default NMS parameters.
+    Inputs are stored as fp32 and the float64 proposals are DEFINED from them by one IEEE double multiplication (coordinates that are
+    not fp32-representable, like get_2D_from_3D's); matrices are pinned by the SHA-256 of the reference's bytes."""
+    import hashlib
+    rng = np.random.default_rng(20260928)
+    n = 500
+    out = {}
+    # ---- 2D: 200 cases ----
+    kinds = [("uniform", None)] * 60 + [("clustered", 8)] * 50 + [("clustered", 32)] * 50 + [("clustered", 125)] * 40
+    b32 = np.zeros((len(kinds), n, 4), np.float32)
+    s32 = np.zeros((len(kinds), n), np.float32)
+    valid, off, prob, sha = [], [0], [], []
+    for c, (kind, per) in enumerate(kinds):
+        b = uniform_boxes_2d(rng, n) if kind == "uniform" else clustered_boxes_2d(rng, n, per)
+        sc = tie_free_scores(rng, n)
+        o = np.argsort(-sc, kind="stable")                                      # lib/rpn_util.py:1260-1262
+        b32[c], s32[c] = b[o], sc[o]
+        aboxes = np.hstack((b32[c].astype(np.float64) * F64_SCALE, s32[c].astype(np.float64)[:, np.newaxis]))    # float64, :1258
+        ious = core.iou(aboxes[:, 0:4], aboxes[:, 0:4], mode='combinations')     # :1295 -- NumPy branch, float64
+        assert ious.dtype == np.float64
+        keep, _, scores_new = gn.differentiable_nms(scores_unsorted=aboxes[:, 4], iou_unsorted=ious, nms_threshold=0.4)   # :1319
+        valid.append(keep.numpy().astype(np.int16))
+        off.append(off[-1] + len(valid[-1]))
+        prob.append(scores_new.numpy().astype(np.float32))
+        sha.append(np.frombuffer(hashlib.sha256(np.ascontiguousarray(ious).tobytes()).digest(), np.uint8))
+    out["d2/boxes32"], out["d2/scores32"] = b32, s32
+    out["d2/valid"], out["d2/valid_off"] = np.concatenate(valid), np.array(off, np.int32)
+    out["d2/prob"], out["d2/iou_sha256"] = np.stack(prob), np.stack(sha)
+    out["f64_scale"] = np.array(F64_SCALE, np.float64)
+    # ---- 3D: 60 cases ----
+    kinds3 = [False] * 20 + [True] * 40
+    p32 = np.zeros((len(kinds3), n, 7), np.float32)
+    s3 = np.zeros((len(kinds3), n), np.float32)
+    valid, off, prob, sha = [], [0], [], []
+    for c, clustered in enumerate(kinds3):
+        p = boxes_3d(rng, n, clustered=clustered, per=8 if c % 2 else 25)
+        sc = tie_free_scores(rng, n)
+        o = np.argsort(-sc, kind="stable")
+        p32[c], s3[c] = p[o], sc[o]
+        raw = p32[c]                                                             # coords_3d_raw: float32 (:1186, :1211)
+        corners = math_3d.get_corners_of_cuboid(x3d=raw[:, 0], y3d=raw[:, 1], z3d=raw[:, 2], w3d=raw[:, 3], h3d=raw[:, 4], l3d=raw[:, 5],
+                                                ry3d=raw[:, 6])                  # :1303-1309 -- NumPy branch
+        assert corners.dtype == np.float64
+        c32 = torch.from_numpy(corners).float()                                  # :1310
+        _, i3 = core.iou3d_approximate(c32.clone(), c32.clone(), mode="combinations", method="generalized")    # :1311
+        ious = (0.5 * (1 + i3)).numpy()                                          # :1312-1313
+        keep, _, scores_new = gn.differentiable_nms(scores_unsorted=s3[c].astype(np.float64), iou_unsorted=ious, nms_threshold=0.4)
+        valid.append(keep.numpy().astype(np.int16))
+        off.append(off[-1] + len(valid[-1]))
+        prob.append(scores_new.numpy().astype(np.float32))
+        sha.append(np.frombuffer(hashlib.sha256(np.ascontiguousarray(c32.numpy()).tobytes()).digest(), np.uint8))
+        if c < 4:
+            out[f"d3/corners32_{c}"] = c32.numpy()                               # a few in full: how far the device's sin / cos are
+    out["d3/params32"], out["d3/scores32"] = p32, s3
+    out["d3/valid"], out["d3/valid_off"] = np.concatenate(valid), np.array(off, np.int32)
+    out["d3/prob"], out["d3/corners32_sha256"] = np.stack(prob), np.stack(sha)
+    np.savez_compressed(os.path.join(OUT, "f64site.npz"), **out)
+
+
+F64_SCALE = 1.0 + 2.0 ** -27          # one double multiplication turns fp32 coordinates into values that are not fp32-representable
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -550,9 +617,17 @@ def main():
     os.unlink(stats_path)
     np.savez_compressed(os.path.join(OUT, "kitti_io.npz"), **kg)
 
-    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz", "aploss.npz", "proposals.npz", "kitti_io.npz"):
+    make_f64_call_site()
+
+    for f in ("nms_small.npz", "boxes_2d.npz", "boxes_3d.npz", "misc.npz", "aploss.npz", "proposals.npz", "kitti_io.npz", "f64site.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "f64site":      # only the float64 call-site fixture (independent RNG stream)
+        torch.manual_seed(0)
+        torch.set_num_threads(4)
+        make_f64_call_site()
+        print("f64site.npz", os.path.getsize(os.path.join(OUT, "f64site.npz")) // 1024, "KiB")
+    else:
+        main()

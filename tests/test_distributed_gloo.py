@@ -39,7 +39,26 @@ def _worker(rank, world, port, total_images, n, out_dir):
 
     hb = gdist.StepHeartbeat()                                                          # the per-step 4-byte all-reduce
     elapsed = gdist.timed_steps(step, steps=2, warmup=1, sync=lambda: None, heartbeat=hb)
-    assert calls["n"] == 3 and hb.on and hb.steps == 3 and int(hb.buf.item()) == 1       # (timed_steps ran hb.check(): every rank, every step)
+    # timed_steps ran hb.check(): every one of the 3 per-step all-reduces summed to world_size on every rank, then the slots were reset
+    assert calls["n"] == 3 and hb.on and hb.steps == 3 and hb.used == 0 and bool((hb.buf == 1).all())
+    # ... and that check can fail: a step whose reduction did not see every rank (here: a slot tampered with) is reported
+    hb2 = gdist.StepHeartbeat()
+    hb2.beat()
+    hb2.works[-1].wait()
+    assert int(hb2.buf[0]) == world
+    hb2.buf[0] = world - 1
+    try:
+        hb2._verify_slots()
+        raise AssertionError("a short per-step reduction went unnoticed")
+    except RuntimeError as e:
+        assert "did not sum to world_size" in str(e)
+    # wrap-around of the slot vector: verified and reused
+    hb3 = gdist.StepHeartbeat()
+    hb3.CAPACITY = 4
+    for _ in range(11):
+        hb3.beat()
+    hb3.steps = 11
+    hb3.check()
     # MAX over ranks: every rank reports the same, largest, time
     gathered = [None] * world
     dist.all_gather_object(gathered, elapsed)

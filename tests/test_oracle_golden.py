@@ -208,3 +208,34 @@ def test_best_targets_oracle_against_reference():
             k = int(np.argmax(ref[:, j]))
             assert ref[k, j] - ref[int(i), j] <= 1e-6
         assert np.array_equal(tg, g[f"best/{tag}/targets"]), tag
+
+
+def test_oracle_float64_call_site(golden_f64site):
+    """The inference call site's float64 NumPy branches (lib/rpn_util.py:1292-1320): the oracle's float64 IoU restatement reproduces
+    the reference's matrix bit for bit (SHA-256 of the bytes) on all 200 cases, and the layer on its fp32 rounding (lib/groomed_nms.py:36)
+    returns the reference's keep lists and probabilities; the corner restatement likewise on the 3D cases (same host, same libm)."""
+    import hashlib
+    from conftest import f64site_aboxes
+    from oracle import oracle as O
+    g = golden_f64site
+    off = g["d2/valid_off"]
+    for c in range(g["d2/boxes32"].shape[0]):
+        ab = f64site_aboxes(g, c)
+        m = O.iou2d_f64(ab[:, :4], ab[:, :4])
+        assert m.dtype == np.float64 and hashlib.sha256(np.ascontiguousarray(m).tobytes()).digest() == g["d2/iou_sha256"][c].tobytes(), c
+        if c % 4 == 0:
+            r = O.differentiable_nms(ab[:, 4].astype(np.float32), m.astype(np.float32))
+            assert sorted(r["valid"].tolist()) == sorted(g["d2/valid"][off[c]:off[c + 1]].tolist()), c
+            assert np.array_equal(r["prob"], g["d2/prob"][c]), c
+    off = g["d3/valid_off"]
+    for c in range(0, g["d3/params32"].shape[0], 3):
+        c32 = O.corners_of_cuboid_numpy_branch(g["d3/params32"][c]).astype(np.float32)
+        if g.has(f"d3/corners32_{c}"):
+            assert np.abs(c32 - g[f"d3/corners32_{c}"]).max() <= 1e-5
+        _, i3 = O.iou3d_approximate(c32, c32, generalized=True)
+        ious = (np.float32(0.5) * (np.float32(1.0) + i3)).astype(np.float32)
+        r = O.differentiable_nms(g["d3/scores32"][c], ious)
+        # (np.cos on float32 is a SIMD kernel whose last bit depends on the host CPU: sets may differ where a corner does)
+        if hashlib.sha256(np.ascontiguousarray(c32).tobytes()).digest() == g["d3/corners32_sha256"][c].tobytes():
+            assert sorted(r["valid"].tolist()) == sorted(g["d3/valid"][off[c]:off[c + 1]].tolist()), c
+            assert np.abs(r["prob"] - g["d3/prob"][c]).max() <= 1e-4, c

@@ -116,13 +116,13 @@ def main():
     args = ap.parse_args()
     from groomed_nms_amd import dist as gdist
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        if torch.cuda.device_count() < args.gpus:
+        if torch.cuda.device_count() < args.gpus and not gdist.share_gpu():
             sys.exit("e2e_bench.py: --gpus %d requested, %d visible; refusing" % (args.gpus, torch.cuda.device_count()))
         sys.exit(gdist.relaunch_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     import groomed_nms_amd as G
     from groomed_nms_amd import proposals as PR
     from groomed_nms_amd.aploss import ap_loss_batched
-    world, rank, local_rank = gdist.init(backend="nccl")
+    world, rank, local_rank = gdist.init(backend="nccl")             # RCCL (GNMS_SHARE_GPU=1, debug: ranks share the visible GPUs over gloo)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     B = args.batch or (4 if args.mode == "train" else 1)
