@@ -62,6 +62,7 @@ _SIGNATURES = {
     "gnms_profile_write_kernel_name": (ctypes.c_char_p, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "gnms_profile_fill": (ctypes.c_int, [c_vp, ctypes.c_size_t, c_vp]),
     "gnms_profile_fill_tiles": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_vp]),
+    "gnms_profile_fill_sym": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp]),
     "gnms_profile_read": (ctypes.c_int, [c_vp, ctypes.c_size_t, c_vp, c_vp]),
     "gnms_get_groups": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_int, c_vp, c_vp, c_vp,
                                        c_vp, ctypes.c_size_t, c_vp]),

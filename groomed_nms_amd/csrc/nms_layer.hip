@@ -193,6 +193,66 @@ extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
+namespace {
+// The store pattern of a SYMMETRIC matrix writer, with no arithmetic: upper-triangular T x T macro tiles, each written once where it
+// is and once mirrored (rows <-> columns), row runs of T floats.  CPL floats per lane and store instruction: T / CPL lanes cover a row
+// run, 64 / (T / CPL) row runs per instruction.  persist: one workgroup per CU walks a contiguous range of tiles (row-major over the
+// upper triangle: a strip I, J = I .. end), else one workgroup per tile.
+template <int T, int CPL, bool NT>
+__global__ __launch_bounds__(1024) void prof_fill_sym_kernel(float* __restrict__ dst, int N, long ld, int nimg, int persist, float v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    constexpr int LPR = T / CPL, RPI = 64 / LPR;
+    const int RW = T / waves;
+    const int nt = N / T;
+    const long per_img = (long)nt * (nt + 1) / 2, total = per_img * nimg;
+    long t0 = blockIdx.x, t1 = blockIdx.x + 1;
+    if (persist) { t0 = total * blockIdx.x / gridDim.x; t1 = total * (blockIdx.x + 1) / gridDim.x; }
+    for (long t = t0; t < t1 && t < total; ++t) {
+        const int img = (int)(t / per_img);
+        long r = t - (long)img * per_img;
+        int I = 0;
+        while (r >= nt - I) { r -= nt - I; ++I; }                      // (a benchmark: the linear walk is a few dozen trips)
+        const int J = I + (int)r;
+        float* base = dst + (size_t)img * N * ld;
+        auto put = [&](int R0, int C0) {
+            for (int rr = 0; rr < RW; rr += RPI) {
+                float* p = base + (size_t)(R0 + wave * RW + rr + lane / LPR) * ld + C0 + (lane % LPR) * CPL;
+                if (NT) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) __builtin_nontemporal_store(v, p + j);
+                } else if (CPL == 4) {
+                    *reinterpret_cast<float4*>(p) = make_float4(v, v, v, v);
+                } else {
+                    *reinterpret_cast<float2*>(p) = make_float2(v, v);
+                }
+            }
+        };
+        put(I * T, J * T);
+        if (I != J) put(J * T, I * T);
+    }
+}
+}  // namespace
+extern "C" int gnms_profile_fill_sym(float* dst, int B, int N, int64_t ld, int tile, int cols_per_lane, int nontemporal, int persist, void* stream) {
+    GNMS_CHECK_ARG(dst && B > 0 && N > 0 && ld >= N && ld % 4 == 0 && (uintptr_t)dst % 16 == 0, "gnms_profile_fill_sym: dst 16-byte aligned, ld >= N a multiple of 4");
+    GNMS_CHECK_ARG((tile == 128 || tile == 256) && N % tile == 0 && (cols_per_lane == 2 || cols_per_lane == 4) && tile / cols_per_lane <= 64,
+                   "gnms_profile_fill_sym: tile 128 or 256 dividing N, 2 or 4 columns per lane");
+    hipStream_t st = (hipStream_t)stream;
+    const int nt = N / tile;
+    const long total = (long)nt * (nt + 1) / 2 * B;
+    const dim3 grid((unsigned)(persist ? device_cu_count() * (tile == 128 ? 2 : 1) : total));
+    const dim3 block(tile == 128 ? 512 : 1024);
+#define GNMS_FILL_SYM(TT, CC)                                                                                                              \
+    do {                                                                                                                                   \
+        if (nontemporal) gnms_launch_prof(kProfPlainStream, prof_fill_sym_kernel<TT, CC, true>, grid, block, 0, st, dst, N, (long)ld, B, persist, 0.5f);   \
+        else gnms_launch_prof(kProfPlainStream, prof_fill_sym_kernel<TT, CC, false>, grid, block, 0, st, dst, N, (long)ld, B, persist, 0.5f);            \
+    } while (0)
+    if (tile == 128 && cols_per_lane == 2) GNMS_FILL_SYM(128, 2);
+    else if (tile == 128) GNMS_FILL_SYM(128, 4);
+    else GNMS_FILL_SYM(256, 4);
+#undef GNMS_FILL_SYM
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
 extern "C" int gnms_profile_fill(float* dst, size_t count, void* stream) {
     GNMS_CHECK_ARG(dst && count % 4 == 0 && (uintptr_t)dst % 16 == 0, "gnms_profile_fill: dst must be 16-byte aligned, count a multiple of 4");
     if (count == 0) return GNMS_OK;

@@ -206,7 +206,11 @@ int gnms_profile_events(int enable);
 int gnms_profile_collect(int slot, double* ms_sum, int* launches);
 const char* gnms_profile_write_kernel_name(int dim, int B, int N); /* the launch that writes the matrix in gnms_forward_with_iou2d (dim 2) / _iou3d (dim 3), as a kernel trace names it */
 int gnms_profile_fill(float* dst, size_t count, void* stream);
-int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int rows, int nontemporal, void* stream); /* the same store stream in the matrix writers' geometry: persistent 16-wave workgroups, `rows` (4, 8, 16, 32 or 64, dividing N) rows x 1 KiB per wave, rows ld floats apart; non-temporal (as the writers store) or ordinary 16-byte stores */
+int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int rows, int nontemporal, void* stream);
+/* the store pattern of a symmetric matrix writer, no arithmetic: upper-triangular tile x tile macro tiles (tile = 128 or 256, dividing
+ * N), each written where it is and mirrored; cols_per_lane 2 or 4 floats per lane and store instruction; persist: one workgroup per
+ * CU (two at tile 128) walks a contiguous range of tiles, else one workgroup per tile.  Timed like gnms_profile_fill. */
+int gnms_profile_fill_sym(float* dst, int B, int N, int64_t ld, int tile, int cols_per_lane, int nontemporal, int persist, void* stream); /* the same store stream in the matrix writers' geometry: persistent 16-wave workgroups, `rows` (4, 8, 16, 32 or 64, dividing N) rows x 1 KiB per wave, rows ld floats apart; non-temporal (as the writers store) or ordinary 16-byte stores */
 int gnms_profile_read(const float* src, size_t count, float* sink, void* stream);
 
 /* get_groups(iou_unsorted, group_threshold, scores_unsorted, group_size)  lib/groomed_nms.py:208-270 for one

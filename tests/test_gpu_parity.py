@@ -204,9 +204,11 @@ def _record(name, obj):
         f.write(json.dumps(obj) + "\n")
 
 
-def _assert_grad_close(got, ref, tag, tol=1e-6):
-    """gradients against the reference's vectors: 1e-6 of the gradient's own scale (d/ds of the soft sort carries a factor 1/T: entries
-    up to 130 at T = 2e-3, where one fp32 ulp is 8e-6; measured 2e-7 of the scale, profiles/r02a_guard_band_and_softsort_diag.json)"""
+def _assert_grad_close(got, ref, tag, tol=4e-6):
+    """gradients against the reference's vectors: 4e-6 of the gradient's own scale (d/ds of the soft sort carries a factor 1/T: entries
+    up to 130 at T = 2e-3, where one fp32 ulp is 8e-6).  Measured on the MI355X (profiles/r03a_grad_errors.jsonl): 9e-8 ... 3.1e-6 of
+    the scale -- the largest on softsort_n16_t0.01/gm (6.7e-6 on a gradient of 2.2: the soft sort's adjoint behind the layer's, both
+    fp32; the reference's own fp32 autograd is as far from an fp64 evaluation); the adjoint against an fp64 evaluation: <= 3.6e-7."""
     scale = max(1.0, float(np.abs(ref).max()))
     err = float(np.abs(got - ref).max())
     _record("grad_errors.jsonl", {"what": tag, "max_abs_err": err, "scale": scale, "err_over_scale": err / scale, "tol_over_scale": tol})
@@ -485,7 +487,7 @@ def test_soft_sort_larger(G, O):
     res = _run_gpu(G, s, m, w, False, sorting_method="soft", sorting_temperature=2e-4)
     np.testing.assert_allclose(res["prob"], ref["prob"], atol=TOL)
     check_index_lists(res["valid"], res["invalid"], ref["valid"], ref["invalid"])
-    _assert_grad_close(res["grad_scores"], ref["grad_scores"], "soft sort n=300 T=2e-4 (fp64 adjoint of the oracle)", tol=1e-5)
+    _assert_grad_close(res["grad_scores"], ref["grad_scores"], "soft sort n=300 T=2e-4 (fp64 adjoint of the oracle)", tol=1e-6)
     # the adjoint through the C ABI with every upstream gradient present, rectangular matrix included
     for k in (n, 77):
         mk = np.ascontiguousarray(m[:, :k])
@@ -501,8 +503,8 @@ def test_soft_sort_larger(G, O):
         E = torch.exp((A - A.max(dim=1, keepdim=True)[0]) / 0.01)
         Cd = E / (E.sum(dim=1) + 1e-3)
         ((Cd @ sd * gs_.double()).sum() + (Cd * gC_.double()).sum() + ((Cd @ md) * gm_.double()).sum()).backward()
-        _assert_grad_close(st.grad.cpu().numpy(), sd.grad.float().cpu().numpy(), f"soft_sort adjoint d_scores k={k}", tol=1e-5)
-        _assert_grad_close(mt.grad.cpu().numpy(), md.grad.float().cpu().numpy(), f"soft_sort adjoint d_matrix k={k}", tol=1e-5)
+        _assert_grad_close(st.grad.cpu().numpy(), sd.grad.float().cpu().numpy(), f"soft_sort adjoint d_scores k={k}", tol=1e-6)
+        _assert_grad_close(mt.grad.cpu().numpy(), md.grad.float().cpu().numpy(), f"soft_sort adjoint d_matrix k={k}", tol=1e-6)
 
 
 def test_classic_nms_wide_rows_and_device_entry(G, O):
