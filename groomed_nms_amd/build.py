@@ -1,4 +1,5 @@
-"""Builds libgroomed_nms_hip.so (gfx950) in-tree with hipcc.  `python -m groomed_nms_amd.build`."""
+"""Builds libgroomed_nms_hip.so (gfx950) in-tree with hipcc, and the C++ torch binding gnms_torch*.so (host compiler, links the
+former).  `python -m groomed_nms_amd.build`."""
 import os
 import subprocess
 import sys
@@ -65,5 +66,45 @@ def build(force=False, verbose=False):
     return OUT
 
 
+TORCH_SRC = os.path.join(CSRC, "torch_binding.cpp")
+
+
+def torch_binding_path():
+    import sysconfig
+    return os.path.join(HERE, "gnms_torch" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_torch_binding(force=False, verbose=False):
+    """The C++ autograd binding (csrc/torch_binding.cpp): one host-compiler invocation against torch's headers, in-tree so that it
+    travels to the GPU box like the HIP library it links (rpath $ORIGIN).  No device code, no GPU needed."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    out = torch_binding_path()
+    lib = build()
+    deps = [TORCH_SRC, os.path.join(HERE, "..", "include", "groomed_nms_hip.h"), os.path.abspath(__file__), lib]
+    if not force and not _stale(out, deps):
+        return out
+    cxx = os.environ.get("CXX", "g++")
+    inc = []
+    for d in ce.include_paths(device_type="cuda") + [sysconfig.get_paths()["include"], os.path.join(os.environ.get("ROCM_HOME", "/opt/rocm"), "include")]:
+        if d not in inc:
+            inc.append(d)
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-deprecated-declarations", "-Wno-unknown-pragmas",
+            "-DTORCH_EXTENSION_NAME=gnms_torch", "-DTORCH_API_INCLUDE_EXTENSION_H", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+           + ["-I" + d for d in inc] + [TORCH_SRC, "-o", out,
+           "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+           "-L" + HERE, "-lgroomed_nms_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib])
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch binding build failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch_binding(force="--force" in sys.argv, verbose=True))

@@ -14,6 +14,7 @@
 #include "iou_tile.h"
 #include "iou3d_pair.h"
 #include "iou3d_tile.h"
+#include "iou3d_sym.h"
 
 namespace {
 
@@ -226,6 +227,17 @@ __global__ __launch_bounds__(kWavesPerWG * 64) __attribute__((amdgpu_waves_per_e
                                         lane, tile_rows, row_end, thr);
 }
 
+// The same matrix for ONE box set with itself, every unordered pair evaluated once (iou3d_sym.h): one 8-wave workgroup per
+// 128 x 128 macro tile of the upper triangle, tile ids [tile0, tile0 + gridDim.x) of every image.
+template <int NW, bool NT>
+__global__ __launch_bounds__(NW * 64) void iou3d_sym_kernel(const float* __restrict__ rec, int N, float* __restrict__ out, long ld, float thr, int tile0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int I, J;
+    gnms_iou3d::sym_tile_of(tile0 + (int)blockIdx.x, (N + gnms_iou3d::kSymT - 1) / gnms_iou3d::kSymT, &I, &J);
+    const int b = blockIdx.z;
+    gnms_iou3d::nms_overlap3d_sym_tile<NW, NT>(rec + (size_t)b * N * kRec, N, out + (size_t)b * N * ld, ld, I, J, thr, reinterpret_cast<float*>(smem));
+}
+
 template <bool VEC, int METHOD>
 void launch_iou3d(const float* ra, const float* rb, int B, int M, int N, float* bev, float* o3, long ld, hipStream_t st) {
     const int tr = tile_rows_for(B, M, N);
@@ -278,6 +290,33 @@ int gnms_internal_records_for_layer(const float* params, int B, int N, float* re
 }
 int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int row0, int row_end) {
     return iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true, row0, row_end, thr);
+}
+// The symmetric writer (iou3d_sym.h) for the square matrix of one box set: the macro tiles [pct0, pct1) percent of every image's
+// upper triangle (a call may split the write over two launches / streams).  Needs ld even and `out` 8-byte aligned.
+bool gnms_internal_overlap3d_sym_ok(int N, int64_t ld, const float* out) {
+    static const int forced = [] { const char* e = getenv("GNMS_3D_SYM"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (forced == 0) return false;
+    return N >= 256 && (ld % 2 == 0) && ((uintptr_t)out % 8 == 0);
+}
+int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1) {
+    const int tiles = gnms_iou3d::sym_tiles_per_image(N);
+    const int t0 = (int)((long long)tiles * pct0 / 100), t1 = (int)((long long)tiles * pct1 / 100);
+    if (t1 <= t0 || B <= 0) return GNMS_OK;
+    static const bool nt = [] { const char* e = getenv("GNMS_3D_SYM_NT"); return !(e && e[0] == '0'); }();      // non-temporal stores measured faster
+    static const int nw = [] { const char* e = getenv("GNMS_3D_SYM_NW"); return e ? atoi(e) : 8; }();
+    const size_t lds = gnms_iou3d::kSymTileBytes;
+    const dim3 grid((unsigned)(t1 - t0), 1, (unsigned)B);
+    int rc;
+#define GNMS_SYM_LAUNCH(NW_, NT_)                                                                                                     \
+    do {                                                                                                                              \
+        if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_kernel<NW_, NT_>), lds))) return rc;                     \
+        gnms_launch_prof(kProfMatrixWrite, iou3d_sym_kernel<NW_, NT_>, grid, dim3(NW_ * 64), lds, st, rec, N, out, (long)ld, thr, t0); \
+    } while (0)
+    if (nw == 16) { if (nt) GNMS_SYM_LAUNCH(16, true); else GNMS_SYM_LAUNCH(16, false); }
+    else { if (nt) GNMS_SYM_LAUNCH(8, true); else GNMS_SYM_LAUNCH(8, false); }
+#undef GNMS_SYM_LAUNCH
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
 }
 // rows [row0, row_end) of every image's square 2D IoU matrix (arguments already checked by the caller)
 int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st, int row0, int row_end) {
@@ -539,6 +578,9 @@ extern "C" int gnms_iou3d_from_params(const float* params_a, const float* params
     return iou3d_common(params_a, params_b, true, B, M, N, method, iou_bev, iou_3d, ld, stream);
 }
 
+bool gnms_internal_overlap3d_sym_ok(int N, int64_t ld, const float* out);
+int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1);
+
 extern "C" int gnms_nms_overlap3d_from_params(const float* params3d, int B, int N, float nms_threshold, float* out, int64_t ld, void* stream) {
     GNMS_CHECK_ARG(B >= 0 && N >= 0, "gnms_nms_overlap3d_from_params: negative size");
     if (B == 0 || N == 0) return GNMS_OK;
@@ -548,7 +590,11 @@ extern "C" int gnms_nms_overlap3d_from_params(const float* params3d, int B, int 
     float* rec = nullptr;
     GNMS_CHECK_HIP(hipMallocAsync((void**)&rec, (size_t)B * N * kRec * sizeof(float), st));
     int rc = gnms_internal_records_from_params(params3d, (long)B * N, rec, st);
-    if (!rc) rc = iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true, 0, 0x7fffffff, nms_threshold);
+    if (!rc) {
+        // one box set against itself: every unordered pair once (iou3d_sym.h), else the all-pairs kernel
+        if (gnms_internal_overlap3d_sym_ok(N, ld, out)) rc = gnms_internal_nms_overlap3d_sym(rec, B, N, out, ld, st, nms_threshold, 0, 100);
+        else rc = iou3d_from_records(rec, rec, B, N, N, 2, nullptr, out, ld, st, true, 0, 0x7fffffff, nms_threshold);
+    }
     const hipError_t fe = hipFreeAsync(rec, st);
     if (rc != GNMS_OK) return rc;
     if (fe != hipSuccess) { gnms_set_error("hipFreeAsync failed: %s", hipGetErrorString(fe)); return GNMS_ERR_HIP; }

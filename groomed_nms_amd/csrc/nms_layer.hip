@@ -15,6 +15,8 @@
 #include "nms_solve_kernels.h"
 
 // defined in iou_kernels.hip
+bool gnms_internal_overlap3d_sym_ok(int N, int64_t ld, const float* out);
+int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1);
 int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st, int row0, int row_end);
 
 // ------------------------------------------------------------------------------------------------
@@ -282,6 +284,22 @@ extern "C" void gnms_default_params(gnms_params* p) {
     p->presorted = 0;
 }
 
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once per (device, kernel); the attribute call is not free
+// (a driver round trip per launch adds up on the small-N path), so what has been granted is remembered.  (Declared in gnms_common.h.)
+int gnms_allow_lds_raw(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return GNMS_OK;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    GNMS_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& g = granted[std::make_pair(dev, kernel)];
+    if (g >= bytes) return GNMS_OK;
+    GNMS_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    g = bytes;
+    return GNMS_OK;
+}
+
 namespace {
 
 using namespace gnms;
@@ -305,21 +323,7 @@ int next_pow2(int n) {
 
 size_t leaders_lds_bytes(int N) { return leaders_lds_size((N + 63) / 64); }
 
-// Kernels that need more than 64 KiB of dynamic LDS must be told so once per (device, kernel); the attribute call is not free
-// (a driver round trip per launch adds up on the small-N path), so what has been granted is remembered.
-int allow_lds_raw(const void* kernel, size_t bytes) {
-    if (bytes <= 64 * 1024) return GNMS_OK;
-    static std::mutex mu;
-    static std::map<std::pair<int, const void*>, size_t> granted;
-    int dev = 0;
-    GNMS_CHECK_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    size_t& g = granted[std::make_pair(dev, kernel)];
-    if (g >= bytes) return GNMS_OK;
-    GNMS_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    g = bytes;
-    return GNMS_OK;
-}
+int allow_lds_raw(const void* kernel, size_t bytes) { return gnms_allow_lds_raw(kernel, bytes); }
 template <typename K>
 int allow_lds(K kernel, size_t bytes) { return allow_lds_raw(reinterpret_cast<const void*>(kernel), bytes); }
 
@@ -923,7 +927,10 @@ int side_stream(SideStream** out) {
         // 128-KiB-LDS workgroup per image) must get the CU slots that free up, not wait for the write to drain
         int least = 0, greatest = 0;
         GNMS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        GNMS_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+        // (GNMS_SIDE_PRIO=normal: an ordinary-priority side stream, for experiments with writers that should SHARE the machine with the
+        // layer's kernels instead of yielding to them)
+        static const bool normal = [] { const char* e = getenv("GNMS_SIDE_PRIO"); return e && e[0] == 'n'; }();
+        GNMS_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, normal ? (least + greatest) / 2 : least));
         GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.fork[0], hipEventDisableTiming));
         GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.fork[1], hipEventDisableTiming));
         GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
@@ -954,6 +961,12 @@ int split_rows(int N, int default_pct) {
     static const int pct = [] { const char* e = getenv("GNMS_SPLIT_PCT"); return e ? atoi(e) : -1; }();
     const int p = pct >= 0 ? pct : default_pct;
     return (int)((long long)N * p / 100) & ~63;
+}
+// the same split as a percentage (of the symmetric writer's macro tiles)
+int split_pct(int default_pct) {
+    static const int pct = [] { const char* e = getenv("GNMS_SPLIT_PCT"); return e ? atoi(e) : -1; }();
+    const int p = pct >= 0 ? pct : default_pct;
+    return p < 0 ? 0 : (p > 100 ? 100 : p);
 }
 // everything enqueued on the side stream so far happens before what is enqueued on `st` from now on
 int side_join(hipStream_t st) {
@@ -1002,6 +1015,17 @@ bool bits_in_write_3d(int N) {
     static const int forced = [] { const char* e = getenv("GNMS_3D_BITS_IN_WRITE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     return forced >= 0 ? forced == 1 : N > 2048;
 }
+// Round 3, large images (the side-stream regime): the matrix is written by the SYMMETRIC writer (iou3d_sym.h: every unordered pair
+// evaluated once -- half the VALU work of a kernel that was VALU-bound at 0.57 of the HBM peak) on the side stream, in two launches
+// over ranges of its macro tiles: the first beside the from-records bit-matrix kernel, the rest beside the one-launch tail.  The
+// write kernel then has VALU to spare for the bit-matrix kernel running beside it, which it did not have when it evaluated all
+// pairs (3.2d), and K3..K6 no longer wait for the write (with the bits in the write they ran 0.32 ms serially behind it at N = 16384).
+// GNMS_3D_SYM_LAYER=0/1 forces.
+bool sym_write_beside_3d(int B, int N, int64_t ld, const float* out) {
+    static const int forced = [] { const char* e = getenv("GNMS_3D_SYM_LAYER"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (!gnms_internal_overlap3d_sym_ok(N, ld, out)) return false;
+    return forced >= 0 ? forced == 1 : use_side_stream(B, N, ld);
+}
 // masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_iou2d_kernel).  GNMS_FUSE_TAIL=0/1 forces.
 bool chain_rides_in_write_launch(int B, int N) {
     static const int forced = [] { const char* e = getenv("GNMS_FUSE_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
@@ -1016,6 +1040,7 @@ bool chain_rides_in_write_launch(int B, int N) {
 // (default parameters, aligned inputs)
 extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (B <= 0 || N <= 0) return "";
+    if (dim == 3 && sym_write_beside_3d(B, N, N, nullptr)) return "iou3d_sym_kernel";
     if (dim == 3 && bits_in_write_3d(N)) return "iou3d_bits_kernel";
     if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : (writers_staged() && N % 4 == 0 ? "write_staged_kernel" : "iou2d_kernel");
     if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
@@ -1092,6 +1117,7 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
 int gnms_internal_records_from_params(const float* params, long count, float* rec, hipStream_t st);
 int gnms_internal_records_for_layer(const float* params, int B, int N, float* rec, char* ws, const gnms_ws_layout& L, float* xkeys, hipStream_t st);
 int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int row0 = 0, int row_end = 0x7fffffff);
+
 
 namespace {
 // ------------------------------------------------------------------------------------------------
@@ -1195,7 +1221,8 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     }
     float* xkeys = rec + (size_t)B * N * gnms_iou3d::kRec;         // [B][N] pseudo boxes; later the rank-ordered records
     if ((rc = gnms_internal_records_for_layer(params3d, B, N, rec, ws, L, xkeys, st))) return rc;
-    if (bits_in_write_3d(N)) {
+    const bool sym_beside = sym_write_beside_3d(B, N, ld, iou_out);
+    if (!sym_beside && bits_in_write_3d(N)) {
         // score sort -> records in rank order -> ONE pass over all pairs writes the matrix and the bit matrix -> K3..K6
         float* recs = xkeys;
         const int P2s = next_pow2(N);
@@ -1229,7 +1256,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
-    const bool beside = use_side_stream(B, N, ld);
+    const bool beside = sym_beside || use_side_stream(B, N, ld);
     const int sym = (P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY) ? 1 : 0;   // the culled kernel writes full symmetric rows of W
     // K3..K6 inside the write launch like the 2D entry -- up to N = 2048 only: the 3D writers are VALU-bound (23 slots per pair) and
     // at the one workgroup per CU that launch runs at they lose more than the overlap buys (B = 8, N = 4096: launch 166 us against a
@@ -1239,11 +1266,16 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     const int P2 = next_pow2(N);
     if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
     SideScope scope(st);
-    const int r1 = beside ? split_rows(N, 20) : 0;
-    if (r1 > 0) {                                                 // first part of the write beside the bit-matrix kernel
+    // the part of the write that runs beside the bit-matrix kernel: rows [0, r1) of the all-pairs kernel, or the first pct1 percent of
+    // the symmetric writer's macro tiles (GNMS_SPLIT_PCT overrides both)
+    const int r1 = (beside && !sym_beside) ? split_rows(N, 20) : 0;
+    const int pct1 = sym_beside ? split_pct(35) : 0;
+    if (r1 > 0 || pct1 > 0) {                                     // first part of the write beside the bit-matrix kernel
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 0))) return rc;
-        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, r1))) return rc;
+        if (sym_beside) rc = gnms_internal_nms_overlap3d_sym(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, pct1);
+        else rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, r1);
+        if (rc) return rc;
     }
     if (!sym) {
         // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
@@ -1262,7 +1294,9 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 1))) return rc;
         if ((rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym))) return rc;
-        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, r1, N))) return rc;
+        if (sym_beside) rc = gnms_internal_nms_overlap3d_sym(rec, B, N, iou_out, ld, side, P.nms_threshold, pct1, 100);
+        else rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, r1, N);
+        if (rc) return rc;
         return scope.join();
     }
     if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);

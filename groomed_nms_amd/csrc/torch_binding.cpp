@@ -1,0 +1,197 @@
+// torch_binding.cpp -- the GrooMeD-NMS layer as a C++ torch::autograd::Function over the C ABI (include/groomed_nms_hip.h).
+//
+// The reference's boundary for this path is a Python call, differentiable_nms (lib/groomed_nms.py:10), whose gradient comes from
+// autograd (:111).  groomed_nms_amd/groomed_nms.py mirrors that boundary; THIS file is what it calls into: outputs, workspace and
+// saved state are allocated here, the gnms_* entry is called with torch's current HIP stream, and the backward is a C++ autograd
+// node -- no ctypes marshalling (17-argument calls) and no Python autograd.Function on the step's host path, which is what bounds the
+// reference's own regime (N <= 500 boxes per image: 0.12-0.145 ms per eager step against 0.04-0.05 ms of GPU time, round 2).
+// PyTorch is plumbing here (device memory, the current stream, the autograd graph); all arithmetic is in libgroomed_nms_hip.so.
+// Built in-tree by groomed_nms_amd/build.py (torch.utils.cpp_extension, host compiler only: no device code in this file).
+#include <torch/extension.h>
+
+// PyTorch-ROCm presents its HIP devices under the device type "cuda"; these are the guard / stream accessors for that device type
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include <cstring>
+
+#include "../../include/groomed_nms_hip.h"
+
+namespace {
+
+using torch::Tensor;
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void check(int rc, const char* what) {
+    if (rc == GNMS_OK) return;
+    const char* m = gnms_last_error();
+    if (rc == GNMS_ERR_UNSUPPORTED && m && std::strstr(m, "not implemented"))
+        TORCH_CHECK_NOT_IMPLEMENTED(false, "Pruning method not implemented!");                 // lib/groomed_nms.py:178
+    TORCH_CHECK(false, "GNMS: ", what, " failed (", rc, "): ", m ? m : "");
+}
+
+// which entry runs the forward pass
+enum Mode : int64_t { kMatrixIn = 0, kWithIou2d = 1, kWithIou3d = 2, kFromBoxes = 3 };
+
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+inline hipStream_t current_stream(const Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
+
+inline const void* cptr(const Tensor& t) { return t.defined() ? t.data_ptr() : nullptr; }
+inline void* mptr(Tensor& t) { return t.defined() ? t.data_ptr() : nullptr; }
+
+// (tensor, ld): unit column stride and image stride N * ld, copying only if needed (groomed_nms.py::_matrix_layout)
+std::pair<Tensor, int64_t> matrix_layout(const Tensor& iou) {
+    const int64_t B = iou.size(0), N = iou.size(1);
+    if (N == 0) return {iou.contiguous(), 1};
+    if (iou.stride(2) == 1 && iou.stride(1) >= N && (B == 1 || iou.stride(0) == N * iou.stride(1))) return {iou, iou.stride(1)};
+    return {iou.contiguous(), N};
+}
+
+struct Layer : public torch::autograd::Function<Layer> {
+    // src: the overlap matrix [B,N,N] (kMatrixIn), 2D boxes [B,N,4] (kWithIou2d, kFromBoxes) or cuboid parameters [B,N,7] (kWithIou3d)
+    static variable_list forward(AutogradContext* ctx, const Tensor& scores, const Tensor& src, const c10::optional<Tensor>& counts_,
+                                 const c10::optional<Tensor>& iou_out_, int64_t mode, double thr, double temp, double vthr, int64_t prune,
+                                 bool sorted_prob, bool group, bool mask, int64_t gsize, bool presorted, bool index_lists) {
+        gnms_params P;
+        P.nms_threshold = (float)thr; P.temperature = (float)temp; P.valid_box_prob_threshold = (float)vthr;
+        P.pruning_method = (int32_t)prune; P.return_sorted_prob = sorted_prob; P.group_boxes = group; P.mask_group_boxes = mask;
+        P.group_size = (int32_t)gsize; P.presorted = presorted;
+        TORCH_CHECK(scores.is_cuda() && scores.dim() == 2 && scores.scalar_type() == at::kFloat, "GNMS: scores must be a CUDA float [B, N] tensor");
+        TORCH_CHECK(src.is_cuda() && src.dim() == 3 && src.scalar_type() == at::kFloat && src.size(0) == scores.size(0) && src.size(1) == scores.size(1),
+                    "GNMS: second argument must be a CUDA float [B, N, .] tensor");
+        const int64_t B = scores.size(0), N = scores.size(1);
+        DeviceGuard guard(scores.device());
+        hipStream_t st = current_stream(scores);
+        Tensor s = scores.contiguous();
+        Tensor counts = counts_.has_value() ? *counts_ : Tensor();
+        const auto f32 = s.options();
+        Tensor prob = at::empty({B, N}, f32);
+        Tensor lists = at::empty({index_lists ? 3 : 1, B, N}, f32.dtype(at::kLong));
+        Tensor cnt = at::empty({2, B}, f32.dtype(at::kInt));
+        Tensor order = lists[0], valid = index_lists ? lists[1] : Tensor(), invalid = index_lists ? lists[2] : Tensor();
+        Tensor nvalid = cnt[0], ninvalid = cnt[1];
+        const size_t wsb = gnms_workspace_bytes((int)B, (int)N, &P);
+        Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 256)}, f32.dtype(at::kByte));
+        Tensor kept, iou;                     // kept: what the backward reads besides the scores (matrix / boxes), if anything
+        int64_t ld = std::max<int64_t>(N, 1);
+        if (mode == kMatrixIn) {
+            TORCH_CHECK(src.size(2) == N, "GNMS: iou must be [B, N, N]");
+            auto ml = matrix_layout(src);
+            kept = ml.first;
+            ld = ml.second;
+            check(gnms_forward((const float*)cptr(s), (const float*)cptr(kept), (int)B, (int)N, ld, (const int32_t*)cptr(counts), &P, (float*)mptr(prob),
+                               (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), (int32_t*)mptr(nvalid), (int32_t*)mptr(ninvalid),
+                               mptr(ws), (size_t)ws.numel(), st), "gnms_forward");
+        } else if (mode == kFromBoxes) {
+            TORCH_CHECK(src.size(2) == 4, "GNMS: boxes must be [B, N, 4]");
+            kept = src.contiguous();
+            check(gnms_forward_from_boxes((const float*)cptr(kept), (const float*)cptr(s), (int)B, (int)N, (const int32_t*)cptr(counts), &P, (float*)mptr(prob),
+                                          (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), (int32_t*)mptr(nvalid),
+                                          (int32_t*)mptr(ninvalid), mptr(ws), (size_t)ws.numel(), st), "gnms_forward_from_boxes");
+        } else {
+            const bool three_d = mode == kWithIou3d;
+            TORCH_CHECK(src.size(2) == (three_d ? 7 : 4), "GNMS: expected [B, N, ", three_d ? 7 : 4, "] as the second argument");
+            Tensor boxes = src.contiguous();
+            iou = iou_out_.has_value() ? *iou_out_ : at::empty({B, N, N}, f32);
+            TORCH_CHECK(iou.is_cuda() && iou.scalar_type() == at::kFloat && iou.is_contiguous() && iou.numel() == B * N * N, "GNMS: iou_out must be a contiguous CUDA float [B, N, N] tensor");
+            auto entry = three_d ? gnms_forward_with_iou3d : gnms_forward_with_iou2d;
+            check(entry((const float*)cptr(boxes), (const float*)cptr(s), (int)B, (int)N, ld, (const int32_t*)cptr(counts), &P, (float*)mptr(iou),
+                        (float*)mptr(prob), (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), (int32_t*)mptr(nvalid),
+                        (int32_t*)mptr(ninvalid), mptr(ws), (size_t)ws.numel(), st), three_d ? "gnms_forward_with_iou3d" : "gnms_forward_with_iou2d");
+            // The masked-group backward (the default) never reads the overlaps, so the matrix is not kept at all.  The unmasked / ungrouped
+            // backward does: there it is saved through autograd, whose version counter then catches a caller that overwrites the
+            // (possibly caller-provided) buffer between forward and backward instead of silently producing wrong gradients.
+            if (!(group && mask)) kept = iou;
+        }
+        ctx->set_materialize_grads(false);                               // no zero-filled "gradients" for the index outputs
+        ctx->saved_data["mode"] = mode;
+        ctx->saved_data["ld"] = ld;
+        ctx->saved_data["params"] = std::vector<double>{thr, temp, vthr, (double)prune, (double)sorted_prob, (double)group, (double)mask, (double)gsize,
+                                                        (double)presorted};
+        ctx->saved_data["has_counts"] = counts.defined();
+        ctx->saved_data["has_kept"] = kept.defined();
+        variable_list saved{s, ws};
+        if (counts.defined()) saved.push_back(counts);
+        if (kept.defined()) saved.push_back(kept);
+        ctx->save_for_backward(saved);
+        // outputs: prob, order, nvalid, ninvalid [, valid, invalid] [, iou] -- defined tensors only (an autograd node cannot return an
+        // undefined one); layer() below puts them into the seven slots of the Python-side convention
+        variable_list out{prob, order, nvalid, ninvalid};
+        if (valid.defined()) { out.push_back(valid); out.push_back(invalid); }
+        if (iou.defined()) out.push_back(iou);
+        ctx->mark_non_differentiable(variable_list(out.begin() + 1, out.end()));
+        return out;
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        variable_list none(15);
+        if (!grads[0].defined()) return none;
+        const auto saved = ctx->get_saved_variables();
+        const int64_t mode = ctx->saved_data["mode"].toInt(), ld = ctx->saved_data["ld"].toInt();
+        const auto pv = ctx->saved_data["params"].toDoubleVector();
+        gnms_params P;
+        P.nms_threshold = (float)pv[0]; P.temperature = (float)pv[1]; P.valid_box_prob_threshold = (float)pv[2]; P.pruning_method = (int32_t)pv[3];
+        P.return_sorted_prob = (int32_t)pv[4]; P.group_boxes = (int32_t)pv[5]; P.mask_group_boxes = (int32_t)pv[6]; P.group_size = (int32_t)pv[7];
+        P.presorted = (int32_t)pv[8];
+        size_t k = 0;
+        Tensor s = saved[k++], ws = saved[k++];
+        Tensor counts = ctx->saved_data["has_counts"].toBool() ? saved[k++] : Tensor();
+        Tensor kept = ctx->saved_data["has_kept"].toBool() ? saved[k++] : Tensor();
+        const int64_t B = s.size(0), N = s.size(1);
+        DeviceGuard guard(s.device());
+        hipStream_t st = current_stream(s);
+        Tensor g = grads[0].contiguous().to(at::kFloat);
+        Tensor gs = at::empty_like(s);
+        Tensor gi;
+        if (mode == kFromBoxes) {
+            check(gnms_backward_from_boxes((const float*)cptr(g), (const float*)cptr(kept), (const float*)cptr(s), (int)B, (int)N, (const int32_t*)cptr(counts), &P,
+                                           (float*)mptr(gs), mptr(ws), (size_t)ws.numel(), st), "gnms_backward_from_boxes");
+        } else {
+            if (mode == kMatrixIn && ctx->needs_input_grad(1)) gi = at::empty({B, N, ld}, s.options());
+            // (masked groups never dereference the matrix pointer: any valid device pointer will do when the matrix was not kept)
+            const float* m = kept.defined() ? (const float*)cptr(kept) : (const float*)cptr(s);
+            check(gnms_backward((const float*)cptr(g), (const float*)cptr(s), m, (int)B, (int)N, ld, (const int32_t*)cptr(counts), &P, (float*)mptr(gs),
+                                (float*)mptr(gi), mptr(ws), (size_t)ws.numel(), st), "gnms_backward");
+            if (gi.defined() && ld != N) gi = gi.slice(2, 0, N);
+        }
+        none[0] = gs;
+        none[1] = gi;
+        return none;
+    }
+};
+
+// -> (prob, order, valid | None, invalid | None, nvalid, ninvalid, iou | None)
+std::vector<c10::optional<Tensor>> layer(const Tensor& scores, const Tensor& src, const c10::optional<Tensor>& counts, const c10::optional<Tensor>& iou_out,
+                                         int64_t mode, double thr, double temp, double vthr, int64_t prune, bool sorted_prob, bool group, bool mask,
+                                         int64_t gsize, bool presorted, bool index_lists) {
+    const variable_list o = Layer::apply(scores, src, counts, iou_out, mode, thr, temp, vthr, prune, sorted_prob, group, mask, gsize, presorted, index_lists);
+    std::vector<c10::optional<Tensor>> r(7);
+    r[0] = o[0]; r[1] = o[1]; r[4] = o[2]; r[5] = o[3];
+    size_t k = 4;
+    if (index_lists) { r[2] = o[k++]; r[3] = o[k++]; }
+    if (k < o.size()) r[6] = o[k];
+    return r;
+}
+
+// lib/core.py:480-508 iou(mode='combinations') for batches: boxes_a [B,M,4], boxes_b [B,N,4] -> [B,M,N]
+Tensor iou2d(const Tensor& a, const Tensor& b, const c10::optional<Tensor>& out_) {
+    TORCH_CHECK(a.is_cuda() && b.is_cuda() && a.dim() == 3 && b.dim() == 3 && a.size(2) == 4 && b.size(2) == 4 && a.size(0) == b.size(0) &&
+                a.scalar_type() == at::kFloat && b.scalar_type() == at::kFloat, "GNMS: iou2d takes CUDA float [B, M, 4] and [B, N, 4]");
+    DeviceGuard guard(a.device());
+    Tensor ac = a.contiguous(), bc = b.contiguous();
+    const int64_t B = ac.size(0), M = ac.size(1), N = bc.size(1);
+    Tensor out = out_.has_value() ? *out_ : at::empty({B, M, N}, ac.options());
+    check(gnms_iou2d((const float*)cptr(ac), (const float*)cptr(bc), (int)B, (int)M, (int)N, (float*)mptr(out), std::max<int64_t>(N, 1),
+                     current_stream(ac)), "gnms_iou2d");
+    return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "GrooMeD-NMS layer: C++ autograd binding of libgroomed_nms_hip.so";
+    m.def("layer", &layer, "forward entry + autograd node (mode 0 matrix in, 1 boxes -> matrix + layer, 2 cuboids -> matrix + layer, 3 from boxes)");
+    m.def("iou2d", &iou2d, "pairwise 2D IoU matrices");
+    m.def("abi_version", [] { return gnms_abi_version(); });
+}

@@ -50,6 +50,44 @@ def _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold
     return p
 
 
+# ----------------------------------------------------------------------------------------------------------------------------------
+# The layer's host path.  Preferred: the C++ binding (csrc/torch_binding.cpp, built in-tree as gnms_torch*.so) -- outputs, workspace,
+# the gnms_* call on torch's current stream and the autograd node all in C++.  Fallback (binding not built, or GNMS_BINDING=ctypes):
+# the ctypes + torch.autograd.Function path below, which calls the same C ABI.  Both are the HIP library; neither computes anything
+# on the host.
+# ----------------------------------------------------------------------------------------------------------------------------------
+_EXT = None
+_MODE_MATRIX, _MODE_IOU2D, _MODE_IOU3D, _MODE_BOXES = 0, 1, 2, 3
+
+
+def _binding():
+    """the C++ autograd binding module, or False when it is unavailable / switched off"""
+    global _EXT
+    if _EXT is None:
+        import os
+        _EXT = False
+        if os.environ.get("GNMS_BINDING", "") != "ctypes":
+            _lib.load()                                   # (fails loudly when the HIP library itself is missing)
+            try:
+                from . import gnms_torch                  # noqa: F401  links libgroomed_nms_hip.so ($ORIGIN)
+                if gnms_torch.abi_version() == 1:
+                    _EXT = gnms_torch
+            except ImportError:
+                _EXT = False
+    return _EXT
+
+
+def _layer(ext, scores, src, counts, iou_out, mode, p):
+    try:
+        return ext.layer(scores, src, counts, iou_out, mode, p.nms_threshold, p.temperature, p.valid_box_prob_threshold, p.pruning_method,
+                         bool(p.return_sorted_prob), bool(p.group_boxes), bool(p.mask_group_boxes), p.group_size, bool(p.presorted),
+                         bool(getattr(p, "index_lists", True)))
+    except NotImplementedError:
+        raise
+    except RuntimeError as e:                              # the C ABI's status codes + gnms_last_error(), raised by the binding
+        raise _lib.GnmsError(str(e)) from None
+
+
 _WS_BYTES = {}
 
 
@@ -345,6 +383,9 @@ def differentiable_nms_batched(scores, iou, counts=None, nms_threshold=0.4, prun
                      mask_group_boxes, group_size, presorted, bool(index_lists))
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
+    ext = _binding()
+    if ext and scores.is_cuda:
+        return tuple(_layer(ext, scores.float(), iou.float(), counts, None, _MODE_MATRIX, params)[:6])
     return _GroomedNMSFunction.apply(scores.float(), iou.float(), counts, params)
 
 
@@ -358,6 +399,9 @@ def differentiable_nms_with_iou2d_batched(scores, boxes, counts=None, iou_out=No
                      mask_group_boxes, group_size, False, bool(index_lists))
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
+    ext = _binding()
+    if ext and scores.is_cuda:
+        return tuple(_layer(ext, scores.float(), boxes.float(), counts, iou_out, _MODE_IOU2D, params))
     return _GroomedNMSWithIouFunction.apply(scores.float(), boxes.float(), counts, params, iou_out)
 
 
@@ -373,6 +417,9 @@ def differentiable_nms_with_iou3d_batched(scores, params3d, counts=None, iou_out
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
     if params3d.shape[-1] != 7:
         raise ValueError("params3d must be [B, N, 7]")
+    ext = _binding()
+    if ext and scores.is_cuda:
+        return tuple(_layer(ext, scores.float(), params3d.float(), counts, iou_out, _MODE_IOU3D, params))
     return _GroomedNMSWithIouFunction.apply(scores.float(), params3d.float(), counts, params, iou_out)
 
 
@@ -386,6 +433,9 @@ def differentiable_nms_from_boxes_batched(scores, boxes, counts=None, nms_thresh
                      mask_group_boxes, group_size, False, bool(index_lists))
     if counts is not None:
         counts = counts.to(device=scores.device, dtype=torch.int32).contiguous()
+    ext = _binding()
+    if ext and scores.is_cuda:
+        return tuple(_layer(ext, scores.float(), boxes.float(), counts, None, _MODE_BOXES, params)[:6])
     return _GroomedNMSFromBoxesFunction.apply(scores.float(), boxes.float(), counts, params)
 
 

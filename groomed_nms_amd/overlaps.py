@@ -40,6 +40,13 @@ def _back(t, kind, device):
 
 def iou_batched(boxes_a, boxes_b=None, out=None):
     """boxes_a [B,M,4], boxes_b [B,N,4] (CUDA fp32) -> [B,M,N].  boxes_b=None means boxes_a."""
+    from .groomed_nms import _binding
+    ext = _binding()
+    if ext and boxes_a.is_cuda and boxes_a.dtype == torch.float32 and (boxes_b is None or boxes_b.dtype == torch.float32):
+        try:
+            return ext.iou2d(boxes_a, boxes_a if boxes_b is None else boxes_b, out)
+        except RuntimeError as e:
+            raise _lib.GnmsError(str(e)) from None
     lib = _lib.load()
     boxes_a = boxes_a.contiguous()
     boxes_b = boxes_a if boxes_b is None else boxes_b.contiguous()

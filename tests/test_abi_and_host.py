@@ -190,3 +190,15 @@ def test_kitti_result_writer_against_reference_vectors(tmp_path):
     res = K.run_kitti_eval_script(str(ev), str(tmp_path), str(tmp_path), ["Car", "Pedestrian"])
     assert set(res) == {"det_2d_car", "det_3d_car"} and np.allclose(res["det_3d_car"], g["stats/r40"])
     assert abs(K.convertAlpha2Rot(0.3, 10.0, 2.0) - (0.3 + np.arctan2(2.0, 10.0))) < 1e-12
+
+
+def test_torch_binding_builds_and_loads():
+    """the C++ autograd binding (csrc/torch_binding.cpp): built in-tree, importable without a GPU, same ABI version as the library;
+    it refuses host tensors (there is no CPU path behind it either)."""
+    from groomed_nms_amd import build as b
+    path = b.build_torch_binding()
+    assert os.path.exists(path) and os.path.dirname(path) == os.path.dirname(b.OUT)
+    from groomed_nms_amd import gnms_torch
+    assert gnms_torch.abi_version() == 1
+    with pytest.raises(RuntimeError):
+        gnms_torch.layer(torch.rand(1, 4), torch.rand(1, 4, 4), None, None, 0, 0.4, 0.01, 0.3, 0, False, True, True, 100, False, True)

@@ -1081,6 +1081,39 @@ def test_iou3d_one_call_against_oracle_at_scale(G, O, B, N, clustered):
             assert float(np.abs(prob - ref2["prob"]).max()) <= 1e-4
 
 
+@pytest.mark.parametrize("B,N,clustered", [(3, 256, True), (2, 258, False), (2, 1000, True), (2, 4096, True), (1, 5000, False), (1, 8192, True)])
+def test_iou3d_symmetric_writer(G, O, B, N, clustered):
+    """The symmetric 3D matrix writer (iou3d_sym_kernel: every unordered pair evaluated once, each 128 x 128 macro tile stored directly
+    and mirrored through LDS) writes the SAME matrix as the all-pairs kernels of the one-call entry (iou3d_nms_fast_kernel /
+    iou3d_bits_kernel: one per-pair definition, iou3d_pair.h), bit for bit -- ragged last tiles, several images, thresholds whose guard
+    band holds many pairs -- and the matrix is symmetric; against the oracle's exact operation order: within 2e-6, equal `> thr`
+    decisions, equal entries inside the band."""
+    from groomed_nms_amd import synthetic, overlaps
+    par, scores = synthetic.batch_3d(900 + N, B, N, clustered=clustered, per=16)
+    pt = torch.from_numpy(par).cuda()
+    st = torch.from_numpy(scores).cuda()
+    for thr in (0.4, 0.05, 0.75):
+        m_sym = overlaps.iou3d_batched(pt, from_params=True, nms_overlap=True, nms_threshold=thr)        # gnms_nms_overlap3d_from_params
+        m_all = G.differentiable_nms_with_iou3d_batched(st, pt, nms_threshold=thr)[6]                    # the one-call entry's writer
+        assert torch.equal(m_sym, m_all), (N, thr, int((m_sym != m_all).sum()))
+        assert torch.equal(m_sym, m_sym.transpose(1, 2))
+    if N <= 4096:
+        exact = overlaps.iou3d_batched(pt, from_params=True, nms_overlap=True)                           # exact-order kernel == oracle (tested above)
+        got, ex = m_sym.cpu().numpy(), exact.cpu().numpy()
+        assert float(np.abs(got - ex).max()) <= 2e-6 and np.array_equal(got > 0.75, ex > 0.75)
+        band = np.abs(ex - np.float32(0.75)) <= 4e-6
+        assert np.array_equal(got[band], ex[band])
+    # a padded leading dimension and an odd one (the latter falls back to the all-pairs kernel): same entries
+    import ctypes
+    from groomed_nms_amd import _lib
+    from groomed_nms_amd._lib import ptr, check, stream_ptr
+    lib = _lib.load()
+    for ld in (N + 6, N + 3):
+        buf = torch.full((B, N, ld), -7.0, device="cuda")
+        check(lib.gnms_nms_overlap3d_from_params(ptr(pt), B, N, 0.75, ptr(buf), ld, stream_ptr(pt.device)), "overlap3d")
+        assert torch.equal(buf[:, :, :N], m_sym) and bool((buf[:, :, N:] == -7.0).all()), ld
+
+
 @pytest.mark.parametrize("B,N,kind", [(2, 4096, "clustered"), (2, 4096, "uniform"), (1, 16384, "clustered"), (1, 16384, "uniform")])
 def test_iou2d_one_call_and_from_boxes_against_oracle_at_scale(G, O, B, N, kind):
     """The 2D one-call entry (gnms_forward_with_iou2d) and the matrix-free entry (gnms_forward_from_boxes) against the CPU oracle

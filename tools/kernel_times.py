@@ -58,9 +58,12 @@ def evt(fn):
 
 
 bytes_ = 4.0 * B * N * N
+# which kernel gnms_nms_overlap3d_from_params runs: the symmetric writer (iou3d_sym.h; GNMS_3D_SYM=0 forces the all-pairs kernel)
+K3 = "iou3d_nms_fast_kernel, all pairs" if os.environ.get("GNMS_3D_SYM") == "0" else (
+    "iou3d_sym_kernel<%s waves>, each pair once, %s stores" % (os.environ.get("GNMS_3D_SYM_NW", "8"), "plain" if os.environ.get("GNMS_3D_SYM_NT") == "0" else "non-temporal"))
 rows = [("iou2d_kernel", timed(lambda o: check(lib.gnms_iou2d(ptr(boxes2), ptr(boxes2), B, N, N, ptr(o), N, sp), "iou2d"))),
-        ("iou3d_nms_fast_kernel thr=0.4", timed(lambda o: check(lib.gnms_nms_overlap3d_from_params(ptr(par3), B, N, 0.4, ptr(o), N, sp), "o3"))),
-        ("iou3d_nms_fast_kernel thr=-100 (no pair in the band)", timed(lambda o: check(lib.gnms_nms_overlap3d_from_params(ptr(par3), B, N, -100.0, ptr(o), N, sp), "o3"))),
+        ("3D NMS overlap thr=0.4 [%s]" % K3, timed(lambda o: check(lib.gnms_nms_overlap3d_from_params(ptr(par3), B, N, 0.4, ptr(o), N, sp), "o3"))),
+        ("3D NMS overlap thr=-100 (no pair in the band) [%s]" % K3, timed(lambda o: check(lib.gnms_nms_overlap3d_from_params(ptr(par3), B, N, -100.0, ptr(o), N, sp), "o3"))),
         ("iou3d_kernel<METHOD 2> (exact order)", timed(lambda o: check(lib.gnms_iou3d_from_params(ptr(par3), ptr(par3), B, N, N, 2, None, ptr(o), N, sp), "o3e"))),
         ("plain fill (same launch events)", timed(lambda o: check(lib.gnms_profile_fill(ptr(o), B * N * N, sp), "fill"), slot=2)),
         ("plain fill, writers' geometry (8 rows x 1 KiB per wave)", timed(lambda o: check(lib.gnms_profile_fill_tiles(ptr(o), B, N, N, 8, 1, sp), "fillt"), slot=2)),
@@ -68,4 +71,4 @@ rows = [("iou2d_kernel", timed(lambda o: check(lib.gnms_iou2d(ptr(boxes2), ptr(b
         ("plain fill, writers' geometry, ordinary stores (8 rows)", timed(lambda o: check(lib.gnms_profile_fill_tiles(ptr(o), B, N, N, 8, 0, sp), "fillt"), slot=2)),
         ("plain fill (events around back-to-back launches)", evt(lambda o: check(lib.gnms_profile_fill(ptr(o), B * N * N, sp), "fill")))]
 for name, ms in rows:
-    print("%-58s %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s" % (name, ms, bytes_ / ms / 1e6, bytes_ / ms / 1e6 / 8000))
+    print("%-92s %8.4f ms  %7.1f GB/s  %.3f of 8 TB/s" % (name, ms, bytes_ / ms / 1e6, bytes_ / ms / 1e6 / 8000))
