@@ -66,7 +66,11 @@ def parse():
                          "lib/rpn_util.py:1258-1266)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: keep processing images of the batch for about this long")
     ap.add_argument("--pmc-summary", default=None,
-                    help="JSON written by tools/pmc.sh in the same session ({kernel: HBM bytes per launch}); fills roofline.traffic (else null)")
+                    help="JSON written by tools/pmc.sh in the same session ({kernel: HBM bytes per launch}); fills roofline.traffic.  Without it "
+                         "the default run collects the counters itself (two short rocprofv3 --pmc passes of this script) when rocprofv3 is on PATH")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip what the default 1-GPU line adds by re-running this script: the PMC passes for roofline.traffic, the `two_calls` "
+                         "key (the reference's unchanged call sites: iou() then differentiable_nms(scores, iou)) and the `dim3` key (3D, N = 4096 and 16384)")
     return ap.parse_args()
 
 
@@ -85,6 +89,73 @@ def launch_ranks_if_needed(args):
     if have < args.gpus and not gdist.share_gpu():          # (GNMS_SHARE_GPU=1: debug mode, ranks fold onto the visible devices over gloo)
         sys.exit("bench.py: --gpus %d requested but this node has %d visible GPU(s); refusing to time fewer GPUs than asked" % (args.gpus, have))
     sys.exit(gdist.relaunch_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+
+
+def _sub_bench(extra, timeout=900):
+    """this script once more with other flags (a child process on the same GPU, this one idle meanwhile); its JSON line as a dict"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-kind", "--no-extras"] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:]))
+    return json.loads(lines[-1])
+
+
+def _brief(d):
+    """what the extra keys keep of a child's line"""
+    def roof(r):
+        return None if not r else {k: r[k] for k in ("kernel", "kernel_ms", "achieved", "frac", "launches_per_step", "algorithmic_bytes") if k in r}
+    out = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"],
+           "roofline": roof(d.get("roofline"))}
+    if d.get("roofline_iou"):
+        out["roofline_iou"] = roof(d["roofline_iou"])
+    return out
+
+
+def _pmc_traffic(workload_args, B, N):
+    """HBM bytes per launch from the PMC counters, collected as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
+    rocprofv3 passes with --kernel-trace only, over a short run of this script.  Corrections: the counters are in KiB; FETCH_SIZE
+    tallies the 128-byte requests of wide coalesced reads as 64 B on gfx950 -> doubled; WRITE_SIZE is calibrated in the same pass on
+    gnms_profile_fill's known store stream (prof_fill_kernel writes exactly 4 B N^2 bytes per launch).  -> ({kernel: bytes}, note)"""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {}, "rocprofv3 not on PATH"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    raw = {}
+    with tempfile.TemporaryDirectory(dir="/tmp", prefix="gnms_pmc_") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-other-kind", "--no-extras"] + list(workload_args)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd="/tmp")
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return {}, "rocprofv3 --pmc %s wrote no counter file (rc %d)" % (counter, r.returncode)
+            agg = collections.defaultdict(list)
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") == counter:
+                        name = re.sub(r"^void ", "", row["Kernel_Name"])
+                        name = re.sub(r"\(anonymous namespace\)::|gnms::|gnms_iou3d::|gnms_iou::", "", name)
+                        agg[re.sub(r"[<(].*", "", name)].append(float(row["Counter_Value"]))
+            raw[counter] = {k: sum(v) / len(v) for k, v in agg.items()}
+    fill = raw["WRITE_SIZE"].get("prof_fill_kernel")
+    wcal = (4.0 * B * N * N / 1024.0) / fill if fill else 1.0
+    traffic = {}
+    for k in set(raw["FETCH_SIZE"]) | set(raw["WRITE_SIZE"]):
+        traffic[k] = raw["FETCH_SIZE"].get(k, 0.0) * 1024 * 2 + raw["WRITE_SIZE"].get(k, 0.0) * 1024 * wcal
+    return traffic, ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes with --kernel-trace only, over `bench.py --steps 5`; KiB counters, "
+                     "FETCH_SIZE x2 (gfx950), WRITE_SIZE x %.4f (calibrated on prof_fill_kernel's known byte count in the same pass)" % wcal)
 
 
 def main():
@@ -116,6 +187,8 @@ def main():
             b_np = np.take_along_axis(b_np, o[:, :, None], axis=1)
         return np.ascontiguousarray(b_np), np.ascontiguousarray(s_np)
 
+    if args.no_other_kind:
+        args.no_extras = True                               # (every tool that asks for the bare line passes --no-other-kind)
     boxes_np, scores_np = make_inputs(args.kind)
     w_np = np.linspace(-1.0, 2.0, N).astype(np.float32)                 # dL/dprob, the SAME fp32 values on the GPU and in the oracle
     w = torch.from_numpy(np.tile(w_np, (B, 1))).to(dev).contiguous()
@@ -262,10 +335,18 @@ def main():
             b_.fill_(0.25)
         read_gbs = stream_rate(lambda b: check(lib.gnms_profile_read(ptr(b), n_fl, ptr(sink), stream_ptr(dev)), "read"), 4.0 * n_fl) if n_fl else 0.0
 
-        pmc = {}
+        pmc, pmc_note = {}, None
+        workload_args = ["--boxes", str(N), "--batch", str(B), "--kind", args.kind, "--dim", str(args.dim)] + (["--two-calls"] if args.two_calls else []) + (
+            ["--sorted-scores"] if args.sorted_scores else [])
         if args.pmc_summary:
             with open(args.pmc_summary) as f:
                 pmc = json.load(f).get("traffic_bytes_per_launch", {})
+            pmc_note = "tools/pmc.sh, " + args.pmc_summary
+        elif world == 1 and not args.no_extras and not args.graph:
+            try:
+                pmc, pmc_note = _pmc_traffic(workload_args, B, N)
+            except Exception as e:                            # the counters are evidence beside the line, never a reason to lose it
+                pmc, pmc_note = {}, "PMC pass failed: %s" % (str(e)[:200],)
 
         def roof(ms_sum, launches, nbytes_per_step, kname, ceiling, what):
             if launches == 0 or ms_sum <= 0:
@@ -273,7 +354,7 @@ def main():
             per_step_ms = ms_sum / k_roof
             ach = nbytes_per_step / (per_step_ms * 1e-3) / 1e9
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": (round(pmc[kname]) if kname in pmc else None), "algorithmic_bytes": round(nbytes_per_step),
+                    "traffic": (round(pmc[kname]) if kname in pmc else None), "traffic_source": pmc_note, "algorithmic_bytes": round(nbytes_per_step),
                     "kernel": kname, "kernel_ms": round(per_step_ms, 4), "launches_per_step": round(launches / k_roof, 2),
                     "ceiling": {"what": what, "GB/s": round(ceiling, 1), "frac_of_ceiling": round(ach / ceiling, 4) if ceiling else None},
                     "measured": "HIP events around the launch inside %d repetitions of the timed step sequence, %d rotating %d-MiB matrix buffers"
@@ -339,6 +420,19 @@ def main():
             dto = gdist.timed_steps(ostep, k_o, max(3, args.warmup // 2), torch.cuda.synchronize)
             out["other_kind"] = {"kind": other, "value": round(B * N * k_o / dto, 1), "unit": "boxes/s", "ms_per_step": round(dto / k_o * 1e3, 4),
                                  "steps": k_o}
+
+        if world == 1 and not args.no_extras and not args.graph and not args.two_calls and args.dim == 2 and not args.sorted_scores:
+            # driver-timed figures for the two other shapes of the path: the reference's UNCHANGED call sites -- iou() then
+            # differentiable_nms(scores, iou): the overlap kernel and the matrix-in layer as two library calls, lib/loss/rpn_3d.py:772-791 --
+            # and the 3D overlap (0.5 (1 + GIoU3D), rpn_3d.py:778-784) at N = 4096 and at C5's N = 16384.  Children of this process, same GPU.
+            st = ["--steps", str(max(20, min(args.steps, 100))), "--warmup", str(max(3, min(args.warmup, 10)))]
+            for key, extra in (("two_calls", ["--two-calls", "--boxes", str(N), "--batch", str(B), "--kind", args.kind] + st),
+                               ("dim3_N4096", ["--dim", "3", "--boxes", "4096", "--batch", str(B), "--kind", args.kind] + st),
+                               ("dim3_N16384", ["--dim", "3", "--boxes", "16384", "--batch", str(B), "--kind", args.kind, "--steps", "20", "--warmup", "3"])):
+                try:
+                    out[key] = _brief(_sub_bench(extra))
+                except Exception as e:
+                    out[key] = {"error": str(e)[:300]}
 
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O

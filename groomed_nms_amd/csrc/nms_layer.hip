@@ -1269,7 +1269,10 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     // the part of the write that runs beside the bit-matrix kernel: rows [0, r1) of the all-pairs kernel, or the first pct1 percent of
     // the symmetric writer's macro tiles (GNMS_SPLIT_PCT overrides both)
     const int r1 = (beside && !sym_beside) ? split_rows(N, 20) : 0;
-    const int pct1 = sym_beside ? split_pct(35) : 0;
+    // (symmetric writer: 0 by default -- beside the bit-matrix kernel its launch takes as much longer as that kernel lasts, both being
+    // slowed by the saturated memory system: B = 8, N = 16384 step 2.18 ms at 0 %, 2.11 at 25-35 %, with the writer's own launches
+    // summing to 1.62 ms (0.66 of the HBM peak) against 2.02 (0.53); the cleaner launch is kept, the 3 % are not worth the second fork)
+    const int pct1 = sym_beside ? split_pct(0) : 0;
     if (r1 > 0 || pct1 > 0) {                                     // first part of the write beside the bit-matrix kernel
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 0))) return rc;

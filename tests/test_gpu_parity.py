@@ -1696,7 +1696,7 @@ def test_bench_line_contract_on_a_small_problem():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     for extra in ([], ["--dim", "3"], ["--two-calls"], ["--graph", "--no-cpu-baseline"]):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--boxes", "512", "--batch", "2", "--steps", "4", "--warmup", "1",
-                            "--cpu-seconds", "0.3"] + extra, env=env, capture_output=True, text=True, timeout=900)
+                            "--cpu-seconds", "0.3", "--no-extras"] + extra, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         d = json.loads(r.stdout.strip().splitlines()[-1])
         for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
