@@ -363,7 +363,7 @@ def main():
         if one_call:
             wname = lib.gnms_profile_write_kernel_name(args.dim, B, N).decode()
         else:
-            wname = "iou2d_kernel" if args.dim == 2 else "iou3d_nms_fast_kernel"
+            wname = "iou2d_kernel" if args.dim == 2 else "iou3d_sym_kernel"
         r_write = roof(ms_write, n_write, alg_write, wname, fill_gbs, fill_what)
         r_read = roof(ms_read, n_read, alg_read, "bitmask_kernel", read_gbs, "plain non-temporal float4 load stream (gnms_profile_read)")
 

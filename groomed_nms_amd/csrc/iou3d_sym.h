@@ -57,19 +57,22 @@ __device__ __forceinline__ void sym_store2(float* p, float a, float b) {
     else *reinterpret_cast<float2*>(p) = make_float2(a, b);
 }
 
-// One workgroup of NW waves: macro tile (I, J), I <= J, of one image.  rec [N][kRec] records, out [N][ld] (ld even, 8-byte aligned),
-// tile: kSymTileBytes of LDS.  Wave w owns the rows 128 I + (128 / NW) w ... of the tile and, in the mirrored pass, as many of its
-// columns; a lane owns the columns 128 J + 2 lane, + 1 (one packed column pair: every v_pk_* works on exactly the lane's two pairs).
-// The row record is wave-uniform: scalar loads.  The caller's __syncthreads() discipline: this function contains ONE barrier when
-// I != J (none on the diagonal) and reads `tile` after it -- a caller that reuses `tile` for the next macro tile must separate the two
-// (sym kernel: one tile per workgroup; persistent callers alternate between two LDS tiles).
+// One workgroup of NW waves: macro tile (I, J), I <= J, of one image, in two passes with a workgroup barrier between them.
+// rec [N][kRec] records, out [N][ld] (ld even, 8-byte aligned), tile: kSymTileBytes of LDS.
+//   sym_tile_compute  wave w owns the rows 128 I + (128 / NW) w ... of the tile; a lane owns the columns 128 J + 2 lane, + 1 (one
+//                     packed column pair: every v_pk_* works on exactly the lane's two pairs).  The row record is wave-uniform:
+//                     scalar loads, the next row's requested before this row's arithmetic.  Stores the rows directly (512-byte
+//                     runs) and, when I != J, parks the tile in LDS.
+//   sym_tile_mirror   (I != J, after a barrier) output row = a column of the tile; its 128 entries = the tile's rows (all of them
+//                     exist: I < J <= last tile).  Lane l stores the entries of the local rows 2 l, 2 l + 1: one 512-byte run per
+//                     instruction (ds_read2_b32 at offsets k, k + 129: the odd pitch spreads a column over the banks).
 template <int NW, bool NT>
-__device__ __forceinline__ void nms_overlap3d_sym_tile(const float* __restrict__ rec, int N, float* __restrict__ out, long ld, int I, int J,
-                                                       float thr, float* __restrict__ tile) {
+__device__ __forceinline__ void sym_tile_compute(const float* __restrict__ rec, int N, float* __restrict__ out, long ld, int I, int J,
+                                                 float thr, float* __restrict__ tile) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: the row records then come by SCALAR loads
     constexpr int RW = kSymT / NW;
-    const int rl0 = wave * RW;                                        // first local row (and, mirrored, first local column) of this wave
+    const int rl0 = wave * RW;
     const int r0 = I * kSymT + rl0;
     const int c = J * kSymT + 2 * lane;
     Cols2 cols;
@@ -106,17 +109,31 @@ __device__ __forceinline__ void nms_overlap3d_sym_tile(const float* __restrict__
         orow += ld;
         trow += kSymPitch;
     }
-    if (!mirror) return;                                              // (wave-uniform and workgroup-uniform)
-    __syncthreads();
-    // mirrored pass: output row = a column of the tile; its 128 entries = the tile's rows (all of them exist: I < J <= last tile).
-    // Lane l stores the entries of the local rows 2 l, 2 l + 1: one 512-byte run per instruction.
+}
+
+template <int NW, bool NT>
+__device__ __forceinline__ void sym_tile_mirror(int N, float* __restrict__ out, long ld, int I, int J, const float* __restrict__ tile) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int RW = kSymT / NW;
+    const int rl0 = wave * RW;
     const float* tcol = tile + (2 * lane) * kSymPitch + rl0;
     float* mrow = out + (size_t)(J * kSymT + rl0) * ld + I * kSymT + 2 * lane;
     const int ncols = min(RW, N - (J * kSymT + rl0));
     for (int k = 0; k < ncols; ++k) {
-        sym_store2<NT>(mrow, tcol[k], tcol[k + kSymPitch]);          // ds_read2_b32, offsets k and k + 129
+        sym_store2<NT>(mrow, tcol[k], tcol[k + kSymPitch]);
         mrow += ld;
     }
+}
+
+// one macro tile per workgroup (iou3d_sym_kernel)
+template <int NW, bool NT>
+__device__ __forceinline__ void nms_overlap3d_sym_tile(const float* __restrict__ rec, int N, float* __restrict__ out, long ld, int I, int J,
+                                                       float thr, float* __restrict__ tile) {
+    sym_tile_compute<NW, NT>(rec, N, out, ld, I, J, thr, tile);
+    if (I == J) return;                                               // (workgroup-uniform)
+    __syncthreads();
+    sym_tile_mirror<NW, NT>(N, out, ld, I, J, tile);
 }
 
 }  // namespace gnms_iou3d

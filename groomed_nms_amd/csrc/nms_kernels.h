@@ -484,8 +484,8 @@ __device__ __forceinline__ float4 load_nt_f4(const float* p) {
     return v;
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+template <bool VEC, int WAVES = kMaskWaves, int RB = kMaskRB>
+__global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                                                   float thr, char* ws, gnms_ws_layout L) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
     // column chunk rotated by the row block: with pre-sorted scores half the tiles exit below, and an un-rotated grid
     // would leave that work on every other XCD (blocks are dealt round-robin to the 8 XCDs)
     const int bx = (blockIdx.x + kb) % gridDim.x;
-    const int c0 = (bx * kMaskWaves + wave) * 256;
+    const int c0 = (bx * WAVES + wave) * 256;
     if (k0 >= n || c0 >= n) return;
     ImgPtrs I = img_ptrs(ws, L, b);
     const bool ident = I.misc[2] != 0;                                   // scores were already sorted: rank == input index
@@ -518,10 +518,10 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll 1
-        for (int rb = 0; rb < 32; rb += kMaskRB) {
-            float v[kMaskRB][4];
+        for (int rb = 0; rb < 32; rb += RB) {
+            float v[RB][4];
 #pragma unroll
-            for (int u = 0; u < kMaskRB; ++u) {
+            for (int u = 0; u < RB; ++u) {
                 const int row = __builtin_amdgcn_readlane(myrow, half * 32 + rb + u);
                 const float* p = m + (size_t)row * ld;
                 if (VEC) {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kMaskWaves * 64) void bitmask_kernel(const float* _
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kMaskRB; ++u) {
+            for (int u = 0; u < RB; ++u) {
                 const unsigned bit = 1u << (rb + u);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wd[half][j] |= !(v[u][j] <= thr) ? bit : 0u;   // lib/groomed_nms.py:250 (NaN -> removed)

@@ -12,6 +12,7 @@
 #include "gnms_prof.h"
 #include "iou_tile.h"
 #include "iou3d_tile.h"
+#include "iou3d_sym.h"
 #include "nms_solve_kernels.h"
 
 // defined in iou_kernels.hip
@@ -355,14 +356,32 @@ int check_common(const char* fn, int B, int N, int64_t ld, const gnms_params* P,
     return GNMS_OK;
 }
 
+// K2, the one full read of the matrix.  Workgroup shape and loads in flight per wave: GNMS_BITMASK_WAVES (8 | 16: 2048 or 4096 columns
+// side by side -- at N = 4096 sixteen waves read whole 16-KiB rows), GNMS_BITMASK_RB (8 | 16 one-KiB loads in flight per wave).
+int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
+    // (measured at B = 8, N = 4096, three interleaved repetitions: 16 waves 91.6-91.8 us = 0.733 of the HBM peak, 8 waves 95.2-95.7 us;
+    // 16 loads in flight per wave change nothing either way)
+    static const int forced_waves = [] { const char* e = getenv("GNMS_BITMASK_WAVES"); return e ? atoi(e) : 0; }();
+    const int waves = forced_waves ? forced_waves : (N >= 4096 ? 16 : kMaskWaves);
+    static const int rbf = [] { const char* e = getenv("GNMS_BITMASK_RB"); return e ? atoi(e) : kMaskRB; }();
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
+#define GNMS_BITMASK(V, W, R)                                                                                                         \
+    gnms_launch_prof(kProfMatrixRead, bitmask_kernel<V, W, R>, dim3(gnms_div_up(N, W * 256), L.NB, B), dim3(W * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L)
+    if (!vec) GNMS_BITMASK(false, kMaskWaves, kMaskRB);
+    else if (waves == 16 && rbf == 16) GNMS_BITMASK(true, 16, 16);
+    else if (waves == 16) GNMS_BITMASK(true, 16, 8);
+    else if (rbf == 16) GNMS_BITMASK(true, 8, 16);
+    else GNMS_BITMASK(true, 8, 8);
+#undef GNMS_BITMASK
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
 // grouping pipeline K2..K4 (shared by gnms_forward and gnms_get_groups)
 int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L,
                  hipStream_t st) {
-    const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
-    dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
-    if (vec) gnms_launch_prof(kProfMatrixRead, bitmask_kernel<true>, gm, dim3(kMaskWaves * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L);
-    else gnms_launch_prof(kProfMatrixRead, bitmask_kernel<false>, gm, dim3(kMaskWaves * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L);
-    GNMS_CHECK_LAUNCH();
+    int rc0 = launch_bitmask(iou, B, N, ld, counts, thr, ws, L, st);
+    if (rc0) return rc0;
     const size_t lds = leaders_lds_bytes(N);
     int rc = allow_lds(leaders_kernel, lds);
     if (rc) return rc;
@@ -587,6 +606,41 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
     }
 }
 
+// SYMMETRIC writers (3D, round 3): the write role of tail_write_kernel for the cuboid overlap -- every unordered pair evaluated once
+// (iou3d_sym.h), the all-pairs 3D writers being VALU-bound at the one workgroup per CU this launch runs at (3.2e).  A persistent
+// 16-wave workgroup claims 128 x 128 macro tiles (upper triangle of every image, image-major) one claim ahead and alternates between
+// TWO LDS tiles, so that ONE barrier per macro tile suffices: it publishes the tile for the mirrored pass AND the next claim, and the
+// waves that finish their mirrored stores early already compute the next tile into the other buffer.
+template <bool NT>
+__device__ __forceinline__ void writers_sym_persistent(const float* __restrict__ rec, int N, float* __restrict__ out, long ld, int nimg, float thr,
+                                                       int* counter) {
+    using namespace gnms_iou3d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const tile0 = reinterpret_cast<float*>(smem);           // two LDS macro tiles, kSymTileBytes apart
+    __shared__ int s_next[2];
+    const int nt = (N + kSymT - 1) / kSymT;
+    const int tpi = sym_tiles_per_image(N), total = tpi * nimg;
+    if (threadIdx.x == 0) s_next[0] = atomicAdd(counter, 1);
+    __syncthreads();
+    int cur = s_next[0], ph = 0;
+    while (cur < total) {
+        int nx = 0;
+        if (threadIdx.x == 0) nx = atomicAdd(counter, 1);          // the claim after this one, in flight during the tile
+        const int img = cur / tpi;
+        int I, J;
+        sym_tile_of(cur - img * tpi, nt, &I, &J);
+        const float* r = rec + (size_t)img * N * kRec;
+        float* o = out + (size_t)img * N * ld;
+        float* const tile = tile0 + (size_t)ph * (kSymTileBytes / sizeof(float));
+        sym_tile_compute<16, NT>(r, N, o, ld, I, J, thr, tile);
+        if (threadIdx.x == 0) s_next[ph ^ 1] = nx;
+        __syncthreads();                                            // the tile is in LDS, the next claim is known; buffer ph ^ 1 is free
+        if (I != J) sym_tile_mirror<16, NT>(N, o, ld, I, J, tile);
+        ph ^= 1;
+        cur = s_next[ph];
+    }
+}
+
 // LARGE images (N > 4096): the matrix write as a launch of its own on the side stream (3.2d), in the same geometry -- persistent
 // workgroups of 16 waves, 8 rows x 256 columns per wave -- because that geometry is what the store stream likes: a plain fill written
 // this way reaches 5.7-5.8 TB/s at N = 4096 ... 16384 where a linear grid-stride fill and gnms_iou2d's 64-row tiles reach 4.6-4.8
@@ -711,6 +765,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         return;
     }
     if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, ws, L); return; }
+    if (SRC == kFromRecords && staged == 2) { writers_sym_persistent<true>(write_src, N, out, ld, nimg, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5); return; }
     writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
 }
 
@@ -798,6 +853,14 @@ int fused_tile_rows() {
     return tr > 64 ? 64 : tr;
 }
 
+// 3D: the write role of that launch as symmetric writers (writers_sym_persistent) -- from N = 1024 on, where an image has enough
+// macro tiles; GNMS_3D_SYM_TAIL=0/1 forces.
+bool sym_writers_in_tail_launch(int N, int64_t ld, const float* out) {
+    static const int forced = [] { const char* e = getenv("GNMS_3D_SYM_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (!gnms_internal_overlap3d_sym_ok(N, ld, out)) return false;
+    return forced >= 0 ? forced == 1 : N > 2048;
+}
+
 // K3..K6 of every image + the matrix in one launch (tail_write_kernel)
 template <int SRC>
 int launch_tail_write(const float* chain_src, const float* write_src, int B, int N, const int32_t* counts, const gnms_params& P, char* ws,
@@ -808,9 +871,14 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
     size_t lds = llds > glds ? llds : glds;
     const int tr = fused_tile_rows();
-    const int staged = (SRC == kFromBoxes && N <= 4096 && writers_staged()) ? 1 : 0;   // writers_staged_2d: the image's boxes in LDS
+    int staged = (SRC == kFromBoxes && N <= 4096 && writers_staged()) ? 1 : 0;   // writers_staged_2d: the image's boxes in LDS
     if (staged && lds < (size_t)N * 16) lds = (size_t)N * 16;
     long writers = write_chunk_count(N, B, tr, 0, N);                // persistent writers: at most one per CU
+    if (SRC == kFromRecords && sym_writers_in_tail_launch(N, ld, out)) {   // writers_sym_persistent: two LDS macro tiles
+        staged = 2;
+        if (lds < 2 * gnms_iou3d::kSymTileBytes) lds = 2 * gnms_iou3d::kSymTileBytes;
+        writers = (long)gnms_iou3d::sym_tiles_per_image(N) * B;
+    }
     const int cus = device_cu_count();
     if (writers > cus) writers = cus;
     const dim3 grid((unsigned)(B + writers));
@@ -854,11 +922,7 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     if (!scores_already_sorted && (rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
 
     if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N)) {
-        const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
-        dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
-        if (vec) gnms_launch_prof(kProfMatrixRead, bitmask_kernel<true>, gm, dim3(kMaskWaves * 64), 0, st, iou, N, (long)ld, counts, P.nms_threshold, ws, L);
-        else gnms_launch_prof(kProfMatrixRead, bitmask_kernel<false>, gm, dim3(kMaskWaves * 64), 0, st, iou, N, (long)ld, counts, P.nms_threshold, ws, L);
-        GNMS_CHECK_LAUNCH();
+        if ((rc = launch_bitmask(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;
         return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 0);
     }
     if (P.group_boxes) {
@@ -1041,6 +1105,7 @@ bool chain_rides_in_write_launch(int B, int N) {
 extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (B <= 0 || N <= 0) return "";
     if (dim == 3 && sym_write_beside_3d(B, N, N, nullptr)) return "iou3d_sym_kernel";
+    if (dim == 3 && chain_rides_in_write_launch(B, N) && sym_writers_in_tail_launch(N, N, nullptr)) return "tail_write_kernel";
     if (dim == 3 && bits_in_write_3d(N)) return "iou3d_bits_kernel";
     if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : (writers_staged() && N % 4 == 0 ? "write_staged_kernel" : "iou2d_kernel");
     if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
@@ -1222,7 +1287,11 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     float* xkeys = rec + (size_t)B * N * gnms_iou3d::kRec;         // [B][N] pseudo boxes; later the rank-ordered records
     if ((rc = gnms_internal_records_for_layer(params3d, B, N, rec, ws, L, xkeys, st))) return rc;
     const bool sym_beside = sym_write_beside_3d(B, N, ld, iou_out);
-    if (!sym_beside && bits_in_write_3d(N)) {
+    // 2048 < N, no side stream: K3..K6 ride in the launch of the SYMMETRIC writers (tail_write_kernel, writers_sym_persistent) behind
+    // the from-records bit-matrix kernel, instead of running serially behind a write kernel that also produces the bits
+    const bool culled_bits = P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY;
+    const bool sym_tail = !sym_beside && culled_bits && chain_rides_in_write_launch(B, N) && sym_writers_in_tail_launch(N, ld, iou_out);
+    if (!sym_beside && !sym_tail && bits_in_write_3d(N)) {
         // score sort -> records in rank order -> ONE pass over all pairs writes the matrix and the bit matrix -> K3..K6
         float* recs = xkeys;
         const int P2s = next_pow2(N);
@@ -1261,7 +1330,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     // K3..K6 inside the write launch like the 2D entry -- up to N = 2048 only: the 3D writers are VALU-bound (23 slots per pair) and
     // at the one workgroup per CU that launch runs at they lose more than the overlap buys (B = 8, N = 4096: launch 166 us against a
     // 107-us write + 55-us chain, step 0.264 against 0.248 ms; N = 2048: 0.117 against 0.163 ms)
-    const bool chain_in_write = !beside && sym && N <= 2048 && chain_rides_in_write_launch(B, N);
+    const bool chain_in_write = !beside && sym && (N <= 2048 || sym_tail) && chain_rides_in_write_launch(B, N);
     if (!beside && !chain_in_write && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st, P.nms_threshold))) return rc;
     const int P2 = next_pow2(N);
     if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
@@ -1551,12 +1620,7 @@ extern "C" int gnms_profile_bitmask(const float* iou, int B, int N, int64_t ld, 
     if (rc) return rc;
     if (B == 0 || N == 0) return GNMS_OK;
     const gnms_ws_layout L = gnms_make_layout(N);
-    const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
-    dim3 gm(gnms_div_up(N, kMaskWaves * 256), L.NB, B);
-    if (vec) gnms_launch_prof(kProfMatrixRead, bitmask_kernel<true>, gm, dim3(kMaskWaves * 64), 0, (hipStream_t)stream, iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
-    else gnms_launch_prof(kProfMatrixRead, bitmask_kernel<false>, gm, dim3(kMaskWaves * 64), 0, (hipStream_t)stream, iou, N, (long)ld, counts, nms_threshold, (char*)workspace, L);
-    GNMS_CHECK_LAUNCH();
-    return GNMS_OK;
+    return launch_bitmask(iou, B, N, ld, counts, nms_threshold, (char*)workspace, L, (hipStream_t)stream);
 }
 
 extern "C" int gnms_profile_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float nms_threshold, void* workspace,
