@@ -9,6 +9,7 @@
 // The C @ iou product is the one dense GEMM on the whole GrooMeD path (2 N^3 flop): it runs on the
 // matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32, = an fmaf chain), 128x128x16 LDS tiles,
 // one wave per 64x64 quadrant (2x2 MFMA tiles, 64 accumulator registers).
+#include <type_traits>
 #include "nms_kernels.h"
 
 namespace {
@@ -159,6 +160,116 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// The large-matrix GEMM (round 3): 256 x 128 block tile, K step 16, 4 waves each owning a 128 x 64 quadrant = 4 x 2 MFMA 32x32 tiles
+// (128 accumulator registers; with the staging and fragment registers a wave stays under 256, so TWO workgroups share a CU and one
+// covers the other's barrier).  What the 128 x 128 kernel above leaves on the table (64 % of the fp32 MFMA peak at 4096^3) is traffic
+// per MFMA: a wave there reads 4 LDS fragments for every 4 MFMAs and the workgroup 32 KiB from L2 per K tile of 64 MFMAs; here
+// 6 fragments feed 8 MFMAs (512 matrix-pipe cycles per K step of 2) and a CU pulls 25 % fewer bytes per flop.
+//   * LDS is double buffered (one barrier per K tile): tile t+1 is staged into the other buffer while tile t is multiplied;
+//   * the global loads of tile t+2 are issued before the MFMAs of tile t (registers): two tiles of slack for the L2 / HBM latency;
+//   * the fragments of K step s+1 are read before the 8 MFMAs of step s issue.
+// (A 256 x 256 tile with 256 accumulators per wave was tried first: the compiler reads all accumulators into VGPRs for the epilogue,
+// and its register allocator then spills the main loop's prefetch registers -- a load, a wait and a scratch store per 16 bytes.)
+// Interior tiles only (M multiple of 256, N of 128, K of 16, 16-byte aligned rows): everything else takes the kernel above.
+// D = A B or D += A B; fp32 exact products and sums in MFMA order (fmaf chain along K), like the kernel above.
+// ------------------------------------------------------------------------------------------------
+constexpr int GM = 256, GN = 128, GK = 16, GLA = 20, GLB = 132;      // LDS row pitches (floats): As[m][k] rows of 16 + 4, Bs[k][n] rows of 128 + 4
+
+// K order inside a tile: MFMA step j multiplies k = j (lanes 0-31) and k = 8 + j (lanes 32-63) -- any pairing that covers the 16 k of a
+// tile once is a valid order of the sum, and this one lets a lane take its eight A values of a row as TWO 16-byte LDS reads from a
+// row-major copy of the A tile, which in turn is staged with plain 16-byte LDS writes of the 16-byte global loads: no element of a
+// loaded vector is ever moved (with a k-major copy the compiler shuffled the components right behind the loads and waited for them
+// there: the prefetch of tile t+2 stalled every tile).
+__global__ __launch_bounds__(256, 2) void sgemm_mfma_big_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D,
+                                                                int K, long lda, long ldb, long ldd, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float As[2][GM][GLA];     // As[buf][m][k]
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLB];     // Bs[buf][k][n]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long m0 = (long)blockIdx.y * GM, n0 = (long)blockIdx.x * GN;
+    const int wm = (wave >> 1) * 128, wn = (wave & 1) * 64;
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    // global -> registers: A: row tid of the tile, its 16 k values (4 float4); B: k rows tid / 32 and + 8, columns 4 (tid % 32) .. (2 float4)
+    const float* ap = A + (m0 + tid) * lda;
+    const float* bp = Bm + (long)(tid >> 5) * ldb + n0 + 4 * (tid & 31);
+    float4 ra0, ra1, ra2, ra3, rb0, rb1;
+    auto fetch = [&](int k0) {
+        ra0 = *reinterpret_cast<const float4*>(ap + k0);
+        ra1 = *reinterpret_cast<const float4*>(ap + k0 + 4);
+        ra2 = *reinterpret_cast<const float4*>(ap + k0 + 8);
+        ra3 = *reinterpret_cast<const float4*>(ap + k0 + 12);
+        rb0 = *reinterpret_cast<const float4*>(bp + (long)k0 * ldb);
+        rb1 = *reinterpret_cast<const float4*>(bp + (long)(k0 + 8) * ldb);
+    };
+    const int kh = lane >> 5, l31 = lane & 31;
+    auto tile = [&](auto bufc, int t, int nk) {
+        constexpr int buf = decltype(bufc)::value;
+        // tile t+1 (in registers since the previous tile) goes to the other LDS buffer; tile t+2 is requested
+        if (t + 1 < nk) {
+            float4* arow = reinterpret_cast<float4*>(&As[buf ^ 1][tid][0]);
+            arow[0] = ra0; arow[1] = ra1; arow[2] = ra2; arow[3] = ra3;
+            *reinterpret_cast<float4*>(&Bs[buf ^ 1][tid >> 5][4 * (tid & 31)]) = rb0;
+            *reinterpret_cast<float4*>(&Bs[buf ^ 1][(tid >> 5) + 8][4 * (tid & 31)]) = rb1;
+        }
+        if (t + 2 < nk) fetch((t + 2) * GK);
+        // the lane's eight k values (k = 8 kh .. 8 kh + 7) of its row in each of the four row tiles: two 16-byte reads each
+        float4 fa[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4* arow = reinterpret_cast<const float4*>(&As[buf][wm + 32 * u + l31][8 * kh]);
+            fa[u][0] = arow[0]; fa[u][1] = arow[1];
+        }
+        auto a_of = [&](int u, int j) { const float4 v = fa[u][j >> 2]; return (j & 3) == 0 ? v.x : (j & 3) == 1 ? v.y : (j & 3) == 2 ? v.z : v.w; };
+        float fb[2][2];
+        fb[0][0] = Bs[buf][8 * kh][wn + l31]; fb[0][1] = Bs[buf][8 * kh][wn + 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < 8) { fb[cur ^ 1][0] = Bs[buf][8 * kh + j + 1][wn + l31]; fb[cur ^ 1][1] = Bs[buf][8 * kh + j + 1][wn + 32 + l31]; }
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_of(ta, j), fb[cur][tb], acc[ta][tb], 0, 0, 0);
+        }
+        __syncthreads();                                              // everyone is done with `buf`; buffer buf ^ 1 is complete
+    };
+    const int nk = K / GK;                                            // even (K % 32 == 0): tiles in pairs, the LDS buffer of every access a constant
+    fetch(0);
+    {
+        float4* arow = reinterpret_cast<float4*>(&As[0][tid][0]);
+        arow[0] = ra0; arow[1] = ra1; arow[2] = ra2; arow[3] = ra3;
+        *reinterpret_cast<float4*>(&Bs[0][tid >> 5][4 * (tid & 31)]) = rb0;
+        *reinterpret_cast<float4*>(&Bs[0][(tid >> 5) + 8][4 * (tid & 31)]) = rb1;
+    }
+    fetch(GK);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < nk; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t, nk);
+        tile(std::integral_constant<int, 1>{}, t + 1, nk);
+    }
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* dbase = D + (m0 + wm + 4 * kh) * ldd + n0 + wn + l31;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            float* dt = dbase + (long)(ta * 32) * ldd + tb * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* d = dt + (long)((r & 3) + 8 * (r >> 2)) * ldd;
+                *d = accumulate ? (*d + acc[ta][tb][r]) : acc[ta][tb][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Adjoint of soft_sort (the reference differentiates lib/groomed_nms.py:145-164 with autograd).  With
 //   A[i][j] = -|s_j - shat_i|,  E = exp((A - rowmax A) / T),  Z[i] = sum_j E[i][j] + 1e-3,  C[i][j] = E[i][j] / Z[j]  (:155),
 //   soft_scores = C s,  soft_matrix = C M
@@ -291,8 +402,14 @@ __global__ __launch_bounds__(256) void softsort_bwd_cols2_kernel(const float* __
 int launch_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd, int accumulate,
                  hipStream_t st) {
     if (M == 0 || N == 0) return GNMS_OK;
-    dim3 grid(gnms_div_up(N, BN), gnms_div_up(M, BM));
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
+    static const int big = [] { const char* e = getenv("GNMS_SGEMM_BIG"); return e ? atoi(e) : 1; }();
+    if (big && aligned && M % GM == 0 && N % GN == 0 && K % (2 * GK) == 0 && K >= 2 * GK && (long)(M / GM) * (N / GN) >= 256) {
+        sgemm_mfma_big_kernel<<<dim3(N / GN, M / GM), 256, 0, st>>>(A, B, D, K, (long)lda, (long)ldb, (long)ldd, accumulate);
+        GNMS_CHECK_LAUNCH();
+        return GNMS_OK;
+    }
+    dim3 grid(gnms_div_up(N, BN), gnms_div_up(M, BM));
     if (aligned) sgemm_mfma_kernel<true><<<grid, 256, 0, st>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd, accumulate);
     else sgemm_mfma_kernel<false><<<grid, 256, 0, st>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd, accumulate);
     GNMS_CHECK_LAUNCH();
