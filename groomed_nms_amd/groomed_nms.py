@@ -486,13 +486,17 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
     if debug:
         print("\nInside diff NMS... After sorting")
         print(non_suppression_prob)
+    # the two counts as ONE tensor without a kernel: nvalid / ninvalid are the two rows of one [2, B] allocation (_outputs, torch_binding.cpp)
+    base = getattr(nvalid, "_base", None)
+    pair = base[:, 0] if (base is not None and base.dim() == 2 and base.shape[0] == 2 and base.shape[1] == nvalid.shape[0]
+                          and ninvalid.data_ptr() == base[1].data_ptr()) else None
     if out_device == dev and LAZY_INDEX_LISTS and n > 0:
         # GPU tensors in: the two index lists have a data-dependent length K, which only the host can turn into a tensor shape.  They
         # come back as LazyIndexList objects that hold the padded device list and its device-side count and become real tensors on
         # first use -- training reads only the probabilities (lib/loss/rpn_3d.py:791 takes `[2]`), so its step never waits for the GPU.
-        both = torch.stack([nvalid[0], ninvalid[0]])
+        both = pair if pair is not None else torch.stack([nvalid[0], ninvalid[0]])
         return (LazyIndexList(valid[0], both, 0, indices), LazyIndexList(invalid[0], both, 1, indices), non_suppression_prob)
-    counts = torch.stack([nvalid[0], ninvalid[0]]).tolist() if n > 0 else [0, 0]   # the one host sync: K is data dependent
+    counts = (pair if pair is not None else torch.stack([nvalid[0], ninvalid[0]])).tolist() if n > 0 else [0, 0]   # the one host sync: K is data dependent
     valid_boxes_index = valid[0, :counts[0]]
     invalid_boxes_index = invalid[0, :counts[1]]
     if indices is not None:

@@ -4,6 +4,8 @@
 #   <tag>_pmc_summary.json                               HBM traffic per launch (tools/pmc.sh), fed back into the bench line's roofline.traffic
 #   <tag>_grid.jsonl                                     N in {256,1024,4096,16384} x {clustered,uniform} (+ 3D at 4096/16384)
 #   <tag>_uniform4096_kernel_stats.csv                   kernel stats of the uniform N=4096 run
+#   <tag>_dim3_n16384_kernel_stats.csv                   kernel stats of the 3D N=16384 run
+#   <tag>_store_geometry.jsonl, _small_n.jsonl, _sgemm_mfma.txt   store-pattern ceilings, host cost of the small-N regime, the fp32 MFMA GEMM
 export TMPDIR=/tmp
 T=$1
 O=gpurun_out/profiles_$T
@@ -14,6 +16,10 @@ python bench.py --steps 200 --warmup 20 --pmc-summary $O/${T}_pmc_summary.json >
 bash tools/prof.sh ${T}_main --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind > $O/prof_main.txt 2>&1
 cp gpurun_out/prof_${T}_main/bench_kernel_stats.csv $O/${T}_bench_kernel_stats.csv
 tail -1 gpurun_out/prof_${T}_main/bench_stdout.txt > $O/${T}_bench_under_rocprof.json
+bash tools/prof.sh ${T}_d3 --steps 30 --warmup 5 --no-cpu-baseline --no-other-kind --dim 3 --boxes 16384 > $O/prof_d3.txt 2>&1
+cp gpurun_out/prof_${T}_d3/bench_kernel_stats.csv $O/${T}_dim3_n16384_kernel_stats.csv
+bash tools/prof.sh ${T}_d34k --steps 100 --warmup 5 --no-cpu-baseline --no-other-kind --dim 3 > $O/prof_d34k.txt 2>&1
+cp gpurun_out/prof_${T}_d34k/bench_kernel_stats.csv $O/${T}_dim3_n4096_kernel_stats.csv
 bash tools/prof.sh ${T}_uni --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind --kind uniform > $O/prof_uni.txt 2>&1
 cp gpurun_out/prof_${T}_uni/bench_kernel_stats.csv $O/${T}_uniform4096_kernel_stats.csv
 tail -1 gpurun_out/prof_${T}_uni/bench_stdout.txt > $O/${T}_uniform4096_bench_under_rocprof.json
@@ -30,6 +36,14 @@ python bench.py --two-calls --steps 100 --warmup 10 --no-other-kind --cpu-second
 for n in 512 1024 2048; do python bench.py --graph --boxes $n --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/${T}_graph.jsonl; done
 python tools/kernel_times.py > $O/${T}_kernel_times.txt 2>/dev/null
 python tools/kernel_times.py --boxes 16384 --reps 10 >> $O/${T}_kernel_times.txt 2>/dev/null
+GNMS_3D_SYM=0 python tools/kernel_times.py 2>/dev/null | grep "3D NMS" >> $O/${T}_kernel_times.txt
+GNMS_3D_SYM=0 python tools/kernel_times.py --boxes 16384 --reps 10 2>/dev/null | grep "3D NMS" >> $O/${T}_kernel_times.txt
+python tools/store_geometry.py 2>/dev/null | grep "^{" > $O/${T}_store_geometry.jsonl
+python tools/store_geometry.py --boxes 16384 2>/dev/null | grep "^{" >> $O/${T}_store_geometry.jsonl
+python tools/small_n.py 2>/dev/null | grep "^{" > $O/${T}_small_n.jsonl
+GNMS_BINDING=ctypes python tools/small_n.py 2>/dev/null | grep "^{" >> $O/${T}_small_n.jsonl
+python tools/sgemm_time.py 1024 2048 4096 8192 2>/dev/null | grep "sgemm\|soft_sort" > $O/${T}_sgemm_mfma.txt
+bash tools/sgemm_pmc.sh 4096 >> $O/${T}_sgemm_mfma.txt 2>/dev/null
 python tools/aploss_time.py > $O/${T}_aploss_times.jsonl 2>/dev/null
 python tools/e2e_bench.py --mode infer --steps 10 2>/dev/null | tail -1 > $O/${T}_e2e.jsonl
 python tools/e2e_bench.py --mode train --steps 10 2>/dev/null | tail -1 >> $O/${T}_e2e.jsonl
