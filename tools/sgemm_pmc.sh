@@ -1,12 +1,13 @@
 #!/bin/bash
-# PMC passes over the fp32 MFMA GEMM (one counter group per pass, --kernel-trace only)
+# PMC passes over the fp32 MFMA GEMM (one counter group per pass, --kernel-trace only).  usage: tools/sgemm_pmc.sh [n | M N K]
+# (SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs and saturates at 2^31: 4096^3 overflows it -- use e.g. 4096 2048 1024)
 export TMPDIR=/tmp
 R=$PWD
 for C in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "MemUnitStalled" "LDSBankConflict" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES"; do
   T=$(echo $C | tr " " "_")
   mkdir -p $R/gpurun_out/pmc_gemm_$T
   cd /tmp
-  rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_gemm_$T -o pmc --output-format csv -- python $R/tools/sgemm_only.py ${1:-4096} > /dev/null 2>&1 || true
+  rocprofv3 --pmc $C --kernel-trace -d $R/gpurun_out/pmc_gemm_$T -o pmc --output-format csv -- python $R/tools/sgemm_only.py ${@:-4096} > /dev/null 2>&1 || true
   cd $R
   python - "$T" <<'PY'
 import csv, glob, sys, collections
