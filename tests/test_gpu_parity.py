@@ -1417,12 +1417,12 @@ def test_ungrouped_mode_with_a_tight_workspace(G, O):
         np.testing.assert_allclose(gs.cpu().numpy(), ref["grad_scores"], atol=5e-4, rtol=1e-3)
 
 
-def _run_py(code, env_extra, timeout=600):
+def _run_py(code, env_extra, timeout=600, argv=()):
     import os, subprocess, sys
     env = dict(os.environ)
     env.update(env_extra)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    return subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    return subprocess.run([sys.executable, "-c", code] + list(argv), cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
 
 
 def test_rccl_single_rank_plumbing():
@@ -1578,6 +1578,57 @@ def test_float64_numpy_call_site(G, golden_f64site):
         json.dump(rec, f)
     print("f64site:", rec)
     assert set_diff_same_corners == 0 and set_diff <= 3 and max_dprob <= 1e-4, rec
+
+
+def test_ctypes_binding_still_serves_the_layer():
+    """The layer's default host path is the C++ binding (gnms_torch); the ctypes + torch.autograd.Function path over the same C ABI is
+    the fallback (GNMS_BINDING=ctypes).  Both must give the oracle's results: a child process runs the four batched entries through
+    ctypes -- forward, index lists, backward -- and compares them bit for bit with what this process gets through the binding."""
+    import os, subprocess, sys, tempfile
+    from groomed_nms_amd import synthetic, groomed_nms as GN, overlaps
+    assert GN._binding(), "the C++ binding is not in use in this process"
+    code = """
+import sys, numpy as np, torch
+from groomed_nms_amd import synthetic, groomed_nms as GN, overlaps
+assert not GN._binding()
+b, s = synthetic.batch_2d(77, 3, 700, "clustered", per=20)
+p3, s3 = synthetic.batch_3d(78, 2, 600, clustered=True, per=12)
+out = {}
+def run(tag, fn, sc, *a, **kw):
+    st = torch.from_numpy(sc).cuda().requires_grad_(True)
+    o = fn(st, *a, **kw)
+    (o[0] * torch.linspace(-1, 2, sc.shape[1], device="cuda")).sum().backward()
+    out[tag + "/prob"] = o[0].detach().cpu().numpy(); out[tag + "/valid"] = o[2].cpu().numpy(); out[tag + "/nv"] = o[4].cpu().numpy()
+    out[tag + "/grad"] = st.grad.cpu().numpy()
+bt = torch.from_numpy(b).cuda()
+run("with2d", GN.differentiable_nms_with_iou2d_batched, s, bt)
+run("boxes", GN.differentiable_nms_from_boxes_batched, s, bt)
+run("matrix", GN.differentiable_nms_batched, s, overlaps.iou_batched(bt))
+run("unmasked", GN.differentiable_nms_batched, s, overlaps.iou_batched(bt), mask_group_boxes=False)
+run("with3d", GN.differentiable_nms_with_iou3d_batched, s3, torch.from_numpy(p3).cuda())
+np.savez(sys.argv[1], **out)
+"""
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "ctypes.npz")
+        r = _run_py(code, {"GNMS_BINDING": "ctypes"}, argv=[path])
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        ref = np.load(path)
+        b, s = synthetic.batch_2d(77, 3, 700, "clustered", per=20)
+        p3, s3 = synthetic.batch_3d(78, 2, 600, clustered=True, per=12)
+        bt = torch.from_numpy(b).cuda()
+
+        def run(tag, fn, sc, *a, **kw):
+            st = torch.from_numpy(sc).cuda().requires_grad_(True)
+            o = fn(st, *a, **kw)
+            (o[0] * torch.linspace(-1, 2, sc.shape[1], device="cuda")).sum().backward()
+            assert np.array_equal(o[0].detach().cpu().numpy(), ref[tag + "/prob"], equal_nan=True), tag
+            assert np.array_equal(o[2].cpu().numpy(), ref[tag + "/valid"]) and np.array_equal(o[4].cpu().numpy(), ref[tag + "/nv"]), tag
+            assert np.array_equal(st.grad.cpu().numpy(), ref[tag + "/grad"]), tag
+        run("with2d", GN.differentiable_nms_with_iou2d_batched, s, bt)
+        run("boxes", GN.differentiable_nms_from_boxes_batched, s, bt)
+        run("matrix", GN.differentiable_nms_batched, s, overlaps.iou_batched(bt))
+        run("unmasked", GN.differentiable_nms_batched, s, overlaps.iou_batched(bt), mask_group_boxes=False)
+        run("with3d", GN.differentiable_nms_with_iou3d_batched, s3, torch.from_numpy(p3).cuda())
 
 
 def test_n_rank_launcher_end_to_end():
