@@ -586,7 +586,10 @@ __device__ __forceinline__ float wave_max_f(float v) { return gnms_wave_max_f(v)
 // row W[kb][.] (indexed by column rank) and leave as one coalesced write of the 64 (kb+1) words a leader scan can read.  Without it
 // every lane scatters its 8-byte words to global memory: 1 M scattered stores per launch at B=8, N=4096 = ~15 us of store
 // throughput, about a third of it exposed.
-template <int CPL, int KBW, bool ROWBUF>
+// CHUNKLOOP (ROWBUF, N > 4096): a wave walks the column chunks wave, wave + 16, ... of its rank block (at N = 16384 four of them), all
+// into the one LDS row of N words (128 KiB), which then leaves as one coalesced write: since round 2 the rows of W are stored in full
+// (the scan pulls), so the scatter version issues N^2 / 64 scattered 8-byte stores per image -- 256 MB per step at B = 8, N = 16384.
+template <int CPL, int KBW, bool ROWBUF, bool CHUNKLOOP = false>
 __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ boxes, int N, const int* __restrict__ counts, float thr, char* ws,
                                                    gnms_ws_layout L, const int b, const int bx) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -602,13 +605,15 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
         for (int i = threadIdx.x; i < L.NC; i += blockDim.x) rowbuf[i] = 0ull;
         __syncthreads();
     }
+    const int nwaves = blockDim.x >> 6;
+    for (int cq = 0; cq < (CHUNKLOOP ? (nchunk + nwaves - 1) / nwaves : 1); ++cq) {
     const int tile = ROWBUF ? bx * nchunk + wave : bx * 4 + wave;
     const int kbg = ROWBUF ? bx : tile / nchunk;        // kbg = group of KBW consecutive rank blocks
-    const int chunk = ROWBUF ? wave : tile - kbg * nchunk;           // ROWBUF: <= 16 chunks, one per wave
+    const int chunk = ROWBUF ? wave + cq * nwaves : tile - kbg * nchunk;   // ROWBUF: one chunk per wave (CHUNKLOOP: every 16th)
     const int c0 = chunk * kCols;
     const bool idle = (kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n || chunk >= nchunk);   // (ragged images)
     if (!ROWBUF && idle) return;
-    if (!idle) {                                                     // (a chunk LOOP here cost 25 % in code quality: 24.5 -> 31 us)
+    if (!idle) {                                                     // (a chunk LOOP here cost 25 % in code quality at N = 4096: 24.5 -> 31 us)
     const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * N;
     // the row boxes of the first rank block are requested before the column side is worked on, so that their two dependent loads
     // (order -> box) overlap the column gathers
@@ -699,6 +704,7 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
             if (crank[j] != 0x7fffffff) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
     }
     }   // !idle
+    }   // chunks of this wave
     if (ROWBUF) {
         __syncthreads();
         u64* Wk = I.W + (size_t)bx * L.NC;
@@ -706,10 +712,10 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     }
 }
 
-template <int CPL, int KBW, bool ROWBUF = false>
+template <int CPL, int KBW, bool ROWBUF = false, bool CHUNKLOOP = false>
 __global__ __launch_bounds__(ROWBUF ? 1024 : 256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
                                                             float thr, char* ws, gnms_ws_layout L) {
-    bitmask_boxes_body<CPL, KBW, ROWBUF>(boxes, N, counts, thr, ws, L, (int)blockIdx.z, (int)blockIdx.x);
+    bitmask_boxes_body<CPL, KBW, ROWBUF, CHUNKLOOP>(boxes, N, counts, thr, ws, L, (int)blockIdx.z, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -868,6 +874,10 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
             if (crank[j] != 0x7fffffff) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
     }
 }
+
+// (Round 3 tried this kernel with the LDS row buffer that won for the 2D boxes at large N -- one 16-wave workgroup per rank block, the
+// full row of W written coalesced: at 106 VGPRs only one such workgroup fits a CU and the record gathers of the column side are exposed:
+// B = 8, N = 16384 step 2.20 -> 2.33 ms, N = 8192 0.593 -> 0.616.  The scatter kernel stays.)
 
 // ------------------------------------------------------------------------------------------------
 // K3: leaders (= the boxes classical greedy NMS keeps).  The scan is inherently sequential over rank

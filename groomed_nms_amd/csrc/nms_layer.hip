@@ -774,7 +774,17 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
 int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
     const int NB = (N + 63) / 64;
     const long long tiles4 = (long long)B * NB * ((N + 255) / 256);
-    if (tiles4 >= 32768) {                          // large images: 4 rank blocks per wave (column side paid once per 256 rows;
+    static const int rowbuf_big = [] { const char* e = getenv("GNMS_BITS_ROWBUF_BIG"); return e ? atoi(e) : 1; }();
+    if (rowbuf_big && tiles4 >= 32768 && (size_t)L.NC * 8 <= 136 * 1024) {
+        // large images (round 3): the LDS row buffer with a chunk loop -- one 16-wave workgroup per rank block, its waves walking the
+        // column chunks, the full row of W leaving as ONE coalesced write.  In round 1 (only the triangle of W stored) the scatter
+        // kernel below was faster (220 vs 297 us at N = 16384); with full rows it issues N^2 / 64 scattered 8-byte stores per image
+        // and loses: B = 8, N = 16384 step 1.907 -> 1.798 ms (uniform 1.997 -> 1.798), N = 8192 0.519 -> 0.496.  GNMS_BITS_ROWBUF_BIG=0 restores it.
+        const size_t lds = (size_t)L.NC * 8;
+        int rc = allow_lds(bitmask_boxes_kernel<4, 1, true, true>, lds);
+        if (rc) return rc;
+        bitmask_boxes_kernel<4, 1, true, true><<<dim3(NB, 1, B), 1024, lds, st>>>(boxes, N, counts, thr, ws, L);
+    } else if (tiles4 >= 32768) {                   // large images: 4 rank blocks per wave (column side paid once per 256 rows;
                                                     // the LDS row buffer measured slower there: 87 vs 73 us at N=8192, 297 vs 220 at 16384)
         bitmask_boxes_kernel<4, 4><<<dim3(gnms_div_up(((NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
     } else if (tiles4 >= 2048 && (N + 255) / 256 <= 16) {
