@@ -1098,7 +1098,10 @@ bool bits_in_write_3d(int N) {
 bool sym_write_beside_3d(int B, int N, int64_t ld, const float* out) {
     static const int forced = [] { const char* e = getenv("GNMS_3D_SYM_LAYER"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (!gnms_internal_overlap3d_sym_ok(N, ld, out)) return false;
-    return forced >= 0 ? forced == 1 : use_side_stream(B, N, ld);
+    // (default off since the symmetric writers also ride in the chain's launch at large N -- measured B = 8: N = 6144 0.385 -> 0.352 ms,
+    // 8192 0.593 -> 0.574, 12288 1.277 -> 1.193, 16384 2.19 -> 2.13: no fork / join, and the persistent double-buffered writers reach
+    // 0.68-0.70 of the HBM peak where the one-tile-per-workgroup kernel beside the layer reached 0.65-0.67)
+    return forced == 1;
 }
 // masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_iou2d_kernel).  GNMS_FUSE_TAIL=0/1 forces.
 bool chain_rides_in_write_launch(int B, int N) {
@@ -1335,7 +1338,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
-    const bool beside = sym_beside || use_side_stream(B, N, ld);
+    const bool beside = sym_beside || (!sym_tail && use_side_stream(B, N, ld));
     const int sym = (P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY) ? 1 : 0;   // the culled kernel writes full symmetric rows of W
     // K3..K6 inside the write launch like the 2D entry -- up to N = 2048 only: the 3D writers are VALU-bound (23 slots per pair) and
     // at the one workgroup per CU that launch runs at they lose more than the overlap buys (B = 8, N = 4096: launch 166 us against a
