@@ -238,6 +238,34 @@ __global__ __launch_bounds__(NW * 64) void iou3d_sym_kernel(const float* __restr
     gnms_iou3d::nms_overlap3d_sym_tile<NW, NT>(rec + (size_t)b * N * kRec, N, out + (size_t)b * N * ld, ld, I, J, thr, reinterpret_cast<float*>(smem));
 }
 
+// The same writer as PERSISTENT workgroups (one 16-wave workgroup per CU): workgroup w takes the macro tiles w, w + G, w + 2 G, ... of
+// the batch (image-major, row-major over each triangle) -- together the G workgroups advance one frontier through the matrices -- and
+// alternates between two LDS tiles, so that one barrier per tile suffices and the mirrored stores of a tile overlap the arithmetic of
+// the next (the layer's writers_sym_persistent, nms_layer.hip, with a static round robin instead of claims: no counter to reset).
+template <bool NT>
+__global__ __launch_bounds__(1024) void iou3d_sym_persistent_kernel(const float* __restrict__ rec, int N, int nimg, float* __restrict__ out, long ld,
+                                                                    float thr) {
+    using namespace gnms_iou3d;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const tile0 = reinterpret_cast<float*>(smem);
+    const int nt = (N + kSymT - 1) / kSymT;
+    const int tpi = sym_tiles_per_image(N);
+    const long total = (long)tpi * nimg;
+    int ph = 0;
+    for (long cur = blockIdx.x; cur < total; cur += gridDim.x) {
+        const int img = (int)(cur / tpi);
+        int I, J;
+        sym_tile_of((int)(cur - (long)img * tpi), nt, &I, &J);
+        const float* r = rec + (size_t)img * N * kRec;
+        float* o = out + (size_t)img * N * ld;
+        float* const tile = tile0 + (size_t)ph * (kSymTileBytes / sizeof(float));
+        sym_tile_compute<16, NT>(r, N, o, ld, I, J, thr, tile);
+        __syncthreads();                                            // the tile is in LDS; the other buffer is free again
+        if (I != J) sym_tile_mirror<16, NT>(N, o, ld, I, J, tile);
+        ph ^= 1;
+    }
+}
+
 template <bool VEC, int METHOD>
 void launch_iou3d(const float* ra, const float* rb, int B, int M, int N, float* bev, float* o3, long ld, hipStream_t st) {
     const int tr = tile_rows_for(B, M, N);
@@ -307,9 +335,28 @@ int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, 
     // nothing with 16), 8 above (N = 16384: 1.645 against 1.666 ms)
     static const int forced_nw = [] { const char* e = getenv("GNMS_3D_SYM_NW"); return e ? atoi(e) : 0; }();
     const int nw = forced_nw ? forced_nw : (N <= 4096 ? 16 : 8);
+    int rc;
+    // persistent workgroups (iou3d_sym_persistent_kernel) for the largest images only: B = 8, N = 16384 1.63 -> 1.565 ms (0.69 of the HBM
+    // peak); at N = 4096 (0.104 -> 0.119) and 8192 (0.38 -> 0.42, the one-tile-per-workgroup kernel reaches 0.71 there) the static round
+    // robin ends unevenly.  GNMS_3D_SYM_PERSIST=0/1 forces.
+    static const int forced_persist = [] { const char* e = getenv("GNMS_3D_SYM_PERSIST"); return e ? atoi(e) : -1; }();
+    const bool persist = forced_persist >= 0 ? forced_persist == 1 : N > 8192;
+    if (persist && pct0 == 0 && pct1 == 100) {
+        const size_t lds2 = 2 * gnms_iou3d::kSymTileBytes;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        GNMS_CHECK_HIP(hipGetDevice(&dev));
+        GNMS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (nt) { if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_persistent_kernel<true>), lds2))) return rc; }
+        else { if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_persistent_kernel<false>), lds2))) return rc; }
+        if (nt) gnms_launch_prof(kProfMatrixWrite, iou3d_sym_persistent_kernel<true>, dim3((unsigned)cus), dim3(1024), lds2, st, rec, N, B, out, (long)ld, thr);
+        else gnms_launch_prof(kProfMatrixWrite, iou3d_sym_persistent_kernel<false>, dim3((unsigned)cus), dim3(1024), lds2, st, rec, N, B, out, (long)ld, thr);
+        GNMS_CHECK_LAUNCH();
+        return GNMS_OK;
+    }
     const size_t lds = gnms_iou3d::kSymTileBytes;
     const dim3 grid((unsigned)(t1 - t0), 1, (unsigned)B);
-    int rc;
 #define GNMS_SYM_LAUNCH(NW_, NT_)                                                                                                     \
     do {                                                                                                                              \
         if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_kernel<NW_, NT_>), lds))) return rc;                     \
