@@ -863,12 +863,12 @@ int fused_tile_rows() {
     return tr > 64 ? 64 : tr;
 }
 
-// 3D: the write role of that launch as symmetric writers (writers_sym_persistent) -- from N = 1024 on, where an image has enough
+// 3D: the write role of that launch as symmetric writers (writers_sym_persistent) -- above N = 1024, where an image has enough
 // macro tiles; GNMS_3D_SYM_TAIL=0/1 forces.
 bool sym_writers_in_tail_launch(int N, int64_t ld, const float* out) {
     static const int forced = [] { const char* e = getenv("GNMS_3D_SYM_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (!gnms_internal_overlap3d_sym_ok(N, ld, out)) return false;
-    return forced >= 0 ? forced == 1 : N > 2048;
+    return forced >= 0 ? forced == 1 : N > 1024;                  // (B = 8: N = 2048 0.110 -> 0.090 ms, 1536 0.0895 -> 0.080, 1024 even)
 }
 
 // K3..K6 of every image + the matrix in one launch (tail_write_kernel)
