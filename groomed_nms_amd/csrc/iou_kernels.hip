@@ -384,6 +384,8 @@ int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64
 // defined in nms_layer.hip (write_staged_kernel)
 bool gnms_internal_iou2d_wants_staged(int B, int M, int N, int64_t ld, const float* out);
 int gnms_internal_iou2d_staged(const float* a, const float* b, int B, int M, int N, float* out, int64_t ld, hipStream_t st);
+bool gnms_internal_iou2d_wants_self(const float* a, const float* b, int B, int M, int N, int64_t ld, const float* out);
+int gnms_internal_iou2d_self(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st);
 
 extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int M, int N, float* out, int64_t ld,
                           void* stream) {
@@ -393,6 +395,7 @@ extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int
     GNMS_CHECK_ARG(ld >= N, "gnms_iou2d: ld (%lld) < N (%d)", (long long)ld, N);
     GNMS_CHECK_ARG(((uintptr_t)boxes_a % 16 == 0) && ((uintptr_t)boxes_b % 16 == 0), "gnms_iou2d: boxes must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    if (gnms_internal_iou2d_wants_self(boxes_a, boxes_b, B, M, N, ld, out)) return gnms_internal_iou2d_self(boxes_a, B, N, out, ld, st);
     if (gnms_internal_iou2d_wants_staged(B, M, N, ld, out)) return gnms_internal_iou2d_staged(boxes_a, boxes_b, B, M, N, out, ld, st);
     const int tr = tile_rows_for(B, M, N);
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);

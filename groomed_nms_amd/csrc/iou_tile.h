@@ -55,7 +55,8 @@ typedef float gnms_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool box_divides_plainly(const float4 v) {
     auto coord_ok = [](float c) {
         const unsigned u = __float_as_uint(c) & 0x7fffffffu;
-        return u == 0u || (u - 0x39000000u) < (0x49800000u - 0x39000000u);   // 0, or 2^-13 <= |c| < 2^20 (NaN / Inf fail)
+        // +0, or 2^-13 <= |c| < 2^20 (NaN / Inf fail; so does -0: the plain row body below must never see a negative zero)
+        return __float_as_uint(c) == 0u || (u - 0x39000000u) < (0x49800000u - 0x39000000u);
     };
     return coord_ok(v.x) && coord_ok(v.y) && coord_ok(v.z) && coord_ok(v.w) && v.z >= v.x && v.w >= v.y;
 }
@@ -75,6 +76,73 @@ __device__ __forceinline__ void div4_plain(const float (&n)[4], const float (&d)
         t = __builtin_elementwise_fma(-b, qq, a);
         qq = __builtin_elementwise_fma(t, r, qq);
         q[2 * p] = qq.x; q[2 * p + 1] = qq.y;
+    }
+}
+
+__device__ __forceinline__ gnms_f2 div2_plain(const gnms_f2 a, const gnms_f2 b) {       // the same steps for one packed pair
+    const gnms_f2 one = {1.0f, 1.0f};
+    gnms_f2 r = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    const gnms_f2 e = __builtin_elementwise_fma(-b, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    gnms_f2 qq = a * r;
+    gnms_f2 t = __builtin_elementwise_fma(-b, qq, a);
+    qq = __builtin_elementwise_fma(t, r, qq);
+    t = __builtin_elementwise_fma(-b, qq, a);
+    return __builtin_elementwise_fma(t, r, qq);
+}
+
+// ---- the intersection of the plain row body --------------------------------------------------------------------------------------
+// lib/core.py:210-212 computes  w = relu(min(ax2, bx2) - max(ax1, bx1)).  min(ax2, bx2) - max(ax1, bx1) is, in exact arithmetic, the
+// smallest of the four differences  ax2 - ax1, bx2 - bx1, ax2 - bx1, bx2 - ax1,  and the subtraction the reference performs is the
+// one of the four that attains it; rounding is monotone, so its fp32 result equals the smallest of the four ROUNDED differences:
+//     w = relu(min(fl(ax2 - bx1), fl(bx2 - ax1), cw, rw))          cw = fl(bx2 - bx1) per column, rw = fl(ax2 - ax1) per row
+//       = med3(min3(fl(ax2 - bx1), fl(bx2 - ax1), cw), 0, rw)      (rw >= 0: box_divides_plainly)
+// bit for bit (finite coordinates, no negative zero: a difference is then never -0, and equal candidates are the same bits).  The two
+// differences are packed subtractions over a column pair (v_pk_add_f32, the row coordinate from an SGPR), cw / rw are the widths the
+// areas need anyway: 3 VALU slots per entry and dimension where min, max, subtract, relu take 4 -- and the products and the union
+// pack as well: 7.5 slots per entry in front of the division instead of 11.  The matrix writers are VALU-bound (3.2e): this is
+// where their time goes.
+struct ColPairs {                       // a lane's four columns as two packed pairs, field by field
+    gnms_f2 x1[2], y1[2], x2[2], y2[2], w[2], h[2], area[2];
+};
+__device__ __forceinline__ void colpairs_set(ColPairs& c, int j, const float4 v) {
+    c.x1[j >> 1][j & 1] = v.x; c.y1[j >> 1][j & 1] = v.y; c.x2[j >> 1][j & 1] = v.z; c.y2[j >> 1][j & 1] = v.w;
+    const float w = v.z - v.x, h = v.w - v.y;
+    c.w[j >> 1][j & 1] = w; c.h[j >> 1][j & 1] = h;
+    c.area[j >> 1][j & 1] = w * h;                                    // lib/core.py:502-503
+}
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_clamp0_s(float x, float hi) { float r; asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi)); return r; }
+
+// Rows of a full tile (every lane owns four existing columns) whose boxes all divide plainly: `ra` holds row i0 + r in lane r;
+// orow = &out[i0][first column of the lane].  ROWS_CT > 0: exactly that many rows, unrolled into one basic block; 0: `rows` at run time.
+template <int ROWS_CT>
+__device__ __forceinline__ void iou2d_rows_plain(const ColPairs& c, const float4 ra, float* __restrict__ orow, long ld, int rows = ROWS_CT) {
+    const float rw = ra.z - ra.x, rh = ra.w - ra.y;
+    const float rarea = rw * rh;                                      // lib/core.py:500-501
+    auto one_row = [&](int r) {
+        const float ax1 = bcast(ra.x, r), ay1 = bcast(ra.y, r), ax2 = bcast(ra.z, r), ay2 = bcast(ra.w, r);
+        const float aw = bcast(rw, r), ah = bcast(rh, r), aarea = bcast(rarea, r);
+        const gnms_f2 sx1 = {ax1, ax1}, sy1 = {ay1, ay1}, sx2 = {ax2, ax2}, sy2 = {ay2, ay2}, sa = {aarea, aarea};
+        gnms_f2 q[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const gnms_f2 dx1 = sx2 - c.x1[p], dx2 = c.x2[p] - sx1;
+            const gnms_f2 dy1 = sy2 - c.y1[p], dy2 = c.y2[p] - sy1;
+            const gnms_f2 w = {hw_clamp0_s(hw_min3(dx1.x, dx2.x, c.w[p].x), aw), hw_clamp0_s(hw_min3(dx1.y, dx2.y, c.w[p].y), aw)};
+            const gnms_f2 h = {hw_clamp0_s(hw_min3(dy1.x, dy2.x, c.h[p].x), ah), hw_clamp0_s(hw_min3(dy1.y, dy2.y, c.h[p].y), ah)};
+            const gnms_f2 inter = w * h;                              // :218
+            const gnms_f2 uni = (sa + c.area[p]) - inter;             // :507
+            q[p] = div2_plain(inter, uni);                            // :508
+        }
+        store_nt_f4(orow, q[0].x, q[0].y, q[1].x, q[1].y);           // (ordinary stores, or a vmcnt throttle per row: both measured slower)
+        orow += ld;
+    };
+    if constexpr (ROWS_CT > 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS_CT; ++r) one_row(r);
+    } else {
+        for (int r = 0; r < rows; ++r) one_row(r);
     }
 }
 
@@ -161,7 +229,12 @@ __device__ __forceinline__ void iou2d_tile(const float* __restrict__ A, const fl
     float4 ra = make_float4(0.f, 0.f, 0.f, 0.f);
     if (myrow < M) ra = *reinterpret_cast<const float4*>(a + (size_t)myrow * 4);
     plain = plain && box_divides_plainly(ra);                     // (the zero box of a lane past the last row passes)
-    if (__all(plain)) iou2d_rows<VEC, 0, false, true>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
+    if (VEC && c0 + kWaveCols <= N && __all(plain)) {             // full tile of plain boxes: the packed row body
+        ColPairs cp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) colpairs_set(cp, j, make_float4(bx1[j], by1[j], bx2[j], by2[j]));
+        iou2d_rows_plain<0>(cp, ra, o + (size_t)i0 * ld + col[0], ld, rows);
+    } else if (__all(plain)) iou2d_rows<VEC, 0, false, true>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
     else iou2d_rows<VEC, 0>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
 }
 
@@ -193,8 +266,11 @@ __device__ __forceinline__ void iou2d_tile_staged(const float4* scol, int colbas
         // branch out holds there is undefined -- the compiler sinks the LDS read of the row box into the branch.  A tile with fewer
         // than 4 * ROWS_CT columns takes the general path below.)
         if (col[0] < N) {
+            ColPairs cp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) colpairs_set(cp, j, make_float4(bx1[j], by1[j], bx2[j], by2[j]));
             issue();
-            iou2d_rows<VEC, ROWS_CT, true, true>(bx1, by1, bx2, by2, barea, col, ra, rows, o, i0, ld, N);
+            iou2d_rows_plain<ROWS_CT>(cp, ra, o + (size_t)i0 * ld + col[0], ld);
             consume();
         }
     } else {

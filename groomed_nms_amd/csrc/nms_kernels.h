@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "gnms_common.h"
 #include "iou3d_pair.h"
+#include "iou_tile.h"
 
 namespace gnms {
 namespace {   // internal linkage: the header is included by several translation units
@@ -309,6 +310,12 @@ __device__ __forceinline__ const float* overlap_src(const float* __restrict__ sr
 // Second, independent sort of the from-boxes path: the boxes by ascending x centre (NaN last).  bitmask_boxes_kernel walks
 // its COLUMNS in this order, so that the 256 columns of a wave tile are spatial neighbours and the rows that cannot touch
 // their hull are skipped.  Thread t owns elements t*E .. t*E+E-1; `keys` = P 64-bit LDS slots.
+// A box the packed intersection of bitmask_boxes_body may see: finite coordinates, no negative zero, x2 >= x1, y2 >= y1
+__device__ __forceinline__ bool box_orders_plainly(const float4 v) {
+    auto fine = [](float c) { const unsigned u = __float_as_uint(c); return u != 0x80000000u && (u & 0x7fffffffu) < 0x7f800000u; };
+    return fine(v.x) && fine(v.y) && fine(v.z) && fine(v.w) && v.z >= v.x && v.w >= v.y;
+}
+
 template <int E>
 __device__ __forceinline__ void sort_boxes_by_x(const float* __restrict__ boxes, int n, const ImgPtrs& I, u64* keys, int P) {
     const float4* bx = reinterpret_cast<const float4*>(boxes);
@@ -323,11 +330,16 @@ __device__ __forceinline__ void sort_boxes_by_x(const float* __restrict__ boxes,
         }
     }
     block_sort<E, u64>(r, keys, P);
+    bool plain = true;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         const int idx = (int)(keys[k] & 0xffffffffu);
         I.xidx[k] = idx;
-        I.xbox[k] = bx[idx];
+        const float4 v = bx[idx];
+        I.xbox[k] = v;
+        plain = plain && box_orders_plainly(v);
     }
+    const int all_plain = __syncthreads_and(plain);
+    if (threadIdx.x == 0) I.misc[6] = all_plain ? 0 : 1;              // bitmask_boxes_body: the packed intersection needs plain boxes
 }
 
 template <int E>
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
     // lib/rpn_util.py:1258-1266): rank == input index, so the bit-matrix kernel can skip the half of the matrix that no
     // leader can reach and needs no scatter.
     const int all_same = __syncthreads_and(same);
-    if (threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;
+    if (threadIdx.x < 8 && !(boxes && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,9 +453,12 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
             if (order_out) order_out[(size_t)b * N + rank] = idx;
         } else {
             I.xidx[rank] = idx;
-            I.xbox[rank] = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];
+            const float4 v = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];
+            I.xbox[rank] = v;
+            same = box_orders_plainly(v);                             // (role 1: "every box of this run is plain")
         }
     }
+    if (role == 1 && !__syncthreads_and(same) && t == 0) I.misc[6] = 1;   // (zeroed by sort_runs_body, a launch earlier; every writer stores 1)
     if (role == 0) {
         // padding ranks map to themselves (order is a permutation of [0, N))
         for (int k = n + r * 1024 + t; k < N; k += R * 1024) {
@@ -637,8 +652,16 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     // uni > 0 and finite, which holds whenever both boxes have a positive finite area (inter <= min(area) in fp32 as in
     // exact arithmetic because subtraction/multiplication round monotonically, so uni >= max(area) > 0): checked once per
     // column box and per row.  Rows/columns that fail, and the pairs inside the guard band, take the exact IEEE division.
+    // (two workgroups per CU leave 64 VGPRs: the columns' ranks, not needed before the words are parked, wait in LDS meanwhile)
+    constexpr bool STASH = ROWBUF && !CHUNKLOOP && CPL == 4;
+    int* const crank_lds = reinterpret_cast<int*>(smem + (size_t)L.NC * 8) + threadIdx.x;   // [CPL][1024]
+    if (STASH) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) crank_lds[j * 1024] = crank[j];
+    }
     const float guard = fmaxf(fabsf(thr), 1.0f) * 9.6e-7f;            // 8 ulp at the threshold's magnitude (>= 1 for tiny thresholds)
     const bool cols_ok = __all(cok);
+    const bool plain_img = I.misc[6] == 0;                            // (sort_boxes_by_x / sort_merge_body: no box that is not plain)
     // hull of the tile's columns
     float hx0 = cb[0].x, hx1 = cb[0].z, hy0 = cb[0].y, hy1 = cb[0].w;
 #pragma unroll
@@ -662,6 +685,81 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
         unsigned wd[2][CPL];
 #pragma unroll
         for (int j = 0; j < CPL; ++j) { wd[0][j] = 0u; wd[1][j] = 0u; }
+        // PLAIN images (misc[6] == 0: every box finite, x2 >= x1, y2 >= y1, no negative zero; decided by the x sort): the intersection
+        // as iou_tile.h derives it -- w = med3(min3(fl(ax2 - bx1), fl(bx2 - ax1), cw), 0, rw), bit for bit the reference's
+        // relu(min - max) -- packed over column pairs, and the decided bit taken from the SIGN of thr * uni - inter (an arithmetic shift
+        // and one v_and_or per entry instead of compare, select, or): 11.5 VALU slots per entry instead of 17.
+        bool fast_rows = false;
+        if constexpr (CPL == 4) fast_rows = plain_img && cols_ok && rows_ok == ~0ull;   // (lanes past the last row hold copies of it)
+        if constexpr (CPL == 4) if (fast_rows) {
+            using gnms_iou::gnms_f2;
+            gnms_f2 cx1[2], cy1[2], cx2[2], cy2[2], cw[2], ch[2], ca[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                cx1[j >> 1][j & 1] = cb[j].x; cy1[j >> 1][j & 1] = cb[j].y; cx2[j >> 1][j & 1] = cb[j].z; cy2[j >> 1][j & 1] = cb[j].w;
+                cw[j >> 1][j & 1] = cb[j].z - cb[j].x; ch[j >> 1][j & 1] = cb[j].w - cb[j].y;
+                ca[j >> 1][j & 1] = carea[j];
+            }
+            const float rw = rb.z - rb.x, rh = rb.w - rb.y;
+            const gnms_f2 sthr = {thr, thr}, sguard = {guard, guard};
+            // one row against the lane's four columns: nd = thr * uni - inter (its sign decides), true if some pair lies in the guard band
+            auto row_core = [&](int r, gnms_f2 (&inter)[2], gnms_f2 (&uni)[2], gnms_f2 (&nd)[2]) -> bool {
+                const float ax1 = gnms_iou::bcast(rb.x, r), ay1 = gnms_iou::bcast(rb.y, r), ax2 = gnms_iou::bcast(rb.z, r), ay2 = gnms_iou::bcast(rb.w, r);
+                const float aw = gnms_iou::bcast(rw, r), ah = gnms_iou::bcast(rh, r), aa = gnms_iou::bcast(rarea, r);
+                const gnms_f2 sx1 = {ax1, ax1}, sy1 = {ay1, ay1}, sx2 = {ax2, ax2}, sy2 = {ay2, ay2}, sa = {aa, aa};
+                bool unsure = false;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const gnms_f2 dx1 = sx2 - cx1[p], dx2 = cx2[p] - sx1;
+                    const gnms_f2 dy1 = sy2 - cy1[p], dy2 = cy2[p] - sy1;
+                    const gnms_f2 w = {gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dx1.x, dx2.x, cw[p].x), aw),
+                                       gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dx1.y, dx2.y, cw[p].y), aw)};
+                    const gnms_f2 h = {gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dy1.x, dy2.x, ch[p].x), ah),
+                                       gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dy1.y, dy2.y, ch[p].y), ah)};
+                    inter[p] = w * h;
+                    uni[p] = (sa + ca[p]) - inter[p];                     // row box is `a`, column (leader) box is `b`
+                    nd[p] = __builtin_elementwise_fma(sthr, uni[p], -inter[p]);   // = -fma(-thr, uni, inter) exactly (one rounding either way)
+                    const gnms_f2 g = sguard * uni[p];
+                    unsure |= !(fabsf(nd[p].x) > g.x) || !(fabsf(nd[p].y) > g.y);   // also true for NaN
+                }
+                return __any(unsure);
+            };
+            // The loop over the surviving rows is BRANCH-FREE, two rows per trip: every bit is taken from the sign of nd, the rows
+            // with a pair in the guard band are only noted (`redo`) and re-decided with the IEEE division behind the loop.  The kernel
+            // is bound by its slowest waves (dense x stretches keep 3x the rows of the mean), not by VALU throughput: what counts
+            // is the latency of ONE wave's row chain, and two independent rows in flight shorten it.
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                unsigned todo = (unsigned)(half ? (active >> 32) : (active & 0xffffffffull));
+                unsigned redo = 0u;
+                while (todo) {                                        // wave-uniform
+                    const int r0 = __builtin_ctz(todo);
+                    todo &= todo - 1u;
+                    const int r1 = todo ? __builtin_ctz(todo) : r0;   // (odd count: the last row twice -- the same bits again)
+                    todo &= todo - 1u;                                // (0 stays 0)
+                    gnms_f2 i0[2], u0[2], n0[2], i1[2], u1[2], n1[2];
+                    const bool q0 = row_core(half * 32 + r0, i0, u0, n0);
+                    const bool q1 = row_core(half * 32 + r1, i1, u1, n1);
+                    const unsigned b0 = 1u << r0, b1 = 1u << r1;
+                    redo |= (q0 ? b0 : 0u) | (q1 ? b1 : 0u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                     // decided pairs: d = -nd != 0, the bit is "nd negative"
+                        wd[half][j] |= (unsigned)(__float_as_int(n0[j >> 1][j & 1]) >> 31) & b0;
+                        wd[half][j] |= (unsigned)(__float_as_int(n1[j >> 1][j & 1]) >> 31) & b1;
+                    }
+                }
+                while (redo) {                                        // rare: a few rows per image
+                    const int rr = __builtin_ctz(redo);
+                    redo &= redo - 1u;
+                    gnms_f2 ii[2], uu[2], nn[2];
+                    row_core(half * 32 + rr, ii, uu, nn);
+                    const unsigned bit = 1u << rr;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wd[half][j] = (wd[half][j] & ~bit) | (!(ii[j >> 1][j & 1] / uu[j >> 1][j & 1] <= thr) ? bit : 0u);
+                }
+            }
+        }
+        if (!fast_rows) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             unsigned todo = (unsigned)(half ? (active >> 32) : (active & 0xffffffffull));
@@ -697,11 +795,14 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
                 }
             }
         }
+        }   // !fast_rows
         // the FULL row of W: the overlap is symmetric, and with all columns present the leader scan can pull (leaders_body, sym)
         u64* Wk = ROWBUF ? rowbuf : I.W + (size_t)kb * L.NC;
 #pragma unroll
-        for (int j = 0; j < CPL; ++j)
-            if (crank[j] != 0x7fffffff) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
+        for (int j = 0; j < CPL; ++j) {
+            const int cr = STASH ? crank_lds[j * 1024] : crank[j];
+            if (cr != 0x7fffffff) Wk[cr] = ((u64)wd[1][j] << 32) | wd[0][j];
+        }
     }
     }   // !idle
     }   // chunks of this wave
@@ -712,8 +813,9 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     }
 }
 
+// (ROWBUF without the chunk loop: two 16-wave workgroups per CU = 8 waves per SIMD, i.e. at most 64 VGPRs -- asked for explicitly)
 template <int CPL, int KBW, bool ROWBUF = false, bool CHUNKLOOP = false>
-__global__ __launch_bounds__(ROWBUF ? 1024 : 256) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
+__global__ __launch_bounds__(ROWBUF ? 1024 : 256, (ROWBUF && !CHUNKLOOP) ? 8 : 1) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
                                                             float thr, char* ws, gnms_ws_layout L) {
     bitmask_boxes_body<CPL, KBW, ROWBUF, CHUNKLOOP>(boxes, N, counts, thr, ws, L, (int)blockIdx.z, (int)blockIdx.x);
 }

@@ -177,7 +177,8 @@ extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int
     GNMS_CHECK_ARG((rows == 4 || rows == 8 || rows == 16 || rows == 32 || rows == 64) && N % rows == 0,
                    "gnms_profile_fill_tiles: rows per wave tile must be 4, 8, 16, 32 or 64 and divide N (rows=%d N=%d)", rows, N);
     static const int order = [] { const char* e = getenv("GNMS_FILL_ORDER"); return e ? atoi(e) : 0; }();
-    const dim3 grid((unsigned)device_cu_count());
+    const char* ge = getenv("GNMS_FILL_GRID");                     // (experiments: the same stream from fewer CUs)
+    const dim3 grid((unsigned)(ge && atoi(ge) > 0 ? atoi(ge) : device_cu_count()));
     hipStream_t st = (hipStream_t)stream;
     const long bands = (long)B * N / rows;
 #define GNMS_FILL_TILES(R)                                                                                                                  \
@@ -210,7 +211,9 @@ __global__ __launch_bounds__(1024) void prof_fill_sym_kernel(float* __restrict__
     const long per_img = (long)nt * (nt + 1) / 2, total = per_img * nimg;
     long t0 = blockIdx.x, t1 = blockIdx.x + 1;
     if (persist) { t0 = total * blockIdx.x / gridDim.x; t1 = total * (blockIdx.x + 1) / gridDim.x; }
-    for (long t = t0; t < t1 && t < total; ++t) {
+    const long step = persist == 2 ? gridDim.x : 1;                  // persist 2: round robin (one compact write frontier), else contiguous strips
+    if (persist == 2) { t0 = blockIdx.x; t1 = total; }
+    for (long t = t0; t < t1 && t < total; t += step) {
         const int img = (int)(t / per_img);
         long r = t - (long)img * per_img;
         int I = 0;
@@ -242,8 +245,10 @@ extern "C" int gnms_profile_fill_sym(float* dst, int B, int N, int64_t ld, int t
     hipStream_t st = (hipStream_t)stream;
     const int nt = N / tile;
     const long total = (long)nt * (nt + 1) / 2 * B;
-    const dim3 grid((unsigned)(persist ? device_cu_count() * (tile == 128 ? 2 : 1) : total));
-    const dim3 block(tile == 128 ? 512 : 1024);
+    const char* ge = getenv("GNMS_FILL_GRID");                     // (experiments; persist only)
+    const dim3 grid((unsigned)(persist ? (ge && atoi(ge) > 0 ? atoi(ge) : device_cu_count() * (tile == 128 ? 2 : 1)) : total));
+    const char* be = getenv("GNMS_FILL_BLOCK");
+    const dim3 block(be && atoi(be) > 0 ? atoi(be) : (tile == 128 ? 512 : 1024));
 #define GNMS_FILL_SYM(TT, CC)                                                                                                              \
     do {                                                                                                                                   \
         if (nontemporal) gnms_launch_prof(kProfPlainStream, prof_fill_sym_kernel<TT, CC, true>, grid, block, 0, st, dst, N, (long)ld, B, persist, 0.5f);   \
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
             if (order_out) order_out[(size_t)b * N + k] = idx;
         }
         const int all_same = __syncthreads_and(same);
-        if (threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;
+        if (threadIdx.x < 8 && !(xsort && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -547,9 +552,17 @@ bool writers_staged() {
     return on;
 }
 
+// (GNMS_FAST_ROWS=0: the tile body of round 2 -- min / max / subtract / relu per entry, columns gathered per unit -- for comparison)
+int fast_rows_2d() {
+    static const int on = [] { const char* e = getenv("GNMS_FAST_ROWS"); return e ? atoi(e) : 1; }();
+    return on;
+}
+
+// claim0 / claim_stride: image i's claim counter is claim0[i * claim_stride] (the layer: misc[5] of the image's workspace; gnms_iou2d:
+// a zeroed array of its own); first_wg: blockIdx.x of the first writer workgroup of the launch
 template <bool VEC>
-__device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxes, int N, float* __restrict__ out, long ld, int nimg, char* ws,
-                                                  gnms_ws_layout L) {
+__device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxes, int N, float* __restrict__ out, long ld, int nimg, int* claim0,
+                                                  size_t claim_stride, const int first_wg, const int fast_rows) {
     using namespace gnms_iou;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sbox = reinterpret_cast<float4*>(smem);                  // [N] boxes of the staged image
@@ -559,10 +572,10 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
     const int nrt = (N + kStagedRows - 1) / kStagedRows;
     const int units = (ncc * nrt + 15) >> 4;
     // thread 0 only: the image it claims from and how many images it has not yet seen exhausted
-    int cur_img = ((int)blockIdx.x - nimg) % nimg, left = nimg;
+    int cur_img = ((int)blockIdx.x - first_wg) % nimg, left = nimg;
     // never 1 at run time, but not provably 0 either: keeps the claim's address lane-dependent in the compiler's eyes
     const int lane_dep = (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) >> 6);
-    auto counter = [&](int img) { return reinterpret_cast<int*>(ws + (size_t)img * L.per_image + L.off_misc) + 5 + lane_dep; };
+    auto counter = [&](int img) { return claim0 + (size_t)img * claim_stride + lane_dep; };
     auto claim_now = [&]() -> int {                                  // the next unit of cur_img, or of the next image that has one
         while (left > 0) {
             const int u = atomicAdd(counter(cur_img), 1);
@@ -575,22 +588,47 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
     if (tid == 0) s_claim[0] = claim_now();
     __syncthreads();
     int cur = s_claim[0], ph = 0, staged = -1;
+    // PLAIN images (every box divides plainly, iou_tile.h -- pixel boxes always do; decided once per staging): the tile runs
+    // iou2d_rows_plain, and the lane's column boxes stay in registers from unit to unit while the wave keeps its column chunk (at
+    // N = 4096 always: a unit is one band of 16 chunks) -- gathering them, their areas and the plain test were 17 % of a tile's VALU work.
+    bool img_plain = false;
+    int cols_of = -1;                                                // the column chunk `cp` holds (of the staged image)
+    ColPairs cp;
+    const bool fast_ok = VEC && (N & 3) == 0 && (N % kStagedRows) == 0 && fast_rows;
     while (cur >= 0) {
         const int img = cur >> 16, u = cur & 0xffff;
         if (img != staged) {                                         // (every wave finished reading the old image before the last barrier)
             const float4* b4 = reinterpret_cast<const float4*>(boxes) + (size_t)img * N;
-            for (int i = tid; i < N; i += 1024) sbox[i] = b4[i];
+            bool ok = true;
+            for (int i = tid; i < N; i += 1024) { const float4 v = b4[i]; sbox[i] = v; ok = ok && box_divides_plainly(v); }
             staged = img;
-            __syncthreads();
+            cols_of = -1;
+            img_plain = __syncthreads_and(ok) != 0;
         }
         int pre = 0;
         const bool claims = tid == 0 && left > 0;
         const int t = u * 16 + wave;                                 // (wave 0's tile always exists: it carries the claim)
         if (t < ncc * nrt) {
             const int rt = t / ncc, cc = t - rt * ncc;
-            iou2d_tile_staged<VEC, kStagedRows>(sbox, 0, sbox + rt * kStagedRows, N, N, out + (size_t)img * N * ld, ld, rt * kStagedRows, cc * kWaveCols, lane,
-                [&] { if (claims) pre = atomicAdd(counter(cur_img), 1); },       // in flight ahead of this tile's stores
-                [&] { asm volatile("" :: "v"(pre)); });                          // every path waits for it here: vmcnt(8) on a full tile
+            const int c0 = cc * kWaveCols;
+            if (fast_ok && img_plain && c0 + 4 * kStagedRows <= N) { // (the first kStagedRows lanes hold the rows AND must own columns)
+                if (cc != cols_of) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) colpairs_set(cp, j, sbox[min(c0 + 4 * lane + j, N - 1)]);
+                    cols_of = cc;
+                }
+                const float4 ra = sbox[rt * kStagedRows + (lane & (kStagedRows - 1))];
+                if (c0 + 4 * lane < N) {
+                    if (claims) pre = atomicAdd(counter(cur_img), 1);                // in flight ahead of this tile's stores
+                    float* o0 = out + (size_t)img * N * ld + (size_t)(rt * kStagedRows) * ld + c0 + 4 * lane;
+                    iou2d_rows_plain<kStagedRows>(cp, ra, o0, ld);
+                    asm volatile("" :: "v"(pre));                                    // every path waits for it here: vmcnt(8) on a full tile
+                }
+            } else {
+                iou2d_tile_staged<VEC, kStagedRows>(sbox, 0, sbox + rt * kStagedRows, N, N, out + (size_t)img * N * ld, ld, rt * kStagedRows, c0, lane,
+                    [&] { if (claims) pre = atomicAdd(counter(cur_img), 1); },
+                    [&] { asm volatile("" :: "v"(pre)); });
+            }
         }
         if (tid == 0) {
             int nx = -1;
@@ -639,6 +677,17 @@ __device__ __forceinline__ void writers_sym_persistent(const float* __restrict__
         ph ^= 1;
         cur = s_next[ph];
     }
+}
+
+// gnms_iou2d of a box set WITH ITSELF (what both reference call sites compute: iou(boxes, boxes)), N <= 4096: the staged writers as a
+// launch of their own -- the same claimed units, tile body and cached columns as in tail_write_kernel, the claim counters in a zeroed
+// array that lives for the call.  (A version that dealt the units statically -- round robin per image, no counters -- reached 0.55 of
+// the HBM peak where this one reaches 0.71 and the 64-row tiles of iou2d_kernel 0.68-0.69: the claims keep an image's write frontier
+// compact when workgroups drift, and the workgroups that run out of units on their image finish the others'.)
+template <bool VEC>
+__global__ __launch_bounds__(1024) void iou2d_self_kernel(const float* __restrict__ boxes, int N, int nimg, float* __restrict__ out, long ld,
+                                                          int* __restrict__ claims) {
+    writers_staged_2d<VEC>(boxes, N, out, ld, nimg, claims, 64, 0, 1);      // (a counter per 256 bytes: each in an L2 line of its own)
 }
 
 // LARGE images (N > 4096): the matrix write as a launch of its own on the side stream (3.2d), in the same geometry -- persistent
@@ -727,10 +776,41 @@ bool gnms_internal_iou2d_wants_staged(int B, int M, int N, int64_t ld, const flo
     // (N <= 4096: the per-unit row fetch and barrier cost more than the geometry gains -- B = 8, M = N = 4096: 108-114 us against the
     // 64-row tiles' 102; N = 16384: 1.61 ms against 1.85)
     const long units = (long)B * ((M + kStagedRows - 1) / kStagedRows) * ((N + 4095) / 4096);
+    static const int forced = [] { const char* e = getenv("GNMS_IOU2D_STAGED"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0 && units >= 4L * device_cu_count();
     return N > 4096 && units >= 4L * device_cu_count();
 }
+// a == b, N <= 4096: iou2d_self_kernel (B = 8, N = 4096: 0.68-0.69 -> 0.71 of the HBM peak); GNMS_IOU2D_SELF=0 keeps iou2d_kernel
+bool gnms_internal_iou2d_wants_self(const float* a, const float* b, int B, int M, int N, int64_t ld, const float* out) {
+    static const int forced = [] { const char* e = getenv("GNMS_IOU2D_SELF"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || a != b || M != N || N > 4096 || !writers_staged()) return false;
+    const long units = (long)B * ((N + kStagedRows - 1) / kStagedRows) * ((N + 4095) / 4096);
+    return units >= 8L * device_cu_count();
+}
+int gnms_internal_iou2d_self(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st) {
+    static const int forced_grid = [] { const char* e = getenv("GNMS_IOU2D_SELF_GRID"); return e ? atoi(e) : 0; }();
+    const int cus = device_cu_count();
+    const int grid = forced_grid > 0 ? forced_grid : cus - 8;       // (alone on the machine the stream likes every CU: 248 -> 0.71, 200 -> 0.64)
+    gnms_async_buffer claims;                                        // [B][64] claim counters, stream-ordered: freed behind the kernel
+    GNMS_CHECK_HIP(claims.alloc((size_t)B * 64 * sizeof(int), st));
+    GNMS_CHECK_HIP(hipMemsetAsync(claims.p, 0, (size_t)B * 64 * sizeof(int), st));
+    size_t lds = (size_t)N * 16;
+    if (lds < 96 * 1024) lds = 96 * 1024;                            // > 80 KiB: one workgroup per CU
+    const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
+    int rc;
+    if (vec) {
+        if ((rc = allow_lds(iou2d_self_kernel<true>, lds))) return rc;
+        gnms_launch_prof(kProfMatrixWrite, iou2d_self_kernel<true>, dim3((unsigned)grid), dim3(1024), lds, st, boxes, N, B, out, (long)ld, claims.as<int>());
+    } else {
+        if ((rc = allow_lds(iou2d_self_kernel<false>, lds))) return rc;
+        gnms_launch_prof(kProfMatrixWrite, iou2d_self_kernel<false>, dim3((unsigned)grid), dim3(1024), lds, st, boxes, N, B, out, (long)ld, claims.as<int>());
+    }
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
 int gnms_internal_iou2d_staged(const float* a, const float* b, int B, int M, int N, float* out, int64_t ld, hipStream_t st) {
-    return launch_write_staged(a, b, B, M, N, out, ld, 0, st);
+    static const int reserve = [] { const char* e = getenv("GNMS_IOU2D_RESERVE"); return e ? atoi(e) : 0; }();   // (experiments)
+    return launch_write_staged(a, b, B, M, N, out, ld, reserve, st);
 }
 namespace {
 
@@ -764,7 +844,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         GNMS_TW_ACC(15);
         return;
     }
-    if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, ws, L); return; }
+    if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, img_ptrs(ws, L, 0).misc + 5, L.per_image / sizeof(int), nimg, staged == 3 ? 0 : staged); return; }   // (3: the columns gathered per unit)
     if (SRC == kFromRecords && staged == 2) { writers_sym_persistent<true>(write_src, N, out, ld, nimg, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5); return; }
     writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
 }
@@ -789,7 +869,7 @@ int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts
         bitmask_boxes_kernel<4, 4><<<dim3(gnms_div_up(((NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
     } else if (tiles4 >= 2048 && (N + 255) / 256 <= 16) {
         // one 16-wave workgroup per rank block: words collected in an LDS copy of the row, written out coalesced
-        bitmask_boxes_kernel<4, 1, true><<<dim3(NB, 1, B), 1024, (size_t)L.NC * 8, st>>>(boxes, N, counts, thr, ws, L);
+        bitmask_boxes_kernel<4, 1, true><<<dim3(NB, 1, B), 1024, (size_t)L.NC * 8 + 4 * 1024 * sizeof(int), st>>>(boxes, N, counts, thr, ws, L);   // + the ranks' stash
     } else if (tiles4 >= 2048) {
         bitmask_boxes_kernel<4, 1><<<dim3(gnms_div_up(NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
     } else {
@@ -881,7 +961,7 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
     size_t lds = llds > glds ? llds : glds;
     const int tr = fused_tile_rows();
-    int staged = (SRC == kFromBoxes && N <= 4096 && writers_staged()) ? 1 : 0;   // writers_staged_2d: the image's boxes in LDS
+    int staged = (SRC == kFromBoxes && N <= 4096 && writers_staged()) ? (fast_rows_2d() ? fast_rows_2d() : 3) : 0;   // writers_staged_2d: the image's boxes in LDS
     if (staged && lds < (size_t)N * 16) lds = (size_t)N * 16;
     long writers = write_chunk_count(N, B, tr, 0, N);                // persistent writers: at most one per CU
     if (SRC == kFromRecords && sym_writers_in_tail_launch(N, ld, out)) {   // writers_sym_persistent: two LDS macro tiles
@@ -891,6 +971,14 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     }
     const int cus = device_cu_count();
     if (writers > cus) writers = cus;
+    // How many CUs write.  With the packed row body (iou_tile.h) a writer workgroup sustains ~29 GB/s and the stream saturates near
+    // 5.8 TB/s from ~200 of them; more writers add nothing to the matrix and slow the chain beside them, whose loads queue behind
+    // the stores (B = 8, N = 4096, same box, clustered / uniform ms per step: 248 writers 0.141 / 0.167, 216 0.139 / 0.162,
+    // 200 0.140 / 0.153, 184 0.147 / 0.152).  A plain fill in this geometry: 6.2-6.4 TB/s from 64-128 workgroups, 5.8 from 248
+    // (tools/fill_grid.py).  GNMS_TAIL_WRITERS overrides.
+    static const int writers_cap = [] { const char* e = getenv("GNMS_TAIL_WRITERS"); return e ? atoi(e) : 0; }();
+    const int cap = writers_cap > 0 ? writers_cap : (staged == 1 ? (cus * 200) / 256 : 0);
+    if (cap > 0 && writers > cap) writers = cap;
     const dim3 grid((unsigned)(B + writers));
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
     int rc;
