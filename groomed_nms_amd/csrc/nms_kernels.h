@@ -1162,6 +1162,33 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
         // batch by batch cost one memory round trip per batch: near push 28k -> 71k ticks on uniform boxes).  An exclusive OR-scan
         // over the lanes tells each leader which bits it is the first to set; it stores those itself (a wave-uniform loop over the new
         // bits with a ballot per bit was tried: one trip per claimed rank, 3900 per clustered image -- leaders 62k -> 134k ticks).
+        if (nl >= L.pull_leaders) {
+            // MANY leaders (uniform boxes: ~470 per super-block): PULL.  The overlap is symmetric, so "rank (T, lane) overlaps a leader of
+            // source block bb" is also bit (leader) of W[bb][rank]: one coalesced 512-byte row segment per source block and target
+            // block, ANDed with the block's leader mask -- 16 loads per target block whatever the number of leaders, where the gather
+            // below fetches one 64-byte line per leader (470 lines = 30 KB against 8 KB), and the first claimer of a rank is the lowest
+            // set bit of the first source block that has one: no scan over the lanes, one coalesced store of rem.  Same masks, same
+            // claimers (sources still arrive in ascending order, a rank some earlier source took keeps its claimer: accAll).
+            const int s0 = src * kSB;
+            const int ns = min(kSB, nb - s0);
+            for (int T = first + w; T < last; T += nw) {
+                const int k = (T << 6) + lane;
+                u64 wv[kSB];
+#pragma unroll
+                for (int bb = 0; bb < kSB; ++bb) wv[bb] = (bb < ns && k < n) ? I.W[(size_t)(s0 + bb) * L.NC + k] : 0ull;
+                const u64 taken = accAll[T];
+                int cl = -1;
+#pragma unroll
+                for (int bb = 0; bb < kSB; ++bb) {
+                    const u64 m = (bb < ns) ? (wv[bb] & lmask[s0 + bb]) : 0ull;
+                    if (cl < 0 && m != 0ull) cl = ((s0 + bb) << 6) + __builtin_ctzll(m);
+                }
+                const u64 hit = __ballot(cl >= 0);
+                if (cl >= 0 && ((taken >> lane) & 1ull) == 0ull) I.rem[k] = cl;
+                if (lane == 0 && (hit & ~taken) != 0ull) atomicOr(reinterpret_cast<unsigned long long*>(&accAll[T]), (unsigned long long)hit);
+            }
+            return;
+        }
         constexpr int PB = 2, PJ = 8;
         for (int base = first + w; base < last; base += PB * nw) {
             u64 a[PB], claimed[PB];
