@@ -1009,6 +1009,10 @@ constexpr int kTabPer = (kSBPairs * 64 + 959) / 960;            // table entries
 #define GNMS_TACC(slot) do {} while (0)
 #endif
 
+// workgroup barrier that waits for this wave's LDS operations only (not for its global loads / stores, as __syncthreads does): for
+// hand-offs that live in LDS.  Beside the matrix writers the drain of a wave's stores takes microseconds.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ u64 uniform64(u64 v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffu));
     const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -1482,18 +1486,22 @@ __device__ __forceinline__ void attribute_image(const float* __restrict__ src, l
     ImgPtrs I = img_ptrs(ws, L, b);
     const float* m = overlap_src<SRC>(src, I, b, N, ld);
     for (int k0 = 0; k0 < n; k0 += 4096) {
-        int g4[4], ca[4], cb[4];
+        int g4[4], ca[4], cb[4], lr4[4];
         float pl[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = k0 + tid + e * 1024;
             const bool ok = k < n;
-            const int lr = ok ? I.rem[k] : 0;
-            g4[e] = I.leadpfx[lr >> 6] + __builtin_popcountll(I.leadw[lr >> 6] & ((1ull << (lr & 63)) - 1ull));
+            lr4[e] = ok ? I.rem[k] : 0;
             ca[e] = ok ? I.order[k] : 0;
         }
+        // (the leader's input index is order[its rank]: the same value as leadc[its ordinal], one dependent load earlier)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) cb[e] = (k0 + tid + e * 1024 < n) ? I.leadc[g4[e]] : 0;
+        for (int e = 0; e < 4; ++e) {
+            const int lr = lr4[e];
+            g4[e] = I.leadpfx[lr >> 6] + __builtin_popcountll(I.leadw[lr >> 6] & ((1ull << (lr & 63)) - 1ull));
+            cb[e] = (k0 + tid + e * 1024 < n) ? I.order[lr] : 0;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) pl[e] = (k0 + tid + e * 1024 < n) ? overlap_at<SRC>(m, ld, ca[e], cb[e], thr) : 0.0f;
 #pragma unroll
@@ -1518,9 +1526,15 @@ __global__ __launch_bounds__(64) void attribute_kernel(const float* __restrict__
 // Arrays head/gpos/gstart/glen/gsorted/plead are indexed by rank; pre is indexed by NMS position q
 // (q = rank for hard sort, q = input index when presorted).
 // ------------------------------------------------------------------------------------------------
-template <int E, int SRC>
+// FUSE (E <= 4, the chain kernels after a scan that has attributed: leaders_body with sym): K4's work -- the leader's ordinal and the
+// overlap with it -- is done HERE, for the very ranks phase 1 and phase 3 of this thread own (k = e * 1024 + t), and what K4 would have
+// parked in global memory for them (gpos, plead) or they would have loaded again (order, sscore, rem, the leader's score) stays in
+// registers across the sort.  Beside the matrix writers every dependent global load of the chain costs ~2 us: K4 -> barrier -> K5 was
+// eight levels of them, this is four (rem / order / sscore -> the leader's order, score, ordinal -> the two boxes -> stores).
+template <int E, int SRC, bool FUSE = false>
 __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                             gnms_params P, char* ws, gnms_ws_layout L, int Ppow2, const int b) {
+    static_assert(!FUSE || E <= 4, "the fused attribution keeps five values per owned rank in registers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* keys = reinterpret_cast<unsigned*>(smem);          // (leader ordinal << 14) | rank : 28 bits (N <= 16384)
     unsigned* info = keys + Ppow2;                               // per rank: head | pos << 14, or ~0 (in no group)
@@ -1532,6 +1546,37 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
     GNMS_T0();
     // key = (ordinal of the leader << 14) | rank: the ordinal (attribute_kernel left it in gpos, with the overlap against that
     // leader in plead) needs only log2(#leaders) bits, i.e. ONE 7-bit radix pass for up to 127 groups
+    int f_lr[FUSE ? E : 1], f_ck[FUSE ? E : 1];                       // FUSE: rem[k], order[k], sscore[k], overlap with and score of the leader
+    float f_sk[FUSE ? E : 1], f_pl[FUSE ? E : 1], f_sl[FUSE ? E : 1];
+    if constexpr (FUSE) {
+        int g[E], cb[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = e * (int)blockDim.x + (int)threadIdx.x;
+            const bool ok = k < n;
+            f_lr[e] = ok ? I.rem[k] : 0;
+            f_ck[e] = ok ? I.order[k] : 0;
+            f_sk[e] = ok ? I.sscore[k] : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int lr = f_lr[e];
+            g[e] = I.leadpfx[lr >> 6] + __builtin_popcountll(I.leadw[lr >> 6] & ((1ull << (lr & 63)) - 1ull));
+            cb[e] = I.order[lr];                                        // (= leadc[g]: the leader's input index)
+            f_sl[e] = I.sscore[lr];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = e * (int)blockDim.x + (int)threadIdx.x;
+            f_pl[e] = (k < n) ? overlap_at<SRC>(m, ld, f_ck[e], cb[e], thr) : 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = e * (int)blockDim.x + (int)threadIdx.x;
+            keys[k] = (k < n && f_pl[e] > thr) ? (((unsigned)g[e] << 14) | (unsigned)k) : ~0u;   // strict > (:249)
+            info[k] = ~0u;
+        }
+    } else {
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int k = e * (int)blockDim.x + (int)threadIdx.x;
@@ -1539,6 +1584,7 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
         if (k < n && I.plead[k] > thr) key = ((unsigned)I.gpos[k] << 14) | (unsigned)k;     // strict > (:249)
         keys[k] = key;
         info[k] = ~0u;
+    }
     }
     GNMS_TACC(8);
     // group by leader: the keys start in rank order, so a STABLE sort on the leader bits alone yields (leader, rank) order
@@ -1630,13 +1676,16 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
         if (h != k) I.glen[k] = 0;                                   // only heads carry an extent
         if (!P.mask_group_boxes) continue;
         float pre = 0.0f, pl = 0.0f;
-        const int ck = (k < n) ? I.order[k] : 0;
+        int ck;
+        float sk;
+        if constexpr (FUSE) { ck = f_ck[e]; sk = f_sk[e]; }
+        else { ck = (k < n) ? I.order[k] : 0; sk = (k < n) ? I.sscore[k] : 0.0f; }
         const int q = P.presorted ? ck : k;
-        const float sk = (k < n) ? I.sscore[k] : 0.0f;
         if (h == k) {
             pre = sk;
         } else if (h >= 0) {
-            const int lr = I.rem[k];
+            int lr;
+            if constexpr (FUSE) lr = f_lr[e]; else lr = I.rem[k];
             float v, sh;
             int ch;
             if (h != lr) {                                           // the leader itself is not a member (NaN / <= thr diagonal)
@@ -1645,8 +1694,11 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
                 sh = I.sscore[h];
             } else {
                 ch = -1;
-                v = I.plead[k];                                      // overlap with the leader, left there by attribute_kernel
-                sh = I.sscore[lr];
+                if constexpr (FUSE) { v = f_pl[e]; sh = f_sl[e]; }
+                else {
+                    v = I.plead[k];                                  // overlap with the leader, left there by attribute_kernel
+                    sh = I.sscore[lr];
+                }
             }
             bool tril = true;                                        // torch.tril in NMS order (:72): always true for hard sort
             if (P.presorted) { if (ch < 0) ch = I.order[h]; tril = ch < ck; }
@@ -1655,6 +1707,17 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
         }
         I.plead[k] = pl;
         I.pre[(k < n) ? q : k] = pre;
+        if constexpr (FUSE) {
+            // K6 starts from the clamped value by NMS position and ends with the input indices of the listed boxes: both are at hand
+            // here and wait for it in LDS (beyond keys / info, both dead for this thread's rank by now) -- finalize_body<E, true> then
+            // begins without a global load and the barrier in front of it need not wait for the stores above
+            if (k < n) {
+                const float r2 = pre < 0.0f ? 0.0f : (pre > 1.0f ? 1.0f : pre);      // torch.clamp keeps NaN
+                I.r2[q] = r2;
+                reinterpret_cast<float*>(smem)[q] = r2;                              // finalize_body's `stage` (the key region)
+                reinterpret_cast<int*>(smem + (size_t)Ppow2 * 8)[k] = ck;            // order[] by rank
+            }
+        }
     }
     GNMS_TACC(11);
 }
@@ -1673,7 +1736,9 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
 // block scan).  valid / invalid are INPUT indices padded with -1; prob is written in the order the
 // reference returns it.
 // ------------------------------------------------------------------------------------------------
-template <int E>
+// STAGED (behind groups_body<E, SRC, true>, masked groups): the clamped values already sit in `stage` and the input index of every
+// rank in LDS behind the key region (ordL); r2 is in global memory as well.
+template <int E, bool STAGED = false>
 __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                               int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
                                               long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
@@ -1689,13 +1754,16 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     // clamp: global loads and stores with lane-contiguous positions (coalesced), staged in LDS for the owner threads below,
     // which need thread-contiguous positions so that the compaction keeps the order
     float* stage = reinterpret_cast<float*>(smem);                 // [Ppow2] floats inside the key region (not yet in use)
-    for (int q = t; q < n; q += T) {
-        const float pre = I.pre[q];
-        const float r2 = pre < 0.0f ? 0.0f : (pre > 1.0f ? 1.0f : pre);          // torch.clamp keeps NaN
-        I.r2[q] = r2;
-        stage[q] = r2;
+    const int* ordL = reinterpret_cast<const int*>(smem + (size_t)Ppow2 * 8);   // STAGED: order[] by rank, behind the key region
+    if constexpr (!STAGED) {
+        for (int q = t; q < n; q += T) {
+            const float pre = I.pre[q];
+            const float r2 = pre < 0.0f ? 0.0f : (pre > 1.0f ? 1.0f : pre);          // torch.clamp keeps NaN
+            I.r2[q] = r2;
+            stage[q] = r2;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // classify
     u64 key[E];
     int cls[E];                                                    // 0 nan, 1 valid, 2 invalid, 3 padding
@@ -1718,8 +1786,6 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     const u64 inc = (u64)gnms_add_scan32((unsigned)(packed & 0xffffffffu)) | ((u64)gnms_add_scan32((unsigned)(packed >> 32)) << 32);
     if (lane == 63) wave_tot[wave] = inc;
     __syncthreads();                                               // every owner has read its staged values
-    for (int i = t; i < Ppow2; i += T) keys[i] = ~0ull;
-    __syncthreads();
     u64 base = 0, total = 0;
     const int nwaves = T >> 6;
     for (int w = 0; w < nwaves; ++w) { const u64 v = wave_tot[w]; if (w < wave) base += v; total += v; }
@@ -1732,7 +1798,8 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
         float* pbq = prob + (size_t)b * N;
         for (int j = t; j < N; j += T) {
             float out = 0.0f;
-            if (j < n) { const float r2j = I.r2[j]; out = P.group_boxes ? r2j : ((r2j < vthr) ? 0.0f : r2j); }   // :124-127
+            // (STAGED: no full barrier since groups_body stored r2 -- the staged copy is the one every thread can see)
+            if (j < n) { const float r2j = STAGED ? stage[j] : I.r2[j]; out = P.group_boxes ? r2j : ((r2j < vthr) ? 0.0f : r2j); }   // :124-127
             pbq[j] = out;
             I.sidx[j] = j;
         }
@@ -1742,6 +1809,8 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
         }
         return;
     }
+    for (int i = t; i < Ppow2; i += T) keys[i] = ~0ull;           // (the staged values end here)
+    __syncthreads();
     // sidx layout: [0,n_nan) NaN by position, [n_nan, n_ge) valid (sorted below), [n_ge, n_ge+ni) invalid by position
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1751,7 +1820,7 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
         else if (cls[e] == 2) {
             const int j = (int)(run >> 32);
             I.sidx[n_ge + j] = q;
-            if (invalid) invalid[(size_t)b * N + j] = P.presorted ? q : I.order[q];
+            if (invalid) invalid[(size_t)b * N + j] = P.presorted ? q : (STAGED ? ordL[q] : I.order[q]);
             run += 1ull << 32;
         }
     }
@@ -1828,7 +1897,7 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
         if (j < nv) {
             const int q = (int)(keys[j] & 0xffffffffu);
             I.sidx[n_nan + j] = q;
-            if (valid) valid[(size_t)b * N + j] = P.presorted ? q : I.order[q];
+            if (valid) valid[(size_t)b * N + j] = P.presorted ? q : (STAGED ? ordL[q] : I.order[q]);
         } else if (valid) valid[(size_t)b * N + j] = -1;
         if (j >= ni && invalid) invalid[(size_t)b * N + j] = -1;
         if (j >= n) I.sidx[j] = j;
@@ -1871,6 +1940,14 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     const int b = blockIdx.x;
     leaders_body(N, counts, ws, L, b, sym);
     __syncthreads();
+    if (E <= 4 && sym && P.mask_group_boxes) {                       // the scan has attributed: K4's rest rides in K5, K6 starts from LDS
+        if constexpr (E <= 4) {
+            groups_body<E, SRC, true>(src, N, ld, counts, P, ws, L, Ppow2, b);
+            lds_barrier();
+            finalize_body<E, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+        }
+        return;
+    }
     attribute_image<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, sym);
     __syncthreads();
     groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);

@@ -834,10 +834,22 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         leaders_body(N, counts, ws, L, b, 1);
         __syncthreads();
         GNMS_TW_ACC(5);
-        attribute_image<SRC>(chain_src, (long)N, N, counts, P.nms_threshold, ws, L, b, 1);
-        __syncthreads();
-        GNMS_TW_ACC(6);
-        groups_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
+        if (E <= 4 && P.mask_group_boxes) {                           // K4's rest rides in K5 (groups_body, FUSE), K6 starts from LDS
+            if constexpr (E <= 4) {
+                GNMS_TW_ACC(6);
+                groups_body<E, SRC, true>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
+                gnms::lds_barrier();
+                GNMS_TW_ACC(7);
+                finalize_body<E, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+                GNMS_TW_ACC(15);
+            }
+            return;
+        } else {
+            attribute_image<SRC>(chain_src, (long)N, N, counts, P.nms_threshold, ws, L, b, 1);
+            __syncthreads();
+            GNMS_TW_ACC(6);
+            groups_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
+        }
         __syncthreads();
         GNMS_TW_ACC(7);
         finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
