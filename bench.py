@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--boxes", type=int, default=4096, help="boxes per image (BASELINE metric: N=4096/img)")
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
-    ap.add_argument("--kind", default="clustered", choices=["uniform", "clustered"])
+    ap.add_argument("--kind", default="uniform", choices=["uniform", "clustered"],
+                    help="box generator: uniform random boxes (the distribution of the reference figure in BASELINE.md; the headline since round 3) or "
+                         "clustered ones (K = N/64 objects x 64 jittered copies: detector-like; the headline of rounds 1-2, now `other_kind`)")
     ap.add_argument("--dim", type=int, default=2, choices=[2, 3], help="2: lib/core.py iou; 3: 0.5*(1+GIoU3D) of the corner AABBs from (x,y,z,w,h,l,ry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-kind", action="store_true")
@@ -426,9 +428,10 @@ def main():
             # differentiable_nms(scores, iou): the overlap kernel and the matrix-in layer as two library calls, lib/loss/rpn_3d.py:772-791 --
             # and the 3D overlap (0.5 (1 + GIoU3D), rpn_3d.py:778-784) at N = 4096 and at C5's N = 16384.  Children of this process, same GPU.
             st = ["--steps", str(max(20, min(args.steps, 100))), "--warmup", str(max(3, min(args.warmup, 10)))]
-            for key, extra in (("two_calls", ["--two-calls", "--boxes", str(N), "--batch", str(B), "--kind", args.kind] + st),
-                               ("dim3_N4096", ["--dim", "3", "--boxes", "4096", "--batch", str(B), "--kind", args.kind] + st),
-                               ("dim3_N16384", ["--dim", "3", "--boxes", "16384", "--batch", str(B), "--kind", args.kind, "--steps", "20", "--warmup", "3"])):
+            # (these three stay on the clustered generator whatever the headline runs on: the figures of rounds 1-3 they continue were taken there)
+            for key, extra in (("two_calls", ["--two-calls", "--boxes", str(N), "--batch", str(B), "--kind", "clustered"] + st),
+                               ("dim3_N4096", ["--dim", "3", "--boxes", "4096", "--batch", str(B), "--kind", "clustered"] + st),
+                               ("dim3_N16384", ["--dim", "3", "--boxes", "16384", "--batch", str(B), "--kind", "clustered", "--steps", "20", "--warmup", "3"])):
                 try:
                     out[key] = _brief(_sub_bench(extra))
                 except Exception as e:

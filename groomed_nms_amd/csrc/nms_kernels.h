@@ -1716,6 +1716,7 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
                 I.r2[q] = r2;
                 reinterpret_cast<float*>(smem)[q] = r2;                              // finalize_body's `stage` (the key region)
                 reinterpret_cast<int*>(smem + (size_t)Ppow2 * 8)[k] = ck;            // order[] by rank
+                reinterpret_cast<float*>(smem + (size_t)Ppow2 * 12)[q] = r2;         // a copy the key sort does not overwrite
             }
         }
     }
@@ -1902,12 +1903,14 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
         if (j >= ni && invalid) invalid[(size_t)b * N + j] = -1;
         if (j >= n) I.sidx[j] = j;
     }
-    __syncthreads();
+    // (STAGED, unsorted output: every value of the last loop comes from LDS -- no barrier for sidx, no global load)
+    const float* r2L = reinterpret_cast<const float*>(smem + (size_t)Ppow2 * 12);
+    if (!STAGED || P.return_sorted_prob) __syncthreads();
     for (int j = t; j < N; j += T) {
         float out = 0.0f;
         if (j < n) {
             if (P.return_sorted_prob) { const float r2q = I.r2[I.sidx[j]]; out = (r2q < vthr) ? 0.0f : r2q; }   // :117
-            else { const float r2j = I.r2[j]; out = P.group_boxes ? r2j : ((r2j < vthr) ? 0.0f : r2j); }       // :124-127
+            else { const float r2j = STAGED ? r2L[j] : I.r2[j]; out = P.group_boxes ? r2j : ((r2j < vthr) ? 0.0f : r2j); }       // :124-127
         }
         pb[j] = out;
     }

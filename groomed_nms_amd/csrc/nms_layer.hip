@@ -985,11 +985,12 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     if (writers > cus) writers = cus;
     // How many CUs write.  With the packed row body (iou_tile.h) a writer workgroup sustains ~29 GB/s and the stream saturates near
     // 5.8 TB/s from ~200 of them; more writers add nothing to the matrix and slow the chain beside them, whose loads queue behind
-    // the stores (B = 8, N = 4096, same box, clustered / uniform ms per step: 248 writers 0.141 / 0.167, 216 0.139 / 0.162,
-    // 200 0.140 / 0.153, 184 0.147 / 0.152).  A plain fill in this geometry: 6.2-6.4 TB/s from 64-128 workgroups, 5.8 from 248
-    // (tools/fill_grid.py).  GNMS_TAIL_WRITERS overrides.
+    // the stores.  B = 8, N = 4096, same box, ms per step clustered / uniform: 216 writers 0.140 / 0.160, 208 0.139 / 0.158,
+    // 200 0.140 / 0.151, 192 0.142 / 0.142, 184 0.144 / 0.144 -- at 24 writers per XCD the chain of the uniform images (1890
+    // leaders each) stops being the longer side of the launch, at the price of 1.5 % on clustered ones.  (A plain fill in this
+    // geometry: 6.2-6.4 TB/s from 64-128 workgroups, 5.8 from 248: tools/fill_grid.py.)  GNMS_TAIL_WRITERS overrides.
     static const int writers_cap = [] { const char* e = getenv("GNMS_TAIL_WRITERS"); return e ? atoi(e) : 0; }();
-    const int cap = writers_cap > 0 ? writers_cap : (staged == 1 ? (cus * 200) / 256 : 0);
+    const int cap = writers_cap > 0 ? writers_cap : (staged == 1 ? (cus * 192) / 256 : 0);
     if (cap > 0 && writers > cap) writers = cap;
     const dim3 grid((unsigned)(B + writers));
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);

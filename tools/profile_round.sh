@@ -3,7 +3,7 @@
 #   <tag>_bench.json + <tag>_bench_kernel_stats.csv      the default bench line and the rocprofv3 --kernel-trace --stats of the same command
 #   <tag>_pmc_summary.json                               HBM traffic per launch (tools/pmc.sh), fed back into the bench line's roofline.traffic
 #   <tag>_grid.jsonl                                     N in {256,1024,4096,16384} x {clustered,uniform} (+ 3D at 4096/16384)
-#   <tag>_uniform4096_kernel_stats.csv                   kernel stats of the uniform N=4096 run
+#   <tag>_clustered4096_kernel_stats.csv                 kernel stats of the clustered N=4096 run (the headline runs on uniform boxes since round 3)
 #   <tag>_dim3_n16384_kernel_stats.csv                   kernel stats of the 3D N=16384 run
 #   <tag>_store_geometry.jsonl, _small_n.jsonl, _sgemm_mfma.txt   store-pattern ceilings, host cost of the small-N regime, the fp32 MFMA GEMM
 export TMPDIR=/tmp
@@ -16,13 +16,13 @@ python bench.py --steps 200 --warmup 20 --pmc-summary $O/${T}_pmc_summary.json >
 bash tools/prof.sh ${T}_main --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind > $O/prof_main.txt 2>&1
 cp gpurun_out/prof_${T}_main/bench_kernel_stats.csv $O/${T}_bench_kernel_stats.csv
 tail -1 gpurun_out/prof_${T}_main/bench_stdout.txt > $O/${T}_bench_under_rocprof.json
-bash tools/prof.sh ${T}_d3 --steps 30 --warmup 5 --no-cpu-baseline --no-other-kind --dim 3 --boxes 16384 > $O/prof_d3.txt 2>&1
+bash tools/prof.sh ${T}_d3 --steps 30 --warmup 5 --no-cpu-baseline --no-other-kind --kind clustered --dim 3 --boxes 16384 > $O/prof_d3.txt 2>&1
 cp gpurun_out/prof_${T}_d3/bench_kernel_stats.csv $O/${T}_dim3_n16384_kernel_stats.csv
-bash tools/prof.sh ${T}_d34k --steps 100 --warmup 5 --no-cpu-baseline --no-other-kind --dim 3 > $O/prof_d34k.txt 2>&1
+bash tools/prof.sh ${T}_d34k --steps 100 --warmup 5 --no-cpu-baseline --no-other-kind --kind clustered --dim 3 > $O/prof_d34k.txt 2>&1
 cp gpurun_out/prof_${T}_d34k/bench_kernel_stats.csv $O/${T}_dim3_n4096_kernel_stats.csv
-bash tools/prof.sh ${T}_uni --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind --kind uniform > $O/prof_uni.txt 2>&1
-cp gpurun_out/prof_${T}_uni/bench_kernel_stats.csv $O/${T}_uniform4096_kernel_stats.csv
-tail -1 gpurun_out/prof_${T}_uni/bench_stdout.txt > $O/${T}_uniform4096_bench_under_rocprof.json
+bash tools/prof.sh ${T}_clu --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind --kind clustered > $O/prof_clu.txt 2>&1
+cp gpurun_out/prof_${T}_clu/bench_kernel_stats.csv $O/${T}_clustered4096_kernel_stats.csv
+tail -1 gpurun_out/prof_${T}_clu/bench_stdout.txt > $O/${T}_clustered4096_bench_under_rocprof.json
 : > $O/${T}_grid.jsonl
 for n in 256 1024 4096 16384; do for k in clustered uniform; do
   st=100; [ $n -ge 16384 ] && st=30
@@ -32,8 +32,8 @@ for n in 4096 16384; do for k in clustered uniform; do
   st=100; [ $n -ge 16384 ] && st=30
   python bench.py --dim 3 --boxes $n --kind $k --steps $st --warmup 10 --no-cpu-baseline --no-other-kind 2>/dev/null | tail -1 >> $O/${T}_grid.jsonl
 done; done
-python bench.py --two-calls --steps 100 --warmup 10 --no-other-kind --cpu-seconds 3 2>/dev/null | tail -1 > $O/${T}_two_calls_bench.json
-for n in 512 1024 2048; do python bench.py --graph --boxes $n --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/${T}_graph.jsonl; done
+python bench.py --two-calls --kind clustered --steps 100 --warmup 10 --no-other-kind --cpu-seconds 3 2>/dev/null | tail -1 > $O/${T}_two_calls_bench.json
+for n in 512 1024 2048; do python bench.py --graph --kind clustered --boxes $n --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/${T}_graph.jsonl; done
 python tools/kernel_times.py > $O/${T}_kernel_times.txt 2>/dev/null
 python tools/kernel_times.py --boxes 16384 --reps 10 >> $O/${T}_kernel_times.txt 2>/dev/null
 GNMS_3D_SYM=0 python tools/kernel_times.py 2>/dev/null | grep "3D NMS" >> $O/${T}_kernel_times.txt
