@@ -398,6 +398,10 @@ __device__ __forceinline__ u64 sort_key_of(int role, const float* __restrict__ s
 }
 
 // (run r of image b, role) -- also called from the launch that carries a slice of the matrix write (nms_layer.hip)
+// COHERENT (sort_fused_kernel): the run and the misc words are handed to other workgroups of the SAME launch -- agent-scope stores
+// (write-through, sc1) instead of plain ones, so that no L2 write-back (__threadfence: microseconds on an L2 full of the last step's
+// lines) stands between the run and its flag
+template <bool COHERENT = false>
 __device__ __forceinline__ void sort_runs_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
                                                const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P, const int r, const int b,
                                                const int role) {
@@ -408,6 +412,11 @@ __device__ __forceinline__ void sort_runs_body(const float* __restrict__ scores,
     u64 k[1];
     k[0] = (i < n) ? sort_key_of(role, scores + (size_t)b * N, boxes ? boxes + (size_t)b * N * 4 : nullptr, i) : ~0ull;
     block_sort<1, u64>(k, keys, 1024);
+    if (COHERENT) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&I.W[(size_t)role * P + i]), (unsigned long long)k[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r == 0 && role == 0 && threadIdx.x < 8) __hip_atomic_store(&I.misc[threadIdx.x], (threadIdx.x == 2) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     I.W[(size_t)role * P + i] = k[0];
     if (r == 0 && role == 0 && threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;   // [2] = "already sorted", cleared below
 }
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict
     sort_runs_body(scores, boxes, N, counts, ws, L, P, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
-template <int R>
+template <int R, bool COHERENT = false>
 __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
                                                 const int* __restrict__ counts, char* ws, gnms_ws_layout L, long long* __restrict__ order_out,
                                                 const int r, const int b, const int role) {
@@ -428,7 +437,9 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
     const int t = threadIdx.x;
     const u64* runs = I.W + (size_t)role * (R * 1024);
 #pragma unroll
-    for (int q = 0; q < R; ++q) all[q * 1024 + t] = runs[q * 1024 + t];
+    for (int q = 0; q < R; ++q)
+        all[q * 1024 + t] = COHERENT ? (u64)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(&runs[q * 1024 + t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : runs[q * 1024 + t];
     __syncthreads();
     const u64 mine = all[r * 1024 + t];
     int same = 1;
@@ -476,6 +487,37 @@ __global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restric
     sort_merge_body<R>(scores, boxes, N, counts, ws, L, order_out, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
+
+// Both halves in ONE launch (round 3): every workgroup sorts its run, publishes it, waits for the other runs of its (image, role) and
+// ranks its keys against them -- one launch skeleton (~3 us of the step) less.  The hand-off is a flag per run in the scratch region
+// behind the runs (W: nothing lives there before K2), written with a per-call 64-bit NONCE the host draws (splitmix of a process-wide
+// counter): a workspace the library has never seen holds the nonce in a flag with probability 2^-64, so no flag has to be cleared in
+// advance; the last workgroup of an image through its wait clears the image's flags again, so a captured launch (same nonce at every
+// replay) starts clean.  A workgroup also waits for run (0, score role) of its image: that workgroup zeroes misc[] before it
+// publishes, and the merges update misc[2] / misc[6] / misc[7] afterwards.  Grid order (run fastest, role slowest) = dispatch order:
+// a workgroup only waits for workgroups dispatched with it or before it.
+template <int R>
+__global__ __launch_bounds__(1024) void sort_fused_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                          const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P,
+                                                          long long* __restrict__ order_out, unsigned long long nonce) {
+    const int r = blockIdx.x, b = blockIdx.y, role = blockIdx.z, t = threadIdx.x;
+    sort_runs_body<true>(scores, boxes, N, counts, ws, L, P, r, b, role);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    unsigned long long* flags = reinterpret_cast<unsigned long long*>(I.W + 2 * (size_t)P);   // [roles][R]
+    __syncthreads();                                                   // every thread's write-through stores are acknowledged (vmcnt 0) ...
+    if (t == 0) __hip_atomic_store(&flags[role * R + r], nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag goes out
+    if (t <= R) {
+        const int j = (t < R) ? role * R + t : 0;
+        while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nonce) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();                                                   // (the runs are read with agent-scope loads: nothing cached to drop)
+    if (t == 0) {
+        const int total = R * (int)gridDim.z;
+        if (atomicAdd(&I.misc[7], 1) == total - 1)                     // the image's last workgroup through the wait: nobody reads the flags any more
+            for (int j = 0; j < total; ++j) __hip_atomic_store(&flags[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    sort_merge_body<R, true>(scores, boxes, N, counts, ws, L, order_out, r, b, role);
+}
 // ------------------------------------------------------------------------------------------------
 // K2: threshold bit matrix -- the ONE full read of the N x N fp32 matrix (HBM-read bound).
 // One wave = 64 rank-rows x 256 input columns.  Rows order[64*kb + r] are contiguous 4N-byte streams

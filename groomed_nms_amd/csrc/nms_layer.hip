@@ -8,6 +8,7 @@
 #include <mutex>
 #include <utility>
 #include <atomic>
+#include <chrono>
 #include <vector>
 #include "gnms_prof.h"
 #include "iou_tile.h"
@@ -903,9 +904,37 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
         return GNMS_OK;
     }
     const int R = P2 / 1024;
+    const size_t lds = (size_t)P2 * 8;
+    // GNMS_SORT_FUSED=1: runs and merge in ONE launch (sort_fused_kernel), the hand-off flags carrying a per-call nonce (splitmix64 of
+    // a process-wide counter that starts at the clock).  Measured B = 8, N = 4096: 13.1 us against 7.8 + 6.2 in two launches -- a launch
+    // boundary between two small kernels costs ~1 us, not the 3 us the bit-matrix kernel's skeleton suggested -- and no change of the
+    // step (0.1418 / 0.1424 against 0.1429 / 0.1419 ms clustered / uniform), so the two launches stay the default.  (With the hand-off
+    // behind __threadfence() instead of write-through stores the fused kernel took 28.7 us: the L2 write-back of a release fence
+    // walks an L2 full of the previous step's lines.)
+    static const bool fused = [] { const char* e = getenv("GNMS_SORT_FUSED"); return e && e[0] == '1'; }();
+    if (fused) {
+        static std::atomic<unsigned long long> ctr{(unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count()};
+        unsigned long long z = ctr.fetch_add(0x9e3779b97f4a7c15ull) + 0x9e3779b97f4a7c15ull;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        const unsigned long long nonce = (z ^ (z >> 31)) | 1ull;
+#define GNMS_FUSED(RR)                                                                                                             \
+        do {                                                                                                                       \
+            if ((rc = allow_lds(sort_fused_kernel<RR>, lds))) return rc;                                                           \
+            sort_fused_kernel<RR><<<dim3(RR, B, roles), 1024, lds, st>>>(scores, boxes, N, counts, ws, L, P2, (long long*)order, nonce); \
+        } while (0)
+        switch (R) {
+            case 2: GNMS_FUSED(2); break;
+            case 4: GNMS_FUSED(4); break;
+            case 8: GNMS_FUSED(8); break;
+            default: GNMS_FUSED(16); break;
+        }
+#undef GNMS_FUSED
+        GNMS_CHECK_LAUNCH();
+        return GNMS_OK;
+    }
     sort_runs_kernel<<<dim3(R, B, roles), 1024, 0, st>>>(scores, boxes, N, counts, ws, L, P2);
     GNMS_CHECK_LAUNCH();
-    const size_t lds = (size_t)P2 * 8;
 #define GNMS_MERGE(RR)                                                                                                    \
     do {                                                                                                                  \
         if ((rc = allow_lds(sort_merge_kernel<RR>, lds))) return rc;                                                      \
