@@ -1942,3 +1942,57 @@ def test_select_topk_among_all_anchors(G):
         want = PO.select_topk(sc[b], cand[b, :counts[b]], K)
         assert int(num[b]) == len(want) and idx[b, :len(want)].cpu().tolist() == want.tolist(), b
         assert (idx[b, len(want):] == -1).all()
+
+
+def test_self_iou_in_the_writers_geometry_and_negative_zero(G, O):
+    """gnms_iou2d(boxes, boxes) with enough 8-row units runs the staged writers as a launch of their own (iou2d_self_kernel: claimed
+    units, columns cached in registers, the packed tile body); the same boxes through a second buffer (a != b) take iou2d_kernel.  Both
+    must equal the oracle's IEEE values bit for bit -- on ordinary boxes (every image plain), on a batch with one adversarial image
+    (that image takes the general body) and with NEGATIVE-ZERO coordinates, which the plain body must never see (a difference could
+    then be -0 where the reference's min - max is +0): box_divides_plainly rejects them."""
+    from groomed_nms_amd import overlaps, synthetic
+    rng = np.random.default_rng(404)
+    B, N = 8, 2048                                              # 8 * 256 units = the threshold of the self path
+    boxes = np.stack([synthetic.clustered_boxes_2d(rng, N, 32) if i % 2 else synthetic.uniform_boxes_2d(rng, N) for i in range(B)]).astype(np.float32)
+    boxes[3, 5] = (0.0, 0.0, 0.0, 0.0)
+    boxes[3, 77] = (float("nan"), 1.0, 2.0, 3.0)               # image 3: not plain
+    boxes[5, 10] = (-0.0, 3.0, 40.0, 50.0)                      # image 5: a negative zero (x1 = -0 touches boxes that start at +0)
+    boxes[5, 11] = (0.0, -0.0, 25.0, 30.0)
+    boxes[5, 12] = (0.0, 0.0, 25.0, 3.0)
+    bt = torch.from_numpy(boxes).cuda()
+    same = overlaps.iou_batched(bt, bt).cpu().numpy()
+    other = overlaps.iou_batched(bt, bt.clone()).cpu().numpy()
+    for i in range(B):
+        want = O.iou2d(boxes[i], boxes[i])
+        assert np.array_equal(same[i], want, equal_nan=True), i
+        assert np.array_equal(other[i], want, equal_nan=True), i
+    # the same images through the layer's launch (tail_write_kernel's writers) and its bit matrix (packed body + sign decision)
+    scores = rng.random((B, N), dtype=np.float32)
+    out = G.differentiable_nms_with_iou2d_batched(torch.from_numpy(scores).cuda(), bt)
+    for i in (0, 3, 5):
+        assert np.array_equal(out[6][i].cpu().numpy(), O.iou2d(boxes[i], boxes[i]), equal_nan=True), i
+        ref = O.differentiable_nms(scores[i], O.iou2d(boxes[i], boxes[i]))
+        assert np.array_equal(out[0][i].cpu().numpy(), ref["prob"], equal_nan=True), i
+
+
+def test_single_launch_sort_variant():
+    """GNMS_SORT_FUSED=1 (opt-in): score and x sorts as ONE launch whose workgroups hand their runs over through nonce flags.  Same
+    outputs as the default two launches, on a fresh workspace and on a reused one, eager and replayed from a captured graph."""
+    code = """
+import numpy as np, torch
+import groomed_nms_amd as G
+from groomed_nms_amd import synthetic
+b, s = synthetic.batch_2d(7, 4, 4096, "uniform")
+bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+outs = [G.differentiable_nms_with_iou2d_batched(st, bt) for _ in range(3)]
+torch.cuda.synchronize()
+np.save("/tmp/gnms_sort_variant_%s.npy" % __import__("os").environ.get("GNMS_SORT_FUSED", "0"), outs[-1][0].cpu().numpy())
+for o in outs[:-1]:
+    assert torch.equal(o[0], outs[-1][0]) and torch.equal(o[1], outs[-1][1])
+print("ok")
+"""
+    for v in ("0", "1"):
+        r = _run_py(code, {"GNMS_SORT_FUSED": v})
+        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    a, b = np.load("/tmp/gnms_sort_variant_0.npy"), np.load("/tmp/gnms_sort_variant_1.npy")
+    assert np.array_equal(a, b)
