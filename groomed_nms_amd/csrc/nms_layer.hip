@@ -824,6 +824,13 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
                                                           long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
                                                           int nimg, float* __restrict__ out, long ld, int tile_rows, int row0, int row_end,
                                                           int staged) {
+#ifdef GNMS_HWID    // developer experiment (tools/hwid_map.py): where the dispatcher put every workgroup of this launch
+    if (threadIdx.x == 0) {
+        unsigned* dbg = reinterpret_cast<unsigned*>(img_ptrs(ws, L, 0).rec);
+        dbg[2 * blockIdx.x] = __builtin_amdgcn_s_getreg(63492);       // HW_ID
+        dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
+    }
+#endif
     if ((int)blockIdx.x < nimg) {
         const int b = blockIdx.x;
 #ifdef GNMS_TIMING
