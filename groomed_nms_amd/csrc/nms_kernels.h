@@ -543,7 +543,7 @@ __device__ __forceinline__ float4 load_nt_f4(const float* p) {
 
 template <bool VEC, int WAVES = kMaskWaves, int RB = kMaskRB>
 __global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
-                                                                  float thr, char* ws, gnms_ws_layout L) {
+                                                                  float thr, char* ws, gnms_ws_layout L, int full) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
@@ -554,10 +554,17 @@ __global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __rest
     // would leave that work on every other XCD (blocks are dealt round-robin to the 8 XCDs)
     const int bx = (blockIdx.x + kb) % gridDim.x;
     const int c0 = (bx * WAVES + wave) * 256;
-    if (k0 >= n || c0 >= n) return;
+    // `full` with ONE 16-wave workgroup per rank block (N <= 4096): the row of W is collected in LDS, by column rank, and leaves as
+    // one coalesced write -- N scattered 8-byte stores per row block otherwise (the triangle alone is half of them); the workgroup
+    // also adds the row block's set bits to misc[4] (wsym_check_kernel: dense images keep the general scan)
+    __shared__ u64 rowbuf[(WAVES == 16) ? 4096 : 1];
+    __shared__ unsigned wave_bits[16];
+    const bool rowbuffered = WAVES == 16 && full && gridDim.x == 1 && L.NC <= 4096;
+    if (k0 >= n) return;                                                 // (workgroup-uniform)
     ImgPtrs I = img_ptrs(ws, L, b);
     const bool ident = I.misc[2] != 0;                                   // scores were already sorted: rank == input index
-    if (ident && c0 >= k0 + 64) return;                                  // no leader of this row block lives in these columns
+    const bool idle = c0 >= n || (ident && c0 >= k0 + 64);               // (pre-sorted: no leader of this row block lives in these columns)
+    if (idle && !rowbuffered) return;
     const float* m = iou + (size_t)b * N * ld;
 
     const int myrank = k0 + lane;
@@ -572,6 +579,7 @@ __global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __rest
     const bool active = VEC ? (col[0] + 3 < ld) : true;
 
     unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (!idle) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll 1
@@ -598,6 +606,7 @@ __global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __rest
             }
         }
     }
+    }
     // scatter each column word to the column's RANK: downstream kernels then read W contiguously
     u64* Wk = I.W + (size_t)kb * L.NC;
     int rk[4];
@@ -609,13 +618,79 @@ __global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __rest
         rk[0] = t.x; rk[1] = t.y; rk[2] = t.z; rk[3] = t.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rk[j] = (col[j] < n) ? I.rankof[col[j]] : -1;
+        for (int j = 0; j < 4; ++j) rk[j] = (col[j] < n) ? I.rankof[col[j]] : col[j];       // (padding: rank == index)
+    }
+    if (rowbuffered) {
+        unsigned bits = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u64 w = (col[j] < n && !idle) ? ((((u64)wd[1][j] << 32) | wd[0][j]) & rowmask) : 0ull;
+            if (col[j] < L.NC && rk[j] >= 0 && rk[j] < L.NC) rowbuf[rk[j]] = w;
+            bits += (unsigned)__builtin_popcountll(w);
+        }
+        bits = (unsigned)gnms_add_scan32(bits);                          // (inclusive: lane 63 holds the wave's sum)
+        if (lane == 63) wave_bits[wave] = bits;
+        __syncthreads();
+        for (int i = threadIdx.x; i < L.NC; i += WAVES * 64) Wk[i] = rowbuf[i];
+        if (threadIdx.x == 0) {
+            unsigned tot = 0u;
+            for (int w = 0; w < WAVES; ++w) tot += wave_bits[w];
+            atomicAdd(&I.misc[4], (int)tot);
+        }
+        return;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        // only words a leader scan can read: the column must outrank some row of the block (the others are never looked at)
-        if (col[j] < n && rk[j] < k0 + 64) Wk[rk[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
+        // only words a leader scan can read: the column must outrank some row of the block (the others are never looked at) -- or,
+        // `full`, the whole row: wsym_check_kernel then decides whether the thresholded matrix is symmetric and the scan may pull
+        if (col[j] < n && (full || rk[j] < k0 + 64)) Wk[rk[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2s: is the thresholded matrix SYMMETRIC?  (matrix-in layer, round 3.)  The callers of differentiable_nms(scores, iou) hand it
+// iou(boxes, boxes) -- symmetric -- but the interface does not say so, and the general scan (candidates push leader by leader: ~130
+// cycles per leader on one wave) is what makes uniform boxes cost 132 us in K3 where the pulling scan of the from-boxes layer takes
+// 25-30.  With the rows of W stored in full (bitmask_kernel, `full`) symmetry is a property of W alone: for every pair of rank blocks
+// (kb <= jb) the 64 x 64 bit block W[kb][64 jb ..] must be the transpose of W[jb][64 kb ..].  One wave per pair: both blocks are one
+// coalesced 512-byte load each, the transpose is six butterfly stages across the lanes.  The verdict lands in misc[3] (1 = not
+// symmetric, or not decidable: pre-sorted scores store only the triangle); K3 / K4 read it when called with sym = 2.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 transpose64(u64 x, int lane) {            // lane r, bit c  <->  lane c, bit r
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) {
+        const u64 m = j == 32 ? 0x00000000ffffffffull : j == 16 ? 0x0000ffff0000ffffull : j == 8 ? 0x00ff00ff00ff00ffull
+                    : j == 4 ? 0x0f0f0f0f0f0f0f0full : j == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;   // bit positions with bit j clear
+        const u64 t = (u64)__shfl_xor((unsigned long long)x, j, 64);
+        x = (lane & j) ? (((t >> j) & m) | (x & ~m)) : ((x & m) | ((t << j) & ~m));
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(256) void wsym_check_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, int dense_bits_per_rank) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int nb = (n + 63) >> 6;
+    const int pairs = nb * (nb + 1) / 2;
+    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6);                   // pair index, row-major over kb <= jb
+    if (pr >= pairs) return;
+    if (I.misc[2] != 0) { if (pr == 0 && lane == 0) I.misc[3] = 1; return; }   // pre-sorted scores: W holds the triangle only
+    // dense images (clustered boxes: ~64 set bits per rank) have few leaders, and for few leaders the general scan is the faster one
+    // (B = 8, N = 4096: 28 against 36 us): they skip the check and keep it.  misc[4]: set bits of W, counted by bitmask_kernel.
+    if (dense_bits_per_rank > 0 && (long long)I.misc[4] > (long long)dense_bits_per_rank * n) { if (pr == 0 && lane == 0) I.misc[3] = 1; return; }
+    // pr -> (kb, jb): pairs before row kb = kb * nb - kb (kb - 1) / 2
+    const float a = (float)(2 * nb + 1);
+    int kb = (int)((a - sqrtf(a * a - 8.0f * (float)pr)) * 0.5f);
+    kb = kb < 0 ? 0 : (kb >= nb ? nb - 1 : kb);
+    while (kb > 0 && kb * nb - kb * (kb - 1) / 2 > pr) --kb;
+    while ((kb + 1) * nb - (kb + 1) * kb / 2 <= pr) ++kb;
+    const int jb = kb + (pr - (kb * nb - kb * (kb - 1) / 2));
+    auto rows_of = [&](int blk) { const int r = min(64, n - blk * 64); return r >= 64 ? ~0ull : ((1ull << r) - 1ull); };
+    // A: rows = ranks of block kb (bits), columns = ranks of block jb (lanes); Bm the other way round
+    const u64 A = (jb * 64 + lane < n) ? (I.W[(size_t)kb * L.NC + jb * 64 + lane] & rows_of(kb)) : 0ull;
+    const u64 Bm = (kb * 64 + lane < n) ? (I.W[(size_t)jb * L.NC + kb * 64 + lane] & rows_of(jb)) : 0ull;
+    if (__any(A != transpose64(Bm, lane)) && lane == 0) I.misc[3] = 1;  // (every writer stores 1; the sort zeroed it)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1107,7 +1182,7 @@ __host__ __device__ __forceinline__ size_t leaders_lds_size(int NB) {
 // a few dozen VALU instructions whatever the number of leaders -- the scalar loop of the general path pays ~130 cycles PER LEADER
 // (uniform boxes: 1890 leaders of 4096 ranks, 0.15 ms on one wave).  sym == 0 (matrix in, possibly asymmetric; classical NMS):
 // table entry (b, b')[lane] = W[b'][rank(b, lane)], what candidate (b, lane) would remove in block b', pushed leader by leader.
-__device__ __forceinline__ void leaders_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int sym) {
+__device__ __forceinline__ void leaders_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int sym_arg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t oa, ol, oc, op;
     leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -1120,6 +1195,7 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
     int* lcount = llist + 2 * kSB * 64;                          // [2]
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
+    const int sym = sym_arg == 2 ? (I.misc[3] == 0 ? 1 : 0) : sym_arg;  // 2: as wsym_check_kernel found this image's matrix
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = (n + 63) >> 6;
     const int nsb = (nb + kSB - 1) / kSB;
@@ -1456,13 +1532,14 @@ __device__ __forceinline__ u64 slab_col(const ImgPtrs& I, const gnms_ws_layout& 
 // N dependent gathers ran on ONE CU (50 us of its 180 at N=16384).  `src`: see kFromMatrix / kFromBoxes / kFromRecords.
 template <int SRC>
 __device__ __forceinline__ void attribute_body(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, float thr, char* ws,
-                                               gnms_ws_layout L, const int b, const int kb, const int lane, const int sym = 0) {
+                                               gnms_ws_layout L, const int b, const int kb, const int lane, const int sym_arg = 0) {
     __shared__ int att_lead[16][64];                   // per wave: ordinal of the leader that claimed rank k0 + i
     int* my_lead = att_lead[(threadIdx.x >> 6) & 15];
     const int n = gnms_count(counts, b, N);
     const int k0 = kb << 6;
     if (k0 >= n) return;
     ImgPtrs I = img_ptrs(ws, L, b);
+    const int sym = sym_arg == 2 ? (I.misc[3] == 0 ? 1 : 0) : sym_arg;  // (2: wsym_check_kernel's verdict)
     const int nrows = min(64, n - k0);
     const u64 want = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
     const u64* slab = I.W + (size_t)kb * L.NC;
@@ -1518,8 +1595,9 @@ __device__ __forceinline__ void attribute_body(const float* __restrict__ src, lo
 // stream is microseconds each: four ranks of a thread side by side, every load of a level issued before the first use, stores last.
 template <int SRC>
 __device__ __forceinline__ void attribute_image(const float* __restrict__ src, long ld, int N, const int* __restrict__ counts, float thr, char* ws,
-                                                gnms_ws_layout L, const int b, const int sym) {
+                                                gnms_ws_layout L, const int b, const int sym_arg) {
     const int tid = threadIdx.x;
+    const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;
     if (!sym) {
         for (int kb = tid >> 6; kb < L.NB; kb += 16) attribute_body<SRC>(src, ld, N, counts, thr, ws, L, b, kb, tid & 63, 0);
         return;
@@ -1981,8 +2059,9 @@ template <int E, int SRC>
 __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
                                                     char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob,
                                                     long long* __restrict__ valid, long long* __restrict__ invalid, int* __restrict__ nvalid,
-                                                    int* __restrict__ ninvalid, int sym) {
+                                                    int* __restrict__ ninvalid, int sym_arg) {
     const int b = blockIdx.x;
+    const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;   // (2: wsym_check_kernel's verdict for this image)
     leaders_body(N, counts, ws, L, b, sym);
     __syncthreads();
     if (E <= 4 && sym && P.mask_group_boxes) {                       // the scan has attributed: K4's rest rides in K5, K6 starts from LDS

@@ -364,7 +364,14 @@ int check_common(const char* fn, int B, int N, int64_t ld, const gnms_params* P,
 
 // K2, the one full read of the matrix.  Workgroup shape and loads in flight per wave: GNMS_BITMASK_WAVES (8 | 16: 2048 or 4096 columns
 // side by side -- at N = 4096 sixteen waves read whole 16-KiB rows), GNMS_BITMASK_RB (8 | 16 one-KiB loads in flight per wave).
-int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
+// The matrix-in layer decides on the device whether the thresholded matrix is symmetric (every caller in the reference passes
+// iou(boxes, boxes)): bitmask_kernel then stores the rows of W in full and wsym_check_kernel compares the 64 x 64 blocks with
+// their transposes; K3 / K4 (sym = 2) take the pulling, attributing scan for the images that pass.  GNMS_MATRIX_SYM=0: never.
+bool matrix_sym_detection(int N) {
+    static const int forced = [] { const char* e = getenv("GNMS_MATRIX_SYM"); return e ? atoi(e) : -1; }();
+    return forced >= 0 ? forced != 0 : N >= 256;
+}
+int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st, int full = 0) {
     // (measured at B = 8, N = 4096, three interleaved repetitions: 16 waves 91.6-91.8 us = 0.733 of the HBM peak, 8 waves 95.2-95.7 us;
     // 16 loads in flight per wave change nothing either way)
     static const int forced_waves = [] { const char* e = getenv("GNMS_BITMASK_WAVES"); return e ? atoi(e) : 0; }();
@@ -372,7 +379,7 @@ int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* co
     static const int rbf = [] { const char* e = getenv("GNMS_BITMASK_RB"); return e ? atoi(e) : kMaskRB; }();
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
 #define GNMS_BITMASK(V, W, R)                                                                                                         \
-    gnms_launch_prof(kProfMatrixRead, bitmask_kernel<V, W, R>, dim3(gnms_div_up(N, W * 256), L.NB, B), dim3(W * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L)
+    gnms_launch_prof(kProfMatrixRead, bitmask_kernel<V, W, R>, dim3(gnms_div_up(N, W * 256), L.NB, B), dim3(W * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L, full)
     if (!vec) GNMS_BITMASK(false, kMaskWaves, kMaskRB);
     else if (waves == 16 && rbf == 16) GNMS_BITMASK(true, 16, 16);
     else if (waves == 16) GNMS_BITMASK(true, 16, 8);
@@ -380,20 +387,29 @@ int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* co
     else GNMS_BITMASK(true, 8, 8);
 #undef GNMS_BITMASK
     GNMS_CHECK_LAUNCH();
+    if (full) {
+        const int nb = (N + 63) / 64;
+        // (the set-bit count that gates it exists where bitmask_kernel collects whole rows: one 16-wave workgroup per rank block)
+        static const int dense = [] { const char* e = getenv("GNMS_MATRIX_SYM_DENSE"); return e ? atoi(e) : 16; }();
+        const bool counted = vec && waves == 16 && gnms_div_up(N, 16 * 256) == 1 && L.NC <= 4096;
+        wsym_check_kernel<<<dim3(gnms_div_up(nb * (nb + 1) / 2, 4), B), 256, 0, st>>>(N, counts, ws, L, counted ? dense : 0);
+        GNMS_CHECK_LAUNCH();
+    }
     return GNMS_OK;
 }
 
 // grouping pipeline K2..K4 (shared by gnms_forward and gnms_get_groups)
 int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L,
                  hipStream_t st) {
-    int rc0 = launch_bitmask(iou, B, N, ld, counts, thr, ws, L, st);
+    const int sym = matrix_sym_detection(N) ? 2 : 0;
+    int rc0 = launch_bitmask(iou, B, N, ld, counts, thr, ws, L, st, sym ? 1 : 0);
     if (rc0) return rc0;
     const size_t lds = leaders_lds_bytes(N);
     int rc = allow_lds(leaders_kernel, lds);
     if (rc) return rc;
-    leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L, 0);
+    leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L, sym);
     GNMS_CHECK_LAUNCH();
-    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, thr, ws, L, 0);
+    attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, thr, ws, L, sym);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -1069,8 +1085,9 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     if (!scores_already_sorted && (rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
 
     if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N)) {
-        if ((rc = launch_bitmask(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;
-        return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 0);
+        const int sym = matrix_sym_detection(N) ? 2 : 0;
+        if ((rc = launch_bitmask(iou, B, N, ld, counts, P.nms_threshold, ws, L, st, sym ? 1 : 0))) return rc;
+        return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);
     }
     if (P.group_boxes) {
         if ((rc = run_grouping(iou, B, N, ld, counts, P.nms_threshold, ws, L, st))) return rc;

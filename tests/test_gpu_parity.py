@@ -1996,3 +1996,34 @@ print("ok")
         assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
     a, b = np.load("/tmp/gnms_sort_variant_0.npy"), np.load("/tmp/gnms_sort_variant_1.npy")
     assert np.array_equal(a, b)
+
+
+def test_matrix_in_layer_detects_symmetry(G, O):
+    """differentiable_nms(scores, iou) cannot know that its matrix is iou(boxes, boxes); since round 3 it finds out on the device
+    (bitmask_kernel stores the rows of the bit matrix in full, wsym_check_kernel compares its 64 x 64 blocks with their transposes)
+    and lets the pulling, attributing scan run where the thresholded matrix is symmetric and sparse.  Every variant must equal the
+    oracle: a symmetric sparse matrix (uniform boxes: the new path), a symmetric dense one (clustered boxes: skipped by the density
+    gate), the same matrices with ONE entry pushed across the threshold on one side only (asymmetric by a single bit: general
+    scan), and a matrix of random numbers; N on both sides of the one-launch tail (2048) and ragged."""
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(2718)
+    for N, kind in ((1000, "uniform"), (2048, "uniform"), (4096, "uniform"), (4096, "clustered")):
+        boxes = (synthetic.uniform_boxes_2d(rng, N) if kind == "uniform" else synthetic.clustered_boxes_2d(rng, N, 32)).astype(np.float32)
+        scores = rng.random(N, dtype=np.float32)
+        sym = O.iou2d(boxes, boxes)
+        asym = sym.copy()
+        i, j = np.argwhere((sym > 0.45) & (np.arange(N)[:, None] != np.arange(N)[None, :]))[0]
+        asym[i, j] = 0.1                                          # (i, j) drops below the threshold, (j, i) stays above it
+        rnd = rng.random((N, N), dtype=np.float32) * 0.6
+        mats = np.stack([sym, asym, rnd])
+        sc = np.stack([scores] * 3)
+        st = torch.from_numpy(sc).cuda().requires_grad_(True)
+        prob, order, valid, invalid, nv, ni = G.differentiable_nms_batched(st, torch.from_numpy(mats).cuda())
+        w = torch.rand((3, N), device="cuda")
+        (prob * w).sum().backward()
+        for b in range(3):
+            ref = O.differentiable_nms(sc[b], mats[b], grad_prob=w[b].cpu().numpy())
+            assert np.array_equal(prob[b].detach().cpu().numpy(), ref["prob"]), (N, kind, b)
+            assert valid[b, :int(nv[b])].tolist() == list(ref["valid"]), (N, kind, b)
+            assert invalid[b, :int(ni[b])].tolist() == list(ref["invalid"]), (N, kind, b)
+            assert np.array_equal(st.grad[b].cpu().numpy(), ref["grad_scores"]), (N, kind, b)
