@@ -39,6 +39,8 @@ void gnms_set_error(const char* fmt, ...);
 
 // allows `bytes` (> 64 KiB) of dynamic LDS for `kernel` on the current device, remembered per (device, kernel); nms_layer.hip
 int gnms_allow_lds_raw(const void* kernel, size_t bytes);
+// compute units of the current device, cached per device (nms_layer.hip)
+int gnms_device_cu_count();
 
 // A stream-ordered temporary (hipMallocAsync) that is returned to the pool on EVERY exit from the scope, error paths included:
 // the GNMS_CHECK_* macros return early.  `release()` frees explicitly and reports the result.

@@ -343,11 +343,7 @@ int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, 
     const bool persist = forced_persist >= 0 ? forced_persist == 1 : N > 8192;
     if (persist && pct0 == 0 && pct1 == 100) {
         const size_t lds2 = 2 * gnms_iou3d::kSymTileBytes;
-        hipDeviceProp_t prop;
-        int dev = 0;
-        GNMS_CHECK_HIP(hipGetDevice(&dev));
-        GNMS_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const int cus = gnms_device_cu_count();                       // (cached per device: nms_layer.hip)
         if (nt) { if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_persistent_kernel<true>), lds2))) return rc; }
         else { if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_persistent_kernel<false>), lds2))) return rc; }
         if (nt) gnms_launch_prof(kProfMatrixWrite, iou3d_sym_persistent_kernel<true>, dim3((unsigned)cus), dim3(1024), lds2, st, rec, N, B, out, (long)ld, thr);

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(1024) void prof_fill_tiles_kernel(float* __restrict
     }
 }
 }  // namespace
+int gnms_device_cu_count() { return device_cu_count(); }
 extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int rows, int nontemporal, void* stream) {
     GNMS_CHECK_ARG(dst && B > 0 && N > 0 && ld >= N && ld % 4 == 0 && (uintptr_t)dst % 16 == 0,
                    "gnms_profile_fill_tiles: dst 16-byte aligned, ld >= N a multiple of 4");
@@ -701,10 +702,19 @@ __device__ __forceinline__ void writers_sym_persistent(const float* __restrict__
 // array that lives for the call.  (A version that dealt the units statically -- round robin per image, no counters -- reached 0.55 of
 // the HBM peak where this one reaches 0.71 and the 64-row tiles of iou2d_kernel 0.68-0.69: the claims keep an image's write frontier
 // compact when workgroups drift, and the workgroups that run out of units on their image finish the others'.)
+// `claims`: one slot of the library's per-device claim ring (claim_ring_slot): [nimg] counters 64 ints apart, then an exit counter.  The
+// slot is all zero when the launch starts, and the LAST workgroup to leave zeroes it again (device-scope exchanges, the path the claims
+// themselves take) -- no memset in front of the launch and no allocation per call.
 template <bool VEC>
 __global__ __launch_bounds__(1024) void iou2d_self_kernel(const float* __restrict__ boxes, int N, int nimg, float* __restrict__ out, long ld,
                                                           int* __restrict__ claims) {
     writers_staged_2d<VEC>(boxes, N, out, ld, nimg, claims, 64, 0, 1);      // (a counter per 256 bytes: each in an L2 line of its own)
+    if (threadIdx.x == 0) {                                                 // (thread 0 issued every claim of this workgroup and has consumed them all)
+        int* done = claims + (size_t)nimg * 64;
+        if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+            for (int i = 0; i <= nimg; ++i) atomicExch(claims + (size_t)i * 64, 0);
+        }
+    }
 }
 
 // LARGE images (N > 4096): the matrix write as a launch of its own on the side stream (3.2d), in the same geometry -- persistent
@@ -800,27 +810,53 @@ bool gnms_internal_iou2d_wants_staged(int B, int M, int N, int64_t ld, const flo
 // a == b, N <= 4096: iou2d_self_kernel (B = 8, N = 4096: 0.68-0.69 -> 0.71 of the HBM peak); GNMS_IOU2D_SELF=0 keeps iou2d_kernel
 bool gnms_internal_iou2d_wants_self(const float* a, const float* b, int B, int M, int N, int64_t ld, const float* out) {
     static const int forced = [] { const char* e = getenv("GNMS_IOU2D_SELF"); return e ? atoi(e) : -1; }();
-    if (forced == 0 || a != b || M != N || N > 4096 || !writers_staged()) return false;
+    if (forced == 0 || a != b || M != N || N > 4096 || B > 127 || !writers_staged()) return false;
     const long units = (long)B * ((N + kStagedRows - 1) / kStagedRows) * ((N + 4095) / 4096);
     return units >= 8L * device_cu_count();
 }
+namespace {
+// The claim counters of iou2d_self_kernel live in a per-device RING of zeroed slots that the library allocates once (the first call on a
+// device; 1 MiB) -- a launch takes the next slot and leaves it zeroed (see the kernel), so a call neither allocates nor memsets.  Two
+// launches share a slot only if kClaimSlots launches of this kernel are in flight on one device at the same time, and one launch alone
+// fills every CU.  Images per call <= kClaimImgs (larger batches take iou2d_kernel).
+constexpr int kClaimSlots = 32, kClaimImgs = 127;
+constexpr size_t kClaimSlotInts = (size_t)(kClaimImgs + 1) * 64;
+int claim_ring_slot(int** slot) {
+    struct Ring { int* base = nullptr; unsigned next = 0; };
+    static std::mutex mu;
+    static std::map<int, Ring> rings;
+    int dev = 0;
+    GNMS_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    Ring& R = rings[dev];
+    if (!R.base) {
+        int* p = nullptr;
+        GNMS_CHECK_HIP(hipMalloc((void**)&p, kClaimSlots * kClaimSlotInts * sizeof(int)));
+        const hipError_t e = hipMemset(p, 0, kClaimSlots * kClaimSlotInts * sizeof(int));
+        if (e != hipSuccess) { (void)hipFree(p); GNMS_CHECK_HIP(e); }
+        R.base = p;
+    }
+    *slot = R.base + (size_t)(R.next++ % kClaimSlots) * kClaimSlotInts;
+    return GNMS_OK;
+}
+}  // namespace
 int gnms_internal_iou2d_self(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st) {
     static const int forced_grid = [] { const char* e = getenv("GNMS_IOU2D_SELF_GRID"); return e ? atoi(e) : 0; }();
     const int cus = device_cu_count();
-    const int grid = forced_grid > 0 ? forced_grid : cus - 8;       // (alone on the machine the stream likes every CU: 248 -> 0.71, 200 -> 0.64)
-    gnms_async_buffer claims;                                        // [B][64] claim counters, stream-ordered: freed behind the kernel
-    GNMS_CHECK_HIP(claims.alloc((size_t)B * 64 * sizeof(int), st));
-    GNMS_CHECK_HIP(hipMemsetAsync(claims.p, 0, (size_t)B * 64 * sizeof(int), st));
+    int grid = forced_grid > 0 ? forced_grid : cus - 8;             // (alone on the machine the stream likes every CU: 248 -> 0.71, 200 -> 0.64)
+    if (grid < 1) grid = 1;
+    int* claims = nullptr;
+    int rc = claim_ring_slot(&claims);
+    if (rc) return rc;
     size_t lds = (size_t)N * 16;
     if (lds < 96 * 1024) lds = 96 * 1024;                            // > 80 KiB: one workgroup per CU
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
-    int rc;
     if (vec) {
         if ((rc = allow_lds(iou2d_self_kernel<true>, lds))) return rc;
-        gnms_launch_prof(kProfMatrixWrite, iou2d_self_kernel<true>, dim3((unsigned)grid), dim3(1024), lds, st, boxes, N, B, out, (long)ld, claims.as<int>());
+        gnms_launch_prof(kProfMatrixWrite, iou2d_self_kernel<true>, dim3((unsigned)grid), dim3(1024), lds, st, boxes, N, B, out, (long)ld, claims);
     } else {
         if ((rc = allow_lds(iou2d_self_kernel<false>, lds))) return rc;
-        gnms_launch_prof(kProfMatrixWrite, iou2d_self_kernel<false>, dim3((unsigned)grid), dim3(1024), lds, st, boxes, N, B, out, (long)ld, claims.as<int>());
+        gnms_launch_prof(kProfMatrixWrite, iou2d_self_kernel<false>, dim3((unsigned)grid), dim3(1024), lds, st, boxes, N, B, out, (long)ld, claims);
     }
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
@@ -987,7 +1023,8 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
                 float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, hipStream_t st, int sym) {
     int P2 = next_pow2(N);
     if (P2 < 1024) P2 = 1024;                                   // the fused kernel always runs 1024 threads
-    const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
+    // (the fused K5 -> K6 hand-off, E <= 4, parks order[] and a copy of r2 behind the key region: 16 bytes per key)
+    const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * (P2 <= 4096 ? 16 : 8);
     const size_t lds = llds > glds ? llds : glds;
     int rc;
     GNMS_DISPATCH_SORT(P2, {
@@ -1022,7 +1059,8 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
                       int64_t ld, hipStream_t st) {
     int P2 = next_pow2(N);
     if (P2 < 1024) P2 = 1024;
-    const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * 8;
+    // (the fused K5 -> K6 hand-off, E <= 4, parks order[] and a copy of r2 behind the key region: 16 bytes per key)
+    const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * (P2 <= 4096 ? 16 : 8);
     size_t lds = llds > glds ? llds : glds;
     const int tr = fused_tile_rows();
     int staged = (SRC == kFromBoxes && N <= 4096 && writers_staged()) ? (fast_rows_2d() ? fast_rows_2d() : 3) : 0;   // writers_staged_2d: the image's boxes in LDS

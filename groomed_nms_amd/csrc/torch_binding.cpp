@@ -181,6 +181,9 @@ Tensor iou2d(const Tensor& a, const Tensor& b, const c10::optional<Tensor>& out_
     DeviceGuard guard(a.device());
     Tensor ac = a.contiguous(), bc = b.contiguous();
     const int64_t B = ac.size(0), M = ac.size(1), N = bc.size(1);
+    if (out_.has_value())
+        TORCH_CHECK(out_->is_cuda() && out_->device() == ac.device() && out_->scalar_type() == at::kFloat && out_->dim() == 3 && out_->size(0) == B &&
+                    out_->size(1) == M && out_->size(2) == N && out_->is_contiguous(), "GNMS: iou2d `out` must be a contiguous CUDA float [B, M, N] tensor on the boxes' device");
     Tensor out = out_.has_value() ? *out_ : at::empty({B, M, N}, ac.options());
     check(gnms_iou2d((const float*)cptr(ac), (const float*)cptr(bc), (int)B, (int)M, (int)N, (float*)mptr(out), std::max<int64_t>(N, 1),
                      current_stream(ac)), "gnms_iou2d");

@@ -84,7 +84,11 @@ def _layer(ext, scores, src, counts, iou_out, mode, p):
                          bool(getattr(p, "index_lists", True)))
     except NotImplementedError:
         raise
-    except RuntimeError as e:                              # the C ABI's status codes + gnms_last_error(), raised by the binding
+    except RuntimeError as e:
+        # only the library's own failures (the C ABI's status codes + gnms_last_error(), raised by the binding as "GNMS: ...") become
+        # GnmsError; torch's errors -- torch.cuda.OutOfMemoryError first of all -- reach the caller as they are, traceback included
+        if isinstance(e, torch.cuda.OutOfMemoryError) or not str(e).startswith("GNMS:"):
+            raise
         raise _lib.GnmsError(str(e)) from None
 
 

@@ -45,7 +45,9 @@ def iou_batched(boxes_a, boxes_b=None, out=None):
     if ext and boxes_a.is_cuda and boxes_a.dtype == torch.float32 and (boxes_b is None or boxes_b.dtype == torch.float32):
         try:
             return ext.iou2d(boxes_a, boxes_a if boxes_b is None else boxes_b, out)
-        except RuntimeError as e:
+        except RuntimeError as e:                           # (the library's own failures only; torch's -- OOM first of all -- pass through)
+            if isinstance(e, torch.cuda.OutOfMemoryError) or not str(e).startswith("GNMS:"):
+                raise
             raise _lib.GnmsError(str(e)) from None
     lib = _lib.load()
     boxes_a = boxes_a.contiguous()
@@ -104,7 +106,8 @@ def intersect(box_a, box_b, mode='combinations', data_type=None):
 def iou(box_a, box_b, mode='combinations', data_type=None):
     """lib/core.py:480-532.  combinations: M x N matrix from the HIP kernel; list: M values."""
     if mode == 'combinations':
-        if _is_f64_array(box_a) and isinstance(box_b, np.ndarray):
+        # (both float64: with a float32 box_b the reference computes area_b in float32 before promoting -- that mix takes the fp32 kernel)
+        if _is_f64_array(box_a) and _is_f64_array(box_b):
             # the reference's NumPy branch in float64 (lib/core.py:205-207, 512-513), the dtype its inference call site passes
             lib = _lib.load()
             dev = _device()

@@ -15,6 +15,9 @@
  *     null stream); no hidden synchronisation and no hidden allocation, except `_nms`, which keeps
  *     the reference's blocking host-pointer contract, and the 3D entries (gnms_iou3d_*, gnms_forward_with_iou3d),
  *     which take a stream-ordered temporary (hipMallocAsync/hipFreeAsync) of 48-64 bytes per box for the cuboid records;
+ *     and gnms_iou2d of a box set with itself (boxes_a == boxes_b, N <= 4096), whose FIRST call on a device allocates a 1-MiB ring
+ *     of claim counters that lives as long as the process (hipMalloc: make that first call outside stream capture; later calls
+ *     allocate nothing and are capturable);
  *   - gnms_forward_with_iou2d / _iou3d on images of more than 4096 boxes issue the matrix write on a library-owned stream
  *     (one per device, lowest priority) that forks from `stream` and joins it again before the call returns control of the
  *     ordering to the caller: to the caller everything is still ordered on `stream` (earlier work happens before, later work
