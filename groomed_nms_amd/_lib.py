@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgroomed_nms_hip.so")
+LIB_PATH = os.environ.get("GNMS_LIB_PATH") or os.path.join(_HERE, "libgroomed_nms_hip.so")   # (GNMS_LIB_PATH: a developer build, e.g. tools/build_timing.sh)
 
 c_f32p = ctypes.c_void_p
 c_vp = ctypes.c_void_p

@@ -212,7 +212,7 @@ int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double
     const size_t lds = leaders_lds_size(L.NB);
     if (lds > 64 * 1024)
         GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L, 0);
+    leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L, 0, 1, 1);
     GNMS_CHECK_LAUNCH();
     classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);
     GNMS_CHECK_LAUNCH();

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/groomed_nms_hip.h"
 
@@ -28,8 +29,12 @@ void gnms_set_error(const char* fmt, ...);
         }                                                                                     \
     } while (0)
 
+// (GNMS_TRACE_LAUNCH=1, developer: every launch site prints its file:line and waits for the device -- a memory fault then aborts
+// right behind the line of the launch that caused it)
+static inline bool gnms_trace_launch() { static const bool on = [] { const char* e = getenv("GNMS_TRACE_LAUNCH"); return e && e[0] == '1'; }(); return on; }
 #define GNMS_CHECK_LAUNCH()                                                                   \
     do {                                                                                      \
+        if (gnms_trace_launch()) { fprintf(stderr, "[gnms launch] %s:%d\n", __FILE__, __LINE__); fflush(stderr); (void)hipDeviceSynchronize(); } \
         hipError_t e__ = hipGetLastError();                                                   \
         if (e__ != hipSuccess) {                                                              \
             gnms_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
@@ -85,7 +90,10 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //     leadr      int32 [N]      rank of the i-th leader
 //     leadw      u64   [NB]     bit k%64 of word k/64 set iff rank k is a leader
 //     leadpfx    int32 [NB+1]   number of leaders in rank blocks < kb
-//     misc       int32 [8]      [0]=number of leaders, [1]=length of hlist
+//     misc       int32 [16]     [0]=number of leaders, [1]=length of hlist, ... [8]=the workspace's call counter (`epoch`: the sorts of every call
+//                               add 1; it tags the hand-offs between the workgroups of one image's leader scan, leaders_sb_body)
+//     gran       u64   [17][32] leader scan across workgroups: [s][2 bb + h] = (epoch << 32 | half h of the leader mask of block bb of super-block
+//                               s), published by the workgroup that resolved s; [16][s] = (epoch << 32 | 1): its rem[] entries are stored
 //     xidx       int32 [N]      from-boxes path: input index of the p-th box by ascending x centre
 //     xbox       float4 [N]     from-boxes path: the boxes in that order
 //     rec        float [N][12]  gnms_forward_with_iou3d: corner-AABB records of the cuboids (iou3d_pair.h)
@@ -96,9 +104,10 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 struct gnms_ws_layout {
     int N, NB, NC;
     size_t off_order, off_sscore, off_rankof, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_hlist, off_plead, off_pre,
-        off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_xidx, off_xbox, off_rec, off_W;
+        off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_gran, off_xidx, off_xbox, off_rec, off_W;
     size_t per_image;  // bytes
     int pull_leaders;  // leaders_body: leaders of a super-block from which its pushes pull (GNMS_PULL_LEADERS; default 128)
+    int scan_v4;       // symmetric matrices: leaders_sym_body (round 4: parallel resolve, left-looking; GNMS_SCAN_V4=0 keeps the round-3 scan)
 };
 
 static inline gnms_ws_layout gnms_make_layout(int N) {
@@ -115,7 +124,8 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     L.off_xsol = take(n4); L.off_gx = take(n4); L.off_leadc = take(n4); L.off_leadr = take(n4);
     L.off_leadw = take((size_t)(L.NB > 0 ? L.NB : 1) * 8);
     L.off_leadpfx = take((size_t)(L.NB + 1) * 4);
-    L.off_misc = take(32);
+    L.off_misc = take(64);
+    L.off_gran = take(17 * 32 * 8);
     L.off_xidx = take(n4);
     L.off_xbox = take(n4 * 4);
     L.off_rec = take(n4 * 12);
@@ -123,6 +133,8 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     L.per_image = o;
     static const int pull = [] { const char* e = getenv("GNMS_PULL_LEADERS"); return e ? atoi(e) : 128; }();
     L.pull_leaders = pull;
+    static const int v4 = [] { const char* e = getenv("GNMS_SCAN_V4"); return e ? atoi(e) : 1; }();
+    L.scan_v4 = v4;
     return L;
 }
 

@@ -251,7 +251,7 @@ __device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
 struct ImgPtrs {
     int* order; float* sscore; int* rankof; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen; int* hlist;
     float* plead; float* pre; float* r2; int* sidx; float* xsol; float* gx; int* leadc; int* leadr; u64* leadw; int* leadpfx;
-    int* misc; int* xidx; float4* xbox; float* rec; u64* W;
+    int* misc; u64* gran; int* xidx; float4* xbox; float* rec; u64* W;
 };
 
 __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_layout& L, int b) {
@@ -263,7 +263,7 @@ __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_lay
     I.pre = (float*)(p + L.off_pre); I.r2 = (float*)(p + L.off_r2); I.sidx = (int*)(p + L.off_sidx);
     I.xsol = (float*)(p + L.off_xsol); I.gx = (float*)(p + L.off_gx); I.leadc = (int*)(p + L.off_leadc); I.leadr = (int*)(p + L.off_leadr);
     I.leadw = (u64*)(p + L.off_leadw); I.leadpfx = (int*)(p + L.off_leadpfx); I.misc = (int*)(p + L.off_misc);
-    I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox); I.rec = (float*)(p + L.off_rec);
+    I.gran = (u64*)(p + L.off_gran); I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox); I.rec = (float*)(p + L.off_rec);
     I.W = (u64*)(p + L.off_W);
     return I;
 }
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
     // leader can reach and needs no scatter.
     const int all_same = __syncthreads_and(same);
     if (threadIdx.x < 8 && !(boxes && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
+    if (threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;                   // the workspace's call counter (leaders_sb_body's hand-off tag)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,10 +399,6 @@ __device__ __forceinline__ u64 sort_key_of(int role, const float* __restrict__ s
 }
 
 // (run r of image b, role) -- also called from the launch that carries a slice of the matrix write (nms_layer.hip)
-// COHERENT (sort_fused_kernel): the run and the misc words are handed to other workgroups of the SAME launch -- agent-scope stores
-// (write-through, sc1) instead of plain ones, so that no L2 write-back (__threadfence: microseconds on an L2 full of the last step's
-// lines) stands between the run and its flag
-template <bool COHERENT = false>
 __device__ __forceinline__ void sort_runs_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
                                                const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P, const int r, const int b,
                                                const int role) {
@@ -412,13 +409,9 @@ __device__ __forceinline__ void sort_runs_body(const float* __restrict__ scores,
     u64 k[1];
     k[0] = (i < n) ? sort_key_of(role, scores + (size_t)b * N, boxes ? boxes + (size_t)b * N * 4 : nullptr, i) : ~0ull;
     block_sort<1, u64>(k, keys, 1024);
-    if (COHERENT) {
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(&I.W[(size_t)role * P + i]), (unsigned long long)k[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (r == 0 && role == 0 && threadIdx.x < 8) __hip_atomic_store(&I.misc[threadIdx.x], (threadIdx.x == 2) ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
     I.W[(size_t)role * P + i] = k[0];
     if (r == 0 && role == 0 && threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;   // [2] = "already sorted", cleared below
+    if (r == 0 && role == 0 && threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;   // the workspace's call counter (leaders_sb_body's hand-off tag)
 }
 
 __global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
@@ -426,7 +419,7 @@ __global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict
     sort_runs_body(scores, boxes, N, counts, ws, L, P, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
-template <int R, bool COHERENT = false>
+template <int R>
 __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
                                                 const int* __restrict__ counts, char* ws, gnms_ws_layout L, long long* __restrict__ order_out,
                                                 const int r, const int b, const int role) {
@@ -438,8 +431,7 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
     const u64* runs = I.W + (size_t)role * (R * 1024);
 #pragma unroll
     for (int q = 0; q < R; ++q)
-        all[q * 1024 + t] = COHERENT ? (u64)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(&runs[q * 1024 + t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                     : runs[q * 1024 + t];
+        all[q * 1024 + t] = runs[q * 1024 + t];
     __syncthreads();
     const u64 mine = all[r * 1024 + t];
     int same = 1;
@@ -488,36 +480,6 @@ __global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restric
 }
 
 
-// Both halves in ONE launch (round 3): every workgroup sorts its run, publishes it, waits for the other runs of its (image, role) and
-// ranks its keys against them -- one launch skeleton (~3 us of the step) less.  The hand-off is a flag per run in the scratch region
-// behind the runs (W: nothing lives there before K2), written with a per-call 64-bit NONCE the host draws (splitmix of a process-wide
-// counter): a workspace the library has never seen holds the nonce in a flag with probability 2^-64, so no flag has to be cleared in
-// advance; the last workgroup of an image through its wait clears the image's flags again, so a captured launch (same nonce at every
-// replay) starts clean.  A workgroup also waits for run (0, score role) of its image: that workgroup zeroes misc[] before it
-// publishes, and the merges update misc[2] / misc[6] / misc[7] afterwards.  Grid order (run fastest, role slowest) = dispatch order:
-// a workgroup only waits for workgroups dispatched with it or before it.
-template <int R>
-__global__ __launch_bounds__(1024) void sort_fused_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
-                                                          const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P,
-                                                          long long* __restrict__ order_out, unsigned long long nonce) {
-    const int r = blockIdx.x, b = blockIdx.y, role = blockIdx.z, t = threadIdx.x;
-    sort_runs_body<true>(scores, boxes, N, counts, ws, L, P, r, b, role);
-    ImgPtrs I = img_ptrs(ws, L, b);
-    unsigned long long* flags = reinterpret_cast<unsigned long long*>(I.W + 2 * (size_t)P);   // [roles][R]
-    __syncthreads();                                                   // every thread's write-through stores are acknowledged (vmcnt 0) ...
-    if (t == 0) __hip_atomic_store(&flags[role * R + r], nonce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the flag goes out
-    if (t <= R) {
-        const int j = (t < R) ? role * R + t : 0;
-        while (__hip_atomic_load(&flags[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nonce) __builtin_amdgcn_s_sleep(4);
-    }
-    __syncthreads();                                                   // (the runs are read with agent-scope loads: nothing cached to drop)
-    if (t == 0) {
-        const int total = R * (int)gridDim.z;
-        if (atomicAdd(&I.misc[7], 1) == total - 1)                     // the image's last workgroup through the wait: nobody reads the flags any more
-            for (int j = 0; j < total; ++j) __hip_atomic_store(&flags[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    sort_merge_body<R, true>(scores, boxes, N, counts, ws, L, order_out, r, b, role);
-}
 // ------------------------------------------------------------------------------------------------
 // K2: threshold bit matrix -- the ONE full read of the N x N fp32 matrix (HBM-read bound).
 // One wave = 64 rank-rows x 256 input columns.  Rows order[64*kb + r] are contiguous 4N-byte streams
@@ -555,10 +517,8 @@ __global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __rest
     const int bx = (blockIdx.x + kb) % gridDim.x;
     const int c0 = (bx * WAVES + wave) * 256;
     // `full` with ONE 16-wave workgroup per rank block (N <= 4096): the row of W is collected in LDS, by column rank, and leaves as
-    // one coalesced write -- N scattered 8-byte stores per row block otherwise (the triangle alone is half of them); the workgroup
-    // also adds the row block's set bits to misc[4] (wsym_check_kernel: dense images keep the general scan)
+    // one coalesced write -- N scattered 8-byte stores per row block otherwise (the triangle alone is half of them)
     __shared__ u64 rowbuf[(WAVES == 16) ? 4096 : 1];
-    __shared__ unsigned wave_bits[16];
     const bool rowbuffered = WAVES == 16 && full && gridDim.x == 1 && L.NC <= 4096;
     if (k0 >= n) return;                                                 // (workgroup-uniform)
     ImgPtrs I = img_ptrs(ws, L, b);
@@ -621,22 +581,13 @@ __global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __rest
         for (int j = 0; j < 4; ++j) rk[j] = (col[j] < n) ? I.rankof[col[j]] : col[j];       // (padding: rank == index)
     }
     if (rowbuffered) {
-        unsigned bits = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const u64 w = (col[j] < n && !idle) ? ((((u64)wd[1][j] << 32) | wd[0][j]) & rowmask) : 0ull;
             if (col[j] < L.NC && rk[j] >= 0 && rk[j] < L.NC) rowbuf[rk[j]] = w;
-            bits += (unsigned)__builtin_popcountll(w);
         }
-        bits = (unsigned)gnms_add_scan32(bits);                          // (inclusive: lane 63 holds the wave's sum)
-        if (lane == 63) wave_bits[wave] = bits;
         __syncthreads();
         for (int i = threadIdx.x; i < L.NC; i += WAVES * 64) Wk[i] = rowbuf[i];
-        if (threadIdx.x == 0) {
-            unsigned tot = 0u;
-            for (int w = 0; w < WAVES; ++w) tot += wave_bits[w];
-            atomicAdd(&I.misc[4], (int)tot);
-        }
         return;
     }
 #pragma unroll
@@ -667,30 +618,39 @@ __device__ __forceinline__ u64 transpose64(u64 x, int lane) {            // lane
     return x;
 }
 
-__global__ __launch_bounds__(256) void wsym_check_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, int dense_bits_per_rank) {
+// (round 4: no
+// density gate any more: with the scan on one workgroup per super-block the symmetric path is the faster one for dense images too)
+constexpr int kSymPairsPerWave = 1;                          // (four pairs per wave, eight loads in flight, measured slower: 13.0 against 10.7 us at B = 8, N = 4096)
+__global__ __launch_bounds__(256) void wsym_check_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int nb = (n + 63) >> 6;
     const int pairs = nb * (nb + 1) / 2;
-    const int pr = blockIdx.x * 4 + (threadIdx.x >> 6);                   // pair index, row-major over kb <= jb
-    if (pr >= pairs) return;
-    if (I.misc[2] != 0) { if (pr == 0 && lane == 0) I.misc[3] = 1; return; }   // pre-sorted scores: W holds the triangle only
-    // dense images (clustered boxes: ~64 set bits per rank) have few leaders, and for few leaders the general scan is the faster one
-    // (B = 8, N = 4096: 28 against 36 us): they skip the check and keep it.  misc[4]: set bits of W, counted by bitmask_kernel.
-    if (dense_bits_per_rank > 0 && (long long)I.misc[4] > (long long)dense_bits_per_rank * n) { if (pr == 0 && lane == 0) I.misc[3] = 1; return; }
+    const int pr0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSymPairsPerWave;      // pair index, row-major over kb <= jb
+    if (pr0 >= pairs) return;
+    if (I.misc[2] != 0) { if (pr0 == 0 && lane == 0) I.misc[3] = 1; return; }   // pre-sorted scores: W holds the triangle only
+    auto rows_of = [&](int blk) { const int r = min(64, n - blk * 64); return r >= 64 ? ~0ull : ((1ull << r) - 1ull); };
     // pr -> (kb, jb): pairs before row kb = kb * nb - kb (kb - 1) / 2
     const float a = (float)(2 * nb + 1);
-    int kb = (int)((a - sqrtf(a * a - 8.0f * (float)pr)) * 0.5f);
+    int kb = (int)((a - sqrtf(a * a - 8.0f * (float)pr0)) * 0.5f);
     kb = kb < 0 ? 0 : (kb >= nb ? nb - 1 : kb);
-    while (kb > 0 && kb * nb - kb * (kb - 1) / 2 > pr) --kb;
-    while ((kb + 1) * nb - (kb + 1) * kb / 2 <= pr) ++kb;
-    const int jb = kb + (pr - (kb * nb - kb * (kb - 1) / 2));
-    auto rows_of = [&](int blk) { const int r = min(64, n - blk * 64); return r >= 64 ? ~0ull : ((1ull << r) - 1ull); };
-    // A: rows = ranks of block kb (bits), columns = ranks of block jb (lanes); Bm the other way round
-    const u64 A = (jb * 64 + lane < n) ? (I.W[(size_t)kb * L.NC + jb * 64 + lane] & rows_of(kb)) : 0ull;
-    const u64 Bm = (kb * 64 + lane < n) ? (I.W[(size_t)jb * L.NC + kb * 64 + lane] & rows_of(jb)) : 0ull;
-    if (__any(A != transpose64(Bm, lane)) && lane == 0) I.misc[3] = 1;  // (every writer stores 1; the sort zeroed it)
+    while (kb > 0 && kb * nb - kb * (kb - 1) / 2 > pr0) --kb;
+    while ((kb + 1) * nb - (kb + 1) * kb / 2 <= pr0) ++kb;
+    int jb = kb + (pr0 - (kb * nb - kb * (kb - 1) / 2));
+    u64 A[kSymPairsPerWave], Bm[kSymPairsPerWave];
+#pragma unroll
+    for (int q = 0; q < kSymPairsPerWave; ++q) {
+        const bool have = pr0 + q < pairs;
+        // A: rows = ranks of block kb (bits), columns = ranks of block jb (lanes); Bm the other way round
+        A[q] = (have && jb * 64 + lane < n) ? (I.W[(size_t)kb * L.NC + jb * 64 + lane] & rows_of(kb)) : 0ull;
+        Bm[q] = (have && kb * 64 + lane < n) ? (I.W[(size_t)jb * L.NC + kb * 64 + lane] & rows_of(jb)) : 0ull;
+        if (++jb >= nb) { ++kb; jb = kb; }                                  // the next pair in row-major order
+    }
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < kSymPairsPerWave; ++q) bad |= A[q] != transpose64(Bm[q], lane);
+    if (__any(bad) && lane == 0) I.misc[3] = 1;                          // (every writer stores 1; the sort zeroed it)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1121,14 +1081,22 @@ constexpr int kTabPer = (kSBPairs * 64 + 959) / 960;            // table entries
 #ifdef GNMS_TIMING   // developer instrumentation (tools/microbench.hip): accumulates s_memtime deltas into ws gx[] of image 0
 #define GNMS_T0() long long t__ = (long long)__builtin_amdgcn_s_memtime()
 #define GNMS_TACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) ((long long*)I.gx)[slot] += n__ - t__; t__ = n__; } while (0)
+#define GNMS_TACC_IF(cond, slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && (cond)) ((long long*)I.gx)[slot] += n__ - t__; t__ = n__; } while (0)
 #else
+#define GNMS_TACC_IF(cond, slot) do {} while (0)
 #define GNMS_T0() do {} while (0)
 #define GNMS_TACC(slot) do {} while (0)
 #endif
 
 // workgroup barrier that waits for this wave's LDS operations only (not for its global loads / stores, as __syncthreads does): for
 // hand-offs that live in LDS.  Beside the matrix writers the drain of a wave's stores takes microseconds.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (LDS-only fences around the barrier builtin, not inline asm with a "memory" clobber: behind the clobber the compiler re-derived
+// everything it had loaded from memory -- kernel arguments, counts[b] -- after EVERY barrier, ~1000 cycles per step of a loop of them)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 __device__ __forceinline__ u64 uniform64(u64 v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffu));
@@ -1142,14 +1110,6 @@ __device__ __forceinline__ u64 readlane64(u64 v, int lane) {
 }
 __device__ __forceinline__ int tri_index(int b, int bp) { return b * kSB - (b * (b - 1)) / 2 + (bp - b); }   // b <= bp < kSB
 
-// f(integral_constant<int, I>) for I = B .. E-1 until f returns false: a loop the compiler cannot decline to unroll
-template <int I, int E, typename F>
-__device__ __forceinline__ void static_for_until(F&& f) {
-    if constexpr (I < E) {
-        if (f(std::integral_constant<int, I>{})) static_for_until<I + 1, E>(f);
-    }
-}
-
 // exclusive OR-scan across the lanes of a wave
 __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
     u64 up = shfl_up_u64(v, 1);                                     // lane i <- lane i-1
@@ -1160,8 +1120,8 @@ __device__ __forceinline__ u64 wave_or_exclusive_scan(u64 v, int lane) {
 __host__ __device__ __forceinline__ size_t leaders_lds_layout(int NB, size_t* off_acc, size_t* off_lm, size_t* off_cand, size_t* off_pair) {
     size_t o = (size_t)kSBPairs * 64 * 8;                       // Xs
     *off_acc = o; o += (size_t)((NB + 1) & ~1) * 8;             // accAll[NB]
-    *off_lm = o; o += (size_t)((NB + 1) & ~1) * 8;              // leader masks of all blocks
-    *off_cand = o; o += 2 * (size_t)kSB * 64 * 4 + 16;         // leader ranks of the last two super-blocks + their counts
+    *off_lm = o; o += (size_t)((NB + 1 + kSB) & ~1) * 8;        // leader masks of all blocks (+ kSB of padding the sym scan may read)
+    *off_cand = o; o += 2 * (size_t)kSB * 64 * 4 + 128;        // leader ranks of the last two super-blocks + their counts (sym scan: list, claims, stamps)
     *off_pair = o; o += 2 * kSBPairs * 4;                       // pair -> (b, b')
     return o;
 }
@@ -1172,17 +1132,275 @@ __host__ __device__ __forceinline__ size_t leaders_lds_size(int NB) {
     return leaders_lds_layout(NB, &a, &l, &c, &p);
 }
 
+// epilogue of the leader scan, off the sequential path: leader lists, per-block words, running counts (lmask[nb] in LDS is final;
+// `scratch` = >= (8 + nb) ints of LDS nobody else uses any more)
+__device__ __forceinline__ void leaders_epilogue(const ImgPtrs& I, const u64* lmask, int nb, int* scratch) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // exclusive prefix of popcounts over blocks: thread i < nb owns block i (nb <= 256)
+    int cnt = (tid < nb) ? __builtin_popcountll(lmask[tid]) : 0;
+    const int inc = (int)gnms_add_scan32((unsigned)cnt);          // DPP prefix sum
+    int* wsum = scratch;
+    if (lane == 63 && wave < 4) wsum[wave] = inc;
+    __syncthreads();
+    int basew = 0;
+    for (int w = 0; w < 4; ++w) if (w < wave) basew += wsum[w];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int* pfx = wsum + 8;                                          // [nb] exclusive prefix
+    if (tid < nb) {
+        pfx[tid] = basew + inc - cnt;
+        I.leadw[tid] = lmask[tid];
+        I.leadpfx[tid + 1] = basew + inc;
+    }
+    __syncthreads();
+    for (int kb = wave; kb < nb; kb += 16) {
+        const u64 mine = lmask[kb];
+        if ((mine >> lane) & 1ull) {
+            const int slot = pfx[kb] + __builtin_popcountll(mine & ((1ull << lane) - 1ull));
+            const int k = (kb << 6) + lane;
+            I.leadc[slot] = I.order[k];
+            I.leadr[slot] = k;
+        }
+    }
+    if (tid == 0) { I.misc[0] = total; I.leadpfx[0] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 for a SYMMETRIC thresholded matrix whose rows W holds in full (from-boxes / from-records bit matrices; a matrix
+// wsym_check_kernel passed) -- round 4: ONE WORKGROUP PER SUPER-BLOCK (16 blocks = 1024 ranks), the workgroups of an image on
+// different CUs, handing the leader masks down the chain.
+//
+// What a super-block's leaders depend on is small -- the leader masks of the super-blocks before it, 128 bytes each -- and what
+// turns those masks into "removed by an earlier leader" is large but has nothing sequential in it: rank (T, lane) overlaps a
+// leader of source block bb iff  W[bb][rank] & mask[bb] != 0  (the matrix is symmetric), one coalesced 512-byte row segment per
+// (source block, target block), 1 MiB per image at N = 4096, 16 MiB at 16384.  One workgroup per image pulled all of that through
+// one CU's memory pipeline (~24 bytes per clock measured: 60k of the scan's 120k ticks on uniform boxes) between resolves that 15 of
+// its 16 waves sat out.  Here workgroup j owns super-block j: it requests the row segments of source super-block s for its own 16
+// blocks BEFORE the masks of s exist (the addresses do not depend on them), takes the masks when the workgroup of s publishes them,
+// ANDs -- sources in ascending order, so the first hit of a rank is its claimer (rem[], what K4 used to compute) -- then resolves its
+// own super-block, publishes, and stores rem[] for its ranks.  The chain is nsb hand-offs long; everything heavy runs beside it.
+//
+// HAND-OFF.  A mask travels as two 8-byte granules {epoch, 32 mask bits} written by single write-through stores and polled with
+// agent-scope loads: a granule is valid iff its tag is the workspace's call counter (misc[8], advanced by the sort kernels of every
+// call -- so stale granules of earlier calls, or of earlier replays of a captured graph, never match, and nothing has to be cleared).
+// No fence anywhere: beside the matrix writers one agent-scope release costs more than the whole scan (nms_layer.hip).  rem[] goes
+// out through write-through stores as well and is read back (groups_body / attribute_*) with agent-scope loads; the workgroup of the
+// LAST super-block waits for the other workgroups' "rem stored" granules and carries on with K4..K6 of the image.
+// A workgroup only ever waits for workgroups with a LOWER block index (dispatched before it).
+//
+// RESOLVE (inside a super-block).  The leaders are the unique solution of
+//     L[r] = !ext[r]  &&  no q < r (same super-block) with L[q] and overlap(q, r).
+// Wave tb owns block tb and iterates: from the current masks of the blocks before it (LDS, read at immediate offsets) and its table
+// words t[bb] = W[kb0 + bb][rank (tb, lane)] (registers) it recomputes its own mask (the in-block fixed point of round 2), all 16
+// waves at once, one LDS barrier per step, until a step changes no mask; a wave whose earlier blocks did not change since it last
+// looked skips the step.  Block tb is exact after step tb + 1 at the latest, NMS inputs settle in 3-5 steps.  (What a step costs is
+// LDS and VALU issue, 16 waves on 4 SIMDs: ~250 cycles for the barrier, ~500 for the 16 x 15 mask reads, ~1000 for the AND/ORs --
+// tools/../build/mb/bar.hip -- so the parallel resolve is no faster than the scalar-unit resolve of round 2 per super-block; what it
+// buys is that no wave idles and nothing else has to be overlapped with it.)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 gran_load(const u64* p) {
+    return (u64)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gran_store(u64* p, u64 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// rem[] as the leader scan leaves it: agent-scope accesses (see above; plain ones would do between kernels, these do everywhere)
+__device__ __forceinline__ int rem_load(const int* rem, int k) { return __hip_atomic_load(rem + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void rem_store(int* rem, int k, int v) { __hip_atomic_store(rem + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// super-block `j` of image `b` (j < nsb of the image); returns true in the workgroup that may go on with K4..K6 of the image:
+// the one of the image's last super-block, after every rem[] entry of the image is visible to it
+__device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int j) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    size_t oa, ol, oc, op;
+    leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
+    u64* Xs = reinterpret_cast<u64*>(smem);                      // [kSBPairs][64] table of the own super-block
+    u64* lmask = reinterpret_cast<u64*>(smem + ol);              // [NB + kSB] leader masks: the earlier super-blocks' as they arrive, then the own
+    int* pair_b = reinterpret_cast<int*>(smem + op);             // [kSBPairs]
+    int* pair_bp = pair_b + kSBPairs;
+    int* stamp = reinterpret_cast<int*>(smem + oc);              // [1] the last resolve step that changed a mask
+    int* bstamp = stamp + 4;                                     // [kSB] per block of the super-block: the last step that changed its mask
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    // (the wave index through readfirstlane: as tid >> 6 it is a VECTOR value to the compiler, and every `bb < tb` below became a 64-bit
+    // lane mask in an SGPR pair -- 186 spilled SGPRs and a v_readlane / s_nop pair around every use)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = (n + 63) >> 6;
+    const int nsb = (nb + kSB - 1) / kSB;
+    const u64 below = (1ull << lane) - 1ull;
+    const int kb0 = j * kSB;
+    const int nblk = min(kSB, nb - kb0);
+    const bool last_sb = j == nsb - 1;
+    const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
+    GNMS_T0();
+    // table layout: pair (source block bb <= target block tb) at tb (tb + 1) / 2 + bb -- a target's words are consecutive, so the wave
+    // that owns it reads them at immediate offsets from one base (the general scan's layout needs the triangular index per word:
+    // ~12 scalar instructions each, and sixteen waves share the CU's one scalar unit)
+    if (tid < kSB) for (int bb = 0; bb <= tid; ++bb) { pair_b[tid * (tid + 1) / 2 + bb] = bb; pair_bp[tid * (tid + 1) / 2 + bb] = tid; }
+    for (int i = tid; i < nb + kSB; i += 1024) lmask[i] = 0ull;
+    if (tid == 0) *stamp = 0;
+    if (tid < kSB) bstamp[tid] = -1;
+    __syncthreads();
+    {   // the own super-block's table: no dependence on anybody (in flight while the first masks are waited for)
+        constexpr int kTabAll = (kSBPairs * 64 + 1023) / 1024;
+        u64 tw[kTabAll];
+#pragma unroll
+        for (int u = 0; u < kTabAll; ++u) {
+            const int e = tid + u * 1024;
+            tw[u] = 0ull;
+            if (e < kSBPairs * 64) {
+                const int pr = e >> 6;
+                const int bb = pair_b[pr], bp = pair_bp[pr];
+                const int k = (kb0 + bp) * 64 + (e & 63);          // row block = the SOURCE block bb, column = target rank (bp, lane)
+                if (bp < nblk && k < n) tw[u] = I.W[(size_t)(kb0 + bb) * L.NC + k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kTabAll; ++u) {
+            const int e = tid + u * 1024;
+            if (e < kSBPairs * 64) Xs[e] = tw[u];
+        }
+    }
+    GNMS_TACC_IF(b == 0 && last_sb, 0);
+    // ---- the earlier super-blocks, in ascending order: row segments requested, masks awaited, ANDed ----
+    const int tb = wave;                                           // this wave's block of the super-block
+    const bool live = tb < nblk;
+    const int kT = ((kb0 + (live ? tb : 0)) << 6) + lane;          // this lane's rank
+    int cl = -1;                                                   // rank of the first leader (of an earlier super-block) that overlaps it
+    for (int s = 0; s < j; ++s) {
+        const int s0 = s * kSB;
+        u64 wv[kSB];
+#pragma unroll
+        for (int bb = 0; bb < kSB; ++bb) wv[bb] = (live && kT < n) ? I.W[(size_t)(s0 + bb) * L.NC + kT] : 0ull;
+        if (wave == 0) {                                           // the masks of super-block s: 32 granules, lane g polls granule g
+            const u64* g = I.gran + (size_t)s * 32 + (lane & 31);
+            u64 v = gran_load(g);
+            while (__ballot((v & 0xffffffff00000000ull) != epoch) != 0ull) { __builtin_amdgcn_s_sleep(2); v = gran_load(g); }
+            reinterpret_cast<unsigned*>(lmask + s0)[lane & 31] = (unsigned)(v & 0xffffffffu);   // (lanes 32..63 write the same words again)
+        }
+        lds_barrier();
+        int c = -1;
+#pragma unroll
+        for (int bb = 0; bb < kSB; ++bb) {
+            const u64 m = wv[bb] & lmask[s0 + bb];
+            if (c < 0 && m != 0ull) c = ((s0 + bb) << 6) + __builtin_ctzll(m);
+        }
+        if (cl < 0) cl = c;
+    }
+    const u64 ext = __ballot(cl >= 0);                             // removed-word of the wave's block (earlier super-blocks' leaders)
+    if (j == 0) __syncthreads();                                   // (the table is in LDS; with j > 0 the barriers above cover it -- tw is consumed before them)
+    GNMS_TACC_IF(b == 0 && last_sb, 1);
+    // ---- resolve of the own super-block: every wave its block, steps until no mask changes ----
+    const int tbc = live ? tb : 0;
+    const int k0 = (kb0 + tbc) << 6;
+    u64 fixed = ext;                                               // never leaders: taken by earlier super-blocks, or past the image's last rank
+    if (live) { const int nrows = min(64, n - k0); if (nrows < 64) fixed |= ~((1ull << nrows) - 1ull); }
+    const u64* myX = Xs + (size_t)(tbc * (tbc + 1) / 2) * 64 + lane;   // this wave's table words: source block bb at myX[bb * 64]
+    const u64* myL = lmask + kb0;                                  // (lmask is padded by kSB entries: no clamp)
+    const u64 cs = live ? (myX[tbc * 64] & below) : 0ull;          // earlier ranks of the block that overlap rank k0 + lane
+    unsigned tlo[kSB - 1], thi[kSB - 1];
+#pragma unroll
+    for (int bb = 0; bb < kSB - 1; ++bb) {                          // (entries past tb belong to other targets: masked)
+        const u64 x = myX[bb * 64];
+        tlo[bb] = (bb < tb) ? (unsigned)(x & 0xffffffffu) : 0u;
+        thi[bb] = (bb < tb) ? (unsigned)(x >> 32) : 0u;
+    }
+    u64 mine = 0ull;                                               // this block's leader mask as last published (lmask[kb0 + tb])
+    {
+        u64 cur_prev = ~0ull;
+        bool first = true;
+        int looked = 0;                                            // the step of this wave's last look at the earlier masks
+        int step = 1;
+        for (;;) {
+            if (live) {                                            // (wave-uniform)
+                // did a block before mine change since I last looked?  (lane bb holds block bb's stamp)
+                const bool dirty = first || __ballot(lane < tb && bstamp[lane < kSB ? lane : 0] >= looked) != 0ull;
+                if (dirty) {
+                    looked = step;
+                    unsigned vlo = 0u, vhi = 0u;
+#pragma unroll
+                    for (int bb = 0; bb < kSB - 1; ++bb) {
+                        const u64 l = myL[bb];
+                        vlo |= tlo[bb] & (unsigned)(l & 0xffffffffu);
+                        vhi |= thi[bb] & (unsigned)(l >> 32);
+                    }
+                    const u64 cur = fixed | __ballot((vlo | vhi) != 0u);
+                    if (first || cur != cur_prev) {                // (the same `cur` gives the same leaders)
+                        cur_prev = cur;
+                        u64 leaders = 0ull;
+                        if (~cur != 0ull) {
+                            const bool cand = ((cur >> lane) & 1ull) == 0ull;
+                            leaders = ~cur;
+                            for (;;) {                             // in-block fixed point: positions < t are final after t rounds
+                                const u64 nl = __ballot(cand && (cs & leaders) == 0ull);
+                                if (nl == leaders) break;
+                                leaders = nl;
+                            }
+                        }
+                        if (leaders != mine) {
+                            mine = leaders;
+                            if (lane == 0) { lmask[kb0 + tb] = leaders; bstamp[tb] = step; *stamp = step; }
+                        }
+                    }
+                    first = false;
+                }
+            }
+            lds_barrier();
+            const int last = *stamp;
+            ++step;
+            if (step - last > 1) break;                            // a whole step without a change (a faster wave may have stamped a later step: still <=)
+        }
+#ifdef GNMS_TIMING
+        if (threadIdx.x == 0 && b == 0 && last_sb) ((long long*)I.gx)[20] += step;
+#endif
+    }
+    // ---- publish the masks (the chain's critical path ends here), then rem[] ----
+    if (!last_sb && wave == 0 && lane < 32) {
+        const unsigned half = reinterpret_cast<const unsigned*>(lmask + kb0)[lane];
+        gran_store(I.gran + (size_t)j * 32 + lane, epoch | half);
+    }
+    GNMS_TACC_IF(b == 0 && last_sb, 2);
+    // rem[] of the wave's block: itself for a leader, else the first claimer -- an earlier super-block's (cl), else the first earlier
+    // block of this super-block with a leader in the table word, else the own block
+    {
+        const int k = k0 + lane;
+        int c = -1;
+#pragma unroll
+        for (int bb = 0; bb < kSB - 1; ++bb) {
+            const u64 l = myL[bb];
+            const unsigned mlo = tlo[bb] & (unsigned)(l & 0xffffffffu), mhi = thi[bb] & (unsigned)(l >> 32);
+            if (c < 0 && (mlo | mhi) != 0u) c = ((kb0 + bb) << 6) + (mlo ? __builtin_ctz(mlo) : 32 + __builtin_ctz(mhi));
+        }
+        if (c < 0) { const u64 m = cs & mine; c = (m != 0ull) ? k0 + __builtin_ctzll(m) : k; }
+        if (live && k < n) {
+            int r = k;
+            if (((mine >> lane) & 1ull) == 0ull) r = ((ext >> lane) & 1ull) ? cl : c;
+            rem_store(I.rem, k, r);
+        }
+    }
+    if (!last_sb) {
+        __syncthreads();                                           // every wave's rem stores are acknowledged (vmcnt 0) ...
+        if (tid == 0) gran_store(I.gran + (size_t)16 * 32 + j, epoch | 1ull);   // ... before "rem stored" goes out
+        return false;
+    }
+    // ---- the image's last super-block: the other workgroups' rem[] must be there, then the per-image epilogue (all masks are in LDS) ----
+    if (wave == 0 && j > 0) {
+        const u64* g = I.gran + (size_t)16 * 32 + (lane < j ? lane : 0);
+        u64 v = gran_load(g);
+        while (__ballot((v & 0xffffffff00000000ull) != epoch) != 0ull) { __builtin_amdgcn_s_sleep(2); v = gran_load(g); }
+    }
+    GNMS_TACC_IF(b == 0 && last_sb, 3);
+    __syncthreads();
+    leaders_epilogue(I, lmask, nb, reinterpret_cast<int*>(Xs));
+    GNMS_TACC_IF(b == 0 && last_sb, 4);
+    return true;
+}
+
 // The four per-image stages K3..K6 are written as device functions (`*_body`, 1024 threads, image index `b`) so that they
 // run either as kernels of their own (thin wrappers below) or back to back inside ONE launch (tail_kernel).
-// sym != 0: the thresholded matrix is SYMMETRIC and W holds its rows in full (the from-boxes / from-records bit-matrix kernels: the
-// overlap of a pair does not depend on which box is the row) -- the resolve then PULLS: table entry (b, b')[lane] = W[b][rank(b', lane)]
-// says which ranks of block b overlap rank (b', lane), so "removed by an earlier leader" is an AND with the leader masks of the
-// earlier blocks, and the leaders of a block are the fixed point of  L[r] = !removed[r] && no q < r with L[q] overlapping r,
-// found by iterating a ballot (positions < t are final after t rounds; NMS inputs need a handful).  Cost per block: ~16 LDS reads and
-// a few dozen VALU instructions whatever the number of leaders -- the scalar loop of the general path pays ~130 cycles PER LEADER
-// (uniform boxes: 1890 leaders of 4096 ranks, 0.15 ms on one wave).  sym == 0 (matrix in, possibly asymmetric; classical NMS):
-// table entry (b, b')[lane] = W[b'][rank(b, lane)], what candidate (b, lane) would remove in block b', pushed leader by leader.
-__device__ __forceinline__ void leaders_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int sym_arg) {
+// leaders_body: the GENERAL scan (matrix in, possibly asymmetric; classical NMS), one workgroup per image.  Table entry
+// (b, b')[lane] = W[b'][rank(b, lane)], what candidate (b, lane) would remove in block b', pushed leader by leader; wave 0 resolves on
+// the scalar unit (~130 cycles per leader) while waves 1..15 prefetch and push.  Symmetric matrices take leaders_sb_body above.
+__device__ __forceinline__ void leaders_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t oa, ol, oc, op;
     leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -1195,20 +1413,12 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
     int* lcount = llist + 2 * kSB * 64;                          // [2]
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
-    const int sym = sym_arg == 2 ? (I.misc[3] == 0 ? 1 : 0) : sym_arg;  // 2: as wsym_check_kernel found this image's matrix
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = (n + 63) >> 6;
     const int nsb = (nb + kSB - 1) / kSB;
     GNMS_T0();
-    if (tid == 0) I.leadpfx[0] = 0;
     if (tid < kSB) for (int bp = tid; bp < kSB; ++bp) { pair_b[tri_index(tid, bp)] = tid; pair_bp[tri_index(tid, bp)] = bp; }
     for (int i = tid; i < nb; i += 1024) { accAll[i] = 0ull; lmask[i] = 0ull; }
-    // sym: the scan also ATTRIBUTES -- rem[k] = rank of the first (lowest-ranked) leader that overlaps rank k, k itself for a leader.
-    // Every word that decides it passes through this kernel anyway: the pushes gather W[target block][leader] for the leaders in
-    // rank order (the first of them to set a bit claims that rank), the resolve's table holds the pairs inside a super-block.  As a
-    // pass of its own (K4) the attribution read W a second time, and beside the matrix write the chain workgroup gets a CU's share
-    // of the memory system and no more: 1 MiB more per image = 103-126k of the chain's 295k ticks on uniform boxes at N = 4096.
-    if (sym) for (int k = tid; k < n; k += 1024) I.rem[k] = k;
     __syncthreads();
 
     // table prefetch of super-block `sb` into registers, by the threads [first, 1024)
@@ -1224,10 +1434,9 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
                 const int pr = e >> 6;
                 const int bb = pair_b[pr], bp = pair_bp[pr];
                 if (bp < nblk) {
-                    // sym: row block = the SOURCE block bb, column = target rank (bp, lane); else row block = the target block bp,
-                    // column = candidate rank (bb, lane).  Contiguous 512 B per (b,b') row either way.
-                    const int k = (kb0 + (sym ? bp : bb)) * 64 + (e & 63);
-                    if (k < n) tw[u] = I.W[(size_t)(kb0 + (sym ? bb : bp)) * L.NC + k];
+                    // row block = the target block bp, column = candidate rank (bb, lane): contiguous 512 B per (b, b') row
+                    const int k = (kb0 + bb) * 64 + (e & 63);
+                    if (k < n) tw[u] = I.W[(size_t)(kb0 + bp) * L.NC + k];
                 }
             }
         }
@@ -1248,149 +1457,36 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
     // push: OR the words of super-block `src`'s leaders into the removed-words of the blocks [first, last); the calling waves are
     // numbered w of nw and take every nw-th block, four blocks at a time.  Lane j gathers the word of the j-th leader (the resolve
     // appends every leader to a list as it finds it) -- exactly the words that matter, and all of a wave's blocks in ONE memory
-    // round trip (the push used to load the 16 full 512-byte row segments of a block and then the next block's: 2-3 dependent
-    // round trips per wave and super-block).
+    // round trip.
     auto push = [&](int src, int first, int last, int w, int nw) {
         const int* list = llist + (src & 1) * (kSB * 64);
         const int nl = lcount[src & 1];
-        // (Pulling full rows instead -- 16 coalesced 512-byte reads per target block, AND with the leader masks, ballot -- was measured
-        // for the many-leaders case, ~470 leaders per super-block on uniform boxes: near push 28k -> 49k ticks, slower.)
-        if (!sym) {
-            for (int base = first + w; base < last; base += 4 * nw) {
-                u64 a[4] = {0ull, 0ull, 0ull, 0ull};
-                for (int j0 = 0; j0 < nl; j0 += 64) {
-                    const int j = j0 + lane;
-                    const int lr = (j < nl) ? list[j] : -1;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int kbp = base + u * nw;
-                        if (lr >= 0 && kbp < last) a[u] |= I.W[(size_t)kbp * L.NC + lr];
-                    }
-                }
+        for (int base = first + w; base < last; base += 4 * nw) {
+            u64 a[4] = {0ull, 0ull, 0ull, 0ull};
+            for (int j0 = 0; j0 < nl; j0 += 64) {
+                const int j = j0 + lane;
+                const int lr = (j < nl) ? list[j] : -1;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int kbp = base + u * nw;
-                    if (kbp < last) {                                  // wave-uniform
-                        const u64 acc = gnms_wave_or(a[u]);
-                        if (lane == 0 && acc != 0ull) atomicOr(reinterpret_cast<unsigned long long*>(&accAll[kbp]), (unsigned long long)acc);
-                    }
-                }
-            }
-            return;
-        }
-        // sym: the push also attributes.  Lane order inside a batch of 64 leaders = rank order, batches ascend: the first lane of the
-        // first batch that has bit r is the claimer of rank r of the target block -- unless an earlier source took it (accAll).
-        // Two target blocks x eight batches (512 leaders) per round, every load of the round issued before the first use (consuming
-        // batch by batch cost one memory round trip per batch: near push 28k -> 71k ticks on uniform boxes).  An exclusive OR-scan
-        // over the lanes tells each leader which bits it is the first to set; it stores those itself (a wave-uniform loop over the new
-        // bits with a ballot per bit was tried: one trip per claimed rank, 3900 per clustered image -- leaders 62k -> 134k ticks).
-        if (nl >= L.pull_leaders) {
-            // MANY leaders (uniform boxes: ~470 per super-block): PULL.  The overlap is symmetric, so "rank (T, lane) overlaps a leader of
-            // source block bb" is also bit (leader) of W[bb][rank]: one coalesced 512-byte row segment per source block and target
-            // block, ANDed with the block's leader mask -- 16 loads per target block whatever the number of leaders, where the gather
-            // below fetches one 64-byte line per leader (470 lines = 30 KB against 8 KB), and the first claimer of a rank is the lowest
-            // set bit of the first source block that has one: no scan over the lanes, one coalesced store of rem.  Same masks, same
-            // claimers (sources still arrive in ascending order, a rank some earlier source took keeps its claimer: accAll).
-            const int s0 = src * kSB;
-            const int ns = min(kSB, nb - s0);
-            for (int T = first + w; T < last; T += nw) {
-                const int k = (T << 6) + lane;
-                u64 wv[kSB];
-#pragma unroll
-                for (int bb = 0; bb < kSB; ++bb) wv[bb] = (bb < ns && k < n) ? I.W[(size_t)(s0 + bb) * L.NC + k] : 0ull;
-                const u64 taken = accAll[T];
-                int cl = -1;
-#pragma unroll
-                for (int bb = 0; bb < kSB; ++bb) {
-                    const u64 m = (bb < ns) ? (wv[bb] & lmask[s0 + bb]) : 0ull;
-                    if (cl < 0 && m != 0ull) cl = ((s0 + bb) << 6) + __builtin_ctzll(m);
-                }
-                const u64 hit = __ballot(cl >= 0);
-                if (cl >= 0 && ((taken >> lane) & 1ull) == 0ull) I.rem[k] = cl;
-                if (lane == 0 && (hit & ~taken) != 0ull) atomicOr(reinterpret_cast<unsigned long long*>(&accAll[T]), (unsigned long long)hit);
-            }
-            return;
-        }
-        constexpr int PB = 2, PJ = 8;
-        for (int base = first + w; base < last; base += PB * nw) {
-            u64 a[PB], claimed[PB];
-#pragma unroll
-            for (int u = 0; u < PB; ++u) {
-                a[u] = 0ull;
-                claimed[u] = (base + u * nw < last) ? accAll[base + u * nw] : ~0ull;
-            }
-            for (int j0 = 0; j0 < nl; j0 += 64 * PJ) {
-                int lr[PJ];
-                u64 wv[PJ][PB];
-#pragma unroll
-                for (int q = 0; q < PJ; ++q) {
-                    const int j = j0 + q * 64 + lane;
-                    lr[q] = (j < nl) ? list[j] : -1;
-                }
-#pragma unroll
-                for (int q = 0; q < PJ; ++q)
-#pragma unroll
-                    for (int u = 0; u < PB; ++u) {
-                        const int kbp = base + u * nw;
-                        wv[q][u] = (lr[q] >= 0 && kbp < last) ? I.W[(size_t)kbp * L.NC + lr[q]] : 0ull;
-                    }
-#pragma unroll
-                for (int q = 0; q < PJ; ++q) {
-                    if (j0 + q * 64 >= nl) break;                      // wave-uniform
-#pragma unroll
-                    for (int u = 0; u < PB; ++u) {
-                        a[u] |= wv[q][u];
-                        if (~claimed[u] == 0ull) continue;             // (wave-uniform) nothing left to claim in this block
-                        if (__any((wv[q][u] & ~claimed[u]) != 0ull)) { // a free bit somewhere: the first lane that has it claims it
-                            const u64 ex = wave_or_exclusive_scan(wv[q][u], lane);
-                            u64 got = wv[q][u] & ~(claimed[u] | ex);
-                            while (got != 0ull) {                      // a leader's own claims in this block, lanes in parallel
-                                I.rem[((base + u * nw) << 6) + __builtin_ctzll(got)] = lr[q];
-                                got &= got - 1;
-                            }
-                            claimed[u] |= readlane64(ex | wv[q][u], 63);   // the OR of all lanes' words comes with the scan
-                        }
-                    }
+                    if (lr >= 0 && kbp < last) a[u] |= I.W[(size_t)kbp * L.NC + lr];
                 }
             }
 #pragma unroll
-            for (int u = 0; u < PB; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int kbp = base + u * nw;
-                if (kbp < last) {                                      // wave-uniform
+                if (kbp < last) {                                  // wave-uniform
                     const u64 acc = gnms_wave_or(a[u]);
                     if (lane == 0 && acc != 0ull) atomicOr(reinterpret_cast<unsigned long long*>(&accAll[kbp]), (unsigned long long)acc);
                 }
             }
         }
     };
-    // sym: the ranks of super-block sb that no earlier super-block's leader took and that are not leaders: their first claimer is a
-    // leader of the super-block itself -- the lowest earlier block of it with a leader in the table word, else the own block.
-    // One wave per block, off the sequential path (between barrier A and the table store that overwrites Xs).
-    auto claim_inside = [&](int sb) {
-        const int kb0 = sb * kSB;
-        const int nblk = min(kSB, nb - kb0);
-        const int tb = wave;
-        if (tb >= nblk) return;
-        const int k = ((kb0 + tb) << 6) + lane;
-        const u64 lead_tb = lmask[kb0 + tb], taken = accAll[kb0 + tb];
-        if (k >= n || (((lead_tb | taken) >> lane) & 1ull)) return;
-        int cl = -1;
-        for (int bb = 0; bb < tb && cl < 0; ++bb) {
-            const u64 m = Xs[(size_t)tri_index(bb, tb) * 64 + lane] & lmask[kb0 + bb];
-            if (m != 0ull) cl = ((kb0 + bb) << 6) + __builtin_ctzll(m);
-        }
-        if (cl < 0) {
-            const u64 m = Xs[(size_t)tri_index(tb, tb) * 64 + lane] & lead_tb & ((1ull << lane) - 1ull);
-            if (m != 0ull) cl = ((kb0 + tb) << 6) + __builtin_ctzll(m);
-        }
-        if (cl >= 0) I.rem[k] = cl;
-    };
 
     // Per super-block sb:  wave 0 resolves it (registers and LDS only) WHILE waves 1..15 prefetch the table of sb+1 and push the
     // leaders of sb-1 into the blocks from super-block sb+1 on ("far" push: nothing the running resolve reads);  then all 16 waves
     // push the new leaders of sb into the 16 blocks of super-block sb+1 ("near" push, one block per wave), the only part of the
-    // push the next resolve has to wait for.  (With the whole push behind the resolve, wave 0 idled 40 % of the kernel: of 57k
-    // cycles at N=4096, 27k were the resolve.)
+    // push the next resolve has to wait for.
     for (int sb = 0; sb < nsb; ++sb) {
         const int kb0 = sb * kSB;
         const int nblk = min(kSB, nb - kb0);
@@ -1403,48 +1499,6 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
             u64 mylead = 0;                                            // lane b' = leader mask of block kb0+b'
             int* list = llist + (sb & 1) * (kSB * 64);
             int filled = 0;                                            // leaders of this super-block so far (wave-uniform)
-            if (sym) {
-                // leader masks of the blocks of this super-block resolved so far (wave-uniform; 0 = not yet resolved).  The block loop
-                // is unrolled in full, so these are registers and every table offset is an immediate.
-                unsigned Llo[kSB], Lhi[kSB];
-#pragma unroll
-                for (int bb = 0; bb < kSB; ++bb) { Llo[bb] = 0u; Lhi[bb] = 0u; }
-                __builtin_amdgcn_s_setprio(3);                                    // the sequential path: first call on the SIMD's issue slots
-                static_for_until<0, kSB>([&](auto tbc) {
-                    constexpr int tb = decltype(tbc)::value;
-                    if (tb >= nblk) return false;
-                    const int k0 = (kb0 + tb) << 6;
-                    const int nrows = min(64, n - k0);
-                    // ranks of this block that overlap a leader of an earlier block of the super-block: tb table reads, one AND-OR each
-                    u64 t[tb + 1];
-#pragma unroll
-                    for (int bb = 0; bb <= tb; ++bb) t[bb] = Xs[(size_t)tri_index(bb, tb) * 64 + lane];
-                    unsigned vlo = 0u, vhi = 0u;
-#pragma unroll
-                    for (int bb = 0; bb < tb; ++bb) {
-                        vlo = ((unsigned)(t[bb] & 0xffffffffu) & Llo[bb]) | vlo;
-                        vhi = ((unsigned)(t[bb] >> 32) & Lhi[bb]) | vhi;
-                    }
-                    u64 cur = readlane64(myacc, tb) | __ballot((vlo | vhi) != 0u);
-                    if (nrows < 64) cur |= ~((1ull << nrows) - 1ull);             // ranks >= n never lead
-                    if (~cur == 0ull) return true;
-                    const u64 c = t[tb] & ((1ull << lane) - 1ull);                 // earlier ranks of the block that overlap rank k0 + lane
-                    const bool cand = ((cur >> lane) & 1ull) == 0ull;
-                    u64 leaders = ~cur;
-                    for (;;) {                                                     // fixed point: a handful of rounds
-                        const u64 nl = __ballot(cand && (c & leaders) == 0ull);
-                        if (nl == leaders) break;
-                        leaders = nl;
-                    }
-                    Llo[tb] = (unsigned)(leaders & 0xffffffffu);
-                    Lhi[tb] = (unsigned)(leaders >> 32);
-                    if (lane == tb) mylead = leaders;
-                    if ((leaders >> lane) & 1ull) list[filled + __builtin_popcountll(leaders & ((1ull << lane) - 1ull))] = k0 + lane;
-                    filled += __builtin_popcountll(leaders);
-                    return true;
-                });
-                __builtin_amdgcn_s_setprio(0);
-            } else
             for (int bb = 0; bb < nblk; ++bb) {
                 const int k0 = (kb0 + bb) << 6;
                 const int nrows = min(64, n - k0);
@@ -1477,47 +1531,44 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
         GNMS_TACC(1);
         __syncthreads();                                               // (A) wave 0 is done with Xs; the far pushes have landed
         GNMS_TACC(2);
-        if (sym) claim_inside(sb);
         push(sb, kb0 + nblk, min(kb0 + nblk + kSB, nb), wave, 16);
-        if (sym && sb + 1 < nsb) __syncthreads();                      // claim_inside has read Xs
         if (sb + 1 < nsb) table_store(64, 960);                        // land the prefetched table for the next super-block
         GNMS_TACC(3);
         __syncthreads();                                               // (B)
         GNMS_TACC(4);
     }
-    // ---- epilogue, off the sequential path: leader lists, per-block words, running counts ----
-    {
-        // exclusive prefix of popcounts over blocks: thread i < nb owns block i (nb <= 256)
-        int cnt = (tid < nb) ? __builtin_popcountll(lmask[tid]) : 0;
-        const int inc = (int)gnms_add_scan32((unsigned)cnt);          // DPP prefix sum
-        int* wsum = reinterpret_cast<int*>(Xs);                      // Xs is free now
-        if (lane == 63 && wave < 4) wsum[wave] = inc;
-        __syncthreads();
-        int basew = 0;
-        for (int w = 0; w < 4; ++w) if (w < wave) basew += wsum[w];
-        const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        int* pfx = wsum + 8;                                          // [nb] exclusive prefix
-        if (tid < nb) {
-            pfx[tid] = basew + inc - cnt;
-            I.leadw[tid] = lmask[tid];
-            I.leadpfx[tid + 1] = basew + inc;
-        }
-        __syncthreads();
-        for (int kb = wave; kb < nb; kb += 16) {
-            const u64 mine = lmask[kb];
-            if ((mine >> lane) & 1ull) {
-                const int slot = pfx[kb] + __builtin_popcountll(mine & ((1ull << lane) - 1ull));
-                const int k = (kb << 6) + lane;
-                I.leadc[slot] = I.order[k];
-                I.leadr[slot] = k;
-            }
-        }
-        if (tid == 0) I.misc[0] = total;
-    }
+    leaders_epilogue(I, lmask, nb, reinterpret_cast<int*>(Xs));
 }
 
-__global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, int sym) {
-    leaders_body(N, counts, ws, L, (int)blockIdx.x, sym);
+// One CHAIN workgroup of a launch that runs the leader scan of B images with `spw` workgroups per image (spw = ceil(NB / 16) when the
+// launch may meet symmetric images -- leaders_chain_wgs --, else 1); chain index c = (workgroup of the image) * B + image, so that the
+// workgroups of the first super-blocks, which wait for nobody, are dispatched first.  sym_arg: 0 general, 1 symmetric (W holds full
+// rows), 2 as wsym_check_kernel found this image's matrix.  Returns true, with *image set, in the ONE workgroup per image that goes
+// on with K4..K6.
+__host__ __device__ inline int leaders_chain_wgs(int N, int sym_arg) { return sym_arg ? max(1, ((N + 63) / 64 + kSB - 1) / kSB) : 1; }
+
+__device__ __forceinline__ bool leaders_chain(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int B, const int spw,
+                                              const int c, const int sym_arg, int* image) {
+    const int jw = c / B, b = c - jw * B;
+    *image = b;
+    const bool lastw = jw == spw - 1;
+    const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;
+    if (!sym) {
+        if (!lastw) return false;
+        leaders_body(N, counts, ws, L, b);
+        return true;
+    }
+    // symmetric: the image's own super-blocks (ragged counts: fewer than spw) -- the last one in the launch's last workgroup of the image
+    const int n = gnms_count(counts, b, N);
+    const int nsb = max(1, (((n + 63) >> 6) + kSB - 1) / kSB);
+    if (lastw) return leaders_sb_body(N, counts, ws, L, b, nsb - 1);
+    if (jw < nsb - 1) leaders_sb_body(N, counts, ws, L, b, jw);
+    return false;
+}
+
+__global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, int sym, int B, int spw) {
+    int b;
+    leaders_chain(N, counts, ws, L, B, spw, (int)blockIdx.x, sym, &b);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1552,7 +1603,7 @@ __device__ __forceinline__ void attribute_body(const float* __restrict__ src, lo
         // overlap with it
         if (lane < nrows) {
             const int k = k0 + lane;
-            const int lr = I.rem[k];
+            const int lr = rem_load(I.rem, k);
             const int g = I.leadpfx[lr >> 6] + __builtin_popcountll(I.leadw[lr >> 6] & ((1ull << (lr & 63)) - 1ull));
             I.gpos[k] = g;
             const float* m = overlap_src<SRC>(src, I, b, N, ld);
@@ -1612,7 +1663,7 @@ __device__ __forceinline__ void attribute_image(const float* __restrict__ src, l
         for (int e = 0; e < 4; ++e) {
             const int k = k0 + tid + e * 1024;
             const bool ok = k < n;
-            lr4[e] = ok ? I.rem[k] : 0;
+            lr4[e] = ok ? rem_load(I.rem, k) : 0;
             ca[e] = ok ? I.order[k] : 0;
         }
         // (the leader's input index is order[its rank]: the same value as leadc[its ordinal], one dependent load earlier)
@@ -1674,7 +1725,7 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
         for (int e = 0; e < E; ++e) {
             const int k = e * (int)blockDim.x + (int)threadIdx.x;
             const bool ok = k < n;
-            f_lr[e] = ok ? I.rem[k] : 0;
+            f_lr[e] = ok ? rem_load(I.rem, k) : 0;
             f_ck[e] = ok ? I.order[k] : 0;
             f_sk[e] = ok ? I.sscore[k] : 0.0f;
         }
@@ -1805,7 +1856,7 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
             pre = sk;
         } else if (h >= 0) {
             int lr;
-            if constexpr (FUSE) lr = f_lr[e]; else lr = I.rem[k];
+            if constexpr (FUSE) lr = f_lr[e]; else lr = rem_load(I.rem, k);
             float v, sh;
             int ch;
             if (h != lr) {                                           // the leader itself is not a member (NaN / <= thr diagonal)
@@ -2059,10 +2110,10 @@ template <int E, int SRC>
 __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
                                                     char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob,
                                                     long long* __restrict__ valid, long long* __restrict__ invalid, int* __restrict__ nvalid,
-                                                    int* __restrict__ ninvalid, int sym_arg) {
-    const int b = blockIdx.x;
+                                                    int* __restrict__ ninvalid, int sym_arg, int B, int spw) {
+    int b;
+    if (!leaders_chain(N, counts, ws, L, B, spw, (int)blockIdx.x, sym_arg, &b)) return;   // (the image's other scan workgroups)
     const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;   // (2: wsym_check_kernel's verdict for this image)
-    leaders_body(N, counts, ws, L, b, sym);
     __syncthreads();
     if (E <= 4 && sym && P.mask_group_boxes) {                       // the scan has attributed: K4's rest rides in K5, K6 starts from LDS
         if constexpr (E <= 4) {

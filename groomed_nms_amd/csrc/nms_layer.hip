@@ -8,7 +8,6 @@
 #include <mutex>
 #include <utility>
 #include <atomic>
-#include <chrono>
 #include <vector>
 #include "gnms_prof.h"
 #include "iou_tile.h"
@@ -390,10 +389,7 @@ int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* co
     GNMS_CHECK_LAUNCH();
     if (full) {
         const int nb = (N + 63) / 64;
-        // (the set-bit count that gates it exists where bitmask_kernel collects whole rows: one 16-wave workgroup per rank block)
-        static const int dense = [] { const char* e = getenv("GNMS_MATRIX_SYM_DENSE"); return e ? atoi(e) : 16; }();
-        const bool counted = vec && waves == 16 && gnms_div_up(N, 16 * 256) == 1 && L.NC <= 4096;
-        wsym_check_kernel<<<dim3(gnms_div_up(nb * (nb + 1) / 2, 4), B), 256, 0, st>>>(N, counts, ws, L, counted ? dense : 0);
+        wsym_check_kernel<<<dim3(gnms_div_up(nb * (nb + 1) / 2, 4 * kSymPairsPerWave), B), 256, 0, st>>>(N, counts, ws, L);
         GNMS_CHECK_LAUNCH();
     }
     return GNMS_OK;
@@ -408,7 +404,7 @@ int run_grouping(const float* iou, int B, int N, int64_t ld, const int32_t* coun
     const size_t lds = leaders_lds_bytes(N);
     int rc = allow_lds(leaders_kernel, lds);
     if (rc) return rc;
-    leaders_kernel<<<B, 1024, lds, st>>>(N, counts, ws, L, sym);
+    { const int spw = leaders_chain_wgs(N, sym); leaders_kernel<<<B * spw, 1024, lds, st>>>(N, counts, ws, L, sym, B, spw); }
     GNMS_CHECK_LAUNCH();
     attribute_kernel<false><<<dim3(L.NB, B), 64, 0, st>>>(iou, (long)ld, N, counts, thr, ws, L, sym);
     GNMS_CHECK_LAUNCH();
@@ -473,6 +469,7 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
         }
         const int all_same = __syncthreads_and(same);
         if (threadIdx.x < 8 && !(xsort && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
+        if (threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;               // the workspace's call counter (leaders_sb_body's hand-off tag)
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -883,15 +880,16 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
     }
 #endif
-    if ((int)blockIdx.x < nimg) {
-        const int b = blockIdx.x;
+    const int spw = leaders_chain_wgs(N, 1);                          // chain workgroups per image (the from-boxes / from-records bit matrices are symmetric)
+    if ((int)blockIdx.x < nimg * spw) {
+        int b;
 #ifdef GNMS_TIMING
         long long tt__ = (long long)__builtin_amdgcn_s_memtime();
 #define GNMS_TW_ACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && b == 0) ((long long*)img_ptrs(ws, L, 0).gx)[slot] += n__ - tt__; tt__ = n__; } while (0)
 #else
 #define GNMS_TW_ACC(slot) do {} while (0)
 #endif
-        leaders_body(N, counts, ws, L, b, 1);
+        if (!leaders_chain(N, counts, ws, L, nimg, spw, (int)blockIdx.x, 1, &b)) return;   // (the image's other scan workgroups)
         __syncthreads();
         GNMS_TW_ACC(5);
         if (E <= 4 && P.mask_group_boxes) {                           // K4's rest rides in K5 (groups_body, FUSE), K6 starts from LDS
@@ -916,7 +914,8 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         GNMS_TW_ACC(15);
         return;
     }
-    if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, img_ptrs(ws, L, 0).misc + 5, L.per_image / sizeof(int), nimg, staged == 3 ? 0 : staged); return; }   // (3: the columns gathered per unit)
+    const int first_writer = nimg * spw;
+    if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, img_ptrs(ws, L, 0).misc + 5, L.per_image / sizeof(int), first_writer, staged == 3 ? 0 : staged); return; }   // (3: the columns gathered per unit)
     if (SRC == kFromRecords && staged == 2) { writers_sym_persistent<true>(write_src, N, out, ld, nimg, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5); return; }
     writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
 }
@@ -964,34 +963,8 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
     }
     const int R = P2 / 1024;
     const size_t lds = (size_t)P2 * 8;
-    // GNMS_SORT_FUSED=1: runs and merge in ONE launch (sort_fused_kernel), the hand-off flags carrying a per-call nonce (splitmix64 of
-    // a process-wide counter that starts at the clock).  Measured B = 8, N = 4096: 13.1 us against 7.8 + 6.2 in two launches -- a launch
-    // boundary between two small kernels costs ~1 us, not the 3 us the bit-matrix kernel's skeleton suggested -- and no change of the
-    // step (0.1418 / 0.1424 against 0.1429 / 0.1419 ms clustered / uniform), so the two launches stay the default.  (With the hand-off
-    // behind __threadfence() instead of write-through stores the fused kernel took 28.7 us: the L2 write-back of a release fence
-    // walks an L2 full of the previous step's lines.)
-    static const bool fused = [] { const char* e = getenv("GNMS_SORT_FUSED"); return e && e[0] == '1'; }();
-    if (fused) {
-        static std::atomic<unsigned long long> ctr{(unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count()};
-        unsigned long long z = ctr.fetch_add(0x9e3779b97f4a7c15ull) + 0x9e3779b97f4a7c15ull;
-        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-        const unsigned long long nonce = (z ^ (z >> 31)) | 1ull;
-#define GNMS_FUSED(RR)                                                                                                             \
-        do {                                                                                                                       \
-            if ((rc = allow_lds(sort_fused_kernel<RR>, lds))) return rc;                                                           \
-            sort_fused_kernel<RR><<<dim3(RR, B, roles), 1024, lds, st>>>(scores, boxes, N, counts, ws, L, P2, (long long*)order, nonce); \
-        } while (0)
-        switch (R) {
-            case 2: GNMS_FUSED(2); break;
-            case 4: GNMS_FUSED(4); break;
-            case 8: GNMS_FUSED(8); break;
-            default: GNMS_FUSED(16); break;
-        }
-#undef GNMS_FUSED
-        GNMS_CHECK_LAUNCH();
-        return GNMS_OK;
-    }
+    // (runs and merge as ONE launch with nonce-flag hand-offs was measured in round 3: 13.1 us against 7.8 + 6.2, the step unchanged -- a launch
+    // boundary between two small kernels costs ~1 us; dropped in round 4, LABNOTES.md)
     sort_runs_kernel<<<dim3(R, B, roles), 1024, 0, st>>>(scores, boxes, N, counts, ws, L, P2);
     GNMS_CHECK_LAUNCH();
 #define GNMS_MERGE(RR)                                                                                                    \
@@ -1011,10 +984,12 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
 }
 
 // K3..K6 as one launch or four?  Measured (HIP-graph replay, B=8): one launch wins 2-2.5 us per step up to N=2048 (three
-// kernel boundaries less) and loses 1.5 us at N=4096 (the attribution runs on one CU instead of 64).  GNMS_TAIL=0/1 forces.
-bool use_tail_kernel(int N) {
+// kernel boundaries less) and, with the general scan, loses 1.5 us at N=4096 (the attribution runs on one CU instead of 64).  Where the
+// scan attributes as it goes (symmetric sources, `sym`), K4 rides in K5 and K6 starts from LDS (groups_body FUSE, E <= 4): one launch
+// up to N = 4096.  GNMS_TAIL=0/1 forces.
+bool use_tail_kernel(int N, int sym = 0) {
     static const int forced = [] { const char* e = getenv("GNMS_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced == 1 : N <= 2048;
+    return forced >= 0 ? forced == 1 : (N <= 2048 || (sym && N <= 4096));
 }
 
 // K3..K6 in one launch (masked groups); SRC/src: kFromMatrix (the matrix), kFromBoxes (the boxes), kFromRecords (src unused)
@@ -1029,8 +1004,9 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     int rc;
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(tail_kernel<E, BOXES>, lds))) return rc;
-        tail_kernel<E, BOXES><<<B, 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
-                                                    ninvalid, sym);
+        const int spw = leaders_chain_wgs(N, sym);
+        tail_kernel<E, BOXES><<<B * spw, 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
+                                                          ninvalid, sym, B, spw);
     });
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
@@ -1080,9 +1056,11 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     // leaders each) stops being the longer side of the launch, at the price of 1.5 % on clustered ones.  (A plain fill in this
     // geometry: 6.2-6.4 TB/s from 64-128 workgroups, 5.8 from 248: tools/fill_grid.py.)  GNMS_TAIL_WRITERS overrides.
     static const int writers_cap = [] { const char* e = getenv("GNMS_TAIL_WRITERS"); return e ? atoi(e) : 0; }();
-    const int cap = writers_cap > 0 ? writers_cap : (staged == 1 ? (cus * 192) / 256 : 0);
+    // (round 4: the scan runs on nsb workgroups per image and the chain is no longer the longer side of the launch -- the cap is what the
+    // store stream itself likes, GNMS_TAIL_WRITERS)
+    const int cap = writers_cap > 0 ? writers_cap : (staged == 1 ? (cus * 208) / 256 : 0);
     if (cap > 0 && writers > cap) writers = cap;
-    const dim3 grid((unsigned)(B + writers));
+    const dim3 grid((unsigned)(B * leaders_chain_wgs(N, 1) + writers));
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
     int rc;
     GNMS_DISPATCH_SORT(P2, {
@@ -1122,7 +1100,7 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
 
     if (!scores_already_sorted && (rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
 
-    if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N)) {
+    if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N, matrix_sym_detection(N) ? 2 : 0)) {
         const int sym = matrix_sym_detection(N) ? 2 : 0;
         if ((rc = launch_bitmask(iou, B, N, ld, counts, P.nms_threshold, ws, L, st, sym ? 1 : 0))) return rc;
         return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);
@@ -1508,10 +1486,10 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         if (vec) gnms_launch_prof(kProfMatrixWrite, iou3d_bits_kernel<true>, grid, dim3(gnms_iou::kWavesPerWG * 64), 0, st, recs, rec, N, counts, P.nms_threshold, iou_out, (long)ld, ws, L);
         else gnms_launch_prof(kProfMatrixWrite, iou3d_bits_kernel<false>, grid, dim3(gnms_iou::kWavesPerWG * 64), 0, st, recs, rec, N, counts, P.nms_threshold, iou_out, (long)ld, ws, L);
         GNMS_CHECK_LAUNCH();
-        if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1);
+        if (use_tail_kernel(N, 1)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1);
         const size_t llds = leaders_lds_bytes(N);
         if ((rc = allow_lds(leaders_kernel, llds))) return rc;
-        leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, 1);
+        { const int spw = leaders_chain_wgs(N, 1); leaders_kernel<<<B * spw, 1024, llds, st>>>(N, counts, ws, L, 1, B, spw); }
         GNMS_CHECK_LAUNCH();
         attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L, 1);
         GNMS_CHECK_LAUNCH();
@@ -1576,10 +1554,10 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         if (rc) return rc;
         return scope.join();
     }
-    if (use_tail_kernel(N)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);
+    if (use_tail_kernel(N, sym)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);
     const size_t llds = leaders_lds_bytes(N);
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
-    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, sym);
+    { const int spw = leaders_chain_wgs(N, sym); leaders_kernel<<<B * spw, 1024, llds, st>>>(N, counts, ws, L, sym, B, spw); }
     GNMS_CHECK_LAUNCH();
     attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L, sym);
     GNMS_CHECK_LAUNCH();
@@ -1753,11 +1731,11 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
         if ((rc = gnms_internal_iou2d_rows(boxes, B, N, mw->out, mw->ld, side, r1, N))) return rc;
         return beside.join();
     }
-    if (P.mask_group_boxes && use_tail_kernel(N))
+    if (P.mask_group_boxes && use_tail_kernel(N, 1))
         return launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1);
     const size_t llds = leaders_lds_bytes(N);
     if ((rc = allow_lds(leaders_kernel, llds))) return rc;
-    leaders_kernel<<<B, 1024, llds, st>>>(N, counts, ws, L, 1);      // bitmask_boxes_kernel wrote full symmetric rows
+    { const int spw = leaders_chain_wgs(N, 1); leaders_kernel<<<B * spw, 1024, llds, st>>>(N, counts, ws, L, 1, B, spw); }   // bitmask_boxes_kernel wrote full symmetric rows
     GNMS_CHECK_LAUNCH();
     attribute_kernel<true><<<dim3(L.NB, B), 64, 0, st>>>(boxes, (long)N, N, counts, P.nms_threshold, ws, L, 1);
     GNMS_CHECK_LAUNCH();

@@ -1975,29 +1975,6 @@ def test_self_iou_in_the_writers_geometry_and_negative_zero(G, O):
         assert np.array_equal(out[0][i].cpu().numpy(), ref["prob"], equal_nan=True), i
 
 
-def test_single_launch_sort_variant():
-    """GNMS_SORT_FUSED=1 (opt-in): score and x sorts as ONE launch whose workgroups hand their runs over through nonce flags.  Same
-    outputs as the default two launches, on a fresh workspace and on a reused one, eager and replayed from a captured graph."""
-    code = """
-import numpy as np, torch
-import groomed_nms_amd as G
-from groomed_nms_amd import synthetic
-b, s = synthetic.batch_2d(7, 4, 4096, "uniform")
-bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
-outs = [G.differentiable_nms_with_iou2d_batched(st, bt) for _ in range(3)]
-torch.cuda.synchronize()
-np.save("/tmp/gnms_sort_variant_%s.npy" % __import__("os").environ.get("GNMS_SORT_FUSED", "0"), outs[-1][0].cpu().numpy())
-for o in outs[:-1]:
-    assert torch.equal(o[0], outs[-1][0]) and torch.equal(o[1], outs[-1][1])
-print("ok")
-"""
-    for v in ("0", "1"):
-        r = _run_py(code, {"GNMS_SORT_FUSED": v})
-        assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
-    a, b = np.load("/tmp/gnms_sort_variant_0.npy"), np.load("/tmp/gnms_sort_variant_1.npy")
-    assert np.array_equal(a, b)
-
-
 def test_matrix_in_layer_detects_symmetry(G, O):
     """differentiable_nms(scores, iou) cannot know that its matrix is iou(boxes, boxes); since round 3 it finds out on the device
     (bitmask_kernel stores the rows of the bit matrix in full, wsym_check_kernel compares its 64 x 64 blocks with their transposes)
