@@ -72,7 +72,8 @@ def parse():
                          "the default run collects the counters itself (two short rocprofv3 --pmc passes of this script) when rocprofv3 is on PATH")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip what the default 1-GPU line adds by re-running this script: the PMC passes for roofline.traffic, the `two_calls` "
-                         "key (the reference's unchanged call sites: iou() then differentiable_nms(scores, iou)) and the `dim3` key (3D, N = 4096 and 16384)")
+                         "keys (the reference's unchanged call sites in 2D and 3D), the `dim3_*` keys (3D, N = 4096 and 16384) and the other box counts / batches "
+                         "north_star names (N256, N1024, N16384, B1_N4096, B4_N4096), timed in this process")
     return ap.parse_args()
 
 
@@ -296,7 +297,8 @@ def main():
             check(lib.gnms_profile_collect(slot, ctypes.byref(ms), ctypes.byref(n)), "profile_collect")
             return ms.value, n.value
 
-        k_roof = max(50, min(args.steps, 200))
+        # (N > 1 ranks: the other ranks sit in the final barrier while rank 0 is in here -- a short event collection, no ceiling streams)
+        k_roof = max(50, min(args.steps, 200)) if world == 1 else max(5, min(args.steps, 20))
         for _ in range(3):
             eager_step()
         torch.cuda.synchronize()
@@ -324,18 +326,20 @@ def main():
             return nbytes * n / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         sink = torch.zeros(4, dtype=torch.float32, device=dev)
         n_fl = B * N * N // 4 * 4
-        fill_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill(ptr(b), n_fl, stream_ptr(dev)), "fill"), 4.0 * n_fl) if n_fl else 0.0
+        fill_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill(ptr(b), n_fl, stream_ptr(dev)), "fill"), 4.0 * n_fl) if (n_fl and world == 1) else 0.0
         fill_what = "plain non-temporal float4 store stream (gnms_profile_fill)"
         for rows_, nt_ in ((8, 1), (16, 1), (8, 0), (16, 0)):   # the same stream in the writers' geometry; the best of the five is the ceiling
-            if N % rows_ == 0 and N >= 256:
+            if N % rows_ == 0 and N >= 256 and world == 1:
                 tiles_gbs = stream_rate(lambda b: check(lib.gnms_profile_fill_tiles(ptr(b), B, N, N, rows_, nt_, stream_ptr(dev)), "fill_tiles"), 4.0 * B * N * N)
                 if tiles_gbs > fill_gbs:
                     fill_gbs = tiles_gbs
                     fill_what = "plain %s store stream, persistent 16-wave workgroups, %d rows x 1 KiB per wave (gnms_profile_fill_tiles)" % (
                         "non-temporal" if nt_ else "16-byte", rows_)
-        for b_ in iou_bufs:
-            b_.fill_(0.25)
-        read_gbs = stream_rate(lambda b: check(lib.gnms_profile_read(ptr(b), n_fl, ptr(sink), stream_ptr(dev)), "read"), 4.0 * n_fl) if n_fl else 0.0
+        read_gbs = 0.0
+        if n_fl and world == 1:
+            for b_ in iou_bufs:
+                b_.fill_(0.25)
+            read_gbs = stream_rate(lambda b: check(lib.gnms_profile_read(ptr(b), n_fl, ptr(sink), stream_ptr(dev)), "read"), 4.0 * n_fl)
 
         pmc, pmc_note = {}, None
         workload_args = ["--boxes", str(N), "--batch", str(B), "--kind", args.kind, "--dim", str(args.dim)] + (["--two-calls"] if args.two_calls else []) + (
@@ -358,7 +362,7 @@ def main():
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": (round(pmc[kname]) if kname in pmc else None), "traffic_source": pmc_note, "algorithmic_bytes": round(nbytes_per_step),
                     "kernel": kname, "kernel_ms": round(per_step_ms, 4), "launches_per_step": round(launches / k_roof, 2),
-                    "ceiling": {"what": what, "GB/s": round(ceiling, 1), "frac_of_ceiling": round(ach / ceiling, 4) if ceiling else None},
+                    "ceiling": ({"what": what, "GB/s": round(ceiling, 1), "frac_of_ceiling": round(ach / ceiling, 4)} if ceiling else None),
                     "measured": "HIP events around the launch inside %d repetitions of the timed step sequence, %d rotating %d-MiB matrix buffers"
                                 % (k_roof, n_buf, mat_bytes >> 20)}
 
@@ -427,18 +431,70 @@ def main():
                                  "steps": k_o}
 
         if world == 1 and not args.no_extras and not args.graph and not args.two_calls and args.dim == 2 and not args.sorted_scores:
-            # driver-timed figures for the two other shapes of the path: the reference's UNCHANGED call sites -- iou() then
-            # differentiable_nms(scores, iou): the overlap kernel and the matrix-in layer as two library calls, lib/loss/rpn_3d.py:772-791 --
-            # and the 3D overlap (0.5 (1 + GIoU3D), rpn_3d.py:778-784) at N = 4096 and at C5's N = 16384.  Children of this process, same GPU.
-            st = ["--steps", str(max(20, min(args.steps, 100))), "--warmup", str(max(3, min(args.warmup, 10)))]
-            # (these three stay on the clustered generator whatever the headline runs on: the figures of rounds 1-3 they continue were taken there)
-            for key, extra in (("two_calls", ["--two-calls", "--boxes", str(N), "--batch", str(B), "--kind", "clustered"] + st),
-                               ("dim3_N4096", ["--dim", "3", "--boxes", "4096", "--batch", str(B), "--kind", "clustered"] + st),
-                               ("dim3_N16384", ["--dim", "3", "--boxes", "16384", "--batch", str(B), "--kind", "clustered", "--steps", "20", "--warmup", "3"])):
+            # driver-timed figures for the other shapes of the path, all on the headline's generator, timed in this
+            # process with the same timed_steps: the reference's UNCHANGED call sites -- iou() then differentiable_nms(scores, iou), the
+            # overlap kernel and the matrix-in layer as two library calls (lib/loss/rpn_3d.py:772-791) -- in 2D and in 3D (corners ->
+            # iou3d_approximate(generalized) -> 0.5 (1 + giou) -> differentiable_nms, rpn_3d.py:776-791), the one-call 3D entry at N = 4096 and
+            # C5's N = 16384, the other box counts north_star names (256, 1024, 16384) and the per-GPU batches of C3 / C4 (B = 1, B = 4).
+            def shape(dim, b_, n_, two_calls=False, ref_3d=False, steps=20, warmup=3):
+                if dim == 2:
+                    bx_np, sc_np = synthetic.batch_2d(1000, b_, n_, args.kind)
+                else:
+                    bx_np, sc_np = synthetic.batch_3d(1000, b_, n_, clustered=(args.kind == "clustered"))
+                bx = torch.from_numpy(np.ascontiguousarray(bx_np)).to(dev)
+                sc = torch.from_numpy(np.ascontiguousarray(sc_np)).to(dev).requires_grad_(True)
+                ww = torch.from_numpy(np.tile(np.linspace(-1.0, 2.0, n_).astype(np.float32), (b_, 1))).to(dev).contiguous()
+                mb = 4 * b_ * n_ * n_
+                nb_ = int(min(max(3, -(-(768 << 20) // max(mb, 1))), 16))
+                bufs = [torch.empty((b_, n_, n_), dtype=torch.float32, device=dev) for _ in range(nb_)]
+                st_ = {"i": 0}
+
+                def one():
+                    st_["i"] = (st_["i"] + 1) % nb_
+                    buf = bufs[st_["i"]]
+                    if ref_3d:          # the reference's own sequence of calls, each its own kernel(s)
+                        c = overlaps.corners_batched(bx)
+                        _, giou = overlaps.iou3d_batched(c, method="generalized", want_bev=True, out=buf)   # both outputs, as the reference computes them
+                        ov = giou.add_(1.0).mul_(0.5)                      # 0.5 * (1 + giou), rpn_3d.py:781 (stock torch, in place)
+                        prob = G.differentiable_nms_batched(sc, ov)[0]
+                    elif two_calls:
+                        ov = overlaps.iou_batched(bx, out=buf) if dim == 2 else overlaps.iou3d_batched(bx, from_params=True, nms_overlap=True, out=buf, nms_threshold=thr)
+                        prob = G.differentiable_nms_batched(sc, ov)[0]
+                    elif dim == 2:
+                        prob = G.differentiable_nms_with_iou2d_batched(sc, bx, iou_out=buf)[0]
+                    else:
+                        prob = G.differentiable_nms_with_iou3d_batched(sc, bx, iou_out=buf)[0]
+                    sc.grad = None
+                    torch.autograd.backward(prob, ww)
+                for _ in range(10):
+                    one()
+                torch.cuda.synchronize()
+                dts = gdist.timed_steps(one, steps, warmup, torch.cuda.synchronize)
+                del bufs
+                return {"value": round(b_ * n_ * steps / dts, 1), "unit": "boxes/s", "ms_per_step": round(dts / steps * 1e3, 4), "steps": steps,
+                        "workload": "%d images x %d %s %dD boxes%s" % (b_, n_, args.kind, dim, ", reference call sequence" if (two_calls or ref_3d) else "")}
+
+            for key, kw in (("two_calls", dict(dim=2, b_=B, n_=N, two_calls=True)),
+                            ("two_calls_3d", dict(dim=3, b_=B, n_=N, ref_3d=True)),
+                            ("dim3_N4096", dict(dim=3, b_=B, n_=4096)),
+                            ("dim3_N16384", dict(dim=3, b_=B, n_=16384, steps=10)),
+                            ("N256", dict(dim=2, b_=B, n_=256)), ("N1024", dict(dim=2, b_=B, n_=1024)),
+                            ("N16384", dict(dim=2, b_=B, n_=16384, steps=10)),
+                            ("B1_N4096", dict(dim=2, b_=1, n_=4096)), ("B4_N4096", dict(dim=2, b_=4, n_=4096))):
                 try:
-                    out[key] = _brief(_sub_bench(extra))
+                    out[key] = shape(**kw)
                 except Exception as e:
                     out[key] = {"error": str(e)[:300]}
+                torch.cuda.empty_cache()
+            out["two_calls_other_kind"] = None
+            try:
+                keep = args.kind
+                args.kind = "uniform" if keep == "clustered" else "clustered"
+                out["two_calls_other_kind"] = shape(dim=2, b_=B, n_=N, two_calls=True)
+            except Exception as e:
+                out["two_calls_other_kind"] = {"error": str(e)[:300]}
+            finally:
+                args.kind = keep
 
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
@@ -483,7 +539,10 @@ def main():
         print(json.dumps(out), flush=True)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
+        t_b = time.perf_counter()
         dist.barrier()
+        # (what the ranks other than 0 spend here is rank 0's post-region work: kept short at N > 1, asserted by test_n_rank_launcher_end_to_end)
+        print("[bench] rank %d waited %.2f s in the final barrier" % (rank, time.perf_counter() - t_b), file=sys.stderr, flush=True)
         dist.destroy_process_group()
 
 

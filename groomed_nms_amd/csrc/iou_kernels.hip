@@ -137,7 +137,34 @@ __global__ __launch_bounds__(256) void aabb_for_layer_kernel(const float* __rest
     xkeys[g] = make_float4(r[3], r[8], r[4], 0.0f);
 }
 
-// pairwise 3D overlap from the records.  METHOD 0 normal, 1 generalized, 2 0.5*(1+generalized).
+// pairwise 3D overlap from the records, the reference's operation order (lib/core.py:305-421), bit for bit the CPU oracle's result.
+// METHOD 0 normal, 1 generalized, 2 0.5*(1+generalized); BEV: iou_bev as a second output of the same pass.
+//
+// Round 4: the PLAIN body.  The reference's expression costs ~64 VALU slots per pair as written (three IEEE divisions at 10 slots,
+// three axes of min / max / subtract / relu twice over) and ran at 0.30-0.35 of the HBM peak; what the 2D tile learned (iou_tile.h)
+// carries over for tiles whose boxes are all SANE (record[11] == 0: extents in (1e-4, 1e5), |coordinates| < 1e5) and free of negative
+// zeros:
+//   * per axis the overlap  relu(min(a1, b1) - max(a0, b0))  and the hull extent  relu(max(a1, b1) - min(a0, b0))  are the smallest /
+//     largest of the SAME four differences a1 - a0, b1 - b0, a1 - b0, b1 - a0; rounding is monotone, so the rounded result of the
+//     subtraction the reference performs is the min / max of the four rounded differences: two packed subtractions per column pair
+//     (the other two are the extents the records carry), v_min3 + v_med3 for the overlap (clamped to [0, row extent]), v_max3 + v_max
+//     for the hull (>= the row extent > 0: the relu is the identity) -- 5 slots per entry and axis instead of 8;
+//   * the divisions are the compiler's fp32 division without V_DIV_SCALE / V_DIV_FIXUP, packed (div2_plain): exact wherever no operand,
+//     reciprocal or quotient comes near the ends of the exponent range.  Sane boxes bound every denominator (u3 >= the larger volume
+//     > 1e-12, hull volume in (1e-12, 1e17), bird's-eye union in (1e-8, 1e11)) and the numerator vh - u3 (0 or >= an ulp of vh); only
+//     the intersections i3 and inter can be arbitrarily small, and a row with one in (0, 2^-60) is evaluated again with IEEE divisions
+//     (an integer min over the row's bit patterns and one compare decide that).
+// ~31 slots per pair (generalized), ~38 with iou_bev; any other tile (a box that is not sane, a negative zero) takes the scalar body.
+// ------------------------------------------------------------------------------------------------
+using gnms_iou3d::f2;
+using gnms_iou3d::splat;
+struct ExCols {                                                     // a lane's four columns as two packed pairs
+    f2 x0[2], x1[2], y0[2], y1[2], z0[2], z1[2], vol[2], area[2], lx[2], ly[2], lz[2];
+};
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max_vs(float x, float s) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(s), "v"(x)); return r; }
+__device__ __forceinline__ bool is_neg_zero(float c) { return __float_as_uint(c) == 0x80000000u; }
+
 template <bool VEC, int METHOD, bool BEV>
 __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M, int N,
                                                     float* __restrict__ out_bev, float* __restrict__ out3d, long ld, int tile_rows) {
@@ -152,43 +179,53 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __
     float* o3 = out3d + (size_t)img * M * ld;
     float* ob = BEV ? out_bev + (size_t)img * M * ld : nullptr;
 
-    float bvol[4], by0[4], by1[4], bx0[4], bx1[4], bz0[4], bz1[4], bar[4];
     int col[4];
+    ExCols c;                                                       // (the scalar body reads the same registers, element j at [j >> 1][j & 1])
+    bool cplain = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
         int cc = col[j] < N ? col[j] : (N - 1);
         const float4* p = reinterpret_cast<const float4*>(rb + (size_t)cc * kRec);
-        float4 u = p[0], v = p[1];
-        bvol[j] = u.x; by0[j] = u.y; by1[j] = u.z; bx0[j] = u.w; bx1[j] = v.x; bz0[j] = v.y; bz1[j] = v.z; bar[j] = v.w;
+        float4 u = p[0], v = p[1], e = p[2];
+        c.vol[j >> 1][j & 1] = u.x; c.y0[j >> 1][j & 1] = u.y; c.y1[j >> 1][j & 1] = u.z; c.x0[j >> 1][j & 1] = u.w; c.x1[j >> 1][j & 1] = v.x;
+        c.z0[j >> 1][j & 1] = v.y; c.z1[j >> 1][j & 1] = v.z; c.area[j >> 1][j & 1] = v.w; c.lx[j >> 1][j & 1] = e.x; c.ly[j >> 1][j & 1] = e.y;
+        c.lz[j >> 1][j & 1] = e.z;
+        cplain = cplain && e.w == 0.0f && !is_neg_zero(u.y) && !is_neg_zero(u.z) && !is_neg_zero(u.w) && !is_neg_zero(v.x) && !is_neg_zero(v.y) && !is_neg_zero(v.z);
     }
     const int myrow = i0 + lane;
-    float4 ru = make_float4(0.f, 0.f, 0.f, 0.f), rv = ru;
+    float4 ru = make_float4(0.f, 0.f, 0.f, 0.f), rv = ru, re = ru;
     if (myrow < M) {
         const float4* p = reinterpret_cast<const float4*>(ra + (size_t)myrow * kRec);
-        ru = p[0]; rv = p[1];
+        ru = p[0]; rv = p[1]; re = p[2];
     }
     const int rows = min(tile_rows, M - i0);
+    const bool rplain = (lane >= rows) || (re.w == 0.0f && !is_neg_zero(ru.y) && !is_neg_zero(ru.z) && !is_neg_zero(ru.w) && !is_neg_zero(rv.x) &&
+                                            !is_neg_zero(rv.y) && !is_neg_zero(rv.z));
+    const bool plain = VEC && __all(cplain && rplain) && (c0 + 4 * 64 <= N);        // (a full tile: every lane owns four existing columns)
 
-    for (int r = 0; r < rows; ++r) {
+    // one row in the reference's scalar order (every tile that is not plain; the rare rows of a plain tile with a tiny intersection)
+    auto scalar_row = [&](int r) {
         const float avol = bcast(ru.x, r), ay0 = bcast(ru.y, r), ay1 = bcast(ru.z, r), ax0 = bcast(ru.w, r);
         const float ax1 = bcast(rv.x, r), az0 = bcast(rv.y, r), az1 = bcast(rv.z, r), aar = bcast(rv.w, r);
         float res3[4], resb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float vol = avol + bvol[j];                                       // lib/core.py:357
-            float yi = relu0(fminf(ay1, by1[j]) - fmaxf(ay0, by0[j]));        // :371-376
-            float w = relu0(fminf(ax1, bx1[j]) - fmaxf(ax0, bx0[j]));         // intersect(bev) :410
-            float h = relu0(fminf(az1, bz1[j]) - fmaxf(az0, bz0[j]));
+            const float bvol = c.vol[j >> 1][j & 1], by0 = c.y0[j >> 1][j & 1], by1 = c.y1[j >> 1][j & 1], bx0 = c.x0[j >> 1][j & 1];
+            const float bx1 = c.x1[j >> 1][j & 1], bz0 = c.z0[j >> 1][j & 1], bz1 = c.z1[j >> 1][j & 1], bar = c.area[j >> 1][j & 1];
+            float vol = avol + bvol;                                          // lib/core.py:357
+            float yi = relu0(fminf(ay1, by1) - fmaxf(ay0, by0));              // :371-376
+            float w = relu0(fminf(ax1, bx1) - fmaxf(ax0, bx0));               // intersect(bev) :410
+            float h = relu0(fminf(az1, bz1) - fmaxf(az0, bz0));
             float inter = w * h;
-            if (BEV) resb[j] = inter / ((aar + bar[j]) - inter);              // iou(bev) :408
+            if (BEV) resb[j] = inter / ((aar + bar) - inter);                 // iou(bev) :408
             float i3 = inter * yi;                                            // :415
             float u3 = vol - i3;                                              // :416
             float q = i3 / u3;                                                // :417
             if (METHOD >= 1) {                                                // :390-406, :418-419
-                float xh = relu0(fmaxf(ax1, bx1[j]) - fminf(ax0, bx0[j]));
-                float yh = relu0(fmaxf(ay1, by1[j]) - fminf(ay0, by0[j]));
-                float zh = relu0(fmaxf(az1, bz1[j]) - fminf(az0, bz0[j]));
+                float xh = relu0(fmaxf(ax1, bx1) - fminf(ax0, bx0));
+                float yh = relu0(fmaxf(ay1, by1) - fminf(ay0, by0));
+                float zh = relu0(fmaxf(az1, bz1) - fminf(az0, bz0));
                 float vh = (xh * yh) * zh;
                 q = q - ((vh - u3) / vh);
             }
@@ -203,6 +240,54 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (col[j] < N) { o3[roff + col[j]] = res3[j]; if (BEV) ob[roff + col[j]] = resb[j]; }
         }
+    };
+    if (!plain) {
+        for (int r = 0; r < rows; ++r) scalar_row(r);
+        return;
+    }
+    unsigned long long redo = 0ull;                                                        // rows of this tile to evaluate again with IEEE divisions
+    for (int r = 0; r < rows; ++r) {
+        const float* rr = ra + (size_t)(i0 + r) * kRec;                       // wave-uniform: scalar loads
+        const float avol = rr[0], ay0 = rr[1], ay1 = rr[2], ax0 = rr[3], ax1 = rr[4], az0 = rr[5], az1 = rr[6], aar = rr[7];
+        const float alx = rr[8], aly = rr[9], alz = rr[10];
+        f2 q3[2], qb[2];
+        unsigned tiny = 0xffffffffu;                                          // min over the row of (bits of the intersections) - 1
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f2 dx1 = splat(ax1) - c.x0[p], dx2 = c.x1[p] - splat(ax0);
+            const f2 dy1 = splat(ay1) - c.y0[p], dy2 = c.y1[p] - splat(ay0);
+            const f2 dz1 = splat(az1) - c.z0[p], dz2 = c.z1[p] - splat(az0);
+            const f2 w = {gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dx1.x, dx2.x, c.lx[p].x), alx), gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dx1.y, dx2.y, c.lx[p].y), alx)};
+            const f2 yi = {gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dy1.x, dy2.x, c.ly[p].x), aly), gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dy1.y, dy2.y, c.ly[p].y), aly)};
+            const f2 h = {gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dz1.x, dz2.x, c.lz[p].x), alz), gnms_iou::hw_clamp0_s(gnms_iou::hw_min3(dz1.y, dz2.y, c.lz[p].y), alz)};
+            const f2 inter = w * h;                                           // :410-412
+            if (BEV) {
+                qb[p] = gnms_iou::div2_plain(inter, (splat(aar) + c.area[p]) - inter);   // :408
+                tiny = min(tiny, min(__float_as_uint(inter.x) - 1u, __float_as_uint(inter.y) - 1u));
+            }
+            const f2 i3 = inter * yi;                                         // :415
+            const f2 u3 = (splat(avol) + c.vol[p]) - i3;                      // :357, :416
+            tiny = min(tiny, min(__float_as_uint(i3.x) - 1u, __float_as_uint(i3.y) - 1u));
+            f2 q = gnms_iou::div2_plain(i3, u3);                              // :417
+            if (METHOD >= 1) {
+                const f2 xh = {hw_max_vs(hw_max3(dx1.x, dx2.x, c.lx[p].x), alx), hw_max_vs(hw_max3(dx1.y, dx2.y, c.lx[p].y), alx)};
+                const f2 yh = {hw_max_vs(hw_max3(dy1.x, dy2.x, c.ly[p].x), aly), hw_max_vs(hw_max3(dy1.y, dy2.y, c.ly[p].y), aly)};
+                const f2 zh = {hw_max_vs(hw_max3(dz1.x, dz2.x, c.lz[p].x), alz), hw_max_vs(hw_max3(dz1.y, dz2.y, c.lz[p].y), alz)};
+                const f2 vh = (xh * yh) * zh;                                 // :390-406
+                q = q - gnms_iou::div2_plain(vh - u3, vh);                    // :418-419
+            }
+            if (METHOD == 2) q = (f2){0.5f, 0.5f} * ((f2){1.0f, 1.0f} + q);   // lib/loss/rpn_3d.py:781
+            q3[p] = q;
+        }
+        if (__any(tiny < 0x21800000u - 1u)) redo |= 1ull << r;                // an intersection in (0, 2^-60): the row again, below
+        float* o = o3 + (size_t)(i0 + r) * ld + col[0];
+        store_nt_f4(o, q3[0].x, q3[0].y, q3[1].x, q3[1].y);
+        if (BEV) store_nt_f4(ob + (size_t)(i0 + r) * ld + col[0], qb[0].x, qb[0].y, qb[1].x, qb[1].y);
+    }
+    while (redo) {                                                            // (wave-uniform; rare)
+        const int r = __builtin_ctzll(redo);
+        redo &= redo - 1ull;
+        scalar_row(r);
     }
 }
 
@@ -215,8 +300,6 @@ __global__ __launch_bounds__(kWavesPerWG * 64) void iou3d_kernel(const float* __
 // About 24 VALU slots per pair instead of 43.  Result within 1e-6 of the exact expression order (tested at 1e-5 against
 // the reference vectors; north_star tolerance 1e-4); gnms_iou3d_approximate / methods 0 and 1 keep the exact kernel above.
 // ------------------------------------------------------------------------------------------------
-using gnms_iou3d::f2;
-
 template <bool VEC>
 __global__ __launch_bounds__(kWavesPerWG * 64) __attribute__((amdgpu_waves_per_eu(7))) void iou3d_nms_fast_kernel(const float* __restrict__ RA, const float* __restrict__ RB, int M,
                                                                           int N, float* __restrict__ out, long ld, int tile_rows, int row0,

@@ -618,8 +618,8 @@ __device__ __forceinline__ u64 transpose64(u64 x, int lane) {            // lane
     return x;
 }
 
-// (round 4: no
-// density gate any more: with the scan on one workgroup per super-block the symmetric path is the faster one for dense images too)
+// (round 4: no density gate any more -- with the scan on one workgroup per super-block the symmetric path is the faster one for dense
+// images too)
 constexpr int kSymPairsPerWave = 1;                          // (four pairs per wave, eight loads in flight, measured slower: 13.0 against 10.7 us at B = 8, N = 4096)
 __global__ __launch_bounds__(256) void wsym_check_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;

@@ -164,6 +164,17 @@ def get_corners_of_cuboid(x3d, y3d, z3d, w3d, h3d, l3d, ry3d, iou_3d_convention=
     return _back(corners, kind, out_device)
 
 
+def corners_batched(params):
+    """params [B,N,7] (x, y, z, w, h, l, ry; CUDA fp32) -> corners [B,N,3,8]: get_corners_of_cuboid for a whole batch in one launch."""
+    lib = _lib.load()
+    params = params.contiguous()
+    B, N = params.shape[0], params.shape[1]
+    corners = torch.empty((B, N, 3, 8), dtype=torch.float32, device=params.device)
+    with on_device(params.device):
+        check(lib.gnms_corners_of_cuboid(ptr(params), B * N, ptr(corners), stream_ptr(params.device)), "gnms_corners_of_cuboid")
+    return corners
+
+
 def iou3d_approximate(corners_3d_b1, corners_3d_b2, mode="list", method="normal"):
     """lib/core.py:305-421.  Returns (iou_bev, iou_3d).  Inputs are NOT modified (the reference overwrites
     the y row of its inputs through a view, :379-380)."""

@@ -1648,8 +1648,12 @@ def test_n_rank_launcher_end_to_end():
         assert len(lines) == 1, r.stdout[-3000:]
         return json.loads(lines[0])
 
-    d = one_json_line(subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
-                                     capture_output=True, text=True, timeout=900))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    d = one_json_line(r)
+    import re
+    waits = [float(x) for x in re.findall(r"rank \d+ waited ([0-9.]+) s in the final barrier", r.stderr)]
+    assert len(waits) == 2 and max(waits) < 60.0, r.stderr[-2000:]          # no rank idles a minute behind rank 0's post-region work
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and "debug_shared_gpu" in d
     assert "asynchronous" in d["config"]["collective"] and d["config"]["parallelism"].endswith("dp2") and d["roofline"]["frac"] > 0
     assert "cpu_baseline" not in d                                           # rank 0 at N = 1 only
