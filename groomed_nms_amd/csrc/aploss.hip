@@ -473,10 +473,9 @@ extern "C" int gnms_aploss(const float* logits, const float* targets, int B, int
         return GNMS_ERR_UNSUPPORTED;
     }
     GNMS_CHECK_ARG(logits && targets && grad, "gnms_aploss: null pointer");
-    // One workgroup per image ranks up to 4096 boxes entirely in LDS; larger images -- and, by request (GNMS_APLOSS_SPREAD=1), any
-    // image whose F x N product makes the one-CU version slow -- run the four-kernel version that spreads the positives over the machine.
-    static const int spread = [] { const char* e = getenv("GNMS_APLOSS_SPREAD"); return e ? atoi(e) : 0; }();
-    if (N > kApMaxN || spread == 1 || (spread == 0 && N >= 2048 && B <= 64)) {
+    // One workgroup per image ranks up to 4096 boxes entirely in LDS; larger images -- and smaller batches of images from 2048 boxes,
+    // whose F x N product makes the one-CU version slow -- run the four-kernel version that spreads the positives over the machine.
+    if (N > kApMaxN || (N >= 2048 && B <= 64)) {
         gnms_async_buffer scratch_buf;                                // returned to the pool on every exit, the early error returns included
         GNMS_CHECK_HIP(scratch_buf.alloc((size_t)B * ap_scratch_words(N) * sizeof(float), st));
         float* scratch = scratch_buf.as<float>();

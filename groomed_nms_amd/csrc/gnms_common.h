@@ -106,8 +106,6 @@ struct gnms_ws_layout {
     size_t off_order, off_sscore, off_rankof, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_hlist, off_plead, off_pre,
         off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_gran, off_xidx, off_xbox, off_rec, off_W;
     size_t per_image;  // bytes
-    int pull_leaders;  // leaders_body: leaders of a super-block from which its pushes pull (GNMS_PULL_LEADERS; default 128)
-    int scan_v4;       // symmetric matrices: leaders_sym_body (round 4: parallel resolve, left-looking; GNMS_SCAN_V4=0 keeps the round-3 scan)
 };
 
 static inline gnms_ws_layout gnms_make_layout(int N) {
@@ -131,10 +129,6 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     L.off_rec = take(n4 * 12);
     L.off_W = take((size_t)(L.NB > 0 ? L.NB : 1) * (size_t)(L.NC > 0 ? L.NC : 4) * 8);
     L.per_image = o;
-    static const int pull = [] { const char* e = getenv("GNMS_PULL_LEADERS"); return e ? atoi(e) : 128; }();
-    L.pull_leaders = pull;
-    static const int v4 = [] { const char* e = getenv("GNMS_SCAN_V4"); return e ? atoi(e) : 1; }();
-    L.scan_v4 = v4;
     return L;
 }
 

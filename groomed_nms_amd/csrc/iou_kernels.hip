@@ -405,32 +405,26 @@ int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int6
 // The symmetric writer (iou3d_sym.h) for the square matrix of one box set: the macro tiles [pct0, pct1) percent of every image's
 // upper triangle (a call may split the write over two launches / streams).  Needs ld even and `out` 8-byte aligned.
 bool gnms_internal_overlap3d_sym_ok(int N, int64_t ld, const float* out) {
-    static const int forced = [] { const char* e = getenv("GNMS_3D_SYM"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    if (forced == 0) return false;
     return N >= 256 && (ld % 2 == 0) && ((uintptr_t)out % 8 == 0);
 }
 int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1) {
     const int tiles = gnms_iou3d::sym_tiles_per_image(N);
     const int t0 = (int)((long long)tiles * pct0 / 100), t1 = (int)((long long)tiles * pct1 / 100);
     if (t1 <= t0 || B <= 0) return GNMS_OK;
-    static const bool nt = [] { const char* e = getenv("GNMS_3D_SYM_NT"); return !(e && e[0] == '0'); }();      // non-temporal stores measured faster
+    // (non-temporal stores throughout: measured faster than ordinary ones)
     // waves per workgroup: 16 up to N = 4096 (0.104 against 0.113 ms at B = 8: the guard band's exact-order branch costs 8 % with 8 waves and
     // nothing with 16), 8 above (N = 16384: 1.645 against 1.666 ms)
-    static const int forced_nw = [] { const char* e = getenv("GNMS_3D_SYM_NW"); return e ? atoi(e) : 0; }();
-    const int nw = forced_nw ? forced_nw : (N <= 4096 ? 16 : 8);
+    const int nw = N <= 4096 ? 16 : 8;
     int rc;
     // persistent workgroups (iou3d_sym_persistent_kernel) for the largest images only: B = 8, N = 16384 1.63 -> 1.565 ms (0.69 of the HBM
     // peak); at N = 4096 (0.104 -> 0.119) and 8192 (0.38 -> 0.42, the one-tile-per-workgroup kernel reaches 0.71 there) the static round
-    // robin ends unevenly.  GNMS_3D_SYM_PERSIST=0/1 forces.
-    static const int forced_persist = [] { const char* e = getenv("GNMS_3D_SYM_PERSIST"); return e ? atoi(e) : -1; }();
-    const bool persist = forced_persist >= 0 ? forced_persist == 1 : N > 8192;
+    // robin ends unevenly.
+    const bool persist = N > 8192;
     if (persist && pct0 == 0 && pct1 == 100) {
         const size_t lds2 = 2 * gnms_iou3d::kSymTileBytes;
         const int cus = gnms_device_cu_count();                       // (cached per device: nms_layer.hip)
-        if (nt) { if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_persistent_kernel<true>), lds2))) return rc; }
-        else { if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_persistent_kernel<false>), lds2))) return rc; }
-        if (nt) gnms_launch_prof(kProfMatrixWrite, iou3d_sym_persistent_kernel<true>, dim3((unsigned)cus), dim3(1024), lds2, st, rec, N, B, out, (long)ld, thr);
-        else gnms_launch_prof(kProfMatrixWrite, iou3d_sym_persistent_kernel<false>, dim3((unsigned)cus), dim3(1024), lds2, st, rec, N, B, out, (long)ld, thr);
+        if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_persistent_kernel<true>), lds2))) return rc;
+        gnms_launch_prof(kProfMatrixWrite, iou3d_sym_persistent_kernel<true>, dim3((unsigned)cus), dim3(1024), lds2, st, rec, N, B, out, (long)ld, thr);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
@@ -441,8 +435,8 @@ int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, 
         if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_kernel<NW_, NT_>), lds))) return rc;                     \
         gnms_launch_prof(kProfMatrixWrite, iou3d_sym_kernel<NW_, NT_>, grid, dim3(NW_ * 64), lds, st, rec, N, out, (long)ld, thr, t0); \
     } while (0)
-    if (nw == 16) { if (nt) GNMS_SYM_LAUNCH(16, true); else GNMS_SYM_LAUNCH(16, false); }
-    else { if (nt) GNMS_SYM_LAUNCH(8, true); else GNMS_SYM_LAUNCH(8, false); }
+    if (nw == 16) GNMS_SYM_LAUNCH(16, true);
+    else GNMS_SYM_LAUNCH(8, true);
 #undef GNMS_SYM_LAUNCH
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;

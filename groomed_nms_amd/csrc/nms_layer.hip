@@ -177,9 +177,8 @@ extern "C" int gnms_profile_fill_tiles(float* dst, int B, int N, int64_t ld, int
                    "gnms_profile_fill_tiles: dst 16-byte aligned, ld >= N a multiple of 4");
     GNMS_CHECK_ARG((rows == 4 || rows == 8 || rows == 16 || rows == 32 || rows == 64) && N % rows == 0,
                    "gnms_profile_fill_tiles: rows per wave tile must be 4, 8, 16, 32 or 64 and divide N (rows=%d N=%d)", rows, N);
-    static const int order = [] { const char* e = getenv("GNMS_FILL_ORDER"); return e ? atoi(e) : 0; }();
-    const char* ge = getenv("GNMS_FILL_GRID");                     // (experiments: the same stream from fewer CUs)
-    const dim3 grid((unsigned)(ge && atoi(ge) > 0 ? atoi(ge) : device_cu_count()));
+    const int order = 0;                                           // row band major (the other orders of round 2 measured slower: LABNOTES.md)
+    const dim3 grid((unsigned)device_cu_count());
     hipStream_t st = (hipStream_t)stream;
     const long bands = (long)B * N / rows;
 #define GNMS_FILL_TILES(R)                                                                                                                  \
@@ -246,10 +245,8 @@ extern "C" int gnms_profile_fill_sym(float* dst, int B, int N, int64_t ld, int t
     hipStream_t st = (hipStream_t)stream;
     const int nt = N / tile;
     const long total = (long)nt * (nt + 1) / 2 * B;
-    const char* ge = getenv("GNMS_FILL_GRID");                     // (experiments; persist only)
-    const dim3 grid((unsigned)(persist ? (ge && atoi(ge) > 0 ? atoi(ge) : device_cu_count() * (tile == 128 ? 2 : 1)) : total));
-    const char* be = getenv("GNMS_FILL_BLOCK");
-    const dim3 block(be && atoi(be) > 0 ? atoi(be) : (tile == 128 ? 512 : 1024));
+    const dim3 grid((unsigned)(persist ? device_cu_count() * (tile == 128 ? 2 : 1) : total));
+    const dim3 block(tile == 128 ? 512 : 1024);
 #define GNMS_FILL_SYM(TT, CC)                                                                                                              \
     do {                                                                                                                                   \
         if (nontemporal) gnms_launch_prof(kProfPlainStream, prof_fill_sym_kernel<TT, CC, true>, grid, block, 0, st, dst, N, (long)ld, B, persist, 0.5f);   \
@@ -362,8 +359,8 @@ int check_common(const char* fn, int B, int N, int64_t ld, const gnms_params* P,
     return GNMS_OK;
 }
 
-// K2, the one full read of the matrix.  Workgroup shape and loads in flight per wave: GNMS_BITMASK_WAVES (8 | 16: 2048 or 4096 columns
-// side by side -- at N = 4096 sixteen waves read whole 16-KiB rows), GNMS_BITMASK_RB (8 | 16 one-KiB loads in flight per wave).
+// K2, the one full read of the matrix: workgroups of 8 waves (2048 columns side by side), 16 from N = 4096 (whole 16-KiB rows), eight
+// one-KiB loads in flight per wave.
 // The matrix-in layer decides on the device whether the thresholded matrix is symmetric (every caller in the reference passes
 // iou(boxes, boxes)): bitmask_kernel then stores the rows of W in full and wsym_check_kernel compares the 64 x 64 blocks with
 // their transposes; K3 / K4 (sym = 2) take the pulling, attributing scan for the images that pass.  GNMS_MATRIX_SYM=0: never.
@@ -374,16 +371,11 @@ bool matrix_sym_detection(int N) {
 int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st, int full = 0) {
     // (measured at B = 8, N = 4096, three interleaved repetitions: 16 waves 91.6-91.8 us = 0.733 of the HBM peak, 8 waves 95.2-95.7 us;
     // 16 loads in flight per wave change nothing either way)
-    static const int forced_waves = [] { const char* e = getenv("GNMS_BITMASK_WAVES"); return e ? atoi(e) : 0; }();
-    const int waves = forced_waves ? forced_waves : (N >= 4096 ? 16 : kMaskWaves);
-    static const int rbf = [] { const char* e = getenv("GNMS_BITMASK_RB"); return e ? atoi(e) : kMaskRB; }();
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
 #define GNMS_BITMASK(V, W, R)                                                                                                         \
     gnms_launch_prof(kProfMatrixRead, bitmask_kernel<V, W, R>, dim3(gnms_div_up(N, W * 256), L.NB, B), dim3(W * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L, full)
     if (!vec) GNMS_BITMASK(false, kMaskWaves, kMaskRB);
-    else if (waves == 16 && rbf == 16) GNMS_BITMASK(true, 16, 16);
-    else if (waves == 16) GNMS_BITMASK(true, 16, 8);
-    else if (rbf == 16) GNMS_BITMASK(true, 8, 16);
+    else if (N >= 4096) GNMS_BITMASK(true, 16, 8);
     else GNMS_BITMASK(true, 8, 8);
 #undef GNMS_BITMASK
     GNMS_CHECK_LAUNCH();
@@ -562,22 +554,12 @@ __device__ __forceinline__ void writers_persistent(const float* __restrict__ in,
 // launch at N = 4096 from 102.5 to 93.0 us and the large-image launch at N = 16384 from 1.57 to 1.45 ms -- twice as many, shorter units
 // even out what 2048 units on 248 workgroups leave uneven; 4 rows lose again, 111 us / 1.77 ms.)
 constexpr int kStagedRows = 8;
-bool writers_staged() {
-    static const bool on = [] { const char* e = getenv("GNMS_WRITERS_STAGED"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-// (GNMS_FAST_ROWS=0: the tile body of round 2 -- min / max / subtract / relu per entry, columns gathered per unit -- for comparison)
-int fast_rows_2d() {
-    static const int on = [] { const char* e = getenv("GNMS_FAST_ROWS"); return e ? atoi(e) : 1; }();
-    return on;
-}
 
 // claim0 / claim_stride: image i's claim counter is claim0[i * claim_stride] (the layer: misc[5] of the image's workspace; gnms_iou2d:
 // a zeroed array of its own); first_wg: blockIdx.x of the first writer workgroup of the launch
 template <bool VEC>
 __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxes, int N, float* __restrict__ out, long ld, int nimg, int* claim0,
-                                                  size_t claim_stride, const int first_wg, const int fast_rows) {
+                                                  size_t claim_stride, const int first_wg) {
     using namespace gnms_iou;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sbox = reinterpret_cast<float4*>(smem);                  // [N] boxes of the staged image
@@ -609,7 +591,7 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
     bool img_plain = false;
     int cols_of = -1;                                                // the column chunk `cp` holds (of the staged image)
     ColPairs cp;
-    const bool fast_ok = VEC && (N & 3) == 0 && (N % kStagedRows) == 0 && fast_rows;
+    const bool fast_ok = VEC && (N & 3) == 0 && (N % kStagedRows) == 0;
     while (cur >= 0) {
         const int img = cur >> 16, u = cur & 0xffff;
         if (img != staged) {                                         // (every wave finished reading the old image before the last barrier)
@@ -705,7 +687,7 @@ __device__ __forceinline__ void writers_sym_persistent(const float* __restrict__
 template <bool VEC>
 __global__ __launch_bounds__(1024) void iou2d_self_kernel(const float* __restrict__ boxes, int N, int nimg, float* __restrict__ out, long ld,
                                                           int* __restrict__ claims) {
-    writers_staged_2d<VEC>(boxes, N, out, ld, nimg, claims, 64, 0, 1);      // (a counter per 256 bytes: each in an L2 line of its own)
+    writers_staged_2d<VEC>(boxes, N, out, ld, nimg, claims, 64, 0);      // (a counter per 256 bytes: each in an L2 line of its own)
     if (threadIdx.x == 0) {                                                 // (thread 0 issued every claim of this workgroup and has consumed them all)
         int* done = claims + (size_t)nimg * 64;
         if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
@@ -796,18 +778,15 @@ int launch_write_staged(const float* a, const float* b, int B, int M, int N, flo
 }  // namespace
 // gnms_iou2d's large-matrix path (iou_kernels.hip): the persistent writers' geometry reaches 5.5-5.6 TB/s where its 64-row tiles reach 4.6-5.2
 bool gnms_internal_iou2d_wants_staged(int B, int M, int N, int64_t ld, const float* out) {
-    if (!writers_staged() || (ld % 4) != 0 || (N % 4) != 0 || ((uintptr_t)out % 16) != 0) return false;
+    if ((ld % 4) != 0 || (N % 4) != 0 || ((uintptr_t)out % 16) != 0) return false;
     // (N <= 4096: the per-unit row fetch and barrier cost more than the geometry gains -- B = 8, M = N = 4096: 108-114 us against the
     // 64-row tiles' 102; N = 16384: 1.61 ms against 1.85)
     const long units = (long)B * ((M + kStagedRows - 1) / kStagedRows) * ((N + 4095) / 4096);
-    static const int forced = [] { const char* e = getenv("GNMS_IOU2D_STAGED"); return e ? atoi(e) : -1; }();
-    if (forced >= 0) return forced != 0 && units >= 4L * device_cu_count();
     return N > 4096 && units >= 4L * device_cu_count();
 }
-// a == b, N <= 4096: iou2d_self_kernel (B = 8, N = 4096: 0.68-0.69 -> 0.71 of the HBM peak); GNMS_IOU2D_SELF=0 keeps iou2d_kernel
+// a == b, N <= 4096: iou2d_self_kernel (B = 8, N = 4096: 0.68-0.69 -> 0.71 of the HBM peak)
 bool gnms_internal_iou2d_wants_self(const float* a, const float* b, int B, int M, int N, int64_t ld, const float* out) {
-    static const int forced = [] { const char* e = getenv("GNMS_IOU2D_SELF"); return e ? atoi(e) : -1; }();
-    if (forced == 0 || a != b || M != N || N > 4096 || B > 127 || !writers_staged()) return false;
+    if (a != b || M != N || N > 4096 || B > 127) return false;
     const long units = (long)B * ((N + kStagedRows - 1) / kStagedRows) * ((N + 4095) / 4096);
     return units >= 8L * device_cu_count();
 }
@@ -838,9 +817,8 @@ int claim_ring_slot(int** slot) {
 }
 }  // namespace
 int gnms_internal_iou2d_self(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st) {
-    static const int forced_grid = [] { const char* e = getenv("GNMS_IOU2D_SELF_GRID"); return e ? atoi(e) : 0; }();
     const int cus = device_cu_count();
-    int grid = forced_grid > 0 ? forced_grid : cus - 8;             // (alone on the machine the stream likes every CU: 248 -> 0.71, 200 -> 0.64)
+    int grid = cus - 8;                                              // (alone on the machine the stream likes every CU: 248 -> 0.71, 200 -> 0.64)
     if (grid < 1) grid = 1;
     int* claims = nullptr;
     int rc = claim_ring_slot(&claims);
@@ -859,8 +837,7 @@ int gnms_internal_iou2d_self(const float* boxes, int B, int N, float* out, int64
     return GNMS_OK;
 }
 int gnms_internal_iou2d_staged(const float* a, const float* b, int B, int M, int N, float* out, int64_t ld, hipStream_t st) {
-    static const int reserve = [] { const char* e = getenv("GNMS_IOU2D_RESERVE"); return e ? atoi(e) : 0; }();   // (experiments)
-    return launch_write_staged(a, b, B, M, N, out, ld, reserve, st);
+    return launch_write_staged(a, b, B, M, N, out, ld, 0, st);
 }
 namespace {
 
@@ -915,7 +892,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         return;
     }
     const int first_writer = nimg * spw;
-    if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, img_ptrs(ws, L, 0).misc + 5, L.per_image / sizeof(int), first_writer, staged == 3 ? 0 : staged); return; }   // (3: the columns gathered per unit)
+    if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, img_ptrs(ws, L, 0).misc + 5, L.per_image / sizeof(int), first_writer); return; }
     if (SRC == kFromRecords && staged == 2) { writers_sym_persistent<true>(write_src, N, out, ld, nimg, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5); return; }
     writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
 }
@@ -925,19 +902,14 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
 int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
     const int NB = (N + 63) / 64;
     const long long tiles4 = (long long)B * NB * ((N + 255) / 256);
-    static const int rowbuf_big = [] { const char* e = getenv("GNMS_BITS_ROWBUF_BIG"); return e ? atoi(e) : 1; }();
-    if (rowbuf_big && tiles4 >= 32768 && (size_t)L.NC * 8 <= 136 * 1024) {
+    if (tiles4 >= 32768) {
         // large images (round 3): the LDS row buffer with a chunk loop -- one 16-wave workgroup per rank block, its waves walking the
-        // column chunks, the full row of W leaving as ONE coalesced write.  In round 1 (only the triangle of W stored) the scatter
-        // kernel below was faster (220 vs 297 us at N = 16384); with full rows it issues N^2 / 64 scattered 8-byte stores per image
-        // and loses: B = 8, N = 16384 step 1.907 -> 1.798 ms (uniform 1.997 -> 1.798), N = 8192 0.519 -> 0.496.  GNMS_BITS_ROWBUF_BIG=0 restores it.
+        // column chunks, the full row of W leaving as ONE coalesced write (N <= GNMS_MAX_BOXES: the row fits 128 KiB).  The scatter
+        // kernel it replaced issued N^2 / 64 scattered 8-byte stores per image: B = 8, N = 16384 step 1.907 -> 1.798 ms.
         const size_t lds = (size_t)L.NC * 8;
         int rc = allow_lds(bitmask_boxes_kernel<4, 1, true, true>, lds);
         if (rc) return rc;
         bitmask_boxes_kernel<4, 1, true, true><<<dim3(NB, 1, B), 1024, lds, st>>>(boxes, N, counts, thr, ws, L);
-    } else if (tiles4 >= 32768) {                   // large images: 4 rank blocks per wave (column side paid once per 256 rows;
-                                                    // the LDS row buffer measured slower there: 87 vs 73 us at N=8192, 297 vs 220 at 16384)
-        bitmask_boxes_kernel<4, 4><<<dim3(gnms_div_up(((NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
     } else if (tiles4 >= 2048 && (N + 255) / 256 <= 16) {
         // one 16-wave workgroup per rank block: words collected in an LDS copy of the row, written out coalesced
         bitmask_boxes_kernel<4, 1, true><<<dim3(NB, 1, B), 1024, (size_t)L.NC * 8 + 4 * 1024 * sizeof(int), st>>>(boxes, N, counts, thr, ws, L);   // + the ranks' stash
@@ -986,10 +958,9 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
 // K3..K6 as one launch or four?  Measured (HIP-graph replay, B=8): one launch wins 2-2.5 us per step up to N=2048 (three
 // kernel boundaries less) and, with the general scan, loses 1.5 us at N=4096 (the attribution runs on one CU instead of 64).  Where the
 // scan attributes as it goes (symmetric sources, `sym`), K4 rides in K5 and K6 starts from LDS (groups_body FUSE, E <= 4): one launch
-// up to N = 4096.  GNMS_TAIL=0/1 forces.
+// up to N = 4096.
 bool use_tail_kernel(int N, int sym = 0) {
-    static const int forced = [] { const char* e = getenv("GNMS_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced == 1 : (N <= 2048 || (sym && N <= 4096));
+    return N <= 2048 || (sym && N <= 4096);
 }
 
 // K3..K6 in one launch (masked groups); SRC/src: kFromMatrix (the matrix), kFromBoxes (the boxes), kFromRecords (src unused)
@@ -1012,20 +983,15 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     return GNMS_OK;
 }
 
-// rows per wave tile of the write role (GNMS_FUSED_TILE_ROWS overrides): 16 measured best at B = 8, N = 4096 (0.168 ms per step; 8: 0.174,
-// 32: 0.175, 64: 0.193 -- the last chunks of a launch end together only if chunks are short)
-int fused_tile_rows() {
-    static const int forced = [] { const char* e = getenv("GNMS_FUSED_TILE_ROWS"); return e ? atoi(e) : 0; }();
-    int tr = forced > 0 ? forced : 16;
-    return tr > 64 ? 64 : tr;
-}
+// rows per wave tile of the write role: 16 measured best at B = 8, N = 4096 (0.168 ms per step; 8: 0.174, 32: 0.175, 64: 0.193 -- the last
+// chunks of a launch end together only if chunks are short)
+constexpr int kFusedTileRows = 16;
 
 // 3D: the write role of that launch as symmetric writers (writers_sym_persistent) -- above N = 1024, where an image has enough
-// macro tiles; GNMS_3D_SYM_TAIL=0/1 forces.
+// macro tiles.
 bool sym_writers_in_tail_launch(int N, int64_t ld, const float* out) {
-    static const int forced = [] { const char* e = getenv("GNMS_3D_SYM_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (!gnms_internal_overlap3d_sym_ok(N, ld, out)) return false;
-    return forced >= 0 ? forced == 1 : N > 1024;                  // (B = 8: N = 2048 0.110 -> 0.090 ms, 1536 0.0895 -> 0.080, 1024 even)
+    return N > 1024;                                              // (B = 8: N = 2048 0.110 -> 0.090 ms, 1536 0.0895 -> 0.080, 1024 even)
 }
 
 // K3..K6 of every image + the matrix in one launch (tail_write_kernel)
@@ -1038,8 +1004,8 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     // (the fused K5 -> K6 hand-off, E <= 4, parks order[] and a copy of r2 behind the key region: 16 bytes per key)
     const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * (P2 <= 4096 ? 16 : 8);
     size_t lds = llds > glds ? llds : glds;
-    const int tr = fused_tile_rows();
-    int staged = (SRC == kFromBoxes && N <= 4096 && writers_staged()) ? (fast_rows_2d() ? fast_rows_2d() : 3) : 0;   // writers_staged_2d: the image's boxes in LDS
+    const int tr = kFusedTileRows;
+    int staged = (SRC == kFromBoxes && N <= 4096) ? 1 : 0;           // writers_staged_2d: the image's boxes in LDS
     if (staged && lds < (size_t)N * 16) lds = (size_t)N * 16;
     long writers = write_chunk_count(N, B, tr, 0, N);                // persistent writers: at most one per CU
     if (SRC == kFromRecords && sym_writers_in_tail_launch(N, ld, out)) {   // writers_sym_persistent: two LDS macro tiles
@@ -1171,10 +1137,7 @@ int side_stream(SideStream** out) {
         // 128-KiB-LDS workgroup per image) must get the CU slots that free up, not wait for the write to drain
         int least = 0, greatest = 0;
         GNMS_CHECK_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        // (GNMS_SIDE_PRIO=normal: an ordinary-priority side stream, for experiments with writers that should SHARE the machine with the
-        // layer's kernels instead of yielding to them)
-        static const bool normal = [] { const char* e = getenv("GNMS_SIDE_PRIO"); return e && e[0] == 'n'; }();
-        GNMS_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, normal ? (least + greatest) / 2 : least));
+        GNMS_CHECK_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
         GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.fork[0], hipEventDisableTiming));
         GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.fork[1], hipEventDisableTiming));
         GNMS_CHECK_HIP(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
@@ -1201,17 +1164,7 @@ struct MatrixWrite { float* out; int64_t ld; bool one_launch; };   // one_launch
 // with the write's), the rest beside the tail.  r as a percentage of N (GNMS_SPLIT_PCT overrides), rounded down to whole 64-row
 // tiles.  Measured B=8: 2D N=8192 0.625 / 0.575 / 0.568 / 0.595 ms at 0 / 20 / 40 / 50 %, N=16384 2.10 / 2.03 / 2.08 / 2.08;
 // 3D N=8192 0.720 / 0.672 / 0.676 / 0.703, N=16384 2.39 / 2.37 / 2.36 / 2.36 (its write kernel has less VALU to spare).
-int split_rows(int N, int default_pct) {
-    static const int pct = [] { const char* e = getenv("GNMS_SPLIT_PCT"); return e ? atoi(e) : -1; }();
-    const int p = pct >= 0 ? pct : default_pct;
-    return (int)((long long)N * p / 100) & ~63;
-}
-// the same split as a percentage (of the symmetric writer's macro tiles)
-int split_pct(int default_pct) {
-    static const int pct = [] { const char* e = getenv("GNMS_SPLIT_PCT"); return e ? atoi(e) : -1; }();
-    const int p = pct >= 0 ? pct : default_pct;
-    return p < 0 ? 0 : (p > 100 ? 100 : p);
-}
+int split_rows(int N, int pct) { return (int)((long long)N * pct / 100) & ~63; }
 // everything enqueued on the side stream so far happens before what is enqueued on `st` from now on
 int side_join(hipStream_t st) {
     std::lock_guard<std::mutex> lock(g_side_mu);
@@ -1250,36 +1203,12 @@ bool sorts_ride_in_iou_launch(int B, int N) {
 }  // namespace
 
 namespace {
-// 3D one-call entry: the matrix-write kernel also produces the threshold bits (iou3d_bits_kernel).  GNMS_3D_BITS_IN_WRITE=0 keeps the
-// separate from-records bit-matrix kernel.
-// Measured at B = 8 (ms per step, separate kernel -> bits in the write): N = 4096 0.248 -> 0.210, 8192 0.686 -> 0.619, 16384 2.51 -> 2.21
-// (its launch then runs at the 4.6 TB/s store ceiling); N <= 2048 loses (0.133 -> 0.182 at 2048: 64-row tiles leave too few
-// workgroups, and there the chain rides in the write launch instead).
-bool bits_in_write_3d(int N) {
-    static const int forced = [] { const char* e = getenv("GNMS_3D_BITS_IN_WRITE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced == 1 : N > 2048;
-}
-// Round 3, large images (the side-stream regime): the matrix is written by the SYMMETRIC writer (iou3d_sym.h: every unordered pair
-// evaluated once -- half the VALU work of a kernel that was VALU-bound at 0.57 of the HBM peak) on the side stream, in two launches
-// over ranges of its macro tiles: the first beside the from-records bit-matrix kernel, the rest beside the one-launch tail.  The
-// write kernel then has VALU to spare for the bit-matrix kernel running beside it, which it did not have when it evaluated all
-// pairs (3.2d), and K3..K6 no longer wait for the write (with the bits in the write they ran 0.32 ms serially behind it at N = 16384).
-// GNMS_3D_SYM_LAYER=0/1 forces.
-bool sym_write_beside_3d(int B, int N, int64_t ld, const float* out) {
-    static const int forced = [] { const char* e = getenv("GNMS_3D_SYM_LAYER"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    if (!gnms_internal_overlap3d_sym_ok(N, ld, out)) return false;
-    // (default off since the symmetric writers also ride in the chain's launch at large N -- measured B = 8: N = 6144 0.385 -> 0.352 ms,
-    // 8192 0.593 -> 0.574, 12288 1.277 -> 1.193, 16384 2.19 -> 2.13: no fork / join, and the persistent double-buffered writers reach
-    // 0.68-0.70 of the HBM peak where the one-tile-per-workgroup kernel beside the layer reached 0.65-0.67)
-    return forced == 1;
-}
-// masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_iou2d_kernel).  GNMS_FUSE_TAIL=0/1 forces.
+// masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_write_kernel).
 bool chain_rides_in_write_launch(int B, int N) {
-    static const int forced = [] { const char* e = getenv("GNMS_FUSE_TAIL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     // (up to N = 1024 the score / x sorts could ride in the IoU launch instead, iou2d_sort_kernel; replayed as a HIP graph -- the GPU's
     // own time -- this sequence measures the same or better there too: B = 8, N = 128 / 256 / 512 / 1024: 42.4 / 41.0 / 41.5 / 52.1 us
     // against 38.0 / 36.6 / 40.0 / 47.5)
-    return forced >= 0 ? forced == 1 : true;
+    return true;
 }
 }  // namespace
 
@@ -1287,10 +1216,8 @@ bool chain_rides_in_write_launch(int B, int N) {
 // (default parameters, aligned inputs)
 extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (B <= 0 || N <= 0) return "";
-    if (dim == 3 && sym_write_beside_3d(B, N, N, nullptr)) return "iou3d_sym_kernel";
     if (dim == 3 && chain_rides_in_write_launch(B, N) && sym_writers_in_tail_launch(N, N, nullptr)) return "tail_write_kernel";
-    if (dim == 3 && bits_in_write_3d(N)) return "iou3d_bits_kernel";
-    if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : (writers_staged() && N % 4 == 0 ? "write_staged_kernel" : "iou2d_kernel");
+    if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : (N % 4 == 0 ? "write_staged_kernel" : "iou2d_kernel");
     if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
     if (dim == 3) return "iou3d_nms_fast_kernel";
     if (sorts_ride_in_iou_launch(B, N)) return "iou2d_sort_kernel";
@@ -1368,93 +1295,6 @@ int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int6
 
 
 namespace {
-// ------------------------------------------------------------------------------------------------
-// 3D one-call entry: the matrix write ALSO yields the threshold bits.
-// The write kernel evaluates every pair anyway; thresholding costs two more VALU instructions per pair on a kernel that is bound by
-// its stores at large N, where the separate from-records bit-matrix kernel (29 slots per pair on the rows its cull keeps: 45 us at
-// B = 8, N = 4096, 0.5-0.6 ms at N = 16384) and the x sort that feeds it were serial work in front of the chain.  For the words to
-// come out in rank space the rows are walked in RANK order: a tile is rank block kb x 256 input columns, row r of the tile is the box
-// of rank 64 kb + r -- its record is read from a rank-ordered copy (records_by_rank_kernel; slot 7 carries the row's input index)
-// and its matrix row is written where it belongs (rows are contiguous 4 N-byte streams whatever the permutation); the column words
-// go to W[kb][rank of the column], full rows, so the leader scan can pull (leaders_body, sym).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void records_by_rank_kernel(const float* __restrict__ rec, int N, char* ws, gnms_ws_layout L,
-                                                              float* __restrict__ recs) {
-    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= N) return;
-    const int idx = img_ptrs(ws, L, b).order[k];
-    const float4* src = reinterpret_cast<const float4*>(rec + ((size_t)b * N + idx) * gnms_iou3d::kRec);
-    float4* dst = reinterpret_cast<float4*>(recs + ((size_t)b * N + k) * gnms_iou3d::kRec);
-    float4 v = src[1];
-    v.w = __int_as_float(idx);                                       // slot 7 (area_bev, unused by the NMS overlap): the row's input index
-    dst[0] = src[0]; dst[1] = v; dst[2] = src[2];
-}
-
-template <bool VEC>
-__global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64) void iou3d_bits_kernel(const float* __restrict__ recs, const float* __restrict__ rec, int N,
-                                                                                const int* __restrict__ counts, float thr, float* __restrict__ out,
-                                                                                long ld, char* ws, gnms_ws_layout L) {
-    using namespace gnms_iou3d;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.z, kb = blockIdx.y;
-    const int c0 = (blockIdx.x * gnms_iou::kWavesPerWG + wave) * gnms_iou::kWaveCols;
-    const int k0 = kb * 64;
-    if (c0 >= N || k0 >= N) return;
-    const int n = gnms_count(counts, b, N);
-    ImgPtrs I = img_ptrs(ws, L, b);
-    const float* ra = recs + (size_t)b * N * kRec;                   // rows: rank order
-    const float* rb = rec + (size_t)b * N * kRec;                    // columns: input order
-    float* o3 = out + (size_t)b * N * ld;
-    Cols2 cols[2];
-    int col[4];
-    unsigned colbad = 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        col[j] = VEC ? (c0 + 4 * lane + j) : (c0 + lane + 64 * j);
-        const int cc = col[j] < N ? col[j] : (N - 1);
-        const float4* p = reinterpret_cast<const float4*>(rb + (size_t)cc * kRec);
-        const float4 e = p[2];
-        cols2_set(cols[j >> 1], j & 1, p[0], p[1], e);
-        colbad |= (e.w != 0.0f) ? (1u << j) : 0u;
-    }
-    const bool cols_sane = __all(colbad == 0u);
-    const int nrows = min(64, N - k0);                                // every row of the matrix is written (padding ranks map to themselves)
-    const int nbits = max(0, min(64, n - k0));                        // ... but only the image's own ranks enter the bit matrix
-    unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int rend = min(32, nrows - half * 32);
-        for (int rr_ = 0; rr_ < rend; ++rr_) {
-            const int r = half * 32 + rr_;
-            const float* rr = ra + (size_t)(k0 + r) * kRec;         // wave-uniform: scalar loads
-            Row a;
-            a.vol = rr[0]; a.y0 = rr[1]; a.y1 = rr[2]; a.x0 = rr[3]; a.x1 = rr[4]; a.z0 = rr[5]; a.z1 = rr[6]; a.lx = rr[8]; a.ly = rr[9]; a.lz = rr[10];
-            a.bad = rr[11];
-            const int orow = __float_as_int(rr[7]);
-            float res[4];
-            nms_overlap3d_guarded4(a, cols, colbad, cols_sane, thr, res);
-            const unsigned bit = (r < nbits) ? (1u << rr_) : 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wd[half][j] |= !(res[j] <= thr) ? bit : 0u;     // lib/groomed_nms.py:250 (NaN -> removed)
-            const size_t roff = (size_t)orow * ld;
-            if (VEC && col[3] < N) {
-                gnms_iou::store_nt_f4(o3 + roff + col[0], res[0], res[1], res[2], res[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (col[j] < N) o3[roff + col[j]] = res[j];
-            }
-        }
-    }
-    if (k0 >= n) return;
-    u64* Wk = I.W + (size_t)kb * L.NC;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (col[j] < n) Wk[I.rankof[col[j]]] = ((u64)wd[1][j] << 32) | wd[0][j];
-}
-
-}  // namespace
-
-namespace {
 // everything of gnms_forward_with_iou3d that uses the temporary `rec` ([B][N] records, then [B][N] pseudo boxes for the x sort).
 // Masked hard-sorted groups: the whole layer runs from the records (threshold bits AND the O(N) single overlaps, same arithmetic
 // as the matrix kernel), so nothing waits for the matrix; large images write it on the side stream beside the one-launch tail.
@@ -1469,46 +1309,11 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     }
     float* xkeys = rec + (size_t)B * N * gnms_iou3d::kRec;         // [B][N] pseudo boxes; later the rank-ordered records
     if ((rc = gnms_internal_records_for_layer(params3d, B, N, rec, ws, L, xkeys, st))) return rc;
-    const bool sym_beside = sym_write_beside_3d(B, N, ld, iou_out);
-    // 2048 < N, no side stream: K3..K6 ride in the launch of the SYMMETRIC writers (tail_write_kernel, writers_sym_persistent) behind
-    // the from-records bit-matrix kernel, instead of running serially behind a write kernel that also produces the bits
+    // 1024 < N, no side stream: K3..K6 ride in the launch of the SYMMETRIC writers (tail_write_kernel, writers_sym_persistent) behind
+    // the from-records bit-matrix kernel
     const bool culled_bits = P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY;
-    const bool sym_tail = !sym_beside && culled_bits && chain_rides_in_write_launch(B, N) && sym_writers_in_tail_launch(N, ld, iou_out);
-    if (!sym_beside && !sym_tail && bits_in_write_3d(N)) {
-        // score sort -> records in rank order -> ONE pass over all pairs writes the matrix and the bit matrix -> K3..K6
-        float* recs = xkeys;
-        const int P2s = next_pow2(N);
-        if ((rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2s, order, st))) return rc;
-        records_by_rank_kernel<<<dim3(gnms_div_up(N, 256), B), 256, 0, st>>>(rec, N, ws, L, recs);
-        GNMS_CHECK_LAUNCH();
-        const bool vec = (ld % 4 == 0) && ((uintptr_t)iou_out % 16 == 0);
-        const dim3 grid(gnms_div_up(N, gnms_iou::kWGCols), L.NB, B);
-        if (vec) gnms_launch_prof(kProfMatrixWrite, iou3d_bits_kernel<true>, grid, dim3(gnms_iou::kWavesPerWG * 64), 0, st, recs, rec, N, counts, P.nms_threshold, iou_out, (long)ld, ws, L);
-        else gnms_launch_prof(kProfMatrixWrite, iou3d_bits_kernel<false>, grid, dim3(gnms_iou::kWavesPerWG * 64), 0, st, recs, rec, N, counts, P.nms_threshold, iou_out, (long)ld, ws, L);
-        GNMS_CHECK_LAUNCH();
-        if (use_tail_kernel(N, 1)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1);
-        const size_t llds = leaders_lds_bytes(N);
-        if ((rc = allow_lds(leaders_kernel, llds))) return rc;
-        { const int spw = leaders_chain_wgs(N, 1); leaders_kernel<<<B * spw, 1024, llds, st>>>(N, counts, ws, L, 1, B, spw); }
-        GNMS_CHECK_LAUNCH();
-        attribute_kernel<kFromRecords><<<dim3(L.NB, B), 64, 0, st>>>(nullptr, (long)ld, N, counts, P.nms_threshold, ws, L, 1);
-        GNMS_CHECK_LAUNCH();
-        const size_t sort_lds = (size_t)P2s * 8;
-        const int sort_threads = P2s <= 1024 ? P2s : 1024;
-        GNMS_DISPATCH_SORT(P2s, {
-            if ((rc = allow_lds(groups_kernel<E, kFromRecords>, sort_lds))) return rc;
-            groups_kernel<E, kFromRecords><<<B, sort_threads, sort_lds, st>>>(nullptr, N, (long)ld, counts, P, ws, L, P2s);
-        });
-        GNMS_CHECK_LAUNCH();
-        GNMS_DISPATCH_SORT(P2s, {
-            if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
-            finalize_kernel<E><<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2s, prob, (long long*)valid, (long long*)invalid, nvalid,
-                                                                   ninvalid);
-        });
-        GNMS_CHECK_LAUNCH();
-        return GNMS_OK;
-    }
-    const bool beside = sym_beside || (!sym_tail && use_side_stream(B, N, ld));
+    const bool sym_tail = culled_bits && chain_rides_in_write_launch(B, N) && sym_writers_in_tail_launch(N, ld, iou_out);
+    const bool beside = !sym_tail && use_side_stream(B, N, ld);
     const int sym = (P.nms_threshold >= 0.01f && P.nms_threshold < INFINITY) ? 1 : 0;   // the culled kernel writes full symmetric rows of W
     // K3..K6 inside the write launch like the 2D entry -- up to N = 2048 only: the 3D writers are VALU-bound (23 slots per pair) and
     // at the one workgroup per CU that launch runs at they lose more than the overlap buys (B = 8, N = 4096: launch 166 us against a
@@ -1518,19 +1323,12 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     const int P2 = next_pow2(N);
     if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
     SideScope scope(st);
-    // the part of the write that runs beside the bit-matrix kernel: rows [0, r1) of the all-pairs kernel, or the first pct1 percent of
-    // the symmetric writer's macro tiles (GNMS_SPLIT_PCT overrides both)
-    const int r1 = (beside && !sym_beside) ? split_rows(N, 20) : 0;
-    // (symmetric writer: 0 by default -- beside the bit-matrix kernel its launch takes as much longer as that kernel lasts, both being
-    // slowed by the saturated memory system: B = 8, N = 16384 step 2.18 ms at 0 %, 2.11 at 25-35 %, with the writer's own launches
-    // summing to 1.62 ms (0.66 of the HBM peak) against 2.02 (0.53); the cleaner launch is kept, the 3 % are not worth the second fork)
-    const int pct1 = sym_beside ? split_pct(0) : 0;
-    if (r1 > 0 || pct1 > 0) {                                     // first part of the write beside the bit-matrix kernel
+    // the part of the write that runs beside the bit-matrix kernel: rows [0, r1) of the all-pairs kernel
+    const int r1 = beside ? split_rows(N, 20) : 0;
+    if (r1 > 0) {                                                 // first part of the write beside the bit-matrix kernel
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 0))) return rc;
-        if (sym_beside) rc = gnms_internal_nms_overlap3d_sym(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, pct1);
-        else rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, r1);
-        if (rc) return rc;
+        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, r1))) return rc;
     }
     if (!sym) {
         // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
@@ -1549,9 +1347,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 1))) return rc;
         if ((rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym))) return rc;
-        if (sym_beside) rc = gnms_internal_nms_overlap3d_sym(rec, B, N, iou_out, ld, side, P.nms_threshold, pct1, 100);
-        else rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, r1, N);
-        if (rc) return rc;
+        if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, r1, N))) return rc;
         return scope.join();
     }
     if (use_tail_kernel(N, sym)) return launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);
@@ -1696,7 +1492,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     // with gnms_iou2d's kernel in two launches beside bit matrix and tail: 2.13).  Forked in front of the bit-matrix kernel the two
     // VALU-heavy kernels share the SIMDs and the sum stays the same (write 1.97 ms, step 2.01); forked in front of the sorts as well,
     // those crawl (step 2.35).
-    const bool persistent_write = mw && !mw->one_launch && writers_staged() && (mw->ld % 4 == 0) && ((uintptr_t)mw->out % 16 == 0) && (N % 4 == 0);
+    const bool persistent_write = mw && !mw->one_launch && (mw->ld % 4 == 0) && ((uintptr_t)mw->out % 16 == 0) && (N % 4 == 0);
     if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
     if (persistent_write) {
         SideScope whole(st);

@@ -403,8 +403,7 @@ int launch_sgemm(const float* A, const float* B, float* D, int M, int N, int K, 
                  hipStream_t st) {
     if (M == 0 || N == 0) return GNMS_OK;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
-    static const int big = [] { const char* e = getenv("GNMS_SGEMM_BIG"); return e ? atoi(e) : 1; }();
-    if (big && aligned && M % GM == 0 && N % GN == 0 && K % (2 * GK) == 0 && K >= 2 * GK && (long)(M / GM) * (N / GN) >= 256) {
+    if (aligned && M % GM == 0 && N % GN == 0 && K % (2 * GK) == 0 && K >= 2 * GK && (long)(M / GM) * (N / GN) >= 256) {
         sgemm_mfma_big_kernel<<<dim3(N / GN, M / GM), 256, 0, st>>>(A, B, D, K, (long)lda, (long)ldb, (long)ldd, accumulate);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;

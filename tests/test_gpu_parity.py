@@ -1979,6 +1979,47 @@ def test_self_iou_in_the_writers_geometry_and_negative_zero(G, O):
         assert np.array_equal(out[0][i].cpu().numpy(), ref["prob"], equal_nan=True), i
 
 
+def test_library_switches():
+    """The four environment switches the shipped library still reads, each against the default run of the
+    same inputs: GNMS_TWO_STREAMS=0 (large images: every launch on the caller's stream instead of the library's side stream),
+    GNMS_MATRIX_SYM=0 (matrix-in layer: the general scan also for symmetric matrices), GNMS_TAIL_WRITERS=n (CUs that write the matrix
+    beside the per-image chain) and GNMS_TRACE_LAUNCH=1 (developer: launch sites printed, device synchronised behind each)."""
+    code = """
+import sys, numpy as np, torch
+import groomed_nms_amd as G
+from groomed_nms_amd import synthetic, overlaps
+out = {}
+b, s = synthetic.batch_2d(7, 2, 4096, "uniform")
+bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+o = G.differentiable_nms_with_iou2d_batched(st, bt)
+out["one_prob"], out["one_valid"], out["one_iou_sum"] = o[0].cpu().numpy(), o[2].cpu().numpy(), o[6].double().sum().cpu().numpy()
+m = G.differentiable_nms_batched(st, overlaps.iou_batched(bt))
+out["two_prob"], out["two_valid"] = m[0].cpu().numpy(), m[2].cpu().numpy()
+b, s = synthetic.batch_2d(8, 2, 8192, "clustered")
+bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+o = G.differentiable_nms_with_iou2d_batched(st, bt)
+out["big_prob"], out["big_valid"], out["big_iou_sum"] = o[0].cpu().numpy(), o[2].cpu().numpy(), o[6].double().sum().cpu().numpy()
+p3, s3 = synthetic.batch_3d(9, 2, 6144, clustered=True)
+o = G.differentiable_nms_with_iou3d_batched(torch.from_numpy(s3).cuda(), torch.from_numpy(p3).cuda())
+out["d3_prob"], out["d3_valid"] = o[0].cpu().numpy(), o[2].cpu().numpy()
+torch.cuda.synchronize()
+np.savez(sys.argv[1], **out)
+print("ok")
+"""
+    runs = {}
+    for tag, env in (("default", {}), ("one_stream", {"GNMS_TWO_STREAMS": "0"}), ("general_scan", {"GNMS_MATRIX_SYM": "0"}),
+                     ("few_writers", {"GNMS_TAIL_WRITERS": "40"}), ("trace", {"GNMS_TRACE_LAUNCH": "1"})):
+        path = "/tmp/gnms_switch_%s.npz" % tag
+        r = _run_py(code, env, argv=(path,))
+        assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stderr[-2000:])
+        if tag == "trace":
+            assert "[gnms launch]" in r.stderr
+        runs[tag] = np.load(path)
+    for tag, d in runs.items():
+        for k in runs["default"].files:
+            assert np.array_equal(d[k], runs["default"][k], equal_nan=True), (tag, k)
+
+
 def test_matrix_in_layer_detects_symmetry(G, O):
     """differentiable_nms(scores, iou) cannot know that its matrix is iou(boxes, boxes); since round 3 it finds out on the device
     (bitmask_kernel stores the rows of the bit matrix in full, wsym_check_kernel compares its 64 x 64 blocks with their transposes)
