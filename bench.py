@@ -370,8 +370,8 @@ def main():
             wname = lib.gnms_profile_write_kernel_name(args.dim, B, N).decode()
         else:
             # gnms_iou2d of a box set with itself: the staged writers as a launch of their own up to N = 4096 (iou2d_self_kernel) when the
-            # batch has enough units, the large-matrix writers above (write_staged_kernel); GNMS_IOU2D_SELF=0 keeps iou2d_kernel
-            self_ok = N <= 4096 and B * ((N + 7) // 8) >= 8 * 256 and os.environ.get("GNMS_IOU2D_SELF", "1") != "0"
+            # batch has enough units, the large-matrix writers above (write_staged_kernel)
+            self_ok = N <= 4096 and B <= 127 and B * ((N + 7) // 8) >= 8 * 256
             wname = ("iou2d_self_kernel" if self_ok else ("write_staged_kernel" if N > 4096 and N % 4 == 0 else "iou2d_kernel")) if args.dim == 2 else "iou3d_sym_kernel"
         r_write = roof(ms_write, n_write, alg_write, wname, fill_gbs, fill_what)
         r_read = roof(ms_read, n_read, alg_read, "bitmask_kernel", read_gbs, "plain non-temporal float4 load stream (gnms_profile_read)")

@@ -1297,6 +1297,12 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
     if (j == 0) __syncthreads();                                   // (the table is in LDS; with j > 0 the barriers above cover it -- tw is consumed before them)
     GNMS_TACC_IF(b == 0 && last_sb, 1);
     // ---- resolve of the own super-block: every wave its block, steps until no mask changes ----
+#ifdef GNMS_TIMING
+    long long r__ = (long long)__builtin_amdgcn_s_memtime();
+#define GNMS_RACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 960 && b == 0 && last_sb) ((long long*)I.gx)[slot] += n__ - r__; r__ = n__; } while (0)
+#else
+#define GNMS_RACC(slot) do {} while (0)
+#endif
     const int tbc = live ? tb : 0;
     const int k0 = (kb0 + tbc) << 6;
     u64 fixed = ext;                                               // never leaders: taken by earlier super-blocks, or past the image's last rank
@@ -1312,6 +1318,7 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
         thi[bb] = (bb < tb) ? (unsigned)(x >> 32) : 0u;
     }
     u64 mine = 0ull;                                               // this block's leader mask as last published (lmask[kb0 + tb])
+    GNMS_RACC(21);
     {
         u64 cur_prev = ~0ull;
         bool first = true;
@@ -1324,13 +1331,16 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
                 if (dirty) {
                     looked = step;
                     unsigned vlo = 0u, vhi = 0u;
+                    if (!first) {                                  // (the first look finds every mask of the super-block still zero)
 #pragma unroll
-                    for (int bb = 0; bb < kSB - 1; ++bb) {
-                        const u64 l = myL[bb];
-                        vlo |= tlo[bb] & (unsigned)(l & 0xffffffffu);
-                        vhi |= thi[bb] & (unsigned)(l >> 32);
+                        for (int bb = 0; bb < kSB - 1; ++bb) {      // (one batch of reads: behind a branch per group of blocks they serialise)
+                            const u64 l = myL[bb];
+                            vlo |= tlo[bb] & (unsigned)(l & 0xffffffffu);
+                            vhi |= thi[bb] & (unsigned)(l >> 32);
+                        }
                     }
                     const u64 cur = fixed | __ballot((vlo | vhi) != 0u);
+                    GNMS_RACC(22);
                     if (first || cur != cur_prev) {                // (the same `cur` gives the same leaders)
                         cur_prev = cur;
                         u64 leaders = 0ull;
@@ -1349,9 +1359,11 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
                         }
                     }
                     first = false;
+                    GNMS_RACC(23);
                 }
             }
             lds_barrier();
+            GNMS_RACC(24);
             const int last = *stamp;
             ++step;
             if (step - last > 1) break;                            // a whole step without a change (a faster wave may have stamped a later step: still <=)

@@ -59,10 +59,8 @@ def evt(fn):
 
 bytes_ = 4.0 * B * N * N
 bev = torch.empty((B, N, N), dtype=torch.float32, device=dev)
-# which kernel gnms_nms_overlap3d_from_params runs: the symmetric writer (iou3d_sym.h; GNMS_3D_SYM=0 forces the all-pairs kernel)
-K3 = "iou3d_nms_fast_kernel, all pairs" if os.environ.get("GNMS_3D_SYM") == "0" else (
-    "iou3d_sym_kernel<%s waves>, each pair once, %s stores" % (os.environ.get("GNMS_3D_SYM_NW", "8"), "plain" if os.environ.get("GNMS_3D_SYM_NT") == "0" else "non-temporal"))
-rows = [("gnms_iou2d(boxes, boxes) [iou2d_self_kernel up to N = 4096, write_staged_kernel above; GNMS_IOU2D_SELF=0: iou2d_kernel]", timed(lambda o: check(lib.gnms_iou2d(ptr(boxes2), ptr(boxes2), B, N, N, ptr(o), N, sp), "iou2d"))),
+K3 = "iou3d_sym_kernel, each pair once, non-temporal stores"
+rows = [("gnms_iou2d(boxes, boxes) [iou2d_self_kernel up to N = 4096, write_staged_kernel above]", timed(lambda o: check(lib.gnms_iou2d(ptr(boxes2), ptr(boxes2), B, N, N, ptr(o), N, sp), "iou2d"))),
         ("3D NMS overlap thr=0.4 [%s]" % K3, timed(lambda o: check(lib.gnms_nms_overlap3d_from_params(ptr(par3), B, N, 0.4, ptr(o), N, sp), "o3"))),
         ("3D NMS overlap thr=-100 (no pair in the band) [%s]" % K3, timed(lambda o: check(lib.gnms_nms_overlap3d_from_params(ptr(par3), B, N, -100.0, ptr(o), N, sp), "o3"))),
         ("iou3d_kernel<METHOD 2> (exact order)", timed(lambda o: check(lib.gnms_iou3d_from_params(ptr(par3), ptr(par3), B, N, N, 2, None, ptr(o), N, sp), "o3e"))),

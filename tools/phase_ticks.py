@@ -18,6 +18,7 @@ ap.add_argument("--boxes", type=int, default=4096)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--kind", default="clustered")
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--lists", action="store_true", help="ask for the valid / invalid index lists (K6 then compacts and sorts)")
 ap.add_argument("--two-calls", action="store_true", help="gnms_iou2d, then the matrix-in layer gnms_forward: the chain kernels alone on the machine")
 a = ap.parse_args()
 lib = _lib.load()
@@ -30,24 +31,29 @@ nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(P))
 ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
 prob = torch.empty((B, N), device="cuda")
 iou = torch.empty((B, N, N), device="cuda")
+vl = torch.empty((B, N), dtype=torch.int64, device="cuda") if a.lists else None
+il = torch.empty((B, N), dtype=torch.int64, device="cuda") if a.lists else None
+nv = torch.empty((B,), dtype=torch.int32, device="cuda") if a.lists else None
+ni = torch.empty((B,), dtype=torch.int32, device="cuda") if a.lists else None
+lp = lambda t: ptr(t) if t is not None else None
 n4 = (4 * N + 255) // 256 * 256
 off_gx = 15 * n4
-names = {20: "leaders_sym resolve rounds (count)", 5: "CHAIN leaders total", 6: "CHAIN attribute total", 7: "CHAIN groups total", 15: "CHAIN finalize total", 0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store",
+names = {21: "resolve (wave 15): table words to registers", 22: "resolve (wave 15): dirty check + AND pass", 23: "resolve (wave 15): in-block fixed point + publish", 24: "resolve (wave 15): barrier", 20: "leaders_sym resolve rounds (count)", 5: "CHAIN leaders total", 6: "CHAIN attribute total", 7: "CHAIN groups total", 15: "CHAIN finalize total", 0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store",
          4: "leaders barrier B", 8: "groups keys", 9: "groups radix", 10: "groups runs", 11: "groups rescoring", 12: "finalize classify", 13: "finalize sort",
          14: "finalize output"}
-tot = np.zeros(24, np.int64)
+tot = np.zeros(28, np.int64)
 for rep in range(a.reps + 2):
-    ws[off_gx:off_gx + 192].zero_()
+    ws[off_gx:off_gx + 224].zero_()
     if a.two_calls:
         check(lib.gnms_iou2d(ptr(boxes), ptr(boxes), B, N, N, ptr(iou), N, None), "iou")
-        check(lib.gnms_forward(ptr(scores), ptr(iou), B, N, N, None, ctypes.byref(P), ptr(prob), None, None, None, None, None, ptr(ws), nbytes, None), "fwd")
+        check(lib.gnms_forward(ptr(scores), ptr(iou), B, N, N, None, ctypes.byref(P), ptr(prob), None, lp(vl), lp(il), lp(nv), lp(ni), ptr(ws), nbytes, None), "fwd")
     else:
-        check(lib.gnms_forward_with_iou2d(ptr(boxes), ptr(scores), B, N, N, None, ctypes.byref(P), ptr(iou), ptr(prob), None, None, None, None, None,
+        check(lib.gnms_forward_with_iou2d(ptr(boxes), ptr(scores), B, N, N, None, ctypes.byref(P), ptr(iou), ptr(prob), None, lp(vl), lp(il), lp(nv), lp(ni),
                                           ptr(ws), nbytes, None), "fwd")
     torch.cuda.synchronize()
-    t = ws[off_gx:off_gx + 192].cpu().numpy().view(np.int64)
+    t = ws[off_gx:off_gx + 224].cpu().numpy().view(np.int64)
     if rep >= 2:
         tot += t
-for k in range(24):
+for k in range(28):
     if tot[k]:
         print("slot %2d %-40s %9.0f ticks" % (k, names.get(k, ""), tot[k] / a.reps))

@@ -36,10 +36,6 @@ python bench.py --two-calls --kind clustered --steps 100 --warmup 10 --no-other-
 for n in 512 1024 2048; do python bench.py --graph --kind clustered --boxes $n --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/${T}_graph.jsonl; done
 python tools/kernel_times.py > $O/${T}_kernel_times.txt 2>/dev/null
 python tools/kernel_times.py --boxes 16384 --reps 10 >> $O/${T}_kernel_times.txt 2>/dev/null
-GNMS_3D_SYM=0 python tools/kernel_times.py 2>/dev/null | grep "3D NMS" >> $O/${T}_kernel_times.txt
-GNMS_3D_SYM=0 python tools/kernel_times.py --boxes 16384 --reps 10 2>/dev/null | grep "3D NMS" >> $O/${T}_kernel_times.txt
-python tools/store_geometry.py 2>/dev/null | grep "^{" > $O/${T}_store_geometry.jsonl
-python tools/store_geometry.py --boxes 16384 2>/dev/null | grep "^{" >> $O/${T}_store_geometry.jsonl
 python tools/small_n.py 2>/dev/null | grep "^{" > $O/${T}_small_n.jsonl
 GNMS_BINDING=ctypes python tools/small_n.py 2>/dev/null | grep "^{" >> $O/${T}_small_n.jsonl
 python tools/sgemm_time.py 1024 2048 4096 8192 2>/dev/null | grep "sgemm\|soft_sort" > $O/${T}_sgemm_mfma.txt
