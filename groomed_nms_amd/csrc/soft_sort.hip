@@ -74,7 +74,13 @@ constexpr int BM = 128, BN = 128, BK = 32, LDP = 132;   // LDS row pitch (floats
 
 template <bool ALIGNED>
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D,
-                                                         int M, int Nn, int K, long lda, long ldb, long ldd, int accumulate) {
+                                                         int M, int Nn, int Kall, long lda, long ldb, long ldd, int accumulate, int kslice,
+                                                         long slice_stride) {
+    // split K (round 4): slice z multiplies the k range [z kslice, (z + 1) kslice) into its own M x Nn panel, D + z slice_stride
+    // (launch_sgemm's scratch; sgemm_reduce_kernel adds the panels in slice order); one slice: the whole K, straight into D
+    const int kbeg = (int)blockIdx.z * kslice;
+    const int K = min(Kall, kbeg + kslice);
+    D += (long)blockIdx.z * slice_stride;
     __shared__ __attribute__((aligned(16))) float As[BK][LDP];   // As[k][m]
     __shared__ __attribute__((aligned(16))) float Bs[BK][LDP];   // Bs[k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(const float* __restrict
             *reinterpret_cast<float4*>(&Bs[b_k + 8 * p][b_n4]) = rb[p];
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < K; k0 += BK) {
         stage();
         __syncthreads();
         if (k0 + BK < K) fetch(k0 + BK);                          // in flight while the MFMAs below run
@@ -399,6 +405,18 @@ __global__ __launch_bounds__(256) void softsort_bwd_cols2_kernel(const float* __
     d_scores[j] = (base[j] + acc) + dshat[I.rankof[j]];
 }
 
+// D (+)= sum over the S split-K panels, slice order
+__global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ part, int S, int M, int N, float* __restrict__ D, long ldd,
+                                                           int accumulate) {
+    const long total = (long)M * N;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        float acc = part[e];
+        for (int z = 1; z < S; ++z) acc += part[(long)z * total + e];
+        float* d = D + (e / N) * ldd + (e % N);
+        *d = accumulate ? (*d + acc) : acc;
+    }
+}
+
 int launch_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd, int accumulate,
                  hipStream_t st) {
     if (M == 0 || N == 0) return GNMS_OK;
@@ -409,8 +427,30 @@ int launch_sgemm(const float* A, const float* B, float* D, int M, int N, int K, 
         return GNMS_OK;
     }
     dim3 grid(gnms_div_up(N, BN), gnms_div_up(M, BM));
-    if (aligned) sgemm_mfma_kernel<true><<<grid, 256, 0, st>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd, accumulate);
-    else sgemm_mfma_kernel<false><<<grid, 256, 0, st>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd, accumulate);
+    // SPLIT K when the tiles alone leave the machine empty (soft sort's own sizes: N <= 500 boxes is 16 tiles on 256 CUs; 1024^3: 64):
+    // S slices of K, each a grid of its own writing an M x N panel of a stream-ordered scratch buffer, then one pass adds the panels
+    // in slice order -- deterministic like the unsplit sum, but a different association of it (S partial fmaf chains).  S doubles
+    // until the launch has two workgroups per CU, a slice keeps at least 64 k.
+    const long tiles = (long)grid.x * grid.y;
+    const int cus = gnms_device_cu_count();
+    int S = 1;
+    while (S < 16 && tiles * S < 2L * cus && K / (2 * S) >= 64) S *= 2;
+    if (S > 1) {
+        const int kslice = gnms_div_up(gnms_div_up(K, S), BK) * BK;
+        S = gnms_div_up(K, kslice);
+        gnms_async_buffer part;
+        GNMS_CHECK_HIP(part.alloc((size_t)S * M * N * sizeof(float), st));
+        grid.z = (unsigned)S;
+        if (aligned) sgemm_mfma_kernel<true><<<grid, 256, 0, st>>>(A, B, part.as<float>(), M, N, K, (long)lda, (long)ldb, (long)N, 0, kslice, (long)M * N);
+        else sgemm_mfma_kernel<false><<<grid, 256, 0, st>>>(A, B, part.as<float>(), M, N, K, (long)lda, (long)ldb, (long)N, 0, kslice, (long)M * N);
+        GNMS_CHECK_LAUNCH();
+        const long total = (long)M * N;
+        sgemm_reduce_kernel<<<(unsigned)std::min<long>((total + 255) / 256, 4096), 256, 0, st>>>(part.as<float>(), S, M, N, D, (long)ldd, accumulate);
+        GNMS_CHECK_LAUNCH();
+        return GNMS_OK;
+    }
+    if (aligned) sgemm_mfma_kernel<true><<<grid, 256, 0, st>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd, accumulate, K, 0L);
+    else sgemm_mfma_kernel<false><<<grid, 256, 0, st>>>(A, B, D, M, N, K, (long)lda, (long)ldb, (long)ldd, accumulate, K, 0L);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

@@ -249,7 +249,9 @@ int gnms_soft_sort_backward(const float* scores, const float* matrix, int N, int
                             void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes, void* stream);
 
 /* D[M x N] = A[M x K] B[K x N], fp32 row-major with leading dimensions lda/ldb/ldd, on the matrix cores
- * (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf chain over k).  The GEMM behind soft_sort's C @ iou (:163). */
+ * (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf chain over k).  The GEMM behind soft_sort's C @ iou (:163).  Small problems (fewer
+ * than two 128 x 128 tiles per CU) split K over up to 16 slices: a stream-ordered temporary of slices x M x N floats, the slices
+ * summed in order (deterministic; a different association of the same sum). */
 int gnms_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd,
                void* stream);
 
