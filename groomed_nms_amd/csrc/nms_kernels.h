@@ -1214,9 +1214,12 @@ __device__ __forceinline__ void gran_store(u64* p, u64 v) {
 __device__ __forceinline__ int rem_load(const int* rem, int k) { return __hip_atomic_load(rem + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void rem_store(int* rem, int k, int v) { __hip_atomic_store(rem + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// super-block `j` of image `b` (j < nsb of the image); returns true in the workgroup that may go on with K4..K6 of the image:
-// the one of the image's last super-block, after every rem[] entry of the image is visible to it
-__device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int j) {
+// The super-blocks [j0, j1) of image `b`, one after the other (j1 <= nsb of the image; workgroup `me` of the image's `nwg` chain
+// workgroups, which own contiguous ascending ranges -- so a workgroup only ever waits for workgroups with a lower index).  Returns true
+// in the workgroup that may go on with K4..K6 of the image: the one whose range ends with the image's last super-block, after every
+// rem[] entry of the image is visible to it.
+__device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int j0,
+                                                const int j1, const int me) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t oa, ol, oc, op;
     leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -1234,9 +1237,8 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
     const int nb = (n + 63) >> 6;
     const int nsb = (nb + kSB - 1) / kSB;
     const u64 below = (1ull << lane) - 1ull;
-    const int kb0 = j * kSB;
-    const int nblk = min(kSB, nb - kb0);
-    const bool last_sb = j == nsb - 1;
+    const bool last_wg = j1 == nsb;                                // this workgroup ends with the image's last super-block
+    int have = 0;                                                  // super-blocks [0, have) have their masks in lmask (workgroup-uniform)
     const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
     GNMS_T0();
     // table layout: pair (source block bb <= target block tb) at tb (tb + 1) / 2 + bb -- a target's words are consecutive, so the wave
@@ -1244,9 +1246,13 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
     // ~12 scalar instructions each, and sixteen waves share the CU's one scalar unit)
     if (tid < kSB) for (int bb = 0; bb <= tid; ++bb) { pair_b[tid * (tid + 1) / 2 + bb] = bb; pair_bp[tid * (tid + 1) / 2 + bb] = tid; }
     for (int i = tid; i < nb + kSB; i += 1024) lmask[i] = 0ull;
+    __syncthreads();
+    for (int j = j0; j < j1; ++j) {
+    const int kb0 = j * kSB;
+    const int nblk = min(kSB, nb - kb0);
+    const bool last_sb = j == nsb - 1;
     if (tid == 0) *stamp = 0;
     if (tid < kSB) bstamp[tid] = -1;
-    __syncthreads();
     {   // the own super-block's table: no dependence on anybody (in flight while the first masks are waited for)
         constexpr int kTabAll = (kSBPairs * 64 + 1023) / 1024;
         u64 tw[kTabAll];
@@ -1273,12 +1279,13 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
     const bool live = tb < nblk;
     const int kT = ((kb0 + (live ? tb : 0)) << 6) + lane;          // this lane's rank
     int cl = -1;                                                   // rank of the first leader (of an earlier super-block) that overlaps it
+    lds_barrier();                                                 // (the previous super-block of this workgroup is done with the table and the stamps)
     for (int s = 0; s < j; ++s) {
         const int s0 = s * kSB;
         u64 wv[kSB];
 #pragma unroll
         for (int bb = 0; bb < kSB; ++bb) wv[bb] = (live && kT < n) ? I.W[(size_t)(s0 + bb) * L.NC + kT] : 0ull;
-        if (wave == 0) {                                           // the masks of super-block s: 32 granules, lane g polls granule g
+        if (wave == 0 && s >= have) {                              // the masks of super-block s (another workgroup's, not seen yet): 32 granules, lane g polls granule g
             const u64* g = I.gran + (size_t)s * 32 + (lane & 31);
             u64 v = gran_load(g);
             while (__ballot((v & 0xffffffff00000000ull) != epoch) != 0ull) { __builtin_amdgcn_s_sleep(2); v = gran_load(g); }
@@ -1293,8 +1300,9 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
         }
         if (cl < 0) cl = c;
     }
+    if (j + 1 > have) have = j + 1;                                // (every super-block up to j is in lmask from here on: polled above, or this workgroup's own)
     const u64 ext = __ballot(cl >= 0);                             // removed-word of the wave's block (earlier super-blocks' leaders)
-    if (j == 0) __syncthreads();                                   // (the table is in LDS; with j > 0 the barriers above cover it -- tw is consumed before them)
+    lds_barrier();                                                 // the table is in LDS
     GNMS_TACC_IF(b == 0 && last_sb, 1);
     // ---- resolve of the own super-block: every wave its block, steps until no mask changes ----
 #ifdef GNMS_TIMING
@@ -1396,21 +1404,22 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
             rem_store(I.rem, k, r);
         }
     }
-    if (!last_sb) {
+    }   // super-blocks of this workgroup
+    if (!last_wg) {
         __syncthreads();                                           // every wave's rem stores are acknowledged (vmcnt 0) ...
-        if (tid == 0) gran_store(I.gran + (size_t)16 * 32 + j, epoch | 1ull);   // ... before "rem stored" goes out
+        if (tid == 0) gran_store(I.gran + (size_t)16 * 32 + me, epoch | 1ull);   // ... before "rem stored" goes out
         return false;
     }
     // ---- the image's last super-block: the other workgroups' rem[] must be there, then the per-image epilogue (all masks are in LDS) ----
-    if (wave == 0 && j > 0) {
-        const u64* g = I.gran + (size_t)16 * 32 + (lane < j ? lane : 0);
+    if (wave == 0 && me > 0) {
+        const u64* g = I.gran + (size_t)16 * 32 + (lane < me ? lane : 0);
         u64 v = gran_load(g);
         while (__ballot((v & 0xffffffff00000000ull) != epoch) != 0ull) { __builtin_amdgcn_s_sleep(2); v = gran_load(g); }
     }
-    GNMS_TACC_IF(b == 0 && last_sb, 3);
+    GNMS_TACC_IF(b == 0 && last_wg, 3);
     __syncthreads();
     leaders_epilogue(I, lmask, nb, reinterpret_cast<int*>(Xs));
-    GNMS_TACC_IF(b == 0 && last_sb, 4);
+    GNMS_TACC_IF(b == 0 && last_wg, 4);
     return true;
 }
 
@@ -1564,25 +1573,31 @@ __device__ __forceinline__ void leaders_body(int N, const int* __restrict__ coun
 // workgroups of the first super-blocks, which wait for nobody, are dispatched first.  sym_arg: 0 general, 1 symmetric (W holds full
 // rows), 2 as wsym_check_kernel found this image's matrix.  Returns true, with *image set, in the ONE workgroup per image that goes
 // on with K4..K6.
-__host__ __device__ inline int leaders_chain_wgs(int N, int sym_arg) { return sym_arg ? max(1, ((N + 63) / 64 + kSB - 1) / kSB) : 1; }
+// workgroups per image: one per super-block, at most `cap` (0: no cap).  The launches that run beside a matrix write of their own
+// (large images) cap it so that the chain leaves the writers their CUs.
+__host__ __device__ inline int leaders_chain_wgs(int N, int sym_arg, int cap = 0) {
+    const int nsb = max(1, ((N + 63) / 64 + kSB - 1) / kSB);
+    const int w = sym_arg ? nsb : 1;
+    return (cap > 0 && w > cap) ? cap : w;
+}
 
 __device__ __forceinline__ bool leaders_chain(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int B, const int spw,
                                               const int c, const int sym_arg, int* image) {
     const int jw = c / B, b = c - jw * B;
     *image = b;
-    const bool lastw = jw == spw - 1;
     const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;
     if (!sym) {
-        if (!lastw) return false;
+        if (jw != spw - 1) return false;
         leaders_body(N, counts, ws, L, b);
         return true;
     }
-    // symmetric: the image's own super-blocks (ragged counts: fewer than spw) -- the last one in the launch's last workgroup of the image
+    // symmetric: the image's own super-blocks (ragged counts: fewer than the launch provides for) in contiguous ranges of q
     const int n = gnms_count(counts, b, N);
     const int nsb = max(1, (((n + 63) >> 6) + kSB - 1) / kSB);
-    if (lastw) return leaders_sb_body(N, counts, ws, L, b, nsb - 1);
-    if (jw < nsb - 1) leaders_sb_body(N, counts, ws, L, b, jw);
-    return false;
+    const int q = (nsb + spw - 1) / spw;
+    const int j0 = jw * q, j1 = min(nsb, j0 + q);
+    if (j0 >= j1) return false;                                    // (workgroup-uniform)
+    return leaders_sb_body(N, counts, ws, L, b, j0, j1, jw);
 }
 
 __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, int sym, int B, int spw) {

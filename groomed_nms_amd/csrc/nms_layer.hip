@@ -963,10 +963,17 @@ bool use_tail_kernel(int N, int sym = 0) {
     return N <= 2048 || (sym && N <= 4096);
 }
 
+// chain workgroups per image when the matrix write runs beside the layer as a launch of its own on the side stream (N > 4096): ONE, which
+// walks the image's super-blocks in order.  The write there is a static partition over (CUs - reserve) persistent workgroups and takes
+// 1.45 ms at B = 8, N = 16384; the scan of a whole image on one CU (~1 ms beside it) hides behind that, while every further chain
+// workgroup either costs the write a CU (32 reserved: write 1.52 ms, step 1.86) or, unreserved, does not find a CU before the writers
+// retire and stalls the chain behind the write (16 per image, 8 reserved: step 1.82 against 1.74).
+constexpr int kBesideChainWGs = 1;
+
 // K3..K6 in one launch (masked groups); SRC/src: kFromMatrix (the matrix), kFromBoxes (the boxes), kFromRecords (src unused)
 template <int BOXES>
 int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* counts, const gnms_params& P, char* ws, const gnms_ws_layout& L,
-                float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, hipStream_t st, int sym) {
+                float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, hipStream_t st, int sym, int chain_cap = 0) {
     int P2 = next_pow2(N);
     if (P2 < 1024) P2 = 1024;                                   // the fused kernel always runs 1024 threads
     // (the fused K5 -> K6 hand-off, E <= 4, parks order[] and a copy of r2 behind the key region: 16 bytes per key)
@@ -975,7 +982,7 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     int rc;
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(tail_kernel<E, BOXES>, lds))) return rc;
-        const int spw = leaders_chain_wgs(N, sym);
+        const int spw = leaders_chain_wgs(N, sym, chain_cap);
         tail_kernel<E, BOXES><<<B * spw, 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
                                                           ninvalid, sym, B, spw);
     });
@@ -1346,7 +1353,7 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     if (beside) {                                                 // see forward_boxes_impl for why the fork sits exactly here
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 1))) return rc;
-        if ((rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym))) return rc;
+        if ((rc = launch_tail<kFromRecords>(nullptr, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym, kBesideChainWGs))) return rc;
         if ((rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, side, P.nms_threshold, r1, N))) return rc;
         return scope.join();
     }
@@ -1499,8 +1506,9 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
         hipStream_t side = nullptr;
         if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
         if ((rc = whole.fork(&side, 0))) return rc;
-        if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1))) return rc;
-        if ((rc = launch_write_staged(boxes, boxes, B, N, N, mw->out, mw->ld, B, side))) return rc;
+        // (the scan on at most kBesideChainWGs workgroups per image: their CUs are the ones the persistent write leaves free)
+        if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1, kBesideChainWGs))) return rc;
+        if ((rc = launch_write_staged(boxes, boxes, B, N, N, mw->out, mw->ld, B * leaders_chain_wgs(N, 1, kBesideChainWGs), side))) return rc;
         return whole.join();
     }
     if (mw && mw->one_launch) {
@@ -1523,7 +1531,7 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
         // the event (same-queue successor ~2 us, cross-queue event ~25 us), and then keep their CUs until the layer is done.
         hipStream_t side = nullptr;
         if ((rc = beside.fork(&side, 1))) return rc;
-        if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1))) return rc;
+        if ((rc = launch_tail<true>(boxes, B, N, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, 1, kBesideChainWGs))) return rc;
         if ((rc = gnms_internal_iou2d_rows(boxes, B, N, mw->out, mw->ld, side, r1, N))) return rc;
         return beside.join();
     }

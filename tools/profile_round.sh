@@ -3,6 +3,7 @@
 #   <tag>_bench.json + <tag>_bench_kernel_stats.csv      the default bench line and the rocprofv3 --kernel-trace --stats of the same command
 #   <tag>_pmc_summary.json                               HBM traffic per launch (tools/pmc.sh), fed back into the bench line's roofline.traffic
 #   <tag>_grid.jsonl                                     N in {256,1024,4096,16384} x {clustered,uniform} (+ 3D at 4096/16384)
+#   <tag>_two_calls_{uniform,clustered}_kernel_stats.csv, _b1_n4096_, _n512_, _n1024_   kernel stats of the reference's call sequence, of one image, of the small-N regime
 #   <tag>_clustered4096_kernel_stats.csv                 kernel stats of the clustered N=4096 run (the headline runs on uniform boxes since round 3)
 #   <tag>_dim3_n16384_kernel_stats.csv                   kernel stats of the 3D N=16384 run
 #   <tag>_store_geometry.jsonl, _small_n.jsonl, _sgemm_mfma.txt   store-pattern ceilings, host cost of the small-N regime, the fp32 MFMA GEMM
@@ -20,6 +21,16 @@ bash tools/prof.sh ${T}_d3 --steps 30 --warmup 5 --no-cpu-baseline --no-other-ki
 cp gpurun_out/prof_${T}_d3/bench_kernel_stats.csv $O/${T}_dim3_n16384_kernel_stats.csv
 bash tools/prof.sh ${T}_d34k --steps 100 --warmup 5 --no-cpu-baseline --no-other-kind --kind clustered --dim 3 > $O/prof_d34k.txt 2>&1
 cp gpurun_out/prof_${T}_d34k/bench_kernel_stats.csv $O/${T}_dim3_n4096_kernel_stats.csv
+for k in uniform clustered; do
+  bash tools/prof.sh ${T}_tc_$k --two-calls --kind $k --steps 100 --warmup 10 --no-cpu-baseline --no-other-kind > $O/prof_tc_$k.txt 2>&1
+  cp gpurun_out/prof_${T}_tc_$k/bench_kernel_stats.csv $O/${T}_two_calls_${k}_kernel_stats.csv
+done
+bash tools/prof.sh ${T}_b1 --batch 1 --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind > $O/prof_b1.txt 2>&1
+cp gpurun_out/prof_${T}_b1/bench_kernel_stats.csv $O/${T}_b1_n4096_kernel_stats.csv
+for n in 512 1024; do
+  bash tools/prof.sh ${T}_n$n --boxes $n --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind > $O/prof_n$n.txt 2>&1
+  cp gpurun_out/prof_${T}_n$n/bench_kernel_stats.csv $O/${T}_n${n}_kernel_stats.csv
+done
 bash tools/prof.sh ${T}_clu --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind --kind clustered > $O/prof_clu.txt 2>&1
 cp gpurun_out/prof_${T}_clu/bench_kernel_stats.csv $O/${T}_clustered4096_kernel_stats.csv
 tail -1 gpurun_out/prof_${T}_clu/bench_stdout.txt > $O/${T}_clustered4096_bench_under_rocprof.json
@@ -32,7 +43,7 @@ for n in 4096 16384; do for k in clustered uniform; do
   st=100; [ $n -ge 16384 ] && st=30
   python bench.py --dim 3 --boxes $n --kind $k --steps $st --warmup 10 --no-cpu-baseline --no-other-kind 2>/dev/null | tail -1 >> $O/${T}_grid.jsonl
 done; done
-python bench.py --two-calls --kind clustered --steps 100 --warmup 10 --no-other-kind --cpu-seconds 3 2>/dev/null | tail -1 > $O/${T}_two_calls_bench.json
+python bench.py --two-calls --kind uniform --steps 100 --warmup 10 --no-other-kind --cpu-seconds 3 2>/dev/null | tail -1 > $O/${T}_two_calls_bench.json
 for n in 512 1024 2048; do python bench.py --graph --kind clustered --boxes $n --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | tail -1 >> $O/${T}_graph.jsonl; done
 python tools/kernel_times.py > $O/${T}_kernel_times.txt 2>/dev/null
 python tools/kernel_times.py --boxes 16384 --reps 10 >> $O/${T}_kernel_times.txt 2>/dev/null
