@@ -380,6 +380,7 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
     const int all_same = __syncthreads_and(same);
     if (threadIdx.x < 8 && !(boxes && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
     if (threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;                   // the workspace's call counter (leaders_sb_body's hand-off tag)
+    for (int i = threadIdx.x; i < 17 * 32; i += blockDim.x) I.gran[i] = 0ull;   // (and no granule of this workspace carries a tag yet)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,6 +413,7 @@ __device__ __forceinline__ void sort_runs_body(const float* __restrict__ scores,
     I.W[(size_t)role * P + i] = k[0];
     if (r == 0 && role == 0 && threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;   // [2] = "already sorted", cleared below
     if (r == 0 && role == 0 && threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;   // the workspace's call counter (leaders_sb_body's hand-off tag)
+    if (r == 0 && role == 0 && threadIdx.x < 17 * 32) I.gran[threadIdx.x] = 0ull;   // (and no granule of this workspace carries a tag yet)
 }
 
 __global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
@@ -1087,7 +1089,7 @@ constexpr int kTabPer = (kSBPairs * 64 + 959) / 960;            // table entries
 
 #ifdef GNMS_TIMING   // developer instrumentation (tools/microbench.hip): accumulates s_memtime deltas into ws gx[] of image 0
 #define GNMS_T0() long long t__ = (long long)__builtin_amdgcn_s_memtime()
-#define GNMS_TACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && blockIdx.x == 0) ((long long*)I.gx)[slot] += n__ - t__; t__ = n__; } while (0)
+#define GNMS_TACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && b == 0) ((long long*)I.gx)[slot] += n__ - t__; t__ = n__; } while (0)   /* image 0's workgroup */
 #define GNMS_TACC_IF(cond, slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && (cond)) ((long long*)I.gx)[slot] += n__ - t__; t__ = n__; } while (0)
 #else
 #define GNMS_TACC_IF(cond, slot) do {} while (0)
@@ -1188,7 +1190,8 @@ __device__ __forceinline__ void leaders_epilogue(const ImgPtrs& I, const u64* lm
 //
 // HAND-OFF.  A mask travels as two 8-byte granules {epoch, 32 mask bits} written by single write-through stores and polled with
 // agent-scope loads: a granule is valid iff its tag is the workspace's call counter (misc[8], advanced by the sort kernels of every
-// call -- so stale granules of earlier calls, or of earlier replays of a captured graph, never match, and nothing has to be cleared).
+// call -- so stale granules of earlier calls, or of earlier replays of a captured graph, never match; the same kernels also zero the
+// image's granules, so that whatever a recycled allocation held where they now lie cannot carry the tag by accident).
 // No fence anywhere: beside the matrix writers one agent-scope release costs more than the whole scan (nms_layer.hip).  rem[] goes
 // out through write-through stores as well and is read back (groups_body / attribute_*) with agent-scope loads; the workgroup of the
 // LAST super-block waits for the other workgroups' "rem stored" granules and carries on with K4..K6 of the image.

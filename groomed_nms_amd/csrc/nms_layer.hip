@@ -462,6 +462,7 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
         const int all_same = __syncthreads_and(same);
         if (threadIdx.x < 8 && !(xsort && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
         if (threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;               // the workspace's call counter (leaders_sb_body's hand-off tag)
+        for (int i = threadIdx.x; i < 17 * 32; i += blockDim.x) I.gran[i] = 0ull;   // (and no granule of this workspace carries a tag yet)
         return;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
