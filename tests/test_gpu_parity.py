@@ -1979,6 +1979,78 @@ def test_self_iou_in_the_writers_geometry_and_negative_zero(G, O):
         assert np.array_equal(out[0][i].cpu().numpy(), ref["prob"], equal_nan=True), i
 
 
+def test_leader_scan_across_workgroups(G, O):
+    """Round 4: the leader scan of a symmetric bit matrix runs on one workgroup per super-block (1024 ranks), the masks handed down
+    the chain as epoch-tagged granules.  Everything the hand-off could get wrong, against the oracle: box counts on both sides of
+    super-block boundaries with ragged images (fewer super-blocks than the launch provides), both entries (bits from the boxes inside
+    the write launch / from the matrix behind the symmetry check), the SAME workspace and buffers reused back to back and replayed from a
+    captured graph (stale granules of earlier calls must never match: the call counter lives in the workspace and advances inside the
+    captured sort kernels), and batches with more chain workgroups than CUs (a workgroup may only wait for ones dispatched before it)."""
+    import ctypes
+    from groomed_nms_amd import synthetic, overlaps, _lib
+    from groomed_nms_amd._lib import GnmsParams, ptr, check
+    for B, N, kind, counts in ((3, 1025, "uniform", [1025, 1024, 7]), (2, 2049, "clustered", [2049, 1100]), (3, 4096, "uniform", [4096, 3073, 3072]),
+                               (2, 6000, "uniform", [6000, 5121]), (2, 9000, "clustered", [9000, 8193])):
+        boxes, scores = synthetic.batch_2d(40 + N, B, N, kind)
+        bt, st = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+        ct = torch.tensor(counts, dtype=torch.int32).cuda()
+        one = G.differentiable_nms_with_iou2d_batched(st, bt, counts=ct)
+        two = G.differentiable_nms_batched(st, overlaps.iou_batched(bt), counts=ct)
+        for b in range(B):
+            n = counts[b]
+            ref = O.differentiable_nms(scores[b][:n], O.iou2d(boxes[b][:n], boxes[b][:n]))
+            for tag, out in (("one-call", one), ("matrix-in", two)):
+                assert np.array_equal(out[0][b, :n].cpu().numpy(), ref["prob"], equal_nan=True), (N, b, tag)
+                assert out[2][b, :int(out[4][b])].tolist() == list(ref["valid"]), (N, b, tag)
+    # one workspace, eager twice, then captured and replayed on new inputs
+    lib = _lib.load()
+    B, N = 3, 4096
+    P = GnmsParams()
+    lib.gnms_default_params(ctypes.byref(P))
+    dev = torch.device("cuda")
+    bx, sc = torch.empty((B, N, 4), device=dev), torch.empty((B, N), device=dev)
+    iou, prob = torch.empty((B, N, N), device=dev), torch.empty((B, N), device=dev)
+    ws = torch.empty(lib.gnms_workspace_bytes(B, N, ctypes.byref(P)), dtype=torch.uint8, device=dev)
+    ws.fill_(0xA5)                                                       # (a recycled allocation, not fresh zeros)
+
+    def run(stream):
+        check(lib.gnms_forward_with_iou2d(ptr(bx), ptr(sc), B, N, N, None, ctypes.byref(P), ptr(iou), ptr(prob), None, None, None, None, None,
+                                          ptr(ws), ws.numel(), ctypes.c_void_p(stream.cuda_stream)), "fwd")
+
+    def load(seed):
+        b, s = synthetic.batch_2d(seed, B, N, "uniform")
+        bx.copy_(torch.from_numpy(b)); sc.copy_(torch.from_numpy(s))
+        return b, s
+
+    def check_against_oracle(b, s, what):
+        torch.cuda.synchronize()
+        for i in range(B):
+            ref = O.differentiable_nms(s[i], O.iou2d(b[i], b[i]))
+            assert np.array_equal(prob[i].cpu().numpy(), ref["prob"]), (what, i)
+    for seed in (1, 2):
+        b, s = load(seed)
+        run(torch.cuda.current_stream())
+        check_against_oracle(b, s, "eager %d" % seed)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run(torch.cuda.current_stream())
+    for seed in (3, 4, 5):
+        b, s = load(seed)
+        graph.replay()
+        check_against_oracle(b, s, "replay %d" % seed)
+    # more chain workgroups than CUs: 160 images x 2 super-blocks (and the writers behind them)
+    B, N = 160, 2048
+    boxes, scores = synthetic.batch_2d(77, 4, N, "uniform")
+    bt = torch.from_numpy(np.tile(boxes, (B // 4, 1, 1))).cuda()
+    stt = torch.from_numpy(np.tile(scores, (B // 4, 1))).cuda()
+    out = G.differentiable_nms_with_iou2d_batched(stt, bt)
+    torch.cuda.synchronize()
+    for b in range(4):
+        ref = O.differentiable_nms(scores[b], O.iou2d(boxes[b], boxes[b]))
+        for rep in (b, b + 4, B - 4 + b):
+            assert np.array_equal(out[0][rep].cpu().numpy(), ref["prob"]), rep
+
+
 def test_library_switches():
     """The four environment switches the shipped library still reads, each against the default run of the
     same inputs: GNMS_TWO_STREAMS=0 (large images: every launch on the caller's stream instead of the library's side stream),
