@@ -10,7 +10,7 @@
 // 5.6 TB/s at N = 4096 and N = 16384 (0.70 of 8 TB/s), 4-7 % below the band geometry of the 2D writers.
 // Values: nms_overlap3d_guarded2 applies iou3d_pair.h's per-pair definition (re-associated expression outside the guard band around
 // `thr`, the reference's exact operation order inside it and for boxes that are not sane), so the matrix equals the one
-// iou3d_nms_fast_kernel / iou3d_bits_kernel write, bit for bit (tests/test_gpu_parity.py::test_iou3d_symmetric_writer).
+// iou3d_nms_fast_kernel writes, bit for bit (tests/test_gpu_parity.py::test_iou3d_symmetric_writer).
 #pragma once
 #include "iou3d_pair.h"
 

@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
     // the ones near the chunk's x range, and a chunk in a dense stretch keeps several times the rows of the mean -- hardly by its row
     // group (ranks are spatially random).  Numbered chunk-fastest, the heavy tiles of an image recurred with period nchunk / 4
     // workgroups, i.e. on one or two of the eight XCDs (workgroup x runs on XCD x mod 8), where they queued eight deep per CU while
-    // the other XCDs ran dry: VALUBusy 55 %, the last 40 % of the kernel a tail.  Now the workgroups of one chunk are
+    // the other XCDs ran dry: VALUBusy 55 %, the last 40 % of the kernel a tail (LABNOTES.md 3.2c).  Now the workgroups of one chunk are
     // consecutive: they spread over all XCDs and over nkbg / 4 different CUs.
     const int nkbg = (L.NB + KBW - 1) / KBW;
     const int chunk = tile / nkbg, kbg = tile - chunk * nkbg;

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
 // The matrix write as a ROLE inside the launch of the per-image chain (masked from-boxes layer, gnms_forward_with_iou2d).
 // Nothing in that layer reads the matrix, so the write is independent of the chain sorts -> threshold bits -> K3..K6.  As launches of
 // their own the chain K3..K6 (one workgroup per image: 8 of 256 CUs at B = 8) ran strictly behind the write; as two streams the fork
-// and join cost more than the overlap bought.  tail_iou2d_kernel is both in ONE launch: the first B workgroups ARE
+// and join cost more than the overlap bought (LABNOTES.md 3.2d).  tail_write_kernel is both in ONE launch: the first B x nsb workgroups ARE
 // the chain (the device functions of tail_kernel), the others write the matrix.  The launch asks for the chain's LDS (> 80 KiB), so a
 // CU holds ONE workgroup: the chain workgroups are dispatched first and have a CU each to themselves (beside the write they run
 // within 10 % of their stand-alone time; sharing a CU with streaming waves they ran 1.5-3x slower), the other CUs stream the matrix;
@@ -1028,7 +1028,7 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     // the stores.  B = 8, N = 4096, same box, ms per step clustered / uniform: 216 writers 0.140 / 0.160, 208 0.139 / 0.158,
     // 200 0.140 / 0.151, 192 0.142 / 0.142, 184 0.144 / 0.144 -- at 24 writers per XCD the chain of the uniform images (1890
     // leaders each) stops being the longer side of the launch, at the price of 1.5 % on clustered ones.  (A plain fill in this
-    // geometry: 6.2-6.4 TB/s from 64-128 workgroups, 5.8 from 248: tools/fill_grid.py.)  GNMS_TAIL_WRITERS overrides.
+    // geometry: 6.2-6.4 TB/s from 64-128 workgroups, 5.8 from 248: profiles/r03*_store_geometry.jsonl.)  GNMS_TAIL_WRITERS overrides.
     static const int writers_cap = [] { const char* e = getenv("GNMS_TAIL_WRITERS"); return e ? atoi(e) : 0; }();
     // (round 4: the scan runs on nsb workgroups per image and the chain is no longer the longer side of the launch -- the cap is what the
     // store stream itself likes, GNMS_TAIL_WRITERS)
@@ -1167,7 +1167,7 @@ int side_fork(hipStream_t st, hipStream_t* side, int which = 0) {
     return GNMS_OK;
 }
 // the matrix write that gnms_forward_with_iou2d hands to the from-boxes layer for the side stream
-struct MatrixWrite { float* out; int64_t ld; bool one_launch; };   // one_launch: inside the chain's launch (tail_iou2d_kernel), else on the side stream
+struct MatrixWrite { float* out; int64_t ld; bool one_launch; };   // one_launch: inside the chain's launch (tail_write_kernel), else on the side stream
 // The write in two launches: rows [0, r) beside the bit-matrix kernel (a VALU-bound kernel of small workgroups, which interleaves
 // with the write's), the rest beside the tail.  r as a percentage of N (GNMS_SPLIT_PCT overrides), rounded down to whole 64-row
 // tiles.  Measured B=8: 2D N=8192 0.625 / 0.575 / 0.568 / 0.595 ms at 0 / 20 / 40 / 50 %, N=16384 2.10 / 2.03 / 2.08 / 2.08;

@@ -136,9 +136,13 @@ def iou(box_a, box_b, mode='combinations', data_type=None):
 
 
 def get_corners_of_cuboid(x3d, y3d, z3d, w3d, h3d, l3d, ry3d, iou_3d_convention=True):
-    """lib/math_3d.py:364-490 (iou_3d_convention=True only: the one the overlap path uses).  N x 3 x 8."""
+    """lib/math_3d.py:364-490, iou_3d_convention=True: the one every caller passes (lib/loss/rpn_3d.py:746-750, lib/rpn_util.py:1303).
+    N x 3 x 8.  The reference's own iou_3d_convention=False branch is not usable: its torch form assigns an [N] tensor to an [N, 4]
+    slice (math_3d.py:423-425: a shape error for every N but 1 and 4), its NumPy form has no such branch at all (:451-476: the box-frame
+    corners stay zero) -- there is no behaviour to be faithful to, so it raises here."""
     if not iou_3d_convention:
-        raise NotImplementedError("only iou_3d_convention=True is on the NMS path (lib/loss/rpn_3d.py:746-750)")
+        raise NotImplementedError("iou_3d_convention=False: the reference's own branch is broken (lib/math_3d.py:423-425 raises a shape error for "
+                                  "N not in {1, 4}; the NumPy form lacks the branch); every caller passes True")
     lib = _lib.load()
     kind = "numpy" if isinstance(x3d, np.ndarray) else "torch"
     if kind == "numpy":

@@ -1085,7 +1085,7 @@ def test_iou3d_one_call_against_oracle_at_scale(G, O, B, N, clustered):
 def test_iou3d_symmetric_writer(G, O, B, N, clustered):
     """The symmetric 3D matrix writer (iou3d_sym_kernel: every unordered pair evaluated once, each 128 x 128 macro tile stored directly
     and mirrored through LDS) writes the SAME matrix as the all-pairs kernels of the one-call entry (iou3d_nms_fast_kernel /
-    iou3d_bits_kernel: one per-pair definition, iou3d_pair.h), bit for bit -- ragged last tiles, several images, thresholds whose guard
+    the bit-matrix kernels: one per-pair definition, iou3d_pair.h), bit for bit -- ragged last tiles, several images, thresholds whose guard
     band holds many pairs -- and the matrix is symmetric; against the oracle's exact operation order: within 2e-6, equal `> thr`
     decisions, equal entries inside the band."""
     from groomed_nms_amd import synthetic, overlaps

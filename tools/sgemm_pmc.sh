@@ -1,6 +1,8 @@
 #!/bin/bash
 # PMC passes over the fp32 MFMA GEMM (one counter group per pass, --kernel-trace only).  usage: tools/sgemm_pmc.sh [n | M N K]
-# (SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs and saturates at 2^31: 4096^3 overflows it -- use e.g. 4096 2048 1024)
+# (SQ_VALU_MFMA_BUSY_CYCLES = MFMA instructions x 64 cycles, summed over the SIMDs -- exactly 2^31 at 4096^3 because every dimension is a
+# power of two, not a saturated counter: 3072^3 gives 905 969 664.  GRBM_GUI_ACTIVE is summed over the 8 XCDs.  MFMA utilisation =
+# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs).)
 export TMPDIR=/tmp
 R=$PWD
 for C in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "MemUnitStalled" "LDSBankConflict" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES"; do
