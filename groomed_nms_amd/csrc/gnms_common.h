@@ -96,6 +96,8 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //                               s), published by the workgroup that resolved s; [16][s] = (epoch << 32 | 1): its rem[] entries are stored
 //     xidx       int32 [N]      from-boxes path: input index of the p-th box by ascending x centre
 //     xbox       float4 [N]     from-boxes path: the boxes in that order
+//     rbox       float4 [N]     from-boxes path: the boxes in RANK order (written by the score sort: the bit-matrix kernel's row boxes
+//                               without the order -> box gather)
 //     rec        float [N][12]  gnms_forward_with_iou3d: corner-AABB records of the cuboids (iou3d_pair.h)
 //     W          u64   [NB][NC] W[kb][k'] bit r set iff !(iou[order[64*kb+r]][order[k']] <= thr): the ranks of block kb that
 //                               rank k', were it a leader, takes out of `remaining` (:249-262).  Rank x rank space: the
@@ -104,7 +106,7 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 struct gnms_ws_layout {
     int N, NB, NC;
     size_t off_order, off_sscore, off_rankof, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_hlist, off_plead, off_pre,
-        off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_gran, off_xidx, off_xbox, off_rec, off_W;
+        off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_gran, off_xidx, off_xbox, off_rbox, off_rec, off_W;
     size_t per_image;  // bytes
 };
 
@@ -126,6 +128,7 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     L.off_gran = take(17 * 32 * 8);
     L.off_xidx = take(n4);
     L.off_xbox = take(n4 * 4);
+    L.off_rbox = take(n4 * 4);
     L.off_rec = take(n4 * 12);
     L.off_W = take((size_t)(L.NB > 0 ? L.NB : 1) * (size_t)(L.NC > 0 ? L.NC : 4) * 8);
     L.per_image = o;

@@ -251,7 +251,7 @@ __device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
 struct ImgPtrs {
     int* order; float* sscore; int* rankof; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen; int* hlist;
     float* plead; float* pre; float* r2; int* sidx; float* xsol; float* gx; int* leadc; int* leadr; u64* leadw; int* leadpfx;
-    int* misc; u64* gran; int* xidx; float4* xbox; float* rec; u64* W;
+    int* misc; u64* gran; int* xidx; float4* xbox; float4* rbox; float* rec; u64* W;
 };
 
 __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_layout& L, int b) {
@@ -263,7 +263,7 @@ __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_lay
     I.pre = (float*)(p + L.off_pre); I.r2 = (float*)(p + L.off_r2); I.sidx = (int*)(p + L.off_sidx);
     I.xsol = (float*)(p + L.off_xsol); I.gx = (float*)(p + L.off_gx); I.leadc = (int*)(p + L.off_leadc); I.leadr = (int*)(p + L.off_leadr);
     I.leadw = (u64*)(p + L.off_leadw); I.leadpfx = (int*)(p + L.off_leadpfx); I.misc = (int*)(p + L.off_misc);
-    I.gran = (u64*)(p + L.off_gran); I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox); I.rec = (float*)(p + L.off_rec);
+    I.gran = (u64*)(p + L.off_gran); I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox); I.rbox = (float4*)(p + L.off_rbox); I.rec = (float*)(p + L.off_rec);
     I.W = (u64*)(p + L.off_W);
     return I;
 }
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
         I.order[k] = idx;
         I.rankof[idx] = k;            // order is a permutation of [0,N) (identity on the padding)
         I.sscore[k] = v;
+        if (boxes && k < n) I.rbox[k] = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];   // (the from-boxes layer: row boxes of the bit matrix)
         if (order_out) order_out[(size_t)b * N + k] = idx;
     }
     // misc[2] = 1 when the scores came in already sorted (both reference call sites do that: lib/loss/rpn_3d.py:731-737,
@@ -455,6 +456,7 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
             I.order[rank] = idx;
             I.rankof[idx] = rank;
             I.sscore[rank] = scores[(size_t)b * N + idx];
+            if (boxes) I.rbox[rank] = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];   // (the from-boxes layer: row boxes of the bit matrix)
             if (order_out) order_out[(size_t)b * N + rank] = idx;
         } else {
             I.xidx[rank] = idx;
@@ -708,10 +710,8 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     const bool idle = (kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n || chunk >= nchunk);   // (ragged images)
     if (!ROWBUF && idle) return;
     if (!idle) {                                                     // (a chunk LOOP here cost 25 % in code quality at N = 4096: 24.5 -> 31 us)
-    const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * N;
-    // the row boxes of the first rank block are requested before the column side is worked on, so that their two dependent loads
-    // (order -> box) overlap the column gathers
-    float4 rb_next = bx[I.order[min(kbg * KBW * 64 + lane, n - 1)]];
+    // the row boxes of the first rank block are requested before the column side is worked on
+    float4 rb_next = I.rbox[min(kbg * KBW * 64 + lane, n - 1)];     // (rank order, written by the score sort: no order -> box gather)
     float4 cb[CPL];
     float carea[CPL];
     int crank[CPL];
@@ -753,7 +753,7 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
         const int k0 = kb * 64;
         if (kb >= L.NB || k0 >= n) break;
         const float4 rb = rb_next;
-        if (KBW > 1 && kw + 1 < KBW && kb + 1 < L.NB && k0 + 64 < n) rb_next = bx[I.order[min(k0 + 64 + lane, n - 1)]];   // next block's rows
+        if (KBW > 1 && kw + 1 < KBW && kb + 1 < L.NB && k0 + 64 < n) rb_next = I.rbox[min(k0 + 64 + lane, n - 1)];   // next block's rows
         const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
         const int nrows = min(64, n - k0);
         const bool row_fine = (rarea > 0.0f) && (rarea < INFINITY);

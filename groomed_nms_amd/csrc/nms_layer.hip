@@ -457,6 +457,7 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
             I.order[k] = idx;
             I.rankof[idx] = k;
             I.sscore[k] = v;
+            if (xsort && k < n) I.rbox[k] = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];   // (the from-boxes layer's row boxes)
             if (order_out) order_out[(size_t)b * N + k] = idx;
         }
         const int all_same = __syncthreads_and(same);
