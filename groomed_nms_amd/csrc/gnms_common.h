@@ -99,6 +99,7 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //     rbox       float4 [N]     from-boxes path: the boxes in RANK order (written by the score sort: the bit-matrix kernel's row boxes
 //                               without the order -> box gather)
 //     rec        float [N][12]  gnms_forward_with_iou3d: corner-AABB records of the cuboids (iou3d_pair.h)
+//     xrec       float [N][12]  the same records in the COLUMN order of the 3D bit-matrix kernel (z band, then x centre; written by the sort)
 //     W          u64   [NB][NC] W[kb][k'] bit r set iff !(iou[order[64*kb+r]][order[k']] <= thr): the ranks of block kb that
 //                               rank k', were it a leader, takes out of `remaining` (:249-262).  Rank x rank space: the
 //                               bit-matrix kernel reads input columns and scatters each word to its rank position.
@@ -106,7 +107,7 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 struct gnms_ws_layout {
     int N, NB, NC;
     size_t off_order, off_sscore, off_rankof, off_rem, off_head, off_gpos, off_gsorted, off_gstart, off_glen, off_hlist, off_plead, off_pre,
-        off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_gran, off_xidx, off_xbox, off_rbox, off_rec, off_W;
+        off_r2, off_sidx, off_xsol, off_gx, off_leadc, off_leadr, off_leadw, off_leadpfx, off_misc, off_gran, off_xidx, off_xbox, off_rbox, off_rec, off_xrec, off_W;
     size_t per_image;  // bytes
 };
 
@@ -130,12 +131,18 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     L.off_xbox = take(n4 * 4);
     L.off_rbox = take(n4 * 4);
     L.off_rec = take(n4 * 12);
+    L.off_xrec = take(n4 * 12);
     L.off_W = take((size_t)(L.NB > 0 ? L.NB : 1) * (size_t)(L.NC > 0 ? L.NC : 4) * 8);
     L.per_image = o;
     return L;
 }
 
 #ifdef __HIPCC__
+// the workspace's call counter (misc[8]) tags the hand-off granules of the leader scan; a granule the sorts have just zeroed carries tag 0, so
+// the counter skips 0 -- a recycled workspace may hold ANY bytes there (0xffffffff: the -1 padding of a freed index list, found by the fuzz
+// test in round 4b), and the sum must not wrap onto the tag of a cleared granule
+__device__ __forceinline__ int gnms_next_epoch(int e) { const int n = e + 1; return n == 0 ? 1 : n; }
+
 // number of boxes of image b: counts[b] clamped to [0, N] (a bad count must not turn into an out-of-bounds access)
 __device__ __forceinline__ int gnms_count(const int* __restrict__ counts, int b, int N) {
     if (!counts) return N;

@@ -109,6 +109,45 @@ __device__ __forceinline__ void nms_overlap3d_guarded4(const Row& a, const Cols2
     }
 }
 
+// ONE column of one row (the slot-culled bit-matrix kernel evaluates a row against the 64-column slots that survive its cull, one slot
+// at a time).  Same operations in the same order as nms_overlap3d, one column wide: the packed instructions round each half exactly like
+// their scalar counterparts (-ffp-contract=off), so the value equals the packed evaluation bit for bit.
+struct Col1 {
+    float x0, x1, y0, y1, z0, z1, vol, lx, ly, lz;
+};
+__device__ __forceinline__ void col1_set(Col1& c, const float4 u, const float4 v, const float4 e) {                  // record = u | v | e
+    c.vol = u.x; c.y0 = u.y; c.y1 = u.z; c.x0 = u.w; c.x1 = v.x; c.z0 = v.y; c.z1 = v.z; c.lx = e.x; c.ly = e.y; c.lz = e.z;
+}
+__device__ __forceinline__ float relu1(float a) { return __builtin_fmaxf(a, 0.0f); }                                 // arithmetic results are canonical
+__device__ __forceinline__ float nms_overlap3d_1(const Row& a, const Col1& b) {
+    const float dx = vmin_s(a.x1, b.x1) - vmax_s(a.x0, b.x0);
+    const float dy = vmin_s(a.y1, b.y1) - vmax_s(a.y0, b.y0);
+    const float dz = vmin_s(a.z1, b.z1) - vmax_s(a.z0, b.z0);
+    const float i3 = (relu1(dx) * relu1(dz)) * relu1(dy);
+    const float u3 = (a.vol + b.vol) - i3;
+    const float hx = (a.lx + b.lx) - dx;
+    const float hy = (a.ly + b.ly) - dy;
+    const float hz = (a.lz + b.lz) - dz;
+    const float vh = (hx * hy) * hz;
+    const float num = __builtin_fmaf(u3, u3, i3 * vh);
+    const float den = u3 * vh;
+    return (num * __builtin_amdgcn_rcpf(den)) * 0.5f;
+}
+// guarded value of one column (the definition of nms_overlap3d_guarded4, one column wide).  colbad: this lane's column is not sane;
+// cols_sane: no lane of the wave has such a column in this slot.
+__device__ __forceinline__ float nms_overlap3d_guarded1(const Row& a, const Col1& b, bool colbad, bool cols_sane, float thr) {
+    float q = nms_overlap3d_1(a, b);
+    const float d = fabsf(q - thr);
+    if (__any(!(d > kGuard3D)) || !cols_sane || a.bad != 0.0f) {              // rare
+        Cols2 c;
+        c.x0 = splat(b.x0); c.x1 = splat(b.x1); c.y0 = splat(b.y0); c.y1 = splat(b.y1); c.z0 = splat(b.z0); c.z1 = splat(b.z1);
+        c.vol = splat(b.vol); c.lx = splat(b.lx); c.ly = splat(b.ly); c.lz = splat(b.lz);
+        const f2 e = nms_overlap3d_exact(a, c);
+        if (a.bad != 0.0f || colbad || !(d > kGuard3D)) q = e.x;
+    }
+    return q;
+}
+
 // The same value for ONE pair of records with per-lane operands (the layer's O(N) single-entry lookups when it runs beside the
 // matrix write instead of after it).  Same operations in the same order as nms_overlap3d / nms_overlap3d_exact, one column wide:
 // with -ffp-contract=off every product, sum, division and the v_rcp_f32 round exactly as there, and v_min/v_max do not depend on

@@ -118,7 +118,8 @@ __global__ void aabb_from_params_kernel(const float* __restrict__ params, long c
 }
 
 // gnms_forward_with_iou3d: the records once contiguous (the matrix kernel's input), once into the per-image workspace regions (the
-// layer's copy), + the pseudo boxes (x0, lx, x1, 0) its x sort orders the columns by -- one pass over the cuboids
+// layer's copy), + the pseudo boxes (x0, lx, x1, z0 + z1) its column sort orders the columns by (z band, then x centre) -- one pass over
+// the cuboids
 __global__ __launch_bounds__(256) void aabb_for_layer_kernel(const float* __restrict__ params, int N, float* __restrict__ rec, char* ws,
                                                              gnms_ws_layout L, float4* __restrict__ xkeys) {
     const int b = blockIdx.y;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void aabb_for_layer_kernel(const float* __rest
     o[0] = u; o[1] = v; o[2] = e;
     float4* w = reinterpret_cast<float4*>(ws + (size_t)b * L.per_image + L.off_rec) + (size_t)i * 3;
     w[0] = u; w[1] = v; w[2] = e;
-    xkeys[g] = make_float4(r[3], r[8], r[4], 0.0f);
+    xkeys[g] = make_float4(r[3], r[8], r[4], r[5] + r[6]);
 }
 
 // pairwise 3D overlap from the records, the reference's operation order (lib/core.py:305-421), bit for bit the CPU oracle's result.
@@ -407,7 +408,8 @@ int gnms_internal_nms_overlap3d(const float* rec, int B, int N, float* out, int6
 bool gnms_internal_overlap3d_sym_ok(int N, int64_t ld, const float* out) {
     return N >= 256 && (ld % 2 == 0) && ((uintptr_t)out % 8 == 0);
 }
-int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1) {
+int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1,
+                                    int leave_cus, int force_persist) {
     const int tiles = gnms_iou3d::sym_tiles_per_image(N);
     const int t0 = (int)((long long)tiles * pct0 / 100), t1 = (int)((long long)tiles * pct1 / 100);
     if (t1 <= t0 || B <= 0) return GNMS_OK;
@@ -419,12 +421,12 @@ int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, 
     // persistent workgroups (iou3d_sym_persistent_kernel) for the largest images only: B = 8, N = 16384 1.63 -> 1.565 ms (0.69 of the HBM
     // peak); at N = 4096 (0.104 -> 0.119) and 8192 (0.38 -> 0.42, the one-tile-per-workgroup kernel reaches 0.71 there) the static round
     // robin ends unevenly.
-    const bool persist = N > 8192;
+    const bool persist = N > 8192 || force_persist;
     if (persist && pct0 == 0 && pct1 == 100) {
         const size_t lds2 = 2 * gnms_iou3d::kSymTileBytes;
         const int cus = gnms_device_cu_count();                       // (cached per device: nms_layer.hip)
         if ((rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(iou3d_sym_persistent_kernel<true>), lds2))) return rc;
-        gnms_launch_prof(kProfMatrixWrite, iou3d_sym_persistent_kernel<true>, dim3((unsigned)cus), dim3(1024), lds2, st, rec, N, B, out, (long)ld, thr);
+        gnms_launch_prof(kProfMatrixWrite, iou3d_sym_persistent_kernel<true>, dim3((unsigned)std::max(1, cus - leave_cus)), dim3(1024), lds2, st, rec, N, B, out, (long)ld, thr);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
@@ -705,7 +707,8 @@ extern "C" int gnms_iou3d_from_params(const float* params_a, const float* params
 }
 
 bool gnms_internal_overlap3d_sym_ok(int N, int64_t ld, const float* out);
-int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1);
+int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1,
+                                    int leave_cus = 0, int force_persist = 0);
 
 extern "C" int gnms_nms_overlap3d_from_params(const float* params3d, int B, int N, float nms_threshold, float* out, int64_t ld, void* stream) {
     GNMS_CHECK_ARG(B >= 0 && N >= 0, "gnms_nms_overlap3d_from_params: negative size");

@@ -251,7 +251,7 @@ __device__ __forceinline__ int lower_bound_lds(const K* keys, int n, K v) {
 struct ImgPtrs {
     int* order; float* sscore; int* rankof; int* rem; int* head; int* gpos; int* gsorted; int* gstart; int* glen; int* hlist;
     float* plead; float* pre; float* r2; int* sidx; float* xsol; float* gx; int* leadc; int* leadr; u64* leadw; int* leadpfx;
-    int* misc; u64* gran; int* xidx; float4* xbox; float4* rbox; float* rec; u64* W;
+    int* misc; u64* gran; int* xidx; float4* xbox; float4* rbox; float* rec; float* xrec; u64* W;
 };
 
 __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_layout& L, int b) {
@@ -263,7 +263,7 @@ __device__ __host__ __forceinline__ ImgPtrs img_ptrs(char* ws, const gnms_ws_lay
     I.pre = (float*)(p + L.off_pre); I.r2 = (float*)(p + L.off_r2); I.sidx = (int*)(p + L.off_sidx);
     I.xsol = (float*)(p + L.off_xsol); I.gx = (float*)(p + L.off_gx); I.leadc = (int*)(p + L.off_leadc); I.leadr = (int*)(p + L.off_leadr);
     I.leadw = (u64*)(p + L.off_leadw); I.leadpfx = (int*)(p + L.off_leadpfx); I.misc = (int*)(p + L.off_misc);
-    I.gran = (u64*)(p + L.off_gran); I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox); I.rbox = (float4*)(p + L.off_rbox); I.rec = (float*)(p + L.off_rec);
+    I.gran = (u64*)(p + L.off_gran); I.xidx = (int*)(p + L.off_xidx); I.xbox = (float4*)(p + L.off_xbox); I.rbox = (float4*)(p + L.off_rbox); I.rec = (float*)(p + L.off_rec); I.xrec = (float*)(p + L.off_xrec);
     I.W = (u64*)(p + L.off_W);
     return I;
 }
@@ -316,26 +316,68 @@ __device__ __forceinline__ bool box_orders_plainly(const float4 v) {
     return fine(v.x) && fine(v.y) && fine(v.z) && fine(v.w) && v.z >= v.x && v.w >= v.y;
 }
 
+// Column order of the 3D bit-matrix kernel (bitmask_rec3d_slots_kernel): the cuboids arrive as pseudo boxes (x0, lx, x1, z0 + z1) and
+// are ordered by (z band, x centre) -- `mode3d` equal-width bands over the image's range of z0 + z1 -- so that 64 consecutive columns
+// (one SLOT of a wave tile) are a compact patch in x AND z and the rows far from it in either direction are skipped.  mode3d = 0: plain
+// 2D boxes by x centre; 1: cuboids, one band.  Key = band << 60 | x key << 28 | input index (N <= 16384): distinct, NaN x last.
+constexpr unsigned kColIdxMask = 0x0fffffffu;
+__device__ __forceinline__ u64 column_key(const float4 v, int i, int nbands, float zlo, float zscale) {
+    unsigned band = 0u;
+    if (nbands > 1) {
+        const float f = (v.w - zlo) * zscale;
+        band = (f == f) ? (unsigned)fminf(fmaxf(f, 0.0f), (float)(nbands - 1)) : (unsigned)(nbands - 1);
+    }
+    return ((u64)band << 60) | ((u64)(~gnms_desc_key(v.x + v.z)) << 28) | (unsigned)i;
+}
+// range of z0 + z1 over the image's finite pseudo boxes -> (zlo, nbands / (zhi - zlo)); every thread of the workgroup returns the same pair
+// (min / max do not depend on the order), so every workgroup of an image bands alike
+__device__ __forceinline__ void block_z_bands(const float4* __restrict__ bx, int n, int nbands, float* zlo_out, float* zscale_out) {
+    __shared__ float zred[2][16];
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float z = bx[i].w;
+        if (fabsf(z) < INFINITY) { lo = fminf(lo, z); hi = fmaxf(hi, z); }
+    }
+    lo = gnms_wave_min_f(lo); hi = gnms_wave_max_f(hi);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { zred[0][wave] = lo; zred[1][wave] = hi; }
+    __syncthreads();
+    lo = INFINITY; hi = -INFINITY;
+    for (int w = 0; w < nw; ++w) { lo = fminf(lo, zred[0][w]); hi = fmaxf(hi, zred[1][w]); }
+    const float span = hi - lo;
+    *zlo_out = lo;
+    *zscale_out = (span > 0.0f && span < INFINITY) ? (float)nbands / span : 0.0f;
+    __syncthreads();
+}
+// what the column sort leaves behind for rank `k` of its order: the input index, the (pseudo) box, and for cuboids the record
+__device__ __forceinline__ void column_store(const ImgPtrs& I, int k, int idx, const float4 v, int mode3d) {
+    I.xidx[k] = idx;
+    I.xbox[k] = v;
+    if (mode3d) {
+        const float4* s = reinterpret_cast<const float4*>(I.rec) + (size_t)idx * 3;
+        float4* d = reinterpret_cast<float4*>(I.xrec) + (size_t)k * 3;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    }
+}
+
 template <int E>
-__device__ __forceinline__ void sort_boxes_by_x(const float* __restrict__ boxes, int n, const ImgPtrs& I, u64* keys, int P) {
+__device__ __forceinline__ void sort_boxes_by_x(const float* __restrict__ boxes, int n, const ImgPtrs& I, u64* keys, int P, int mode3d = 0) {
     const float4* bx = reinterpret_cast<const float4*>(boxes);
+    float zlo = 0.0f, zscale = 0.0f;
+    if (mode3d > 1) block_z_bands(bx, n, mode3d, &zlo, &zscale);
     u64 r[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = threadIdx.x * E + e;
         r[e] = ~0ull;
-        if (i < n) {
-            const float4 v = bx[i];
-            r[e] = ((u64)(~gnms_desc_key(v.x + v.z)) << 32) | (unsigned)i;
-        }
+        if (i < n) r[e] = column_key(bx[i], i, mode3d, zlo, zscale);
     }
     block_sort<E, u64>(r, keys, P);
     bool plain = true;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const int idx = (int)(keys[k] & 0xffffffffu);
-        I.xidx[k] = idx;
+        const int idx = (int)((unsigned)keys[k] & kColIdxMask);
         const float4 v = bx[idx];
-        I.xbox[k] = v;
+        column_store(I, k, idx, v, mode3d);
         plain = plain && box_orders_plainly(v);
     }
     const int all_plain = __syncthreads_and(plain);
@@ -345,7 +387,7 @@ __device__ __forceinline__ void sort_boxes_by_x(const float* __restrict__ boxes,
 template <int E>
 __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restrict__ scores, int N, const int* __restrict__ counts,
                                                            char* ws, gnms_ws_layout L, int P, long long* __restrict__ order_out,
-                                                           const float* __restrict__ boxes) {
+                                                           const float* __restrict__ boxes, int mode3d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);
     const int b = blockIdx.x;
@@ -353,7 +395,7 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
     const float* s = scores + (size_t)b * N;
     ImgPtrs I = img_ptrs(ws, L, b);
     if (blockIdx.y == 1) {                      // from-boxes path only: grid (B, 2)
-        sort_boxes_by_x<E>(boxes + (size_t)b * N * 4, n, I, keys, P);
+        sort_boxes_by_x<E>(boxes + (size_t)b * N * 4, n, I, keys, P, mode3d);
         return;
     }
     u64 r[E];
@@ -380,7 +422,7 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
     // leader can reach and needs no scatter.
     const int all_same = __syncthreads_and(same);
     if (threadIdx.x < 8 && !(boxes && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
-    if (threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;                   // the workspace's call counter (leaders_sb_body's hand-off tag)
+    if (threadIdx.x == 8) I.misc[8] = gnms_next_epoch(I.misc[8]);                   // the workspace's call counter (leaders_sb_body's hand-off tag)
     for (int i = threadIdx.x; i < 17 * 32; i += blockDim.x) I.gran[i] = 0ull;   // (and no granule of this workspace carries a tag yet)
 }
 
@@ -394,38 +436,40 @@ __global__ __launch_bounds__(1024) void sort_scores_kernel(const float* __restri
 // One workgroup per image needs 23 us at N=4096 and 103 us at N=16384 on its single CU; this needs about 10 / 20 us.
 // role (blockIdx.z): 0 = scores, 1 = boxes by x centre (from-boxes path).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 sort_key_of(int role, const float* __restrict__ scores_img, const float* __restrict__ boxes_img, int i) {
+__device__ __forceinline__ u64 sort_key_of(int role, const float* __restrict__ scores_img, const float* __restrict__ boxes_img, int i,
+                                           int nbands, float zlo, float zscale) {
     if (role == 0) return ((u64)gnms_desc_key(scores_img[i]) << 32) | (unsigned)i;
-    const float4 v = reinterpret_cast<const float4*>(boxes_img)[i];
-    return ((u64)(~gnms_desc_key(v.x + v.z)) << 32) | (unsigned)i;
+    return column_key(reinterpret_cast<const float4*>(boxes_img)[i], i, nbands, zlo, zscale);
 }
 
 // (run r of image b, role) -- also called from the launch that carries a slice of the matrix write (nms_layer.hip)
 __device__ __forceinline__ void sort_runs_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
                                                const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P, const int r, const int b,
-                                               const int role) {
+                                               const int role, const int mode3d = 0) {
     __shared__ u64 keys[1024];
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int i = r * 1024 + (int)threadIdx.x;
+    float zlo = 0.0f, zscale = 0.0f;
+    if (role == 1 && mode3d > 1) block_z_bands(reinterpret_cast<const float4*>(boxes + (size_t)b * N * 4), n, mode3d, &zlo, &zscale);
     u64 k[1];
-    k[0] = (i < n) ? sort_key_of(role, scores + (size_t)b * N, boxes ? boxes + (size_t)b * N * 4 : nullptr, i) : ~0ull;
+    k[0] = (i < n) ? sort_key_of(role, scores + (size_t)b * N, boxes ? boxes + (size_t)b * N * 4 : nullptr, i, mode3d, zlo, zscale) : ~0ull;
     block_sort<1, u64>(k, keys, 1024);
     I.W[(size_t)role * P + i] = k[0];
     if (r == 0 && role == 0 && threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;   // [2] = "already sorted", cleared below
-    if (r == 0 && role == 0 && threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;   // the workspace's call counter (leaders_sb_body's hand-off tag)
+    if (r == 0 && role == 0 && threadIdx.x == 8) I.misc[8] = gnms_next_epoch(I.misc[8]);   // the workspace's call counter (leaders_sb_body's hand-off tag)
     if (r == 0 && role == 0 && threadIdx.x < 17 * 32) I.gran[threadIdx.x] = 0ull;   // (and no granule of this workspace carries a tag yet)
 }
 
 __global__ __launch_bounds__(1024) void sort_runs_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
-                                                         const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P) {
-    sort_runs_body(scores, boxes, N, counts, ws, L, P, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+                                                         const int* __restrict__ counts, char* ws, gnms_ws_layout L, int P, int mode3d) {
+    sort_runs_body(scores, boxes, N, counts, ws, L, P, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, mode3d);
 }
 
 template <int R>
 __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
                                                 const int* __restrict__ counts, char* ws, gnms_ws_layout L, long long* __restrict__ order_out,
-                                                const int r, const int b, const int role) {
+                                                const int r, const int b, const int role, const int mode3d = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* all = reinterpret_cast<u64*>(smem);                          // [R][1024]
     const int n = gnms_count(counts, b, N);
@@ -450,7 +494,7 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
         int rank = 0;
 #pragma unroll
         for (int q = 0; q < R; ++q) rank += (q == r) ? t : pos[q] + ((all[q * 1024 + pos[q]] < mine) ? 1 : 0);
-        const int idx = (int)(mine & 0xffffffffu);
+        const int idx = (int)((unsigned)mine & (role == 0 ? 0xffffffffu : kColIdxMask));
         if (role == 0) {
             same = (idx == rank);
             I.order[rank] = idx;
@@ -459,9 +503,8 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
             if (boxes) I.rbox[rank] = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];   // (the from-boxes layer: row boxes of the bit matrix)
             if (order_out) order_out[(size_t)b * N + rank] = idx;
         } else {
-            I.xidx[rank] = idx;
             const float4 v = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];
-            I.xbox[rank] = v;
+            column_store(I, rank, idx, v, mode3d);
             same = box_orders_plainly(v);                             // (role 1: "every box of this run is plain")
         }
     }
@@ -479,8 +522,8 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
 template <int R>
 __global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
                                                           const int* __restrict__ counts, char* ws, gnms_ws_layout L,
-                                                          long long* __restrict__ order_out) {
-    sort_merge_body<R>(scores, boxes, N, counts, ws, L, order_out, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+                                                          long long* __restrict__ order_out, int mode3d) {
+    sort_merge_body<R>(scores, boxes, N, counts, ws, L, order_out, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, mode3d);
 }
 
 
@@ -971,58 +1014,70 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_kernel(int N, const int* __
         if (col[j] < n) Wk[col[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
 }
 
-// K2c with columns in x order and row culling (the 3D counterpart of bitmask_boxes_kernel).  For GIoU a DISJOINT pair can still
-// exceed the threshold, so "does not reach the hull" is not enough; what holds for two boxes separated in x by a gap g >= 0 is
+// K2c with spatially ordered columns and row culling (the 3D counterpart of bitmask_boxes_kernel).  For GIoU a DISJOINT pair can
+// still exceed the threshold, so "does not reach the hull" is not enough; what holds for two boxes separated along an axis (x or z) by
+// a gap g >= 0 is
 //     i3 = 0,   q = u3 / (2 vh),   u3 = vol_a + vol_b <= (lx_a + lx_b) * max(ly) * max(lz),   vh >= (lx_a + lx_b + g) * max(ly) * max(lz)
 //     =>  q <= (lx_a + lx_b) / (2 (lx_a + lx_b + g))  <=  thr     as soon as     g >= (lx_a + lx_b) * (1 / (2 thr) - 1).
-// A row is skipped when its gap to the tile hull satisfies that with the tile's largest lx and an ADDITIVE 1e-3 on the factor
-// (relative margin 2e-3 thr on q: three orders above the fp32 rounding of the matrix kernel, so the thresholded matrix has a 0
-// there too).  Needs finite positive extents on both sides and thr >= 0.01; everything else is evaluated.  xbox holds
-// (x0, lx, x1, -) of the cuboids in x order, xidx their input indices (the second sort role, fed pseudo boxes).
+// A row is skipped against a set of columns when its gap to the set's hull satisfies that with the set's largest extent and an ADDITIVE
+// 1e-3 on the factor (relative margin 2e-3 thr on q: three orders above the fp32 rounding of the matrix kernel, so the thresholded matrix
+// has a 0 there too).  Needs finite positive extents on both sides and thr >= 0.01; everything else is evaluated.
+// Round 4b: the cull works per SLOT.  The columns come in (z band, x centre) order (column_key; records in that order: xrec), a wave tile
+// is 4 slots of 64 consecutive columns (lane l holds column 64 j + l of slot j), each slot a compact patch in x and z with its own hulls,
+// and a row is evaluated only against the slots it can reach -- one column wide (nms_overlap3d_guarded1: v_pk_* run at the scalar rate on
+// gfx950, so four single evaluations cost what two packed ones did).  With one x-ordered 256-column hull per tile 27 % of the (row, tile)
+// pairs survived at N = 4096 (the gap bound lets boxes ~4 units apart through, the scene is 60 x 55); per slot ~12 % do.
+// Tile numbering.  A tile scatters its 256 words over a whole row of W (column p goes to word rank(p)); what completes the 64-byte lines
+// is the L2.  `pinned` (N > 4096: rows of >= 64 KiB): the row groups are dealt to the XCDs (workgroup x runs on XCD x mod 8; the four waves of
+// a workgroup are four consecutive chunks of one row group, consecutive workgroups of an XCD walk the chunks of a row group), so that every
+// row is written through ONE L2 by workgroups that run together: B = 8, N = 16384 409 -> 331 us, 8192 135 -> 129.  Otherwise ROW GROUP
+// FASTEST (round 4): what a tile costs is set by its column chunk, hardly by its row group (ranks are spatially random); numbered chunk-fastest
+// the heavy tiles of an image recurred on one or two XCDs, where they queued eight deep per CU while the others ran dry (LABNOTES.md 3.2c).
+// (Persistent waves claiming tiles from a counter, round 4b: 75 us instead of 46 at N = 4096, 481 instead of 409 at 16384 -- ~1 700 claims
+// per image on one address serialise in the memory-side atomic unit; LABNOTES R4b.)
 template <int KBW>
-__global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const int* __restrict__ counts, float thr, char* ws, gnms_ws_layout L) {
+__global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const int* __restrict__ counts, float thr, char* ws, gnms_ws_layout L, int pinned) {
     using namespace gnms_iou3d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.z;
     const int n = gnms_count(counts, b, N);
     const int nchunk = (N + 255) >> 8;
-    const int tile = blockIdx.x * 4 + wave;
-    // Tiles numbered ROW GROUP FASTEST (round 4).  What a tile costs is set by its column chunk -- the rows that survive the cull are
-    // the ones near the chunk's x range, and a chunk in a dense stretch keeps several times the rows of the mean -- hardly by its row
-    // group (ranks are spatially random).  Numbered chunk-fastest, the heavy tiles of an image recurred with period nchunk / 4
-    // workgroups, i.e. on one or two of the eight XCDs (workgroup x runs on XCD x mod 8), where they queued eight deep per CU while
-    // the other XCDs ran dry: VALUBusy 55 %, the last 40 % of the kernel a tail (LABNOTES.md 3.2c).  Now the workgroups of one chunk are
-    // consecutive: they spread over all XCDs and over nkbg / 4 different CUs.
     const int nkbg = (L.NB + KBW - 1) / KBW;
-    const int chunk = tile / nkbg, kbg = tile - chunk * nkbg;
+    int chunk, kbg;
+    if (pinned) {
+        const int wpk = (nchunk + 3) >> 2, x = blockIdx.x, s = x >> 3;
+        kbg = (s / wpk) * 8 + (x & 7);
+        chunk = (s % wpk) * 4 + wave;
+    } else {
+        const int tile = blockIdx.x * 4 + wave;
+        chunk = tile / nkbg;
+        kbg = tile - chunk * nkbg;
+    }
     const int c0 = chunk * 256;
-    if (chunk >= nchunk || kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n) return;
+    if (chunk >= nchunk || kbg >= nkbg || kbg * KBW >= L.NB || kbg * KBW * 64 >= n || c0 >= n) return;
     ImgPtrs I = img_ptrs(ws, L, b);
-    Cols2 cols[2];
+    const bool thr_ok = (thr >= 0.01f) && (thr < INFINITY);
+    const float kappa = fmaxf(1.0f / (2.0f * thr) - 1.0f, 0.0f) + 1e-3f;
+    {
+    Col1 col[4];
     int crank[4];
-    unsigned colbad = 0u;
-    float hx0 = INFINITY, hx1 = -INFINITY, maxlx = 0.0f;
-    float hz0 = INFINITY, hz1 = -INFINITY, maxlz = 0.0f;          // the same bound holds along z (it culls another 5 % of the rows)
-    bool cok = true;
+    bool colbad[4], sane[4], cullj[4];
+    float hx0[4], hx1[4], mlx[4], hz0[4], hz1[4], mlz[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int p = c0 + 4 * lane + j;
+        const int p = c0 + 64 * j + lane;
         const int pp = p < n ? p : n - 1;
-        const int idx = I.xidx[pp];
-        const float4* rp = reinterpret_cast<const float4*>(I.rec + (size_t)idx * kRec);
+        const float4* rp = reinterpret_cast<const float4*>(I.xrec) + (size_t)pp * 3;
         const float4 u = rp[0], v = rp[1], e = rp[2];
-        cols2_set(cols[j >> 1], j & 1, u, v, e);
-        colbad |= (e.w != 0.0f) ? (1u << j) : 0u;
-        crank[j] = (p < n) ? I.rankof[idx] : 0x7fffffff;
-        hx0 = fminf(hx0, u.w); hx1 = fmaxf(hx1, v.x); maxlx = fmaxf(maxlx, e.x);
-        hz0 = fminf(hz0, v.y); hz1 = fmaxf(hz1, v.z); maxlz = fmaxf(maxlz, e.z);
-        cok &= (e.x > 0.0f) && (e.y > 0.0f) && (e.z > 0.0f) && (u.x > 0.0f) && (u.x < INFINITY);   // extents and volume positive, finite
+        col1_set(col[j], u, v, e);
+        colbad[j] = e.w != 0.0f;
+        crank[j] = (p < n) ? I.rankof[I.xidx[pp]] : 0x7fffffff;
+        const bool cok = (e.x > 0.0f) && (e.y > 0.0f) && (e.z > 0.0f) && (u.x > 0.0f) && (u.x < INFINITY);   // extents and volume positive, finite
+        hx0[j] = wave_min_f(u.w); hx1[j] = wave_max_f(v.x); mlx[j] = wave_max_f(e.x);
+        hz0[j] = wave_min_f(v.y); hz1[j] = wave_max_f(v.z); mlz[j] = wave_max_f(e.z);
+        cullj[j] = __all(cok) && thr_ok;
+        sane[j] = __all(!colbad[j]);
     }
-    hx0 = wave_min_f(hx0); hx1 = wave_max_f(hx1); maxlx = wave_max_f(maxlx);
-    hz0 = wave_min_f(hz0); hz1 = wave_max_f(hz1); maxlz = wave_max_f(maxlz);
-    const bool cull = __all(cok) && (thr >= 0.01f) && (thr < INFINITY);
-    const bool cols_sane = __all(colbad == 0u);
-    const float kappa = fmaxf(1.0f / (2.0f * thr) - 1.0f, 0.0f) + 1e-3f;
 #pragma unroll 1
     for (int kw = 0; kw < KBW; ++kw) {
         const int kb = kbg * KBW + kw;
@@ -1032,15 +1087,20 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
         const float4 ru = rp[0], rv = rp[1], re = rp[2];
         const int nrows = min(64, n - k0);
         const bool row_fine = (re.x > 0.0f) && (re.y > 0.0f) && (re.z > 0.0f) && (ru.x > 0.0f) && (ru.x < INFINITY);
-        const float gap = fmaxf(hx0 - rv.x, ru.w - hx1);              // >= 0: the row box lies beside the hull (x0 = ru.w, x1 = rv.x)
-        const float gapz = fmaxf(hz0 - rv.z, rv.y - hz1);             // z0 = rv.y, z1 = rv.z
-        const bool skip = cull && row_fine && (((gap >= 0.0f) && (gap >= (re.x + maxlx) * kappa)) ||
-                                               ((gapz >= 0.0f) && (gapz >= (re.z + maxlz) * kappa)));
-        const u64 active = __ballot((lane < nrows) && !skip);
+        u64 act[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gap = fmaxf(hx0[j] - rv.x, ru.w - hx1[j]);    // >= 0: the row box lies beside the slot's hull (x0 = ru.w, x1 = rv.x)
+            const float gapz = fmaxf(hz0[j] - rv.z, rv.y - hz1[j]);   // z0 = rv.y, z1 = rv.z
+            const bool skip = cullj[j] && row_fine && (((gap >= 0.0f) && (gap >= (re.x + mlx[j]) * kappa)) ||
+                                                       ((gapz >= 0.0f) && (gapz >= (re.z + mlz[j]) * kappa)));
+            act[j] = __ballot((lane < nrows) && !skip);
+        }
+        const u64 any = (act[0] | act[1]) | (act[2] | act[3]);
         unsigned wd[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            unsigned todo = (unsigned)(half ? (active >> 32) : (active & 0xffffffffull));
+            unsigned todo = (unsigned)(half ? (any >> 32) : (any & 0xffffffffull));
             while (todo) {
                 const int rr = __builtin_ctz(todo);
                 todo &= todo - 1u;
@@ -1050,16 +1110,21 @@ __global__ __launch_bounds__(256) void bitmask_rec3d_culled_kernel(int N, const 
                 a.vol = bc(ru.x); a.y0 = bc(ru.y); a.y1 = bc(ru.z); a.x0 = bc(ru.w); a.x1 = bc(rv.x); a.z0 = bc(rv.y); a.z1 = bc(rv.z);
                 a.lx = bc(re.x); a.ly = bc(re.y); a.lz = bc(re.z); a.bad = bc(re.w);
                 const unsigned bit = 1u << rr;
-                float q[4];
-                nms_overlap3d_guarded4(a, cols, colbad, cols_sane, thr, q);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wd[half][j] |= !(q[j] <= thr) ? bit : 0u;
+                for (int j = 0; j < 4; ++j) {
+                    if ((act[j] >> r) & 1ull) {                        // wave-uniform
+                        const float q = nms_overlap3d_guarded1(a, col[j], colbad[j], sane[j], thr);
+                        wd[half][j] |= !(q <= thr) ? bit : 0u;
+                    }
+                }
             }
         }
         u64* Wk = I.W + (size_t)kb * L.NC;                             // full rows (symmetric overlap): see bitmask_boxes_kernel
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
             if (crank[j] != 0x7fffffff) Wk[crank[j]] = ((u64)wd[1][j] << 32) | wd[0][j];
+        }
+    }
     }
 }
 

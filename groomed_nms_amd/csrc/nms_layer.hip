@@ -17,7 +17,8 @@
 
 // defined in iou_kernels.hip
 bool gnms_internal_overlap3d_sym_ok(int N, int64_t ld, const float* out);
-int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1);
+int gnms_internal_nms_overlap3d_sym(const float* rec, int B, int N, float* out, int64_t ld, hipStream_t st, float thr, int pct0, int pct1,
+                                    int leave_cus = 0, int force_persist = 0);
 int gnms_internal_iou2d_rows(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st, int row0, int row_end);
 
 // ------------------------------------------------------------------------------------------------
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kern
         }
         const int all_same = __syncthreads_and(same);
         if (threadIdx.x < 8 && !(xsort && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
-        if (threadIdx.x == 8) I.misc[8] = I.misc[8] + 1;               // the workspace's call counter (leaders_sb_body's hand-off tag)
+        if (threadIdx.x == 8) I.misc[8] = gnms_next_epoch(I.misc[8]);               // the workspace's call counter (leaders_sb_body's hand-off tag)
         for (int i = threadIdx.x; i < 17 * 32; i += blockDim.x) I.gran[i] = 0ull;   // (and no granule of this workspace carries a tag yet)
         return;
     }
@@ -926,12 +927,14 @@ int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts
 
 // K1: stable descending score sort (+ the x-centre sort of the boxes when `boxes` is given).  One workgroup per image up to
 // 1024 keys, the cooperative two-kernel sort above that.
+// mode3d: 0 = `boxes` are 2D boxes (columns by x centre); >= 1 = pseudo boxes of cuboids whose records lie in the workspace (columns by
+// (z band, x centre) with that many bands; the sort also leaves the records in column order, ImgPtrs::xrec)
 int launch_sorts(const float* scores, const float* boxes, int B, int N, const int32_t* counts, char* ws, const gnms_ws_layout& L, int P2,
-                 int64_t* order, hipStream_t st) {
+                 int64_t* order, hipStream_t st, int mode3d = 0) {
     int rc;
     const int roles = boxes ? 2 : 1;
     if (P2 <= 1024) {
-        sort_scores_kernel<1><<<dim3(B, roles), P2, (size_t)P2 * 8, st>>>(scores, N, counts, ws, L, P2, (long long*)order, boxes);
+        sort_scores_kernel<1><<<dim3(B, roles), P2, (size_t)P2 * 8, st>>>(scores, N, counts, ws, L, P2, (long long*)order, boxes, mode3d);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
@@ -939,12 +942,12 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
     const size_t lds = (size_t)P2 * 8;
     // (runs and merge as ONE launch with nonce-flag hand-offs was measured in round 3: 13.1 us against 7.8 + 6.2, the step unchanged -- a launch
     // boundary between two small kernels costs ~1 us; dropped in round 4, LABNOTES.md)
-    sort_runs_kernel<<<dim3(R, B, roles), 1024, 0, st>>>(scores, boxes, N, counts, ws, L, P2);
+    sort_runs_kernel<<<dim3(R, B, roles), 1024, 0, st>>>(scores, boxes, N, counts, ws, L, P2, mode3d);
     GNMS_CHECK_LAUNCH();
 #define GNMS_MERGE(RR)                                                                                                    \
     do {                                                                                                                  \
         if ((rc = allow_lds(sort_merge_kernel<RR>, lds))) return rc;                                                      \
-        sort_merge_kernel<RR><<<dim3(RR, B, roles), 1024, lds, st>>>(scores, boxes, N, counts, ws, L, (long long*)order); \
+        sort_merge_kernel<RR><<<dim3(RR, B, roles), 1024, lds, st>>>(scores, boxes, N, counts, ws, L, (long long*)order, mode3d); \
     } while (0)
     switch (R) {
         case 2: GNMS_MERGE(2); break;
@@ -1330,7 +1333,11 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     const bool chain_in_write = !beside && sym && (N <= 2048 || sym_tail) && chain_rides_in_write_launch(B, N);
     if (!beside && !chain_in_write && (rc = gnms_internal_nms_overlap3d(rec, B, N, iou_out, ld, st, P.nms_threshold))) return rc;
     const int P2 = next_pow2(N);
-    if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st))) return rc;   // + cuboids by x
+    // + the cuboids in the column order of the bit-matrix kernel: (z band, x centre).  Bands: so that a slot of 64 consecutive columns is
+    // about as deep in z as it is wide in x (a handful of bands of >= 512 cuboids each; one band up to N = 1024)
+    // (B = 8 uniform cuboids, bit-matrix kernel: N = 4096 52 / 47 / 46 / 46.5 us with 1 / 4 / 8 / 12 bands, N = 16384 494 / 409 / 407 with 1 / 8 / 15)
+    const int bands = std::max(1, std::min(8, N / 512));
+    if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st, bands))) return rc;
     SideScope scope(st);
     // the part of the write that runs beside the bit-matrix kernel: rows [0, r1) of the all-pairs kernel
     const int r1 = beside ? split_rows(N, 20) : 0;
@@ -1343,11 +1350,16 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
         // no culling possible below that threshold: the triangular tile set does half the pairs of the square one
         bitmask_rec3d_kernel<<<dim3(gnms_div_up(tri_tile_count(L.NB), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
     } else {
+        // row groups of 4 blocks where there are plenty of tiles; from N > 4096 the row groups are dealt to the XCDs (see the kernel)
         const long long tiles = (long long)B * L.NB * ((N + 255) / 256);
-        if (tiles >= 32768)
-            bitmask_rec3d_culled_kernel<4><<<dim3(gnms_div_up(((L.NB + 3) / 4) * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+        const int kbw = tiles >= 32768 ? 4 : 1;                       // (N = 4096: 46 / 48 / 59 us with 1 / 2 / 4; N = 16384: 338 with 2, 325 with 4)
+        const int pinned = N > 4096 ? 1 : 0;
+        const int nkbg = gnms_div_up(L.NB, kbw), nchunk = (N + 255) / 256;
+        const unsigned gx = pinned ? (unsigned)(gnms_div_up(nkbg, 8) * gnms_div_up(nchunk, 4) * 8) : (unsigned)gnms_div_up(nkbg * nchunk, 4);
+        if (kbw >= 4)
+            bitmask_rec3d_culled_kernel<4><<<dim3(gx, 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L, pinned);
         else
-            bitmask_rec3d_culled_kernel<1><<<dim3(gnms_div_up(L.NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L);
+            bitmask_rec3d_culled_kernel<1><<<dim3(gx, 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L, pinned);
     }
     GNMS_CHECK_LAUNCH();
     if (chain_in_write)                                           // K3..K6 and the matrix in one launch, like the 2D entry
@@ -1668,7 +1680,7 @@ extern "C" int gnms_get_groups(const float* scores, const float* iou, int N, int
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(sort_scores_kernel<E>, sort_lds))) return rc;
-        sort_scores_kernel<E><<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr, nullptr);
+        sort_scores_kernel<E><<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr, nullptr, 0);
     });
     GNMS_CHECK_LAUNCH();
     if ((rc = run_grouping(iou, 1, N, ld, nullptr, group_threshold, ws, L, st))) return rc;

@@ -541,7 +541,7 @@ extern "C" int gnms_soft_sort(const float* scores, const float* iou, int N, int6
         if (sort_lds > 64 * 1024)                                                                                                \
             GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_scores_kernel<EE>),                             \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));                      \
-        sort_scores_kernel<EE><<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr, nullptr);                     \
+        sort_scores_kernel<EE><<<1, sort_threads, sort_lds, st>>>(scores, N, nullptr, ws, L, P2, nullptr, nullptr, 0);                     \
     } while (0)
     switch (P2 <= 1024 ? 1 : P2 / 1024) {
         case 1: GNMS_SS_SORT(1); break;

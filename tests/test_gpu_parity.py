@@ -2121,3 +2121,75 @@ def test_matrix_in_layer_detects_symmetry(G, O):
             assert valid[b, :int(nv[b])].tolist() == list(ref["valid"]), (N, kind, b)
             assert invalid[b, :int(ni[b])].tolist() == list(ref["invalid"]), (N, kind, b)
             assert np.array_equal(st.grad[b].cpu().numpy(), ref["grad_scores"]), (N, kind, b)
+
+
+@pytest.mark.gpu
+def test_recycled_workspace_bytes(G, O):
+    """The workspace and the matrix are caller memory with ANY previous contents -- the torch allocator hands the layer the bytes of freed
+    index lists (all 0xff: the -1 padding), of old matrices, of old workspaces.  Every entry must produce, bit for bit, what it produces on
+    zeroed memory.  (Round 4b: a workspace whose call counter read 0xffffffff wrapped to 0, the tag of a freshly cleared hand-off granule,
+    and the leader scan of the matrix-in layer ran ahead of its predecessors -- found by test_fuzz_layer_against_oracle when the layout moved.)"""
+    import ctypes
+    from groomed_nms_amd import synthetic, _lib
+    from groomed_nms_amd._lib import GnmsParams, ptr, check
+    lib = _lib.load()
+    P = GnmsParams()
+    lib.gnms_default_params(ctypes.byref(P))
+    dev = torch.device("cuda")
+
+    def fills(nbytes):
+        yield "zero", (lambda t: t.zero_())
+        yield "ff", (lambda t: t.fill_(0xFF))
+        yield "a5", (lambda t: t.fill_(0xA5))
+        yield "7f", (lambda t: t.fill_(0x7F))
+        yield "rand", (lambda t: t.copy_(torch.randint(0, 256, (t.numel(),), dtype=torch.uint8, device=dev)))
+
+    for dim, B, N, counts in ((2, 2, 300, [300, 77]), (2, 2, 2300, [2300, 1331]), (2, 2, 4096, [4096, 3000]), (2, 1, 6000, [6000]),
+                              (3, 2, 700, [700, 130]), (3, 2, 2300, [2300, 1331]), (3, 1, 5000, [5000])):
+        if dim == 2:
+            src_np, sc_np = synthetic.batch_2d(7 + N, B, N, "clustered", per=40)
+        else:
+            src_np, sc_np = synthetic.batch_3d(7 + N, B, N, clustered=True, per=40)
+        src, sc = torch.from_numpy(src_np).to(dev), torch.from_numpy(sc_np).to(dev)
+        ct = torch.tensor(counts, dtype=torch.int32, device=dev)
+        nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(P))
+        ref = {}
+        for name, fill in fills(nbytes):
+            for entry in ("one_call", "matrix_in"):
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                fill(ws)
+                iou = torch.empty((B, N, N), device=dev)
+                fill(iou.view(torch.uint8).view(-1))
+                prob = torch.empty((B, N), device=dev)
+                valid = torch.empty((B, N), dtype=torch.int64, device=dev)
+                invalid = torch.empty((B, N), dtype=torch.int64, device=dev)
+                nv, ni = torch.empty((B,), dtype=torch.int32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev)
+                grad = torch.empty((B, N), device=dev)
+                wgt = torch.linspace(-1.0, 2.0, N, device=dev).repeat(B, 1).contiguous()
+                if entry == "one_call":
+                    fwd = lib.gnms_forward_with_iou2d if dim == 2 else lib.gnms_forward_with_iou3d
+                    check(fwd(ptr(src), ptr(sc), B, N, N, ptr(ct), ctypes.byref(P), ptr(iou), ptr(prob), None, ptr(valid), ptr(invalid), ptr(nv), ptr(ni),
+                              ptr(ws), nbytes, None), "fwd")
+                else:
+                    if dim == 2:
+                        check(lib.gnms_iou2d(ptr(src), ptr(src), B, N, N, ptr(iou), N, None), "iou2d")
+                    else:
+                        check(lib.gnms_nms_overlap3d_from_params(ptr(src), B, N, float(P.nms_threshold), ptr(iou), N, None), "overlap3d")
+                    check(lib.gnms_forward(ptr(sc), ptr(iou), B, N, N, ptr(ct), ctypes.byref(P), ptr(prob), None, ptr(valid), ptr(invalid), ptr(nv), ptr(ni),
+                                           ptr(ws), nbytes, None), "fwd")
+                check(lib.gnms_backward(ptr(wgt), ptr(sc), ptr(iou), B, N, N, ptr(ct), ctypes.byref(P), ptr(grad), None, ptr(ws), nbytes, None), "bwd")
+                torch.cuda.synchronize()
+                got = []
+                for b in range(B):
+                    n = counts[b]
+                    got.append((prob[b, :n].cpu().numpy().copy(), grad[b, :n].cpu().numpy().copy(), valid[b, :int(nv[b])].cpu().numpy().copy(),
+                                invalid[b, :int(ni[b])].cpu().numpy().copy()))
+                if name == "zero":
+                    ref[entry] = got
+                    continue
+                for b in range(B):
+                    for a, r in zip(got[b], ref[entry][b]):
+                        assert np.array_equal(a, r, equal_nan=True), (dim, N, entry, name, b)
+        # and the two entries agree on the probabilities (2D: bit for bit; 3D: the matrix-in layer thresholds the very matrix the one-call entry wrote)
+        for b in range(B):
+            assert np.array_equal(ref["one_call"][b][0], ref["matrix_in"][b][0], equal_nan=True), (dim, N, b)
