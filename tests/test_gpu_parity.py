@@ -2144,8 +2144,10 @@ def test_recycled_workspace_bytes(G, O):
         yield "7f", (lambda t: t.fill_(0x7F))
         yield "rand", (lambda t: t.copy_(torch.randint(0, 256, (t.numel(),), dtype=torch.uint8, device=dev)))
 
-    for dim, B, N, counts in ((2, 2, 300, [300, 77]), (2, 2, 2300, [2300, 1331]), (2, 2, 4096, [4096, 3000]), (2, 1, 6000, [6000]),
-                              (3, 2, 700, [700, 130]), (3, 2, 2300, [2300, 1331]), (3, 1, 5000, [5000])):
+    for dim, B, N, counts, mode in ((2, 2, 300, [300, 77], "gm"), (2, 2, 2300, [2300, 1331], "gm"), (2, 2, 4096, [4096, 3000], "gm"), (2, 1, 6000, [6000], "gm"),
+                                    (3, 2, 700, [700, 130], "gm"), (3, 2, 2300, [2300, 1331], "gm"), (3, 1, 5000, [5000], "gm"),
+                                    (2, 2, 1500, [1500, 700], "gu"), (2, 2, 1500, [1500, 700], "un"), (3, 2, 1500, [1500, 700], "gu"), (2, 2, 200, [200, 64], "un")):
+        P.group_boxes, P.mask_group_boxes = (1, 1) if mode == "gm" else ((1, 0) if mode == "gu" else (0, 0))   # grouped + masked / grouped / ungrouped
         if dim == 2:
             src_np, sc_np = synthetic.batch_2d(7 + N, B, N, "clustered", per=40)
         else:
@@ -2189,7 +2191,7 @@ def test_recycled_workspace_bytes(G, O):
                     continue
                 for b in range(B):
                     for a, r in zip(got[b], ref[entry][b]):
-                        assert np.array_equal(a, r, equal_nan=True), (dim, N, entry, name, b)
+                        assert np.array_equal(a, r, equal_nan=True), (dim, N, mode, entry, name, b)
         # and the two entries agree on the probabilities (2D: bit for bit; 3D: the matrix-in layer thresholds the very matrix the one-call entry wrote)
         for b in range(B):
-            assert np.array_equal(ref["one_call"][b][0], ref["matrix_in"][b][0], equal_nan=True), (dim, N, b)
+            assert np.array_equal(ref["one_call"][b][0], ref["matrix_in"][b][0], equal_nan=True), (dim, N, mode, b)
