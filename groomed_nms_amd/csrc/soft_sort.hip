@@ -186,8 +186,13 @@ constexpr int GM = 256, GN = 128, GK = 16, GLA = 20, GLB = 132;      // LDS row 
 // row-major copy of the A tile, which in turn is staged with plain 16-byte LDS writes of the 16-byte global loads: no element of a
 // loaded vector is ever moved (with a k-major copy the compiler shuffled the components right behind the loads and waited for them
 // there: the prefetch of tile t+2 stalled every tile).
+// Split K (round 4b): slice z = blockIdx.z multiplies the k range [z K, (z + 1) K) into its own panel D + z slice_stride (launch_sgemm's
+// scratch, summed in slice order by sgemm_reduce_kernel) -- for the sizes whose tiles alone leave the machine empty (1024^3: 32 tiles).
 __global__ __launch_bounds__(256, 2) void sgemm_mfma_big_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D,
-                                                                int K, long lda, long ldb, long ldd, int accumulate) {
+                                                                int K, long lda, long ldb, long ldd, int accumulate, long slice_stride) {
+    A += (long)blockIdx.z * K;                                        // (K = the slice's length: a multiple of 32)
+    Bm += (long)blockIdx.z * K * ldb;
+    D += (long)blockIdx.z * slice_stride;
     __shared__ __attribute__((aligned(16))) float As[2][GM][GLA];     // As[buf][m][k]
     __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLB];     // Bs[buf][k][n]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -409,6 +414,18 @@ __global__ __launch_bounds__(256) void softsort_bwd_cols2_kernel(const float* __
 __global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ part, int S, int M, int N, float* __restrict__ D, long ldd,
                                                            int accumulate) {
     const long total = (long)M * N;
+    if ((N % 4 == 0) && (ldd % 4 == 0) && ((uintptr_t)D % 16 == 0)) {                  // 16-byte lanes (the panels are dense M x N: aligned)
+        const float4* p4 = reinterpret_cast<const float4*>(part);
+        const long tot4 = total / 4;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot4; e += (long)gridDim.x * 256) {
+            float4 acc = p4[e];
+            for (int z = 1; z < S; ++z) { const float4 v = p4[(long)z * tot4 + e]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            float4* d = reinterpret_cast<float4*>(D + (e * 4 / N) * ldd + (e * 4 % N));
+            if (accumulate) { const float4 o = *d; acc.x = o.x + acc.x; acc.y = o.y + acc.y; acc.z = o.z + acc.z; acc.w = o.w + acc.w; }
+            *d = acc;
+        }
+        return;
+    }
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         float acc = part[e];
         for (int z = 1; z < S; ++z) acc += part[(long)z * total + e];
@@ -421,10 +438,29 @@ int launch_sgemm(const float* A, const float* B, float* D, int M, int N, int K, 
                  hipStream_t st) {
     if (M == 0 || N == 0) return GNMS_OK;
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
-    if (aligned && M % GM == 0 && N % GN == 0 && K % (2 * GK) == 0 && K >= 2 * GK && (long)(M / GM) * (N / GN) >= 256) {
-        sgemm_mfma_big_kernel<<<dim3(N / GN, M / GM), 256, 0, st>>>(A, B, D, K, (long)lda, (long)ldb, (long)ldd, accumulate);
-        GNMS_CHECK_LAUNCH();
-        return GNMS_OK;
+    if (aligned && M % GM == 0 && N % GN == 0 && K % (2 * GK) == 0 && K >= 2 * GK) {
+        const long big_tiles = (long)(M / GM) * (N / GN);
+        if (big_tiles >= 256) {
+            sgemm_mfma_big_kernel<<<dim3(N / GN, M / GM), 256, 0, st>>>(A, B, D, K, (long)lda, (long)ldb, (long)ldd, accumulate, 0L);
+            GNMS_CHECK_LAUNCH();
+            return GNMS_OK;
+        }
+        // the same kernel over S slices of K when its tiles alone do not fill the machine: S doubles until there are two workgroups per CU
+        // (the kernel is built for two per CU), a slice keeps >= 128 k and a multiple of 32.  1024^3: 32 tiles x 8 slices; 2048^3: 128 x 4.
+        const int cus = gnms_device_cu_count();
+        int S = 1;
+        while (S < 16 && big_tiles * S < 2L * cus && K % (2 * S * 2 * GK) == 0 && K / (2 * S) >= 128) S *= 2;
+        if (S > 1 && big_tiles * S >= cus) {
+            const int kslice = K / S;
+            gnms_async_buffer part;
+            GNMS_CHECK_HIP(part.alloc((size_t)S * M * N * sizeof(float), st));
+            sgemm_mfma_big_kernel<<<dim3(N / GN, M / GM, S), 256, 0, st>>>(A, B, part.as<float>(), kslice, (long)lda, (long)ldb, (long)N, 0, (long)M * N);
+            GNMS_CHECK_LAUNCH();
+            const long total = (long)M * N;
+            sgemm_reduce_kernel<<<(unsigned)std::min<long>((total / 4 + 255) / 256, 8192), 256, 0, st>>>(part.as<float>(), S, M, N, D, (long)ldd, accumulate);
+            GNMS_CHECK_LAUNCH();
+            return GNMS_OK;
+        }
     }
     dim3 grid(gnms_div_up(N, BN), gnms_div_up(M, BM));
     // SPLIT K when the tiles alone leave the machine empty (soft sort's own sizes: N <= 500 boxes is 16 tiles on 256 CUs; 1024^3: 64):

@@ -238,7 +238,9 @@ def test_soft_sort(G, golden_misc):
 def test_sgemm_mfma(G):
     from groomed_nms_amd.groomed_nms import _sgemm
     rng = np.random.default_rng(0)
-    for M, N, K in ((1, 1, 1), (33, 65, 17), (128, 128, 128), (200, 300, 250), (512, 384, 1024)):
+    # (the last four: the 256 x 128 kernel -- one slice of K at 4096 x 2048, split K below that: 4 x 2 tiles x 16 / 8, 8 x 8 x 4 slices)
+    for M, N, K in ((1, 1, 1), (33, 65, 17), (128, 128, 128), (200, 300, 250), (512, 384, 1024), (1024, 1024, 1024), (512, 256, 2048), (2048, 1024, 512),
+                    (4096, 2048, 64)):
         a = rng.uniform(-1, 1, size=(M, K)).astype(np.float32)
         b = rng.uniform(-1, 1, size=(K, N)).astype(np.float32)     # asymmetric operands
         got = _sgemm(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy()
