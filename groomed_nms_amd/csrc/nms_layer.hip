@@ -415,62 +415,6 @@ extern "C" size_t gnms_workspace_bytes(int B, int N, const gnms_params* params) 
 
 namespace {
 
-// Fused launch: the pairwise IoU tiles of gnms_iou2d PLUS, in the LAST grid slice, one workgroup per image that sorts
-// the scores (K1).  The sort does not depend on the overlaps, so it needs neither its own launch nor a kernel boundary:
-// its workgroups slip into the CUs that the IoU tiles vacate at the end of the launch.  Measured (N=4096, B=8): IoU
-// alone 95 us, IoU + separate sort launch 121 us, fused 104 us.  (Sort workgroups in the FIRST slice co-run with 32
-// streaming waves per CU and take 5x longer even at s_setprio 3: 113 us.)
-template <bool VEC, int E>
-__global__ __launch_bounds__(gnms_iou::kWavesPerWG * 64, 8) void iou2d_sort_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                                                int N, const int* __restrict__ counts, float* __restrict__ out,
-                                                                                long ld, char* ws, gnms_ws_layout L, int P2,
-                                                                                long long* __restrict__ order_out, int xsort, int tile_rows) {
-    using namespace gnms_iou;
-    if (blockIdx.z == gridDim.z - 1) {
-        const int nimg = (int)gridDim.z - 1;
-        int b = blockIdx.y * gridDim.x + blockIdx.x;                // image to sort: [0, B) by score, [B, 2B) by x centre (from-boxes layer)
-        if (b >= (xsort ? 2 * nimg : nimg)) return;
-        extern __shared__ __attribute__((aligned(16))) char smem[];
-        u64* keys = reinterpret_cast<u64*>(smem);
-        if (b >= nimg) {
-            b -= nimg;
-            sort_boxes_by_x<E>(boxes + (size_t)b * N * 4, gnms_count(counts, b, N), img_ptrs(ws, L, b), keys, P2);
-            return;
-        }
-        const int n = gnms_count(counts, b, N);
-        const float* s = scores + (size_t)b * N;
-        ImgPtrs I = img_ptrs(ws, L, b);
-        u64 r[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = threadIdx.x * E + e;
-            r[e] = (i < n) ? (((u64)gnms_desc_key(s[i]) << 32) | (unsigned)i) : ~0ull;
-        }
-        block_sort<E, u64>(r, keys, P2);
-        int same = 1;
-        for (int k = threadIdx.x; k < N; k += blockDim.x) {
-            int idx = k;
-            float v = 0.0f;
-            // the score is decoded from the key instead of gathered: this workgroup shares its CU's memory pipeline with
-            // streaming IoU tiles, where every dependent memory round trip costs tens of microseconds
-            if (k < n) { idx = (int)(keys[k] & 0xffffffffu); v = gnms_desc_key_decode((uint32_t)(keys[k] >> 32)); }
-            same &= (idx == k);
-            I.order[k] = idx;
-            I.rankof[idx] = k;
-            I.sscore[k] = v;
-            if (xsort && k < n) I.rbox[k] = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];   // (the from-boxes layer's row boxes)
-            if (order_out) order_out[(size_t)b * N + k] = idx;
-        }
-        const int all_same = __syncthreads_and(same);
-        if (threadIdx.x < 8 && !(xsort && threadIdx.x == 6)) I.misc[threadIdx.x] = (threadIdx.x == 2) ? all_same : 0;   // ([6]: the x sort's)
-        if (threadIdx.x == 8) I.misc[8] = gnms_next_epoch(I.misc[8]);               // the workspace's call counter (leaders_sb_body's hand-off tag)
-        for (int i = threadIdx.x; i < 17 * 32; i += blockDim.x) I.gran[i] = 0ull;   // (and no granule of this workspace carries a tag yet)
-        return;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    iou2d_tile<VEC>(boxes, boxes, N, N, out, ld, blockIdx.z, blockIdx.y * tile_rows, blockIdx.x * kWGCols + wave * kWaveCols, lane, tile_rows);
-}
-
 // ------------------------------------------------------------------------------------------------
 // The matrix write as a ROLE inside the launch of the per-image chain (masked from-boxes layer, gnms_forward_with_iou2d).
 // Nothing in that layer reads the matrix, so the write is independent of the chain sorts -> threshold bits -> K3..K6.  As launches of
@@ -888,6 +832,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
             GNMS_TW_ACC(6);
             groups_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
         }
+        if (!P.mask_group_boxes) return;                              // unmasked groups: the solves (a launch of their own) come before K6
         __syncthreads();
         GNMS_TW_ACC(7);
         finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
@@ -1206,18 +1151,9 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
 }
 
 namespace {
-// fused launch: sort on 512 threads (P2 >= 512), <= 32 KiB of LDS per workgroup (P2 <= 4096), one sort workgroup per image in the last slice
-bool sorts_ride_in_iou_launch(int B, int N) {
-    const int P2 = next_pow2(N);
-    return B > 0 && N > 0 && P2 >= 512 && P2 <= 4096 &&
-           (long long)gnms_div_up(N, gnms_iou::kWGCols) * gnms_div_up(N, gnms_iou::tile_rows_for(B, N, N)) >= 2 * B;
-}
-}  // namespace
-
-namespace {
 // masked from-boxes layer: K3..K6 of every image and the matrix write as ONE launch (tail_write_kernel).
 bool chain_rides_in_write_launch(int B, int N) {
-    // (up to N = 1024 the score / x sorts could ride in the IoU launch instead, iou2d_sort_kernel; replayed as a HIP graph -- the GPU's
+    // (up to N = 1024 the score / x sorts could ride in the IoU launch instead, rounds 1-3's iou2d_sort_kernel; replayed as a HIP graph -- the GPU's
     // own time -- this sequence measures the same or better there too: B = 8, N = 128 / 256 / 512 / 1024: 42.4 / 41.0 / 41.5 / 52.1 us
     // against 38.0 / 36.6 / 40.0 / 47.5)
     return true;
@@ -1232,7 +1168,6 @@ extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : (N % 4 == 0 ? "write_staged_kernel" : "iou2d_kernel");
     if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
     if (dim == 3) return "iou3d_nms_fast_kernel";
-    if (sorts_ride_in_iou_launch(B, N)) return "iou2d_sort_kernel";
     return "iou2d_kernel";
 }
 
@@ -1247,57 +1182,29 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
     int rc = check_common("gnms_forward_with_iou2d", B, N, ld, params, workspace, workspace_bytes);
     if (rc) return rc;
     if (B > 0 && N > 0) GNMS_CHECK_ARG(boxes && scores && iou_out && prob, "gnms_forward_with_iou2d: null pointer");
-    const int P2 = next_pow2(N);
     const bool from_boxes = params->group_boxes && !params->presorted && ((uintptr_t)boxes % 16 == 0);
     const bool beside = B > 0 && N > 0 && from_boxes && params->mask_group_boxes && use_side_stream(B, N, ld);
-    const bool chain_in_write = B > 0 && N > 0 && from_boxes && params->mask_group_boxes && !beside && chain_rides_in_write_launch(B, N);
-    const bool fuse = ((uintptr_t)boxes % 16 == 0) && !beside && !chain_in_write && sorts_ride_in_iou_launch(B, N);
+    // (unmasked groups, round 4b: K3..K5's group structure rides in the write launch too, up to N = 4096; the per-group solves and K6 follow)
+    const bool chain_in_write = B > 0 && N > 0 && from_boxes && (params->mask_group_boxes || N <= 4096) && !beside && chain_rides_in_write_launch(B, N);
     if (chain_in_write) {
         const MatrixWrite mw = {iou_out, ld, true};
         return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
                                   workspace_bytes, stream, false, &mw);
     }
-    if (!fuse) {
-        if (beside) {
-            const MatrixWrite mw = {iou_out, ld, false};
-            return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
-                                      workspace_bytes, stream, false, &mw);
-        }
-        if (B > 0 && N > 0 && (rc = gnms_iou2d(boxes, boxes, B, N, N, iou_out, ld, stream))) return rc;
-        if (from_boxes)
-            return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
-                                      workspace_bytes, stream, false);
-        return forward_impl("gnms_forward_with_iou2d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid,
-                            ninvalid, workspace, workspace_bytes, stream, false);
+    if (beside) {
+        const MatrixWrite mw = {iou_out, ld, false};
+        return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
+                                  workspace_bytes, stream, false, &mw);
     }
-    hipStream_t st = (hipStream_t)stream;
-    const gnms_ws_layout L = gnms_make_layout(N);
-    const size_t sort_lds = (size_t)P2 * 8;
-    const bool vec = (ld % 4 == 0) && ((uintptr_t)iou_out % 16 == 0);
-    const int tr = gnms_iou::tile_rows_for(B, N, N);
-    dim3 grid(gnms_div_up(N, gnms_iou::kWGCols), gnms_div_up(N, tr), B + 1);
-    const int threads = gnms_iou::kWavesPerWG * 64;                                   // 512: E = P2 / 512
-    const int xs = from_boxes ? 1 : 0;
-#define GNMS_LAUNCH_FUSED(EE)                                                                                                           \
-    do {                                                                                                                                \
-        if (vec) gnms_launch_prof(kProfMatrixWrite, iou2d_sort_kernel<true, EE>, grid, dim3(threads), sort_lds, st, boxes, scores, N, counts,   \
-                                  iou_out, (long)ld, (char*)workspace, L, P2, (long long*)order, xs, tr);                              \
-        else gnms_launch_prof(kProfMatrixWrite, iou2d_sort_kernel<false, EE>, grid, dim3(threads), sort_lds, st, boxes, scores, N, counts,      \
-                              iou_out, (long)ld, (char*)workspace, L, P2, (long long*)order, xs, tr);                                  \
-    } while (0)
-    switch (P2 / threads) {
-        case 1: GNMS_LAUNCH_FUSED(1); break;
-        case 2: GNMS_LAUNCH_FUSED(2); break;
-        case 4: GNMS_LAUNCH_FUSED(4); break;
-        default: GNMS_LAUNCH_FUSED(8); break;
-    }
-#undef GNMS_LAUNCH_FUSED
-    GNMS_CHECK_LAUNCH();
+    // every other mode: the matrix by gnms_iou2d's own kernels (the persistent writers for a box set with itself), then the layer.
+    // (Rounds 1-3 carried the score sort in the last grid slice of a 64 x 256-tile IoU launch here, iou2d_sort_kernel: 135 us at B = 8,
+    // N = 4096 where the writers take 92 and the two sort launches 15; removed in round 4b.)
+    if (B > 0 && N > 0 && (rc = gnms_iou2d(boxes, boxes, B, N, N, iou_out, ld, stream))) return rc;
     if (from_boxes)
         return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
-                                  workspace_bytes, stream, true);
+                                  workspace_bytes, stream, false);
     return forward_impl("gnms_forward_with_iou2d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid,
-                        ninvalid, workspace, workspace_bytes, stream, true);
+                        ninvalid, workspace, workspace_bytes, stream, false);
 }
 
 // defined in iou_kernels.hip
@@ -1527,7 +1434,19 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     }
     if (mw && mw->one_launch) {
         if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
-        return launch_tail_write<kFromBoxes>(boxes, boxes, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, mw->out, mw->ld, st);
+        if ((rc = launch_tail_write<kFromBoxes>(boxes, boxes, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, mw->out, mw->ld, st))) return rc;
+        if (!P.mask_group_boxes) {                                    // unmasked groups: the chain stopped behind K5's group structure
+            const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+            if ((rc = allow_lds(solve_groups_kernel<false, true>, lds))) return rc;
+            solve_groups_kernel<false, true><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, nullptr, nullptr);
+            GNMS_CHECK_LAUNCH();
+            GNMS_DISPATCH_SORT(P2, {
+                if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
+                finalize_kernel<E><<<B, sort_threads, sort_lds, st>>>(N, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid);
+            });
+            GNMS_CHECK_LAUNCH();
+        }
+        return GNMS_OK;
     }
     SideScope beside(st);
     const int r1 = mw ? split_rows(N, 20) : 0;

@@ -52,9 +52,73 @@ __global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restri
     const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
     float* gi = (BWD && grad_iou && !BOXES) ? grad_iou + (size_t)b * N * ld : nullptr;
     const int nheads = I.misc[1];
+    // ---- small groups: ONE WAVE per group (round 4b).  Lane a holds member a; the substitution's step bb broadcasts x_bb (and the box of
+    // member bb) with v_readlane: no LDS, no barrier, four groups per workgroup at a time.  NMS inputs have ~1 000 groups of 2-4 members per
+    // image (uniform boxes, N = 4096): one workgroup per group, a barrier per step and five dependent loads in front of each group made this
+    // kernel 53 us forward and 53 us backward for a few hundred FLOP per group.  Same operations in the same order as the workgroup path
+    // below (x_a -= P_ab * x_b for ascending b; transposed for the backward).  From the matrix every step is a dependent load: 16 members at most.
+    constexpr int kWaveGroup = BOXES ? 64 : 16;
+    const bool wave_path = !P.presorted;                            // (pre-sorted scores re-order the members by input index: workgroup path)
+    if (wave_path) {
+        const int lane = tid & 63, wave = tid >> 6, nwv = T >> 6;
+        const float4* bx4 = reinterpret_cast<const float4*>(m);
+        auto bcf = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+        for (int hi = blockIdx.x * nwv + wave; hi < nheads; hi += gridDim.x * nwv) {
+            const int k = __builtin_amdgcn_readfirstlane(I.hlist[hi]);
+            const int g = __builtin_amdgcn_readfirstlane(I.glen[k]), start = __builtin_amdgcn_readfirstlane(I.gstart[k]);
+            if (g > kWaveGroup) continue;                               // (wave-uniform)
+            const bool on = lane < g;
+            const int mk = on ? I.gsorted[start + lane] : 0;            // NMS position of member `lane` (= its rank: scores not pre-sorted)
+            const int c = on ? I.order[mk] : 0;
+            float x = on ? (BWD ? I.gx[mk] : I.sscore[mk]) : 0.0f;
+            float4 ba = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (BOXES && on) ba = bx4[c];
+            if (!BWD) {
+                for (int bb = 0; bb < g - 1; ++bb) {
+                    const float xb = bcf(x, bb);
+                    float ov = 0.0f;
+                    if (BOXES) {
+                        const float4 bq = make_float4(bcf(ba.x, bb), bcf(ba.y, bb), bcf(ba.z, bb), bcf(ba.w, bb));
+                        ov = pair_iou(ba, bq);                         // row = member a, column = member bb
+                    } else {
+                        const int cb = __builtin_amdgcn_readlane(c, bb);
+                        if (on && lane > bb) ov = m[(size_t)c * ld + cb];
+                    }
+                    if (on && lane > bb) x -= gnms_prune(ov, P.nms_threshold, P.temperature, P.pruning_method) * xb;
+                }
+                if (on) I.pre[mk] = x;
+            } else {
+                for (int bb = g - 1; bb > 0; --bb) {
+                    const float yb = bcf(x, bb);
+                    float ov = 0.0f;
+                    if (BOXES) {
+                        const float4 bq = make_float4(bcf(ba.x, bb), bcf(ba.y, bb), bcf(ba.z, bb), bcf(ba.w, bb));
+                        ov = pair_iou(bq, ba);                         // row = member bb, column = member a
+                    } else {
+                        const int cb = __builtin_amdgcn_readlane(c, bb);
+                        if (lane < bb) ov = m[(size_t)cb * ld + c];
+                    }
+                    if (lane < bb) x -= gnms_prune(ov, P.nms_threshold, P.temperature, P.pruning_method) * yb;
+                }
+                if (on) gs[c] = x;
+                if (gi) {
+                    const float prev = on ? I.pre[mk] : 0.0f;
+                    for (int bb = 0; bb < g - 1; ++bb) {
+                        const int cb = __builtin_amdgcn_readlane(c, bb);
+                        const float pb = bcf(prev, bb);
+                        if (on && lane > bb) {
+                            const size_t off = (size_t)c * ld + cb;
+                            gi[off] = (-(x * pb)) * gnms_prune_grad(m[off], P.nms_threshold, P.temperature, P.pruning_method);
+                        }
+                    }
+                }
+            }
+        }
+    }
     for (int hi = blockIdx.x; hi < nheads; hi += gridDim.x) {
         const int k = I.hlist[hi];
         const int g = I.glen[k], start = I.gstart[k];
+        if (wave_path && g <= kWaveGroup) continue;                     // (done above; workgroup-uniform)
         const bool tiled = g <= kGroupTileCap;
         const int ts = g + 1;   // padded tile stride
         __syncthreads();        // the previous group's LDS is consumed
