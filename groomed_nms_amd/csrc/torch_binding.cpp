@@ -74,6 +74,7 @@ struct Layer : public torch::autograd::Function<Layer> {
         const size_t wsb = gnms_workspace_bytes((int)B, (int)N, &P);
         Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 256)}, f32.dtype(at::kByte));
         Tensor kept, iou;                     // kept: what the backward reads besides the scores (matrix / boxes), if anything
+        bool bwd_boxes = mode == kFromBoxes;  // the backward takes its overlaps from `kept` = boxes
         int64_t ld = std::max<int64_t>(N, 1);
         if (mode == kMatrixIn) {
             TORCH_CHECK(src.size(2) == N, "GNMS: iou must be [B, N, N]");
@@ -102,7 +103,10 @@ struct Layer : public torch::autograd::Function<Layer> {
             // The masked-group backward (the default) never reads the overlaps, so the matrix is not kept at all.  The unmasked / ungrouped
             // backward does: there it is saved through autograd, whose version counter then catches a caller that overwrites the
             // (possibly caller-provided) buffer between forward and backward instead of silently producing wrong gradients.
-            if (!(group && mask)) kept = iou;
+            // Grouped unmasked 2D: the backward solves its groups from the BOXES (gnms_backward_from_boxes: bit-identical overlaps, no matrix
+            // reads, a caller may reuse iou_out at once); only the ungrouped mode and the 3D entry still read the matrix back.
+            if (!three_d && group && !mask && !presorted) { kept = boxes; bwd_boxes = true; }
+            else if (!(group && mask)) kept = iou;
         }
         ctx->set_materialize_grads(false);                               // no zero-filled "gradients" for the index outputs
         ctx->saved_data["mode"] = mode;
@@ -111,6 +115,7 @@ struct Layer : public torch::autograd::Function<Layer> {
                                                         (double)presorted};
         ctx->saved_data["has_counts"] = counts.defined();
         ctx->saved_data["has_kept"] = kept.defined();
+        ctx->saved_data["bwd_boxes"] = bwd_boxes;
         variable_list saved{s, ws};
         if (counts.defined()) saved.push_back(counts);
         if (kept.defined()) saved.push_back(kept);
@@ -144,7 +149,7 @@ struct Layer : public torch::autograd::Function<Layer> {
         Tensor g = grads[0].contiguous().to(at::kFloat);
         Tensor gs = at::empty_like(s);
         Tensor gi;
-        if (mode == kFromBoxes) {
+        if (ctx->saved_data["bwd_boxes"].toBool()) {
             check(gnms_backward_from_boxes((const float*)cptr(g), (const float*)cptr(kept), (const float*)cptr(s), (int)B, (int)N, (const int32_t*)cptr(counts), &P,
                                            (float*)mptr(gs), mptr(ws), (size_t)ws.numel(), st), "gnms_backward_from_boxes");
         } else {

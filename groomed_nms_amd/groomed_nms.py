@@ -198,8 +198,12 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         # The masked-group backward (the default) never reads the overlaps, so the matrix is not kept at all.  The unmasked / ungrouped
         # backward does read it: there it is saved through autograd, whose version counter then catches a caller that overwrites the
         # (possibly caller-provided) `iou_out` buffer between forward and backward instead of silently producing wrong gradients.
-        ctx.reads_iou = not (params.group_boxes and params.mask_group_boxes)
-        if ctx.reads_iou:
+        # Grouped unmasked 2D: the backward solves its groups from the boxes (gnms_backward_from_boxes: bit-identical overlaps, no matrix reads).
+        ctx.bwd_boxes = bool((not three_d) and params.group_boxes and not params.mask_group_boxes and not params.presorted)
+        ctx.reads_iou = not (params.group_boxes and params.mask_group_boxes) and not ctx.bwd_boxes
+        if ctx.bwd_boxes:
+            ctx.save_for_backward(scores_c, counts, ws, boxes_c)
+        elif ctx.reads_iou:
             ctx.save_for_backward(scores_c, counts, ws, iou)
         else:
             ctx.save_for_backward(scores_c, counts, ws)
@@ -210,6 +214,16 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         if grad_prob is None:
             return None, None, None, None, None
         lib = _lib.load()
+        if ctx.bwd_boxes:
+            scores_c, counts, ws, boxes_c = ctx.saved_tensors
+            B, N = scores_c.shape
+            dev = scores_c.device
+            grad_prob = grad_prob.contiguous().float()
+            grad_scores = torch.empty_like(scores_c)
+            with on_device(dev):
+                check(lib.gnms_backward_from_boxes(ptr(grad_prob), ptr(boxes_c), ptr(scores_c), B, N, ptr(counts), ctypes.byref(ctx.params),
+                                                   ptr(grad_scores), ptr(ws), ws.numel(), stream_ptr(dev)), "gnms_backward_from_boxes")
+            return grad_scores, None, None, None, None
         if ctx.reads_iou:
             scores_c, counts, ws, iou_c = ctx.saved_tensors
         else:

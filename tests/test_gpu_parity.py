@@ -1372,23 +1372,27 @@ def test_soft_sort_rectangular_matrix(G, O):
 
 
 def test_overwritten_matrix_buffer_is_caught(G):
-    """The unmasked backward reads the overlap matrix: a caller that overwrites the iou_out buffer between forward and backward gets
-    autograd's version-counter error, not silently wrong gradients; the masked default never reads it and is unaffected."""
+    """The ungrouped backward reads the overlap matrix: a caller that overwrites the iou_out buffer between forward and backward gets
+    autograd's version-counter error, not silently wrong gradients.  The masked default never reads it, and the grouped unmasked
+    backward solves its groups from the boxes (round 4b): both are unaffected, gradients identical to a run that left the buffer alone."""
     from groomed_nms_amd import synthetic
     boxes, scores = synthetic.batch_2d(3, 2, 300, "clustered", per=20)
     bt = torch.from_numpy(boxes).cuda()
     buf = torch.empty((2, 300, 300), device="cuda")
     s = torch.from_numpy(scores).cuda().requires_grad_(True)
-    out = G.differentiable_nms_with_iou2d_batched(s, bt, iou_out=buf, mask_group_boxes=False)
+    out = G.differentiable_nms_with_iou2d_batched(s, bt, iou_out=buf, group_boxes=False)
     buf.zero_()
     with pytest.raises(RuntimeError):
         out[0].sum().backward()
-    s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
-    out = G.differentiable_nms_with_iou2d_batched(s2, bt, iou_out=buf)
-    ref = G.differentiable_nms_with_iou2d_batched(s2.detach().clone().requires_grad_(True), bt)
-    buf.zero_()
-    out[0].sum().backward()
-    assert torch.isfinite(s2.grad).all() and torch.equal(out[0], ref[0])
+    for kw in (dict(), dict(mask_group_boxes=False)):
+        s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        s3 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        out = G.differentiable_nms_with_iou2d_batched(s2, bt, iou_out=buf, **kw)
+        ref = G.differentiable_nms_with_iou2d_batched(s3, bt, **kw)
+        buf.zero_()
+        out[0].sum().backward()
+        ref[0].sum().backward()
+        assert torch.isfinite(s2.grad).all() and torch.equal(out[0], ref[0]) and torch.equal(s2.grad, s3.grad), kw
 
 
 def test_ungrouped_mode_with_a_tight_workspace(G, O):
