@@ -79,7 +79,8 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //     gsorted    int32 [N]      ranks sorted by (leader, rank), members only: the groups as contiguous runs
 //     gstart     int32 [N]      for rank k: index into gsorted where k's group starts (valid when head>=0)
 //     glen       int32 [N]      for rank k: number of members of k's group kept under the cap
-//     hlist      int32 [N]      ranks of the heads of groups with more than one member (misc[1] of them, any order)
+//     hlist      int32 [N]      ranks of the heads of groups with more than one member (misc[1] of them, any order); from the END, the heads of
+//                               groups of more than 16 members once more (misc[4] of them)
 //     plead      float [N]      masked mode: prune(iou[k][head]) after tril (0 for heads / non-members)
 //     pre        float [N]      (M s)_k before the clamp (lib/groomed_nms.py:111); NMS order
 //     r2         float [N]      clamp(pre, 0, 1)

@@ -1804,6 +1804,8 @@ __global__ __launch_bounds__(64) void attribute_kernel(const float* __restrict__
 // parked in global memory for them (gpos, plead) or they would have loaded again (order, sscore, rem, the leader's score) stays in
 // registers across the sort.  Beside the matrix writers every dependent global load of the chain costs ~2 us: K4 -> barrier -> K5 was
 // eight levels of them, this is four (rem / order / sscore -> the leader's order, score, ordinal -> the two boxes -> stores).
+constexpr int kBigGroupList = 16;     // groups above this size are also listed from the end of hlist (groups_body, solve_groups_kernel)
+
 template <int E, int SRC, bool FUSE = false>
 __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                             gnms_params P, char* ws, gnms_ws_layout L, int Ppow2, const int b) {
@@ -1917,6 +1919,9 @@ __device__ __forceinline__ void groups_body(const float* __restrict__ iou, int N
                         I.glen[hd] = (int)(len < cap ? len : cap);
                         big_head = len > 1;
                         hk = (int)hd;
+                        // groups of more than kBigGroupList members are listed a second time, from the END of hlist (misc[4] of them): the
+                        // unmasked solves hand those to whole workgroups and everything smaller to single waves (nms_solve_kernels.h)
+                        if ((len < cap ? len : cap) > kBigGroupList) I.hlist[N - 1 - atomicAdd(&I.misc[4], 1)] = hk;
                     }
                 }
             }

@@ -1036,9 +1036,9 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
         });
         GNMS_CHECK_LAUNCH();
         if (!P.mask_group_boxes) {
-            const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+            const size_t lds = kSolveGroupsLds;
             if ((rc = allow_lds(solve_groups_kernel<false, false>, lds))) return rc;
-            solve_groups_kernel<false, false><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, nullptr, nullptr);
+            solve_groups_kernel<false, false><<<dim3(solve_groups_wgs(B, device_cu_count()), B), 1024, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, nullptr, nullptr);
             GNMS_CHECK_LAUNCH();
         }
     } else {
@@ -1368,9 +1368,9 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
             GNMS_CHECK_LAUNCH();
         }
     } else if (P.group_boxes) {
-        const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+        const size_t lds = kSolveGroupsLds;
         if ((rc = allow_lds(solve_groups_kernel<true, false>, lds))) return rc;
-        solve_groups_kernel<true, false><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
+        solve_groups_kernel<true, false><<<dim3(solve_groups_wgs(B, device_cu_count()), B), 1024, lds, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_scores, grad_iou);
         GNMS_CHECK_LAUNCH();
     } else {
         const float* Ps = reinterpret_cast<const float*>(ws + (size_t)B * L.per_image);   // written by the forward pass
@@ -1436,9 +1436,9 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
         if ((rc = launch_bitmask_boxes(boxes, B, N, counts, P.nms_threshold, ws, L, st))) return rc;
         if ((rc = launch_tail_write<kFromBoxes>(boxes, boxes, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, mw->out, mw->ld, st))) return rc;
         if (!P.mask_group_boxes) {                                    // unmasked groups: the chain stopped behind K5's group structure
-            const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+            const size_t lds = kSolveGroupsLds;
             if ((rc = allow_lds(solve_groups_kernel<false, true>, lds))) return rc;
-            solve_groups_kernel<false, true><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, nullptr, nullptr);
+            solve_groups_kernel<false, true><<<dim3(solve_groups_wgs(B, device_cu_count()), B), 1024, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, nullptr, nullptr);
             GNMS_CHECK_LAUNCH();
             GNMS_DISPATCH_SORT(P2, {
                 if ((rc = allow_lds(finalize_kernel<E>, sort_lds))) return rc;
@@ -1482,9 +1482,9 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     });
     GNMS_CHECK_LAUNCH();
     if (!P.mask_group_boxes) {
-        const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+        const size_t lds = kSolveGroupsLds;
         if ((rc = allow_lds(solve_groups_kernel<false, true>, lds))) return rc;
-        solve_groups_kernel<false, true><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, nullptr, nullptr);
+        solve_groups_kernel<false, true><<<dim3(solve_groups_wgs(B, device_cu_count()), B), 1024, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, nullptr, nullptr);
         GNMS_CHECK_LAUNCH();
     }
     GNMS_DISPATCH_SORT(P2, {
@@ -1523,9 +1523,9 @@ extern "C" int gnms_backward_from_boxes(const float* grad_prob, const float* box
     char* ws = (char*)workspace;
     bwd_gx_kernel<<<dim3(gnms_div_up(N, 256), B), 256, 0, st>>>(grad_prob, N, counts, P, ws, L);
     GNMS_CHECK_LAUNCH();
-    const size_t lds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+    const size_t lds = kSolveGroupsLds;
     if ((rc = allow_lds(solve_groups_kernel<true, true>, lds))) return rc;
-    solve_groups_kernel<true, true><<<dim3(kSolveGroupWGs, B), 256, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, grad_scores, nullptr);
+    solve_groups_kernel<true, true><<<dim3(solve_groups_wgs(B, device_cu_count()), B), 1024, lds, st>>>(boxes, N, (long)N, counts, P, ws, L, grad_scores, nullptr);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }

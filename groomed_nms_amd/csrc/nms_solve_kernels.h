@@ -16,19 +16,28 @@ constexpr int kGroupTileCap = 128;    // groups up to this size keep P_g in LDS 
 constexpr int kGroupMaxMembers = 2048;
 
 // ------------------------------------------------------------------------------------------------
-// unmasked groups: grid (kSolveGroupWGs, B) x 256 threads.  Every workgroup first settles its share of the trivial boxes
-// (padding, boxes in no group, groups of one), then walks the head list of the multi-member groups (hlist, built by
-// groups_kernel) with stride gridDim.x: one workgroup per group, tile fill by all 4 waves, substitution with a barrier per
-// step.  (The first version launched one 64-thread workgroup per BOX with 90 KB of LDS each: 32768 workgroups, one per CU
-// at a time, ~200 us of pure dispatch at B=8, N=4096.)
+// unmasked groups: grid (solve_groups_wgs(B), B) x 1024 threads, one workgroup per CU.  Every workgroup first settles its share of the
+// trivial boxes (padding, boxes in no group, groups of one); then
+//   * SMALL groups (<= 32 members from the boxes, <= 16 from the matrix, where every step is a dependent load): ONE WAVE per group,
+//     walking the head list hlist with stride (workgroups x 16).  Lane a holds member a; step bb of the substitution broadcasts x_bb
+//     (and member bb's box) with v_readlane, P_ab of step bb + 1 is computed while step bb's update is in flight: no LDS, no barrier.
+//     NMS inputs have ~1 000 groups of 2-4 members per image (uniform boxes, N = 4096): with one 256-thread workgroup per group, a
+//     barrier per step and five dependent loads in front of each group this kernel took 53 us forward and 53 backward (rounds 1-4a);
+//     now 12 / 11.
+//   * BIG groups (the second list groups_body keeps at the end of hlist): one workgroup per group -- all 1024 threads fill the
+//     triangular tile P_g in LDS (up to 128 members: the default cap is 101), then wave 0 alone substitutes out of LDS, two members per
+//     lane, the next step's entries read ahead; beyond 128 members entry by entry with a barrier per step, as before.
+// (History: the first version launched one 64-thread workgroup per BOX with 90 KB of LDS each: 32768 workgroups, ~200 us of dispatch.)
+// Same operations in the same order everywhere: x_a -= P_ab * x_b for ascending b (forward), y_a -= P_ba * y_b for descending b (backward).
 // dynamic LDS: int sc[G], int sq[G], float acc[G], float Pl[tile*(tile+1)]   with G = kGroupMaxMembers
 // ------------------------------------------------------------------------------------------------
-constexpr int kSolveGroupWGs = 128;
+constexpr size_t kSolveGroupsLds = (size_t)kGroupMaxMembers * 12 + (size_t)kGroupTileCap * (kGroupTileCap + 1) * 4;
+static inline int solve_groups_wgs(int B, int cus) { const int w = cus / (B > 0 ? B : 1); return w < 16 ? 16 : (w > 256 ? 256 : w); }
 
 template <bool BWD, bool BOXES>
-__global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
-                                                           gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores,
-                                                           float* __restrict__ grad_iou) {
+__global__ __launch_bounds__(1024) void solve_groups_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                                            gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ grad_scores,
+                                                            float* __restrict__ grad_iou) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* sc = reinterpret_cast<int*>(smem);
     int* sq = sc + kGroupMaxMembers;
@@ -38,6 +47,7 @@ __global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restri
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int tid = threadIdx.x, T = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = T >> 6;
     float* gs = BWD ? grad_scores + (size_t)b * N : nullptr;
     // ---- trivial boxes ----
     for (int k = blockIdx.x * T + tid; k < N; k += gridDim.x * T) {
@@ -52,17 +62,12 @@ __global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restri
     const float* m = iou + (BOXES ? (size_t)b * N * 4 : (size_t)b * N * ld);   // BOXES: `iou` holds the boxes [B][N][4]
     float* gi = (BWD && grad_iou && !BOXES) ? grad_iou + (size_t)b * N * ld : nullptr;
     const int nheads = I.misc[1];
-    // ---- small groups: ONE WAVE per group (round 4b).  Lane a holds member a; the substitution's step bb broadcasts x_bb (and the box of
-    // member bb) with v_readlane: no LDS, no barrier, four groups per workgroup at a time.  NMS inputs have ~1 000 groups of 2-4 members per
-    // image (uniform boxes, N = 4096): one workgroup per group, a barrier per step and five dependent loads in front of each group made this
-    // kernel 53 us forward and 53 us backward for a few hundred FLOP per group.  Same operations in the same order as the workgroup path
-    // below (x_a -= P_ab * x_b for ascending b; transposed for the backward).  From the matrix every step is a dependent load: 16 members at most.
-    constexpr int kWaveGroup = BOXES ? 64 : 16;
+    constexpr int kWaveGroup = BOXES ? 32 : 16;                     // (>= kBigGroupList: every group above it is in the second list)
+    static_assert(kWaveGroup >= kBigGroupList, "groups between the two thresholds would be solved by nobody");
     const bool wave_path = !P.presorted;                            // (pre-sorted scores re-order the members by input index: workgroup path)
+    auto bcf = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     if (wave_path) {
-        const int lane = tid & 63, wave = tid >> 6, nwv = T >> 6;
         const float4* bx4 = reinterpret_cast<const float4*>(m);
-        auto bcf = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
         for (int hi = blockIdx.x * nwv + wave; hi < nheads; hi += gridDim.x * nwv) {
             const int k = __builtin_amdgcn_readfirstlane(I.hlist[hi]);
             const int g = __builtin_amdgcn_readfirstlane(I.glen[k]), start = __builtin_amdgcn_readfirstlane(I.gstart[k]);
@@ -73,32 +78,34 @@ __global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restri
             float x = on ? (BWD ? I.gx[mk] : I.sscore[mk]) : 0.0f;
             float4 ba = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (BOXES && on) ba = bx4[c];
+            // P between member `lane` and member bb (fwd: row = lane, column = bb; backward: the transpose)
+            auto p_of = [&](int bb, bool fwd) -> float {
+                float ov;
+                if (BOXES) {
+                    const float4 bq = make_float4(bcf(ba.x, bb), bcf(ba.y, bb), bcf(ba.z, bb), bcf(ba.w, bb));
+                    ov = fwd ? pair_iou(ba, bq) : pair_iou(bq, ba);
+                } else {
+                    const int cb = __builtin_amdgcn_readlane(c, bb);
+                    ov = fwd ? m[(size_t)c * ld + cb] : m[(size_t)cb * ld + c];
+                }
+                return gnms_prune(ov, P.nms_threshold, P.temperature, P.pruning_method);
+            };
             if (!BWD) {
+                float pc = (g > 1 && on && lane > 0) ? p_of(0, true) : 0.0f;
                 for (int bb = 0; bb < g - 1; ++bb) {
                     const float xb = bcf(x, bb);
-                    float ov = 0.0f;
-                    if (BOXES) {
-                        const float4 bq = make_float4(bcf(ba.x, bb), bcf(ba.y, bb), bcf(ba.z, bb), bcf(ba.w, bb));
-                        ov = pair_iou(ba, bq);                         // row = member a, column = member bb
-                    } else {
-                        const int cb = __builtin_amdgcn_readlane(c, bb);
-                        if (on && lane > bb) ov = m[(size_t)c * ld + cb];
-                    }
-                    if (on && lane > bb) x -= gnms_prune(ov, P.nms_threshold, P.temperature, P.pruning_method) * xb;
+                    const float pn = (bb + 1 < g - 1 && on && lane > bb + 1) ? p_of(bb + 1, true) : 0.0f;
+                    if (on && lane > bb) x -= pc * xb;
+                    pc = pn;
                 }
                 if (on) I.pre[mk] = x;
             } else {
+                float pc = (g > 1 && lane < g - 1) ? p_of(g - 1, false) : 0.0f;
                 for (int bb = g - 1; bb > 0; --bb) {
                     const float yb = bcf(x, bb);
-                    float ov = 0.0f;
-                    if (BOXES) {
-                        const float4 bq = make_float4(bcf(ba.x, bb), bcf(ba.y, bb), bcf(ba.z, bb), bcf(ba.w, bb));
-                        ov = pair_iou(bq, ba);                         // row = member bb, column = member a
-                    } else {
-                        const int cb = __builtin_amdgcn_readlane(c, bb);
-                        if (lane < bb) ov = m[(size_t)cb * ld + c];
-                    }
-                    if (lane < bb) x -= gnms_prune(ov, P.nms_threshold, P.temperature, P.pruning_method) * yb;
+                    const float pn = (bb - 1 > 0 && lane < bb - 1) ? p_of(bb - 1, false) : 0.0f;
+                    if (lane < bb) x -= pc * yb;
+                    pc = pn;
                 }
                 if (on) gs[c] = x;
                 if (gi) {
@@ -115,8 +122,10 @@ __global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restri
             }
         }
     }
-    for (int hi = blockIdx.x; hi < nheads; hi += gridDim.x) {
-        const int k = I.hlist[hi];
+    // ---- big groups (every multi-member group when the scores came pre-sorted): one workgroup each ----
+    const int nlist = wave_path ? I.misc[4] : nheads;
+    for (int hi = blockIdx.x; hi < nlist; hi += gridDim.x) {
+        const int k = wave_path ? I.hlist[N - 1 - hi] : I.hlist[hi];
         const int g = I.glen[k], start = I.gstart[k];
         if (wave_path && g <= kWaveGroup) continue;                     // (done above; workgroup-uniform)
         const bool tiled = g <= kGroupTileCap;
@@ -141,22 +150,57 @@ __global__ __launch_bounds__(256) void solve_groups_kernel(const float* __restri
                 Pl[a * ts + bb] = (bb < a) ? gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb], P.nms_threshold), P.nms_threshold, P.temperature, P.pruning_method) : 0.0f;
             }
             __syncthreads();
+            // the substitution out of LDS on ONE wave (members lane and lane + 64), no barrier per step; the next step's entries read ahead
+            if (wave == 0) {
+                const int a0 = lane, a1 = lane + 64;
+                const bool on0 = a0 < g, on1 = a1 < g;
+                float x0 = on0 ? acc[a0] : 0.0f, x1 = on1 ? acc[a1] : 0.0f;
+                auto x_of = [&](int bb) { return bb >= 64 ? bcf(x1, bb - 64) : bcf(x0, bb); };
+                if (!BWD) {
+                    float p0 = (g > 1 && on0) ? Pl[a0 * ts] : 0.0f, p1 = (g > 1 && on1) ? Pl[a1 * ts] : 0.0f;
+                    for (int bb = 0; bb < g - 1; ++bb) {
+                        const float xb = x_of(bb);
+                        const bool more = bb + 1 < g - 1;
+                        const float n0 = (more && on0) ? Pl[a0 * ts + bb + 1] : 0.0f, n1 = (more && on1) ? Pl[a1 * ts + bb + 1] : 0.0f;
+                        if (on0 && a0 > bb) x0 -= p0 * xb;
+                        if (on1 && a1 > bb) x1 -= p1 * xb;
+                        p0 = n0; p1 = n1;
+                    }
+                } else {
+                    float p0 = (g > 1 && on0) ? Pl[(g - 1) * ts + a0] : 0.0f, p1 = (g > 1 && on1) ? Pl[(g - 1) * ts + a1] : 0.0f;
+                    for (int bb = g - 1; bb > 0; --bb) {
+                        const float yb = x_of(bb);
+                        const bool more = bb - 1 > 0;
+                        const float n0 = (more && on0) ? Pl[(bb - 1) * ts + a0] : 0.0f, n1 = (more && on1) ? Pl[(bb - 1) * ts + a1] : 0.0f;
+                        if (a0 < bb) x0 -= p0 * yb;
+                        if (a1 < bb) x1 -= p1 * yb;
+                        p0 = n0; p1 = n1;
+                    }
+                }
+                if (on0) acc[a0] = x0;
+                if (on1) acc[a1] = x1;
+            }
+            __syncthreads();
         }
         auto Pab = [&](int a, int bb) -> float {
             return tiled ? Pl[a * ts + bb] : gnms_prune(overlap_at<BOXES>(m, ld, sc[a], sc[bb], P.nms_threshold), P.nms_threshold, P.temperature, P.pruning_method);
         };
         if (!BWD) {
-            for (int bb = 0; bb < g - 1; ++bb) {
-                const float xb = acc[bb];
-                for (int a = bb + 1 + tid; a < g; a += T) acc[a] -= Pab(a, bb) * xb;
-                __syncthreads();
+            if (!tiled) {
+                for (int bb = 0; bb < g - 1; ++bb) {
+                    const float xb = acc[bb];
+                    for (int a = bb + 1 + tid; a < g; a += T) acc[a] -= Pab(a, bb) * xb;
+                    __syncthreads();
+                }
             }
             for (int t = tid; t < g; t += T) I.pre[sq[t]] = acc[t];
         } else {
-            for (int bb = g - 1; bb > 0; --bb) {
-                const float yb = acc[bb];
-                for (int a = tid; a < bb; a += T) acc[a] -= Pab(bb, a) * yb;
-                __syncthreads();
+            if (!tiled) {
+                for (int bb = g - 1; bb > 0; --bb) {
+                    const float yb = acc[bb];
+                    for (int a = tid; a < bb; a += T) acc[a] -= Pab(bb, a) * yb;
+                    __syncthreads();
+                }
             }
             for (int t = tid; t < g; t += T) gs[sc[t]] = acc[t];
             if (gi) {
