@@ -1003,7 +1003,10 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
 
 int forward_impl(const char* fn, const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
                  const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid,
-                 int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted) {
+                 int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted,
+                 const float* boxes2d = nullptr) {
+    // boxes2d: the 2D boxes `iou` was computed from (gnms_forward_with_iou2d), 16-byte aligned, or null: the ungrouped mode then builds
+    // its pruned lower-triangular matrix from them instead of reading `iou` back
     int rc = check_common(fn, B, N, ld, params, workspace, workspace_bytes);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -1021,7 +1024,9 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
 
-    if (!scores_already_sorted && (rc = launch_sorts(scores, nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
+    const bool permute_from_boxes = boxes2d && !P.group_boxes && !P.presorted && !scores_already_sorted;
+    // (with the boxes the score sort also leaves them in rank order, rbox; its second role, the boxes by x centre, is not used here)
+    if (!scores_already_sorted && (rc = launch_sorts(scores, permute_from_boxes ? boxes2d : nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
 
     if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N, matrix_sym_detection(N) ? 2 : 0)) {
         const int sym = matrix_sym_detection(N) ? 2 : 0;
@@ -1047,7 +1052,8 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
         if ((rc = allow_lds(ungrouped_permute_kernel, plds))) return rc;
         ungrouped_prepare_kernel<<<dim3(gnms_div_up(N, 1024), B), 1024, 0, st>>>(N, counts, P, ws, L);
         GNMS_CHECK_LAUNCH();
-        ungrouped_permute_kernel<<<dim3(N, B), 256, plds, st>>>(iou, N, (long)ld, counts, P, ws, L, Ps);
+        if (permute_from_boxes) ungrouped_permute_boxes_kernel<<<dim3(gnms_div_up(N, kPermuteRows), B), 256, 0, st>>>(N, counts, P, ws, L, Ps);
+        else ungrouped_permute_kernel<<<dim3(N, B), 256, plds, st>>>(iou, N, (long)ld, counts, P, ws, L, Ps);
         GNMS_CHECK_LAUNCH();
         ungrouped_solve_forward_kernel<<<dim3(L.NB, B), 256, 0, st>>>(scores, N, counts, P, ws, L, Ps);
         GNMS_CHECK_LAUNCH();
@@ -1204,7 +1210,7 @@ extern "C" int gnms_forward_with_iou2d(const float* boxes, const float* scores, 
         return forward_boxes_impl(boxes, scores, B, N, counts, params, prob, order, valid, invalid, nvalid, ninvalid, workspace,
                                   workspace_bytes, stream, false);
     return forward_impl("gnms_forward_with_iou2d", scores, iou_out, B, N, ld, counts, params, prob, order, valid, invalid, nvalid,
-                        ninvalid, workspace, workspace_bytes, stream, false);
+                        ninvalid, workspace, workspace_bytes, stream, false, ((uintptr_t)boxes % 16 == 0) ? boxes : nullptr);
 }
 
 // defined in iou_kernels.hip

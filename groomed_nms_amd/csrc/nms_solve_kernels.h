@@ -279,6 +279,34 @@ __global__ __launch_bounds__(256) void ungrouped_permute_kernel(const float* __r
     }
 }
 
+// U1 straight from the boxes (gnms_forward_with_iou2d, round 4b): Ps[i][j] = f(iou(box at position i, box at position j)), j < i, with the
+// matrix kernel's own arithmetic (pair_iou: bit-identical entries) from the boxes in rank order the score sort leaves in rbox -- no read
+// of the 4 N^2-byte matrix (it is written beside, by gnms_iou2d's writers), 2 N^2 bytes out in 16-byte stores.  Hard-sorted scores only.
+// B = 8, N = 4096: 258 -> ?? us.
+constexpr int kPermuteRows = 16;      // rows per workgroup of ungrouped_permute_boxes_kernel: the column boxes are loaded once for all of them
+__global__ __launch_bounds__(256) void ungrouped_permute_boxes_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
+                                                                      float* __restrict__ Ps_all) {
+    const int b = blockIdx.y, i0 = blockIdx.x * kPermuteRows;
+    const int n = gnms_count(counts, b, N);
+    if (i0 >= n) return;
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int iend = min(i0 + kPermuteRows, n);                      // rows [i0, iend); row i has the columns j < i
+    const size_t ldp = ungrouped_ld(N);
+    float* out0 = Ps_all + ((size_t)b * N + i0) * ldp;
+    for (int j = threadIdx.x * 4; j < iend - 1; j += 1024) {        // (entries on / above the diagonal inside a row's last vector: never read)
+        float4 cb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cb[u] = I.rbox[min(j + u, n - 1)];
+        for (int i = max(i0, j + 1); i < iend; ++i) {
+            const float4 a = I.rbox[i];                                // (workgroup-uniform address)
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = gnms_prune(pair_iou(a, cb[u]), P.nms_threshold, P.temperature, P.pruning_method);
+            *reinterpret_cast<float4*>(out0 + (size_t)(i - i0) * ldp + j) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // 256 threads: thread t owns row t>>2 of the block and 16 consecutive columns (t&3)*16.. of every 64-column tile
 __device__ __forceinline__ void ungrouped_load_tile(const float* __restrict__ p, bool live, float4 (&dst)[4]) {
 #pragma unroll

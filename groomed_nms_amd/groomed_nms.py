@@ -172,7 +172,7 @@ class _GroomedNMSFunction(torch.autograd.Function):
 
 class _GroomedNMSWithIouFunction(torch.autograd.Function):
     """(prob, ..., iou) = 2D IoU matrix + GrooMeD-NMS in one library call (gnms_forward_with_iou2d): same results as
-    overlaps.iou_batched followed by _GroomedNMSFunction; the score sort rides inside the IoU launch.  The matrix comes
+    overlaps.iou_batched followed by _GroomedNMSFunction; in the grouped modes the layer runs from the boxes beside the matrix write.  The matrix comes
     back detached, as the reference's loss feeds it (lib/loss/rpn_3d.py:791 `.clone().detach()`)."""
 
     @staticmethod
