@@ -23,7 +23,7 @@ constexpr int kGroupMaxMembers = 2048;
 //     (and member bb's box) with v_readlane, P_ab of step bb + 1 is computed while step bb's update is in flight: no LDS, no barrier.
 //     NMS inputs have ~1 000 groups of 2-4 members per image (uniform boxes, N = 4096): with one 256-thread workgroup per group, a
 //     barrier per step and five dependent loads in front of each group this kernel took 53 us forward and 53 backward (rounds 1-4a);
-//     now 12 / 11.
+//     now 9 / 8.
 //   * BIG groups (the second list groups_body keeps at the end of hlist): one workgroup per group -- all 1024 threads fill the
 //     triangular tile P_g in LDS (up to 128 members: the default cap is 101), then wave 0 alone substitutes out of LDS, two members per
 //     lane, the next step's entries read ahead; beyond 128 members entry by entry with a barrier per step, as before.
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void ungrouped_permute_kernel(const float* __r
 // U1 straight from the boxes (gnms_forward_with_iou2d, round 4b): Ps[i][j] = f(iou(box at position i, box at position j)), j < i, with the
 // matrix kernel's own arithmetic (pair_iou: bit-identical entries) from the boxes in rank order the score sort leaves in rbox -- no read
 // of the 4 N^2-byte matrix (it is written beside, by gnms_iou2d's writers), 2 N^2 bytes out in 16-byte stores.  Hard-sorted scores only.
-// B = 8, N = 4096: 258 -> ?? us.
+// B = 8, N = 4096: 258 -> 95 us (one workgroup per row: 161 -- 32 768 workgroups of at most four vectors per thread).
 constexpr int kPermuteRows = 16;      // rows per workgroup of ungrouped_permute_boxes_kernel: the column boxes are loaded once for all of them
 __global__ __launch_bounds__(256) void ungrouped_permute_boxes_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                                                       float* __restrict__ Ps_all) {
