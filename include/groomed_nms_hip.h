@@ -140,13 +140,14 @@ int gnms_forward(const float* scores, const float* iou, int B, int N, int64_t ld
                  int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream);
 
 /* gnms_iou2d + gnms_forward in one call, as lib/loss/rpn_3d.py:772-791 runs them back to back: boxes [B][N][4] ->
- * iou_out [B][N][ld] (kept for the caller) -> the outputs of gnms_forward.  The score sort does not depend on the
- * overlaps, so for N <= 4096 it rides in the last grid slice of the IoU launch (one workgroup per image: no launch of its
- * own, no kernel boundary); larger N run the two calls in sequence.  With the boxes at hand the grouped hard-sort modes
- * take their threshold bits and group overlaps from the boxes (the from-boxes kernels below, bit-identical) instead of
- * reading back the matrix they just wrote; ungrouped / presorted modes read it.  N > 4096 (masked groups): nothing in the
- * layer reads the matrix, so its write runs beside the layer on the library's side stream (see Conventions).
- * gnms_backward pairs with it unchanged. */
+ * iou_out [B][N][ld] (kept for the caller) -> the outputs of gnms_forward.  With the boxes at hand the grouped hard-sort
+ * modes take their threshold bits and group overlaps from the boxes (the from-boxes kernels below, bit-identical) instead
+ * of reading back the matrix they just wrote: nothing in the layer waits for the matrix, and up to N = 4096 its write
+ * shares ONE launch with the per-image chain (masked groups: K3..K6; unmasked: up to the group structure, the per-group
+ * solves and K6 follow).  N > 4096 (masked groups): the write runs beside the layer on the library's side stream (see
+ * Conventions).  The ungrouped mode builds its pruned triangular matrix from the boxes as well; only pre-sorted scores
+ * read the matrix back.  gnms_backward pairs with it unchanged (grouped unmasked: gnms_backward_from_boxes does too, and
+ * never reads the matrix). */
 int gnms_forward_with_iou2d(const float* boxes, const float* scores, int B, int N, int64_t ld, const int32_t* counts,
                             const gnms_params* params, float* iou_out, float* prob, int64_t* order, int64_t* valid,
                             int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
