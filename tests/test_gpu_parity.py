@@ -2201,3 +2201,41 @@ def test_recycled_workspace_bytes(G, O):
         # and the two entries agree on the probabilities (2D: bit for bit; 3D: the matrix-in layer thresholds the very matrix the one-call entry wrote)
         for b in range(B):
             assert np.array_equal(ref["one_call"][b][0], ref["matrix_in"][b][0], equal_nan=True), (dim, N, mode, b)
+
+
+@pytest.mark.gpu
+def test_non_default_modes_one_call_against_matrix_in_and_oracle(G, O):
+    """Round 4b: behind gnms_forward_with_iou2d the grouped unmasked mode runs its group structure inside the write launch (N <= 4096), solves
+    its groups one wave / one workgroup each from the BOXES (forward and backward) and the ungrouped mode builds its pruned triangular matrix
+    from the boxes.  Against the matrix-in entry (bit for bit: the same solves on bit-identical overlaps) and the oracle (TOL): group sizes on
+    both sides of the wave path's 32 and the tile's 128 members, ragged counts, N on both sides of 1024 / 4096 for the unmasked mode; the
+    ungrouped mode at sizes that are not multiples of 16 or 64 (its solution is ill-conditioned beyond a few hundred boxes)."""
+    from groomed_nms_amd import synthetic, overlaps
+    rng = np.random.default_rng(77)
+    cases = [(2, 257, 8, dict(mask_group_boxes=False), [257, 100]), (2, 1500, 40, dict(mask_group_boxes=False), [1500, 1111]),
+             (2, 1500, 150, dict(mask_group_boxes=False, group_size=300), [1500, 900]), (1, 4096, 64, dict(mask_group_boxes=False), [4096]),
+             (2, 5000, 20, dict(mask_group_boxes=False, group_size=3), [5000, 4097]),
+             (2, 300, 150, dict(mask_group_boxes=False, pruning_method="sigmoidal", temperature=0.3), [300, 299]),
+             (2, 191, 8, dict(group_boxes=False), [191, 65]), (1, 100, 4, dict(group_boxes=False), [100]), (2, 272, 8, dict(group_boxes=False), [272, 17])]
+    for B, N, per, kw, counts in cases:
+        boxes, scores = synthetic.batch_2d(int(rng.integers(1 << 30)), B, N, "clustered", per=per)
+        w = rng.uniform(-1, 2, (B, N)).astype(np.float32)
+        bt, wt = torch.from_numpy(boxes).cuda(), torch.from_numpy(w).cuda()
+        ct = torch.tensor(counts, dtype=torch.int32).cuda()
+        s1 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        one = G.differentiable_nms_with_iou2d_batched(s1, bt, counts=ct, **kw)
+        two = G.differentiable_nms_batched(s2, overlaps.iou_batched(bt), counts=ct, **kw)
+        (one[0] * wt).sum().backward()
+        (two[0] * wt).sum().backward()
+        tag = (B, N, per, kw)
+        for a, b2 in zip(one[:6], two):
+            assert torch.equal(a, b2) or torch.allclose(a, b2, atol=0, rtol=0, equal_nan=True), tag
+        assert torch.equal(s1.grad, s2.grad), tag
+        if N > 2000 and not kw.get("group_boxes", True):
+            continue
+        for b in range(B):
+            n = counts[b]
+            ref = O.differentiable_nms(scores[b, :n], O.iou2d(boxes[b, :n], boxes[b, :n]), grad_prob=w[b, :n], **kw)
+            np.testing.assert_allclose(one[0][b, :n].detach().cpu().numpy(), ref["prob"], atol=TOL, err_msg=str(tag))
+            np.testing.assert_allclose(s1.grad[b, :n].cpu().numpy(), ref["grad_scores"], atol=5e-4, rtol=1e-3, err_msg=str(tag))
