@@ -942,6 +942,18 @@ __global__ __launch_bounds__(ROWBUF ? 1024 : 256, (ROWBUF && !CHUNKLOOP) ? 8 : 1
     bitmask_boxes_body<CPL, KBW, ROWBUF, CHUNKLOOP>(boxes, N, counts, thr, ws, L, (int)blockIdx.z, (int)blockIdx.x);
 }
 
+// The scatter variant (no LDS row) with the row groups dealt to the XCDs, as bitmask_rec3d_culled_kernel does (round 4b): workgroup x runs on
+// XCD x mod 8, its four waves are four consecutive column chunks of one row group, consecutive workgroups of an XCD walk the chunks of a
+// row group -- every row of W is completed in ONE L2.  Needs a whole number of workgroups per row group (N a multiple of 1024).
+template <int KBW>
+__global__ __launch_bounds__(256) void bitmask_boxes_pinned_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts, float thr,
+                                                                   char* ws, gnms_ws_layout L) {
+    const int wpk = ((N + 255) >> 8) >> 2;                           // workgroups per row group
+    const int x = (int)blockIdx.x, s = x >> 3;
+    const int kbg = (s / wpk) * 8 + (x & 7);
+    bitmask_boxes_body<4, KBW, false, false>(boxes, N, counts, thr, ws, L, (int)blockIdx.z, kbg * wpk + (s % wpk));
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2c: threshold bit matrix of the 3D NMS overlap straight from the cuboid records (gnms_forward_with_iou3d: the matrix is an
 // output, the layer does not read it back).  Wave tile = 64 rank-rows x 256 RANK columns (records gathered through `order`);

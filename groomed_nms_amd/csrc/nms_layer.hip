@@ -850,7 +850,16 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
 int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
     const int NB = (N + 63) / 64;
     const long long tiles4 = (long long)B * NB * ((N + 255) / 256);
-    if (tiles4 >= 32768) {
+    if (N > 4096 && N % 1024 == 0) {
+        // large images (round 4b): the scatter kernel with the row groups dealt to the XCDs (bitmask_boxes_pinned_kernel) -- a row of W is
+        // >= 64 KiB here and completing its lines in ONE L2 costs less than collecting it in LDS first (one 16-wave workgroup per CU):
+        // B = 8, N = 16384 280 -> 189 us (step 1.74 -> 1.66 ms), 8192 82 -> 61.  Row groups of 4 blocks where there are plenty of tiles
+        // (16384: 288 / 217 / 189 / 184 us with 1 / 2 / 4 / 8).
+        const int kbw = tiles4 >= 32768 ? 4 : 1;
+        const unsigned gx = (unsigned)(gnms_div_up(gnms_div_up(NB, kbw), 8) * (((N + 255) / 256) / 4) * 8);
+        if (kbw >= 4) bitmask_boxes_pinned_kernel<4><<<dim3(gx, 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
+        else bitmask_boxes_pinned_kernel<1><<<dim3(gx, 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);
+    } else if (tiles4 >= 32768) {
         // large images (round 3): the LDS row buffer with a chunk loop -- one 16-wave workgroup per rank block, its waves walking the
         // column chunks, the full row of W leaving as ONE coalesced write (N <= GNMS_MAX_BOXES: the row fits 128 KiB).  The scatter
         // kernel it replaced issued N^2 / 64 scattered 8-byte stores per image: B = 8, N = 16384 step 1.907 -> 1.798 ms.
