@@ -2239,3 +2239,45 @@ def test_non_default_modes_one_call_against_matrix_in_and_oracle(G, O):
             ref = O.differentiable_nms(scores[b, :n], O.iou2d(boxes[b, :n], boxes[b, :n]), grad_prob=w[b, :n], **kw)
             np.testing.assert_allclose(one[0][b, :n].detach().cpu().numpy(), ref["prob"], atol=TOL, err_msg=str(tag))
             np.testing.assert_allclose(s1.grad[b, :n].cpu().numpy(), ref["grad_scores"], atol=5e-4, rtol=1e-3, err_msg=str(tag))
+
+
+@pytest.mark.gpu
+def test_fuzz_3d_one_call_against_its_own_matrix(G):
+    """Seeded fuzz of the 3D one-call entry (records -> column sort by (z band, x centre) -> slot-culled bit matrix -> chain beside the
+    symmetric writers): the layer it runs from the RECORDS must agree, bit for bit, with the matrix-in layer run on the very matrix it wrote
+    -- every cull of the bit-matrix kernel is then proven conservative and every evaluated decision equal to thresholding the entry.
+    Box counts on both sides of 64 / 256 / 1024 / 4096, ragged counts, thresholds on both sides of the cull's 0.01 limit, scenes that are
+    flat in z (one band gets everything), clustered and uniform, and cuboids with zero / negative / NaN extents (never culled, exact order)."""
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(20260929)
+    for trial in range(100):
+        B = int(rng.integers(1, 4))
+        N = int(rng.choice([3, 63, 64, 65, 130, 257, 520, 1024, 1025, 1500, 2300, 4096, 4100, 5000]))
+        clustered = bool(rng.uniform() < 0.5)
+        par, scores = synthetic.batch_3d(int(rng.integers(1 << 30)), B, N, clustered=clustered, per=int(rng.choice([4, 32, 120])))
+        style = rng.uniform()
+        if style < 0.2:
+            par[:, :, 2] = 20.0                                              # every cuboid at one depth
+        elif style < 0.4:
+            par[:, :, 0] *= 0.05                                             # a narrow scene: everything reaches everything in x
+        if rng.uniform() < 0.3 and N >= 8:
+            bad = rng.integers(0, N, size=(B, 4))
+            for b in range(B):
+                par[b, bad[b, 0], 3] = 0.0                                    # zero width
+                par[b, bad[b, 1], 5] = -1.0                                   # negative length
+                par[b, bad[b, 2], 0] = np.nan
+                par[b, bad[b, 3], 4] = np.inf
+        thr = float(rng.choice([0.005, 0.2, 0.4, 0.55, 0.75]))
+        counts = [N] + [int(rng.integers(1, N + 1)) for _ in range(B - 1)]
+        ct = torch.tensor(counts, dtype=torch.int32).cuda()
+        pt, st = torch.from_numpy(par).cuda(), torch.from_numpy(scores).cuda()
+        one = G.differentiable_nms_with_iou3d_batched(st, pt, counts=ct, nms_threshold=thr)
+        two = G.differentiable_nms_batched(st, one[6], counts=ct, nms_threshold=thr)
+        tag = (trial, B, N, clustered, thr, counts)
+        for b in range(B):
+            n = counts[b]
+            m = one[6][b, :n, :n]
+            if not torch.isfinite(m).all():
+                continue                                                      # NaN overlaps: the order among NaN rows is the sort's, compared elsewhere
+            assert torch.equal(one[0][b, :n], two[0][b, :n]), tag
+            assert int(one[4][b]) == int(two[4][b]) and torch.equal(one[2][b, :int(one[4][b])], two[2][b, :int(two[4][b])]), tag
