@@ -470,7 +470,10 @@ extern "C" int gnms_iou2d(const float* boxes_a, const float* boxes_b, int B, int
     GNMS_CHECK_ARG(ld >= N, "gnms_iou2d: ld (%lld) < N (%d)", (long long)ld, N);
     GNMS_CHECK_ARG(((uintptr_t)boxes_a % 16 == 0) && ((uintptr_t)boxes_b % 16 == 0), "gnms_iou2d: boxes must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (gnms_internal_iou2d_wants_self(boxes_a, boxes_b, B, M, N, ld, out)) return gnms_internal_iou2d_self(boxes_a, B, N, out, ld, st);
+    if (gnms_internal_iou2d_wants_self(boxes_a, boxes_b, B, M, N, ld, out)) {
+        const int rc = gnms_internal_iou2d_self(boxes_a, B, N, out, ld, st);
+        if (rc <= 0) return rc;                                     // (1: no claim slot for this stream / capture -- the tiles below)
+    }
     if (gnms_internal_iou2d_wants_staged(B, M, N, ld, out)) return gnms_internal_iou2d_staged(boxes_a, boxes_b, B, M, N, out, ld, st);
     const int tr = tile_rows_for(B, M, N);
     dim3 grid(gnms_div_up(N, kWGCols), gnms_div_up(M, tr), B);

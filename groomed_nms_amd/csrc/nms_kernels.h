@@ -1298,8 +1298,25 @@ __device__ __forceinline__ void rem_store(int* rem, int k, int v) { __hip_atomic
 // workgroups, which own contiguous ascending ranges -- so a workgroup only ever waits for workgroups with a lower index).  Returns true
 // in the workgroup that may go on with K4..K6 of the image: the one whose range ends with the image's last super-block, after every
 // rem[] entry of the image is visible to it.
-__device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int j0,
-                                                const int j1, const int me) {
+//
+// STAGE (round 5, the fast tail; STAGE = the overlap source, kFromMatrix / kFromBoxes / kFromRecords, or kNoStage): masked groups, hard sort.
+// The workgroup that resolved a super-block knows, per rank k, the leader lr = rem[k] that took it -- and with it everything K5 computes for
+// k as long as two things hold for the IMAGE: every leader is a member of its own group (overlap(L, L) > thr: any box of positive finite
+// area), so head == leader, and no group is longer than the cap, so every member is kept.  It therefore evaluates
+//     member = overlap(k, lr) > thr;  plead = prune(overlap);  pre = s_k - plead * s_lr  (s_k for a leader);  r2 = clamp(pre)
+// right behind its resolve, for its own 1024 ranks, beside the chain (the masks are out by then), and stores head / plead / pre / r2
+// write-through in front of its "rem stored" granule; a leader outside its own group raises the granule's `complex` bit.  The image's last
+// workgroup then only has to check the two conditions (fast_final_body) before K6 -- no sort of the groups on the path to the
+// probabilities -- and the groups' CSR the backward reads is built beside K6 by one more workgroup (csr_build_body).
+// Returns 0 in the workgroups that are done, 1 in the image's last one (2: STAGE and some leader is outside its own group).
+constexpr int kNoStage = -1;
+constexpr int kGranVerdict = 30;     // gran[16][30]: the last workgroup's verdict for csr_build_body (payload 1 = fast tail, 2 = K5 ran, nothing to do)
+
+template <int STAGE = kNoStage>
+__device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int j0,
+                                               const int j1, const int me, const float* __restrict__ stage_src = nullptr, long stage_ld = 0,
+                                               const float stage_thr = 0.0f, const float stage_temp = 0.0f, const int stage_prune = 0,
+                                               const int Ppow2 = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t oa, ol, oc, op;
     leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -1315,10 +1332,12 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
     // lane mask in an SGPR pair -- 186 spilled SGPRs and a v_readlane / s_nop pair around every use)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb = (n + 63) >> 6;
-    const int nsb = (nb + kSB - 1) / kSB;
+    const int nsb = max(1, (nb + kSB - 1) / kSB);                  // (an EMPTY image still has one -- empty -- super-block: leaders_chain's count; its
+                                                                   // workgroup must reach K4..K6, the only writers of the image's outputs)
     const u64 below = (1ull << lane) - 1ull;
     const bool last_wg = j1 == nsb;                                // this workgroup ends with the image's last super-block
     int have = 0;                                                  // super-blocks [0, have) have their masks in lmask (workgroup-uniform)
+    int complex_img = 0;                                           // STAGE: a leader of this workgroup's ranks is outside its own group
     const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
     GNMS_T0();
     // table layout: pair (source block bb <= target block tb) at tb (tb + 1) / 2 + bb -- a target's words are consecutive, so the wave
@@ -1331,6 +1350,18 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
     const int kb0 = j * kSB;
     const int nblk = min(kSB, nb - kb0);
     const bool last_sb = j == nsb - 1;
+    // STAGE: what the rank needs of itself (score, input index, box) is requested before anything is waited for
+    float st_sk = 0.0f;
+    int st_ck = 0;
+    float4 st_bk = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (STAGE != kNoStage) {
+        const int kk = ((kb0 + (wave < nblk ? wave : 0)) << 6) + lane;
+        if (wave < nblk && kk < n) {
+            st_sk = I.sscore[kk];
+            st_ck = I.order[kk];
+            if (STAGE == kFromBoxes) st_bk = I.rbox[kk];
+        }
+    }
     if (tid == 0) *stamp = 0;
     if (tid < kSB) bstamp[tid] = -1;
     {   // the own super-block's table: no dependence on anybody (in flight while the first masks are waited for)
@@ -1478,29 +1509,73 @@ __device__ __forceinline__ bool leaders_sb_body(int N, const int* __restrict__ c
             if (c < 0 && (mlo | mhi) != 0u) c = ((kb0 + bb) << 6) + (mlo ? __builtin_ctz(mlo) : 32 + __builtin_ctz(mhi));
         }
         if (c < 0) { const u64 m = cs & mine; c = (m != 0ull) ? k0 + __builtin_ctzll(m) : k; }
-        if (live && k < n) {
-            int r = k;
-            if (((mine >> lane) & 1ull) == 0ull) r = ((ext >> lane) & 1ull) ? cl : c;
-            rem_store(I.rem, k, r);
+        int r = k;
+        if (((mine >> lane) & 1ull) == 0ull) r = ((ext >> lane) & 1ull) ? cl : c;
+        if constexpr (STAGE != kNoStage) {
+            // the last workgroup's last super-block stays in LDS for fast_final_body (the table is dead: every wave has passed a barrier behind
+            // its last read of it): r2 by position, the input index by rank, a second copy of r2, head by rank -- finalize_body<E, true>'s layout
+            const bool park = last_wg && j == j1 - 1;
+            float* stageL = reinterpret_cast<float*>(smem);
+            int* hdL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4);
+            int* ordL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 8);
+            float* r2L = reinterpret_cast<float*>(smem + (size_t)Ppow2 * 12);
+            if (live && k < n) {
+                const int lr = r;
+                float sl = st_sk, ov;
+                if (STAGE == kFromBoxes) {
+                    float4 bl = st_bk;
+                    if (lr != k) { bl = I.rbox[lr]; sl = I.sscore[lr]; }
+                    ov = pair_iou(st_bk, bl);
+                } else {
+                    int cb = st_ck;
+                    if (lr != k) { cb = I.order[lr]; sl = I.sscore[lr]; }
+                    ov = overlap_at<STAGE>(overlap_src<STAGE>(stage_src, I, b, N, stage_ld), stage_ld, st_ck, cb, stage_thr);
+                }
+                float pre = 0.0f, pl = 0.0f;
+                int hd = -1;
+                if (ov > stage_thr) {                              // strict > (:249)
+                    hd = lr;
+                    if (lr == k) pre = st_sk;
+                    else { pl = gnms_prune(ov, stage_thr, stage_temp, stage_prune); pre = st_sk - pl * sl; }
+                } else if (lr == k) complex_img = 1;               // a leader outside its own group (NaN / <= thr diagonal): K5 proper decides the heads
+                const float r2 = pre < 0.0f ? 0.0f : (pre > 1.0f ? 1.0f : pre);      // torch.clamp keeps NaN
+                if (park) { stageL[k] = r2; hdL[k] = hd; ordL[k] = st_ck; r2L[k] = r2; }
+                rem_store(I.rem, k, r);
+                rem_store(I.head, k, hd);
+                __hip_atomic_store(I.plead + k, pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(I.pre + k, pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(I.r2 + k, r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (live && k < n) rem_store(I.rem, k, r);
         }
     }
+    GNMS_TACC_IF(b == 0 && last_sb, 4);
     }   // super-blocks of this workgroup
     if (!last_wg) {
-        __syncthreads();                                           // every wave's rem stores are acknowledged (vmcnt 0) ...
-        if (tid == 0) gran_store(I.gran + (size_t)16 * 32 + me, epoch | 1ull);   // ... before "rem stored" goes out
-        return false;
+        // every wave waits for the acknowledgement of its OWN write-through stores (s_waitcnt vmcnt(0): the barrier alone is an
+        // s_barrier, which orders nothing in memory -- ADVICE r4), then the barrier, then "rem stored" goes out
+        __builtin_amdgcn_s_waitcnt(0x0f70);                        // vmcnt(0) (gfx9 encoding: vmcnt = bits 3:0 + 15:14; expcnt / lgkmcnt left at their maxima)
+        const int cx = (STAGE != kNoStage) ? __syncthreads_or(complex_img) : (__syncthreads(), 0);
+        if (tid == 0) gran_store(I.gran + (size_t)16 * 32 + me, epoch | 1ull | (cx ? 2ull : 0ull));
+        return 0;
     }
     // ---- the image's last super-block: the other workgroups' rem[] must be there, then the per-image epilogue (all masks are in LDS) ----
     if (wave == 0 && me > 0) {
         const u64* g = I.gran + (size_t)16 * 32 + (lane < me ? lane : 0);
         u64 v = gran_load(g);
         while (__ballot((v & 0xffffffff00000000ull) != epoch) != 0ull) { __builtin_amdgcn_s_sleep(2); v = gran_load(g); }
+        if (STAGE != kNoStage && __ballot((v & 2ull) != 0ull) != 0ull) complex_img = 1;
     }
     GNMS_TACC_IF(b == 0 && last_wg, 3);
-    __syncthreads();
-    leaders_epilogue(I, lmask, nb, reinterpret_cast<int*>(Xs));
-    GNMS_TACC_IF(b == 0 && last_wg, 4);
-    return true;
+    if constexpr (STAGE != kNoStage) {
+        return __syncthreads_or(complex_img) ? 2 : 1;              // (leaders_epilogue: only the slow path needs the lists -- fast_final_body)
+    } else {
+        __syncthreads();
+        leaders_epilogue(I, lmask, nb, reinterpret_cast<int*>(Xs));
+        GNMS_TACC_IF(b == 0 && last_wg, 4);
+        return 1;
+    }
 }
 
 // The four per-image stages K3..K6 are written as device functions (`*_body`, 1024 threads, image index `b`) so that they
@@ -1661,23 +1736,28 @@ __host__ __device__ inline int leaders_chain_wgs(int N, int sym_arg, int cap = 0
     return (cap > 0 && w > cap) ? cap : w;
 }
 
-__device__ __forceinline__ bool leaders_chain(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int B, const int spw,
-                                              const int c, const int sym_arg, int* image) {
+// Returns 0 in the workgroups that are done; in the ONE workgroup per image that goes on with K4..K6: 1 (symmetric scan; with STAGE the
+// fast tail's values are stored, see leaders_sb_body), 2 (the same, but some leader is outside its own group), 3 (general scan).
+template <int STAGE = kNoStage>
+__device__ __forceinline__ int leaders_chain(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int B, const int spw,
+                                             const int c, const int sym_arg, int* image, const float* __restrict__ stage_src = nullptr,
+                                             long stage_ld = 0, const float stage_thr = 0.0f, const float stage_temp = 0.0f,
+                                             const int stage_prune = 0, const int Ppow2 = 0) {
     const int jw = c / B, b = c - jw * B;
     *image = b;
     const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;
     if (!sym) {
-        if (jw != spw - 1) return false;
+        if (jw != spw - 1) return 0;
         leaders_body(N, counts, ws, L, b);
-        return true;
+        return 3;
     }
     // symmetric: the image's own super-blocks (ragged counts: fewer than the launch provides for) in contiguous ranges of q
     const int n = gnms_count(counts, b, N);
     const int nsb = max(1, (((n + 63) >> 6) + kSB - 1) / kSB);
     const int q = (nsb + spw - 1) / spw;
     const int j0 = jw * q, j1 = min(nsb, j0 + q);
-    if (j0 >= j1) return false;                                    // (workgroup-uniform)
-    return leaders_sb_body(N, counts, ws, L, b, j0, j1, jw);
+    if (j0 >= j1) return 0;                                        // (workgroup-uniform)
+    return leaders_sb_body<STAGE>(N, counts, ws, L, b, j0, j1, jw, stage_src, stage_ld, stage_thr, stage_temp, stage_prune, Ppow2);
 }
 
 __global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, int sym, int B, int spw) {
@@ -2029,7 +2109,8 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // STAGED (behind groups_body<E, SRC, true>, masked groups): the clamped values already sit in `stage` and the input index of every
 // rank in LDS behind the key region (ordL); r2 is in global memory as well.
-template <int E, bool STAGED = false>
+// HEADS (the fast tail): the valid heads come in sorted order (see the sort below).
+template <int E, bool STAGED = false, bool HEADS = false>
 __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                               int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
                                               long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
@@ -2199,7 +2280,7 @@ __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ cou
     for (int j = t; j < N; j += T) {
         float out = 0.0f;
         if (j < n) {
-            if (P.return_sorted_prob) { const float r2q = I.r2[I.sidx[j]]; out = (r2q < vthr) ? 0.0f : r2q; }   // :117
+            if (P.return_sorted_prob) { const int sj = I.sidx[j]; const float r2q = STAGED ? r2L[sj] : I.r2[sj]; out = (r2q < vthr) ? 0.0f : r2q; }   // :117
             else { const float r2j = STAGED ? r2L[j] : I.r2[j]; out = P.group_boxes ? r2j : ((r2j < vthr) ? 0.0f : r2j); }       // :124-127
         }
         pb[j] = out;
@@ -2216,21 +2297,211 @@ __global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __rest
                                                         int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
                                                         long long* __restrict__ invalid, int* __restrict__ nvalid,
                                                         int* __restrict__ ninvalid) {
-    finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, (int)blockIdx.x);
+    finalize_body<E, false, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3..K6 in ONE launch (masked groups): leaders -> attribution -> groups + rescoring -> finalize, one workgroup of 1024 threads
-// per image.  All four stages are per-image and already ran one workgroup per image (attribution: one wave per rank block,
-// here 16 waves striding the blocks), so nothing is lost in parallelism; three kernel boundaries (launch, drain, refill) go.
-// Ppow2 >= 1024 (smaller images pad their keys).  dynamic LDS = max(leaders table, Ppow2 * 8).
+// The FAST TAIL (round 5): masked groups, hard sort, symmetric scan, N <= 4096.
+//   leaders_sb_body<STAGE>   every scan workgroup: head / plead / pre / r2 of its own ranks right behind its resolve (see there)
+//   fast_final_body          the image's last scan workgroup: verdict (no leader outside its own group, no group above the cap), then K6
+//                            from LDS -- or, verdict "slow", K5 proper (groups_body) as before
+//   csr_build_body           ONE MORE workgroup per image, beside K6: the groups as contiguous runs (gsorted / gstart / glen / gpos / hlist),
+//                            which only the backward reads -- a counting sort on the leader's RANK (LDS atomics), members ranked inside
+//                            their run by comparison, so that the result does not depend on the order the atomics were served in
+// What it takes off the path to the probabilities: the attribution gathers (four dependent levels on one CU -> one level on nsb CUs),
+// both radix passes, the run scan and K5's stores: scan + groups + finalize 63 -> ~40 us at B = 8, N = 4096 (profiles/r05*).
 // ------------------------------------------------------------------------------------------------
+// dynamic LDS: the scan's structures, then cnt[N] (fast_final_body); csr_build_body: 4 arrays of Ppow2 ints
+__host__ __device__ __forceinline__ size_t fast_tail_cnt_offset(int NB) { return (leaders_lds_size(NB) + 15) & ~(size_t)15; }
+__host__ __device__ __forceinline__ size_t fast_tail_lds_size(int N, int Ppow2) {
+    const size_t a = fast_tail_cnt_offset((N + 63) / 64) + (size_t)N * 4, c = (size_t)Ppow2 * 16;
+    return a > c ? a : c;
+}
+
+template <int E, int SRC>
+__device__ __forceinline__ void fast_final_body(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
+                                                char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
+                                                long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
+                                                const int b, const int last) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* stageL = reinterpret_cast<float*>(smem);                                  // r2 by position (finalize_body<E, true>'s `stage`)
+    int* hdL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4);                     // head by rank (dead once the verdict is in)
+    int* ordL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 8);                    // input index by rank
+    float* r2L = reinterpret_cast<float*>(smem + (size_t)Ppow2 * 12);                // r2 once more (the key sort overwrites `stage`)
+    int* cnt = reinterpret_cast<int*>(smem + fast_tail_cnt_offset(L.NB));            // members per leader rank
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int tid = threadIdx.x;
+    const int nb = (n + 63) >> 6;
+    const int nsb = max(1, (nb + kSB - 1) / kSB);
+    const int own0 = (nsb - 1) * kSB * 64;                                           // the parked super-block: [own0, n)
+    const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
+    const long long cap = (long long)P.group_size + 1;
+    int slow = last == 2;
+    GNMS_T0();
+    if (!slow) {
+        // the other super-blocks' ranks: what their workgroups stored (write-through, in front of their granules)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = e * 1024 + tid;
+            if (k < own0) {
+                const int hd = rem_load(I.head, k);
+                const float r2 = __hip_atomic_load(I.r2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int ck = I.order[k];
+                stageL[k] = r2; hdL[k] = hd; ordL[k] = ck; r2L[k] = r2;
+            }
+        }
+        if (cap < (long long)n) {                                                    // (else no group can be longer than the cap)
+            for (int i = tid; i < n; i += 1024) cnt[i] = 0;
+            lds_barrier();
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int k = e * 1024 + tid;
+                const int hd = (k < n) ? hdL[k] : -1;
+                if (hd >= 0) atomicAdd(&cnt[hd], 1);
+            }
+            lds_barrier();
+            int over = 0;
+            for (int i = tid; i < n; i += 1024) over |= (long long)cnt[i] > cap;
+            slow = __syncthreads_or(over);
+        }
+    }
+    // this workgroup's own write-through stores (leaders_sb_body) are acknowledged before the verdict -- csr_build_body's go-ahead -- leaves
+    GNMS_TACC(8);
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                              // vmcnt(0)
+    __syncthreads();
+    GNMS_TACC(9);
+    if (tid == 0) gran_store(I.gran + (size_t)16 * 32 + kGranVerdict, epoch | (slow ? 2ull : 1ull));
+    if (slow) {
+        size_t oa, ol, oc, op;
+        leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
+        leaders_epilogue(I, reinterpret_cast<const u64*>(smem + ol), nb, reinterpret_cast<int*>(smem));
+        __syncthreads();
+        groups_body<E, SRC, true>(src, N, ld, counts, P, ws, L, Ppow2, b);
+        lds_barrier();
+        finalize_body<E, true, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+        return;
+    }
+    finalize_body<E, true, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+}
+
+template <int E>
+__device__ __forceinline__ void csr_build_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* cnt = reinterpret_cast<int*>(smem);                                         // members per leader rank
+    int* fill = cnt + E * 1024;
+    int* seg = fill + E * 1024;                                                      // the runs, members in arrival order
+    int* startL = seg + E * 1024;
+    __shared__ int s_cnt[4];                                                         // [0] verdict, [1] multi-member heads, [2] big heads
+    __shared__ int wave_tot[16];
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
+    if (wave == 0) {
+        const u64* g = I.gran + (size_t)16 * 32 + kGranVerdict;
+        u64 v = gran_load(g);
+        while ((v & 0xffffffff00000000ull) != epoch) { __builtin_amdgcn_s_sleep(8); v = gran_load(g); }
+        if (lane == 0) { s_cnt[0] = (int)(v & 3ull); s_cnt[1] = 0; s_cnt[2] = 0; }
+    }
+    for (int i = tid; i < E * 1024; i += 1024) { cnt[i] = 0; fill[i] = 0; }
+    __syncthreads();
+    if (s_cnt[0] != 1) return;                                                       // K5 proper ran (or runs): it builds the runs itself
+    int hd[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = e * 1024 + tid;
+        hd[e] = (k < n) ? rem_load(I.head, k) : -1;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) if (hd[e] >= 0) atomicAdd(&cnt[hd[e]], 1);
+    __syncthreads();
+    // run starts: exclusive scan of the counts over the ranks (thread t owns ranks t * E .. t * E + E - 1)
+    int c[E], sum = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { c[e] = cnt[tid * E + e]; sum += c[e]; }
+    const int inc = (int)gnms_add_scan32((unsigned)sum);
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { const int v = wave_tot[w]; if (w < wave) base += v; total += v; }
+    int run = base + inc - sum;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        startL[i] = run;
+        if (i < n) { I.gstart[i] = run; I.glen[i] = c[e]; }
+        // heads of multi-member groups -> hlist (any order), the big ones once more from the end (bwd_masked_*, solve_groups_kernel)
+        const bool multi = i < n && c[e] > 1;
+        const unsigned long long bm = __ballot(multi);
+        if (bm) {
+            int hb = 0;
+            if (lane == __builtin_ctzll(bm)) hb = atomicAdd(&s_cnt[1], __builtin_popcountll(bm));
+            hb = __builtin_amdgcn_readlane(hb, __builtin_ctzll(bm));
+            if (multi) I.hlist[hb + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = i;
+        }
+        if (i < n && c[e] > kBigGroupList) I.hlist[N - 1 - atomicAdd(&s_cnt[2], 1)] = i;
+        run += c[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) if (hd[e] >= 0) seg[startL[hd[e]] + atomicAdd(&fill[hd[e]], 1)] = e * 1024 + tid;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = e * 1024 + tid;
+        if (k >= N) continue;
+        int pos = -1;
+        if (hd[e] >= 0) {
+            const int st = startL[hd[e]], len = cnt[hd[e]];
+            pos = 0;
+            for (int i = 0; i < len; ++i) pos += seg[st + i] < k ? 1 : 0;            // rank order inside the run, whatever order the atomics ran in
+            I.gsorted[st + pos] = k;
+        }
+        I.gpos[k] = pos;
+        if (k >= n) { I.head[k] = -1; I.glen[k] = 0; }                               // padding ranks: in no group
+    }
+    for (int i = total + tid; i < n; i += 1024) I.gsorted[i] = -1;                   // (behind the members, as K5's sort leaves it)
+    if (tid == 0) { I.misc[1] = s_cnt[1]; I.misc[4] = s_cnt[2]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3..K6 in ONE launch (masked groups): leaders -> attribution -> groups + rescoring -> finalize.  Chain workgroups per image: `spw` for
+// the scan (the last one goes on with K4..K6), plus -- `fast` -- one for csr_build_body.
+// Ppow2 >= 1024 (smaller images pad their keys).  dynamic LDS = max(leaders table (+ cnt), Ppow2 * 16).
+// ------------------------------------------------------------------------------------------------
+// is the fast tail possible for this launch? (decided on the host; the kernels get it as `fast`)
+__host__ __device__ inline bool fast_tail_ok(int N, const gnms_params& P, int sym_arg, int chain_cap = 0) {
+    return N <= 4096 && P.group_boxes && P.mask_group_boxes && !P.presorted && sym_arg != 0 && chain_cap == 0;
+}
+
 template <int E, int SRC>
 __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
                                                     char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob,
                                                     long long* __restrict__ valid, long long* __restrict__ invalid, int* __restrict__ nvalid,
-                                                    int* __restrict__ ninvalid, int sym_arg, int B, int spw) {
+                                                    int* __restrict__ ninvalid, int sym_arg, int B, int spw, int fast) {
     int b;
+    if constexpr (E <= 4) {
+        if (fast) {
+            if ((int)blockIdx.x >= B * spw) {                            // the image's CSR workgroup
+                b = (int)blockIdx.x - B * spw;
+                const int symb = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;
+                if (symb) csr_build_body<E>(N, counts, ws, L, b);
+                return;
+            }
+            const int last = leaders_chain<SRC>(N, counts, ws, L, B, spw, (int)blockIdx.x, sym_arg, &b, src, ld, P.nms_threshold, P.temperature,
+                                                P.pruning_method, Ppow2);
+            if (!last) return;
+            if (last != 3) { fast_final_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b, last); return; }
+            __syncthreads();                                             // general scan: K4..K6 as before
+            attribute_image<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, 0);
+            __syncthreads();
+            groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
+            __syncthreads();
+            finalize_body<E, false, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+            return;
+        }
+    }
     if (!leaders_chain(N, counts, ws, L, B, spw, (int)blockIdx.x, sym_arg, &b)) return;   // (the image's other scan workgroups)
     const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;   // (2: wsym_check_kernel's verdict for this image)
     __syncthreads();
@@ -2238,7 +2509,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
         if constexpr (E <= 4) {
             groups_body<E, SRC, true>(src, N, ld, counts, P, ws, L, Ppow2, b);
             lds_barrier();
-            finalize_body<E, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+            finalize_body<E, true, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
         }
         return;
     }
@@ -2246,7 +2517,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     __syncthreads();
     groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
     __syncthreads();
-    finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+    finalize_body<E, false, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
 }
 
 }  // namespace

@@ -738,37 +738,59 @@ bool gnms_internal_iou2d_wants_self(const float* a, const float* b, int B, int M
     return units >= 8L * device_cu_count();
 }
 namespace {
-// The claim counters of iou2d_self_kernel live in a per-device RING of zeroed slots that the library allocates once (the first call on a
-// device; 1 MiB) -- a launch takes the next slot and leaves it zeroed (see the kernel), so a call neither allocates nor memsets.  Two
-// launches share a slot only if kClaimSlots launches of this kernel are in flight on one device at the same time, and one launch alone
-// fills every CU.  Images per call <= kClaimImgs (larger batches take iou2d_kernel).
-constexpr int kClaimSlots = 32, kClaimImgs = 127;
+// The claim counters of iou2d_self_kernel live in zeroed SLOTS of a per-device pool that the library allocates once (the first eager call on
+// a device; 2 MiB) -- a launch leaves its slot zeroed (see the kernel), so a call neither allocates nor memsets.  Who may share a slot
+// (a host-side round robin handed the same slot to launches that can run at the same time -- another stream, or a replayed graph
+// that had the pointer baked in -- which then shared claim and exit counters and each wrote only part of its matrix):
+//   * eager launches: ONE slot per (device, stream) -- launches of one stream run one after the other;
+//   * a launch that is being CAPTURED: a slot of its own, never handed out again -- whatever the graph later runs beside, nobody else
+//     counts in its slot (two replays of the same executable graph do not overlap);
+//   * no slot left, or a capture before the pool exists (no allocation inside a capture): the caller falls back to iou2d_kernel.
+// Images per call <= kClaimImgs (larger batches take iou2d_kernel).
+constexpr int kClaimSlots = 64, kClaimImgs = 127;
 constexpr size_t kClaimSlotInts = (size_t)(kClaimImgs + 1) * 64;
-int claim_ring_slot(int** slot) {
-    struct Ring { int* base = nullptr; unsigned next = 0; };
+constexpr int kNoClaimSlot = 1;                                      // (> 0: not an error code)
+int claim_slot_for(hipStream_t st, int** slot) {
+    struct Pool { int* base = nullptr; int eager_next = 0, capture_next = kClaimSlots - 1; std::map<hipStream_t, int> by_stream; };
     static std::mutex mu;
-    static std::map<int, Ring> rings;
+    static std::map<int, Pool> pools;
     int dev = 0;
     GNMS_CHECK_HIP(hipGetDevice(&dev));
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     std::lock_guard<std::mutex> lock(mu);
-    Ring& R = rings[dev];
+    Pool& R = pools[dev];
     if (!R.base) {
+        if (capturing) return kNoClaimSlot;
         int* p = nullptr;
         GNMS_CHECK_HIP(hipMalloc((void**)&p, kClaimSlots * kClaimSlotInts * sizeof(int)));
         const hipError_t e = hipMemset(p, 0, kClaimSlots * kClaimSlotInts * sizeof(int));
         if (e != hipSuccess) { (void)hipFree(p); GNMS_CHECK_HIP(e); }
         R.base = p;
     }
-    *slot = R.base + (size_t)(R.next++ % kClaimSlots) * kClaimSlotInts;
+    int idx;
+    if (capturing) {
+        if (R.capture_next < R.eager_next) return kNoClaimSlot;
+        idx = R.capture_next--;
+    } else {
+        auto it = R.by_stream.find(st);
+        if (it != R.by_stream.end()) idx = it->second;
+        else {
+            if (R.eager_next > R.capture_next) return kNoClaimSlot;
+            idx = R.by_stream[st] = R.eager_next++;
+        }
+    }
+    *slot = R.base + (size_t)idx * kClaimSlotInts;
     return GNMS_OK;
 }
 }  // namespace
+// (returns 1 -- not an error -- when no claim slot is to be had: gnms_iou2d then runs iou2d_kernel)
 int gnms_internal_iou2d_self(const float* boxes, int B, int N, float* out, int64_t ld, hipStream_t st) {
     const int cus = device_cu_count();
     int grid = cus - 8;                                              // (alone on the machine the stream likes every CU: 248 -> 0.71, 200 -> 0.64)
     if (grid < 1) grid = 1;
     int* claims = nullptr;
-    int rc = claim_ring_slot(&claims);
+    int rc = claim_slot_for(st, &claims);
     if (rc) return rc;
     size_t lds = (size_t)N * 16;
     if (lds < 96 * 1024) lds = 96 * 1024;                            // > 80 KiB: one workgroup per CU
@@ -796,7 +818,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
                                                           float* __restrict__ prob, long long* __restrict__ valid,
                                                           long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
                                                           int nimg, float* __restrict__ out, long ld, int tile_rows, int row0, int row_end,
-                                                          int staged) {
+                                                          int staged, int fast) {
 #ifdef GNMS_HWID    // developer experiment (tools/hwid_map.py): where the dispatcher put every workgroup of this launch
     if (threadIdx.x == 0) {
         unsigned* dbg = reinterpret_cast<unsigned*>(img_ptrs(ws, L, 0).rec);
@@ -804,8 +826,9 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         dbg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg(63508);   // XCC_ID
     }
 #endif
-    const int spw = leaders_chain_wgs(N, 1);                          // chain workgroups per image (the from-boxes / from-records bit matrices are symmetric)
-    if ((int)blockIdx.x < nimg * spw) {
+    const int spw = leaders_chain_wgs(N, 1);                          // scan workgroups per image (the from-boxes / from-records bit matrices are symmetric)
+    const int cwg = spw + (fast ? 1 : 0);                             // + the fast tail's CSR workgroup (csr_build_body)
+    if ((int)blockIdx.x < nimg * cwg) {
         int b;
 #ifdef GNMS_TIMING
         long long tt__ = (long long)__builtin_amdgcn_s_memtime();
@@ -813,6 +836,17 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
 #else
 #define GNMS_TW_ACC(slot) do {} while (0)
 #endif
+        if constexpr (E <= 4) {
+            if (fast) {                                               // masked groups: leaders_sb_body<STAGE> -> fast_final_body ‖ csr_build_body
+                if ((int)blockIdx.x >= nimg * spw) { csr_build_body<E>(N, counts, ws, L, (int)blockIdx.x - nimg * spw); return; }
+                const int last = leaders_chain<SRC>(N, counts, ws, L, nimg, spw, (int)blockIdx.x, 1, &b, chain_src, (long)N, P.nms_threshold,
+                                                    P.temperature, P.pruning_method, Ppow2);
+                GNMS_TW_ACC(5);
+                if (last) fast_final_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b, last);
+                GNMS_TW_ACC(15);
+                return;
+            }
+        }
         if (!leaders_chain(N, counts, ws, L, nimg, spw, (int)blockIdx.x, 1, &b)) return;   // (the image's other scan workgroups)
         __syncthreads();
         GNMS_TW_ACC(5);
@@ -822,7 +856,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
                 groups_body<E, SRC, true>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
                 gnms::lds_barrier();
                 GNMS_TW_ACC(7);
-                finalize_body<E, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+                finalize_body<E, true, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
                 GNMS_TW_ACC(15);
             }
             return;
@@ -835,11 +869,11 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         if (!P.mask_group_boxes) return;                              // unmasked groups: the solves (a launch of their own) come before K6
         __syncthreads();
         GNMS_TW_ACC(7);
-        finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+        finalize_body<E, false, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
         GNMS_TW_ACC(15);
         return;
     }
-    const int first_writer = nimg * spw;
+    const int first_writer = nimg * cwg;
     if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, img_ptrs(ws, L, 0).misc + 5, L.per_image / sizeof(int), first_writer); return; }
     if (SRC == kFromRecords && staged == 2) { writers_sym_persistent<true>(write_src, N, out, ld, nimg, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5); return; }
     writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
@@ -930,6 +964,12 @@ bool use_tail_kernel(int N, int sym = 0) {
 constexpr int kBesideChainWGs = 1;
 
 // K3..K6 in one launch (masked groups); SRC/src: kFromMatrix (the matrix), kFromBoxes (the boxes), kFromRecords (src unused)
+// the fast tail (nms_kernels.h): on unless GNMS_FAST_TAIL=0 (developer switch: the K5-proper path stays reachable for A/B runs and tests)
+bool fast_tail_enabled() {
+    static const bool on = [] { const char* e = getenv("GNMS_FAST_TAIL"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int BOXES>
 int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* counts, const gnms_params& P, char* ws, const gnms_ws_layout& L,
                 float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, hipStream_t st, int sym, int chain_cap = 0) {
@@ -937,13 +977,15 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     if (P2 < 1024) P2 = 1024;                                   // the fused kernel always runs 1024 threads
     // (the fused K5 -> K6 hand-off, E <= 4, parks order[] and a copy of r2 behind the key region: 16 bytes per key)
     const size_t llds = leaders_lds_bytes(N), glds = (size_t)P2 * (P2 <= 4096 ? 16 : 8);
-    const size_t lds = llds > glds ? llds : glds;
+    size_t lds = llds > glds ? llds : glds;
+    const int fast = (fast_tail_enabled() && fast_tail_ok(N, P, sym, chain_cap)) ? 1 : 0;
+    if (fast && lds < fast_tail_lds_size(N, P2)) lds = fast_tail_lds_size(N, P2);
     int rc;
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(tail_kernel<E, BOXES>, lds))) return rc;
         const int spw = leaders_chain_wgs(N, sym, chain_cap);
-        tail_kernel<E, BOXES><<<B * spw, 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
-                                                          ninvalid, sym, B, spw);
+        tail_kernel<E, BOXES><<<B * (spw + fast), 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
+                                                          ninvalid, sym, B, spw, fast);
     });
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
@@ -979,6 +1021,8 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
         if (lds < 2 * gnms_iou3d::kSymTileBytes) lds = 2 * gnms_iou3d::kSymTileBytes;
         writers = (long)gnms_iou3d::sym_tiles_per_image(N) * B;
     }
+    const int fast = (fast_tail_enabled() && fast_tail_ok(N, P, 1)) ? 1 : 0;
+    if (fast && lds < fast_tail_lds_size(N, P2)) lds = fast_tail_lds_size(N, P2);
     const int cus = device_cu_count();
     if (writers > cus) writers = cus;
     // How many CUs write.  With the packed row body (iou_tile.h) a writer workgroup sustains ~29 GB/s and the stream saturates near
@@ -992,18 +1036,18 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     // store stream itself likes, GNMS_TAIL_WRITERS)
     const int cap = writers_cap > 0 ? writers_cap : (staged == 1 ? (cus * 208) / 256 : 0);
     if (cap > 0 && writers > cap) writers = cap;
-    const dim3 grid((unsigned)(B * leaders_chain_wgs(N, 1) + writers));
+    const dim3 grid((unsigned)(B * (leaders_chain_wgs(N, 1) + fast) + writers));
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
     int rc;
     GNMS_DISPATCH_SORT(P2, {
         if (vec) {
             if ((rc = allow_lds(tail_write_kernel<true, E, SRC>, lds))) return rc;
             gnms_launch_prof(kProfMatrixWrite, tail_write_kernel<true, E, SRC>, grid, dim3(1024), lds, st, chain_src, write_src, N, counts, P, ws,
-                             L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, staged);
+                             L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, staged, fast);
         } else {
             if ((rc = allow_lds(tail_write_kernel<false, E, SRC>, lds))) return rc;
             gnms_launch_prof(kProfMatrixWrite, tail_write_kernel<false, E, SRC>, grid, dim3(1024), lds, st, chain_src, write_src, N, counts, P,
-                             ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, staged);
+                             ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, staged, fast);
         }
     });
     GNMS_CHECK_LAUNCH();

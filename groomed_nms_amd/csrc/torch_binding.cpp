@@ -105,7 +105,9 @@ struct Layer : public torch::autograd::Function<Layer> {
             // (possibly caller-provided) buffer between forward and backward instead of silently producing wrong gradients.
             // Grouped unmasked 2D: the backward solves its groups from the BOXES (gnms_backward_from_boxes: bit-identical overlaps, no matrix
             // reads, a caller may reuse iou_out at once); only the ungrouped mode and the 3D entry still read the matrix back.
-            if (!three_d && group && !mask && !presorted) { kept = boxes; bwd_boxes = true; }
+            // (the same predicate as gnms_forward_with_iou2d's from-boxes gate, alignment included: for an unaligned view of the boxes the forward took
+            // the matrix path, and the backward must not run float4 loads on that pointer -- ADVICE r4)
+            if (!three_d && group && !mask && !presorted && (reinterpret_cast<uintptr_t>(boxes.data_ptr()) % 16 == 0)) { kept = boxes; bwd_boxes = true; }
             else if (!(group && mask)) kept = iou;
         }
         ctx->set_materialize_grads(false);                               // no zero-filled "gradients" for the index outputs

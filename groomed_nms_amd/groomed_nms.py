@@ -199,7 +199,9 @@ class _GroomedNMSWithIouFunction(torch.autograd.Function):
         # backward does read it: there it is saved through autograd, whose version counter then catches a caller that overwrites the
         # (possibly caller-provided) `iou_out` buffer between forward and backward instead of silently producing wrong gradients.
         # Grouped unmasked 2D: the backward solves its groups from the boxes (gnms_backward_from_boxes: bit-identical overlaps, no matrix reads).
-        ctx.bwd_boxes = bool((not three_d) and params.group_boxes and not params.mask_group_boxes and not params.presorted)
+        # (the forward's own from-boxes gate, alignment included: an unaligned view took the matrix path and keeps the matrix -- ADVICE r4)
+        ctx.bwd_boxes = bool((not three_d) and params.group_boxes and not params.mask_group_boxes and not params.presorted
+                             and boxes_c.data_ptr() % 16 == 0)
         ctx.reads_iou = not (params.group_boxes and params.mask_group_boxes) and not ctx.bwd_boxes
         if ctx.bwd_boxes:
             ctx.save_for_backward(scores_c, counts, ws, boxes_c)

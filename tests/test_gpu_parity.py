@@ -2058,8 +2058,9 @@ def test_leader_scan_across_workgroups(G, O):
 
 
 def test_library_switches():
-    """The four environment switches the shipped library still reads, each against the default run of the
-    same inputs: GNMS_TWO_STREAMS=0 (large images: every launch on the caller's stream instead of the library's side stream),
+    """The five environment switches the shipped library still reads, each against the default run of the
+    same inputs: GNMS_FAST_TAIL=0 (round 5: K5 proper -- the sort of the groups -- instead of the fast tail; probabilities, lists AND gradients,
+    i.e. the groups' runs the backward reads, must be the same bit for bit), GNMS_TWO_STREAMS=0 (large images: every launch on the caller's stream instead of the library's side stream),
     GNMS_MATRIX_SYM=0 (matrix-in layer: the general scan also for symmetric matrices), GNMS_TAIL_WRITERS=n (CUs that write the matrix
     beside the per-image chain) and GNMS_TRACE_LAUNCH=1 (developer: launch sites printed, device synchronised behind each)."""
     code = """
@@ -2069,10 +2070,23 @@ from groomed_nms_amd import synthetic, overlaps
 out = {}
 b, s = synthetic.batch_2d(7, 2, 4096, "uniform")
 bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+st.requires_grad_(True)
+wt = torch.linspace(-1.0, 2.0, 4096, device="cuda").repeat(2, 1)
 o = G.differentiable_nms_with_iou2d_batched(st, bt)
-out["one_prob"], out["one_valid"], out["one_iou_sum"] = o[0].cpu().numpy(), o[2].cpu().numpy(), o[6].double().sum().cpu().numpy()
+out["one_prob"], out["one_valid"], out["one_iou_sum"] = o[0].detach().cpu().numpy(), o[2].cpu().numpy(), o[6].double().sum().cpu().numpy()
+(o[0] * wt).sum().backward()
+out["one_grad"] = st.grad.cpu().numpy().copy()
+st.grad = None
 m = G.differentiable_nms_batched(st, overlaps.iou_batched(bt))
-out["two_prob"], out["two_valid"] = m[0].cpu().numpy(), m[2].cpu().numpy()
+out["two_prob"], out["two_valid"] = m[0].detach().cpu().numpy(), m[2].cpu().numpy()
+(m[0] * wt).sum().backward()
+out["two_grad"] = st.grad.cpu().numpy().copy()
+for gs in (2, 30):            # groups above the cap: the fast tail's verdict is "slow"
+    bc, sc_ = synthetic.batch_2d(11, 2, 3000, "clustered")
+    sct = torch.from_numpy(sc_).cuda().requires_grad_(True)
+    o = G.differentiable_nms_with_iou2d_batched(sct, torch.from_numpy(bc).cuda(), group_size=gs)
+    (o[0] * wt[:, :3000]).sum().backward()
+    out["cap%d_prob" % gs], out["cap%d_valid" % gs], out["cap%d_grad" % gs] = o[0].detach().cpu().numpy(), o[2].cpu().numpy(), sct.grad.cpu().numpy().copy()
 b, s = synthetic.batch_2d(8, 2, 8192, "clustered")
 bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
 o = G.differentiable_nms_with_iou2d_batched(st, bt)
@@ -2086,7 +2100,7 @@ print("ok")
 """
     runs = {}
     for tag, env in (("default", {}), ("one_stream", {"GNMS_TWO_STREAMS": "0"}), ("general_scan", {"GNMS_MATRIX_SYM": "0"}),
-                     ("few_writers", {"GNMS_TAIL_WRITERS": "40"}), ("trace", {"GNMS_TRACE_LAUNCH": "1"})):
+                     ("few_writers", {"GNMS_TAIL_WRITERS": "40"}), ("trace", {"GNMS_TRACE_LAUNCH": "1"}), ("k5_proper", {"GNMS_FAST_TAIL": "0"})):
         path = "/tmp/gnms_switch_%s.npz" % tag
         r = _run_py(code, env, argv=(path,))
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stderr[-2000:])
@@ -2281,3 +2295,83 @@ def test_fuzz_3d_one_call_against_its_own_matrix(G):
                 continue                                                      # NaN overlaps: the order among NaN rows is the sort's, compared elsewhere
             assert torch.equal(one[0][b, :n], two[0][b, :n]), tag
             assert int(one[4][b]) == int(two[4][b]) and torch.equal(one[2][b, :int(one[4][b])], two[2][b, :int(two[4][b])]), tag
+
+
+@pytest.mark.gpu
+def test_empty_images_and_the_fast_tail_on_poisoned_outputs(G, O):
+    """an image with counts[b] == 0 must still get its outputs -- the symmetric scan's one (empty) super-block has to reach
+    K6, the only writer of prob / nvalid / ninvalid / the index lists.  Every entry that takes that scan (one-call 2D / 3D, from boxes, matrix-in
+    with the symmetry check from N = 256), output buffers POISONED before the call (0xff bytes: NaN probabilities, -1 counts would pass as
+    padding, so the lists are poisoned with 0x7f) and compared over the FULL rows; counts that leave whole super-blocks of the launch without
+    work; and the non-empty images of the same batch against the oracle, gradients included (the fast tail's CSR workgroup built the runs)."""
+    import ctypes
+    from groomed_nms_amd import synthetic, _lib
+    from groomed_nms_amd._lib import GnmsParams, ptr, check
+    lib = _lib.load()
+    P = GnmsParams()
+    lib.gnms_default_params(ctypes.byref(P))
+    dev = torch.device("cuda")
+    for dim, N, counts in ((2, 256, [0, 256, 0, 100]), (2, 1024, [0, 1024, 1, 0]), (2, 4096, [0, 4096, 1024, 1025, 0]), (2, 8192, [0, 8192, 100]),
+                           (3, 256, [0, 256, 7]), (3, 2048, [2048, 0, 1000]), (3, 4096, [0, 3000, 0]), (2, 3000, [0, 0, 0])):
+        B = len(counts)
+        if dim == 2:
+            src_np, sc_np = synthetic.batch_2d(50 + N, B, N, "uniform")
+        else:
+            src_np, sc_np = synthetic.batch_3d(50 + N, B, N, clustered=False)
+        src, sc = torch.from_numpy(src_np).to(dev), torch.from_numpy(sc_np).to(dev)
+        ct = torch.tensor(counts, dtype=torch.int32, device=dev)
+        nbytes = lib.gnms_workspace_bytes(B, N, ctypes.byref(P))
+        wgt = torch.linspace(-1.0, 2.0, N, device=dev).repeat(B, 1).contiguous()
+        entries = ("one_call", "matrix_in") + (("from_boxes",) if dim == 2 else ())
+        for entry in entries:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev).fill_(0xA5)
+            iou = torch.empty((B, N, N), device=dev)
+            prob = torch.empty((B, N), device=dev)
+            prob.view(torch.uint8).fill_(0xFF)
+            valid = torch.empty((B, N), dtype=torch.int64, device=dev)
+            invalid = torch.empty((B, N), dtype=torch.int64, device=dev)
+            valid.view(torch.uint8).fill_(0x7F)
+            invalid.view(torch.uint8).fill_(0x7F)
+            nv = torch.full((B,), -7, dtype=torch.int32, device=dev)
+            ni = torch.full((B,), -7, dtype=torch.int32, device=dev)
+            grad = torch.empty((B, N), device=dev)
+            grad.view(torch.uint8).fill_(0xFF)
+            if entry == "one_call":
+                fwd = lib.gnms_forward_with_iou2d if dim == 2 else lib.gnms_forward_with_iou3d
+                check(fwd(ptr(src), ptr(sc), B, N, N, ptr(ct), ctypes.byref(P), ptr(iou), ptr(prob), None, ptr(valid), ptr(invalid), ptr(nv), ptr(ni),
+                          ptr(ws), nbytes, None), "fwd")
+            elif entry == "from_boxes":
+                check(lib.gnms_forward_from_boxes(ptr(src), ptr(sc), B, N, ptr(ct), ctypes.byref(P), ptr(prob), None, ptr(valid), ptr(invalid), ptr(nv),
+                                                  ptr(ni), ptr(ws), nbytes, None), "fwd")
+            else:
+                if dim == 2:
+                    check(lib.gnms_iou2d(ptr(src), ptr(src), B, N, N, ptr(iou), N, None), "iou2d")
+                else:
+                    check(lib.gnms_nms_overlap3d_from_params(ptr(src), B, N, float(P.nms_threshold), ptr(iou), N, None), "overlap3d")
+                check(lib.gnms_forward(ptr(sc), ptr(iou), B, N, N, ptr(ct), ctypes.byref(P), ptr(prob), None, ptr(valid), ptr(invalid), ptr(nv), ptr(ni),
+                                       ptr(ws), nbytes, None), "fwd")
+            check(lib.gnms_backward(ptr(wgt), ptr(sc), ptr(iou), B, N, N, ptr(ct), ctypes.byref(P), ptr(grad), None, ptr(ws), nbytes, None), "bwd")
+            torch.cuda.synchronize()
+            for b in range(B):
+                n, tag = counts[b], (dim, N, entry, b)
+                k, j = int(nv[b]), int(ni[b])
+                assert k >= 0 and j >= 0 and k + j <= n, tag
+                pb = prob[b].cpu().numpy()
+                assert np.all(pb[n:] == 0), tag                                     # (no NaN poison left: every entry of the row was written)
+                assert torch.all(valid[b, k:] == -1) and torch.all(invalid[b, j:] == -1), tag
+                assert torch.all(grad[b, n:] == 0), tag
+                if n == 0:
+                    continue
+                if dim == 2:
+                    m = O.iou2d(src_np[b, :n], src_np[b, :n])
+                else:
+                    m = _oracle_overlap3d(O, O.corners_of_cuboid(src_np[b, :n]))
+                ref = O.differentiable_nms(sc_np[b, :n], m, grad_prob=wgt[b, :n].cpu().numpy())
+                if dim == 2:
+                    assert np.array_equal(pb[:n], ref["prob"]), tag
+                    assert valid[b, :k].tolist() == list(ref["valid"]) and invalid[b, :j].tolist() == list(ref["invalid"]), tag
+                    assert np.array_equal(grad[b, :n].cpu().numpy(), ref["grad_scores"]), tag
+                else:                                                               # (guard band of the 3D overlap: TOL, conftest)
+                    np.testing.assert_allclose(pb[:n], ref["prob"], atol=TOL, err_msg=str(tag))
+                    np.testing.assert_allclose(grad[b, :n].cpu().numpy(), ref["grad_scores"], atol=TOL, rtol=1e-4, err_msg=str(tag))
+                    check_index_lists(valid[b, :k].cpu().numpy(), invalid[b, :j].cpu().numpy(), ref["valid"], ref["invalid"])

@@ -38,8 +38,8 @@ ni = torch.empty((B,), dtype=torch.int32, device="cuda") if a.lists else None
 lp = lambda t: ptr(t) if t is not None else None
 n4 = (4 * N + 255) // 256 * 256
 off_gx = 15 * n4
-names = {21: "resolve (wave 15): table words to registers", 22: "resolve (wave 15): dirty check + AND pass", 23: "resolve (wave 15): in-block fixed point + publish", 24: "resolve (wave 15): barrier", 20: "leaders_sym resolve rounds (count)", 5: "CHAIN leaders total", 6: "CHAIN attribute total", 7: "CHAIN groups total", 15: "CHAIN finalize total", 0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store",
-         4: "leaders barrier B", 8: "groups keys", 9: "groups radix", 10: "groups runs", 11: "groups rescoring", 12: "finalize classify", 13: "finalize sort",
+names = {21: "resolve (wave 15): table words to registers", 22: "resolve (wave 15): dirty check + AND pass", 23: "resolve (wave 15): in-block fixed point + publish", 24: "resolve (wave 15): barrier", 20: "leaders_sym resolve rounds (count)", 5: "CHAIN leaders total", 6: "CHAIN attribute total", 7: "CHAIN groups total", 15: "CHAIN finalize total", 0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store / sym scan: wait for the other workgroups",
+         4: "leaders barrier B / sym scan: rem + fast-tail stage A", 8: "groups keys / fast tail: loads + cap check", 9: "groups radix / fast tail: store acks + barrier", 10: "groups runs", 11: "groups rescoring", 12: "finalize classify", 13: "finalize sort",
          14: "finalize output"}
 tot = np.zeros(28, np.int64)
 for rep in range(a.reps + 2):
