@@ -1164,11 +1164,19 @@ constexpr int kSB = 16;
 constexpr int kSBPairs = kSB * (kSB + 1) / 2;
 constexpr int kTabPer = (kSBPairs * 64 + 959) / 960;            // table entries per prefetching thread (waves 1..15)
 
-#ifdef GNMS_TIMING   // developer instrumentation (tools/microbench.hip): accumulates s_memtime deltas into ws gx[] of image 0
+#ifdef GNMS_TIMING   // developer instrumentation (tools/phase_ticks.py): s_memtime deltas of thread 0 (GNMS_RACC: thread 960) of image 0's workgroups
+// accumulate in LDS -- round 5: a global read-modify-write per marker stalled wave 0 for a memory round trip, which the next barrier then
+// waited for (every slot read ~1 us too long) -- and go to ws gx[] of image 0 once, at the end of the kernel (GNMS_TFLUSH)
+__device__ __forceinline__ long long* gnms_tbuf() { __shared__ long long buf[32]; return buf; }
+#define GNMS_TINIT() do { if (threadIdx.x < 32) gnms::gnms_tbuf()[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define GNMS_TFLUSH(ws_, L_, img_) do { __syncthreads(); if (threadIdx.x < 32 && (img_) == 0 && gnms::gnms_tbuf()[threadIdx.x]) \
+        atomicAdd(reinterpret_cast<unsigned long long*>(gnms::img_ptrs(ws_, L_, 0).gx) + threadIdx.x, (unsigned long long)gnms::gnms_tbuf()[threadIdx.x]); } while (0)
 #define GNMS_T0() long long t__ = (long long)__builtin_amdgcn_s_memtime()
-#define GNMS_TACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && b == 0) ((long long*)I.gx)[slot] += n__ - t__; t__ = n__; } while (0)   /* image 0's workgroup */
-#define GNMS_TACC_IF(cond, slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && (cond)) ((long long*)I.gx)[slot] += n__ - t__; t__ = n__; } while (0)
+#define GNMS_TACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && b == 0) gnms::gnms_tbuf()[slot] += n__ - t__; t__ = n__; } while (0)   /* image 0's workgroup */
+#define GNMS_TACC_IF(cond, slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && (cond)) gnms::gnms_tbuf()[slot] += n__ - t__; t__ = n__; } while (0)
 #else
+#define GNMS_TINIT() do {} while (0)
+#define GNMS_TFLUSH(ws_, L_, img_) do {} while (0)
 #define GNMS_TACC_IF(cond, slot) do {} while (0)
 #define GNMS_T0() do {} while (0)
 #define GNMS_TACC(slot) do {} while (0)
@@ -1385,47 +1393,21 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
         }
     }
     GNMS_TACC_IF(b == 0 && last_sb, 0);
-    // ---- the earlier super-blocks, in ascending order: row segments requested, masks awaited, ANDed ----
     const int tb = wave;                                           // this wave's block of the super-block
     const bool live = tb < nblk;
     const int kT = ((kb0 + (live ? tb : 0)) << 6) + lane;          // this lane's rank
-    int cl = -1;                                                   // rank of the first leader (of an earlier super-block) that overlaps it
-    lds_barrier();                                                 // (the previous super-block of this workgroup is done with the table and the stamps)
-    for (int s = 0; s < j; ++s) {
-        const int s0 = s * kSB;
-        u64 wv[kSB];
-#pragma unroll
-        for (int bb = 0; bb < kSB; ++bb) wv[bb] = (live && kT < n) ? I.W[(size_t)(s0 + bb) * L.NC + kT] : 0ull;
-        if (wave == 0 && s >= have) {                              // the masks of super-block s (another workgroup's, not seen yet): 32 granules, lane g polls granule g
-            const u64* g = I.gran + (size_t)s * 32 + (lane & 31);
-            u64 v = gran_load(g);
-            while (__ballot((v & 0xffffffff00000000ull) != epoch) != 0ull) { __builtin_amdgcn_s_sleep(2); v = gran_load(g); }
-            reinterpret_cast<unsigned*>(lmask + s0)[lane & 31] = (unsigned)(v & 0xffffffffu);   // (lanes 32..63 write the same words again)
-        }
-        lds_barrier();
-        int c = -1;
-#pragma unroll
-        for (int bb = 0; bb < kSB; ++bb) {
-            const u64 m = wv[bb] & lmask[s0 + bb];
-            if (c < 0 && m != 0ull) c = ((s0 + bb) << 6) + __builtin_ctzll(m);
-        }
-        if (cl < 0) cl = c;
-    }
-    if (j + 1 > have) have = j + 1;                                // (every super-block up to j is in lmask from here on: polled above, or this workgroup's own)
-    const u64 ext = __ballot(cl >= 0);                             // removed-word of the wave's block (earlier super-blocks' leaders)
-    lds_barrier();                                                 // the table is in LDS
-    GNMS_TACC_IF(b == 0 && last_sb, 1);
+    lds_barrier();                                                 // the table is in LDS (and the previous super-block of this workgroup is done with it and the stamps)
     // ---- resolve of the own super-block: every wave its block, steps until no mask changes ----
 #ifdef GNMS_TIMING
     long long r__ = (long long)__builtin_amdgcn_s_memtime();
-#define GNMS_RACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 960 && b == 0 && last_sb) ((long long*)I.gx)[slot] += n__ - r__; r__ = n__; } while (0)
+#define GNMS_RACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 960 && b == 0 && last_sb) gnms_tbuf()[slot] += n__ - r__; r__ = n__; } while (0)
 #else
 #define GNMS_RACC(slot) do {} while (0)
 #endif
     const int tbc = live ? tb : 0;
     const int k0 = (kb0 + tbc) << 6;
-    u64 fixed = ext;                                               // never leaders: taken by earlier super-blocks, or past the image's last rank
-    if (live) { const int nrows = min(64, n - k0); if (nrows < 64) fixed |= ~((1ull << nrows) - 1ull); }
+    u64 tailmask = 0ull;                                           // past the image's last rank: never leaders
+    if (live) { const int nrows = min(64, n - k0); if (nrows < 64) tailmask = ~((1ull << nrows) - 1ull); }
     const u64* myX = Xs + (size_t)(tbc * (tbc + 1) / 2) * 64 + lane;   // this wave's table words: source block bb at myX[bb * 64]
     const u64* myL = lmask + kb0;                                  // (lmask is padded by kSB entries: no clamp)
     const u64 cs = live ? (myX[tbc * 64] & below) : 0ull;          // earlier ranks of the block that overlap rank k0 + lane
@@ -1438,19 +1420,25 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
     }
     u64 mine = 0ull;                                               // this block's leader mask as last published (lmask[kb0 + tb])
     GNMS_RACC(21);
-    {
-        u64 cur_prev = ~0ull;
-        bool first = true;
-        int looked = 0;                                            // the step of this wave's last look at the earlier masks
-        int step = 1;
+    // (Round 5 ran this fixed point SPECULATIVELY while the workgroup waits -- cold with no external removals, then warm after every source
+    // ANDed in -- so that only a confirming step or two would be left behind the last source's masks.  Measured: no gain; on NMS inputs every
+    // source removes ranks in all 16 blocks, the repair cascades through the blocks like a cold resolve (17 steps in all where there were 4,
+    // the final call as long as before, the chain 10 k ticks longer).  One call, behind the last source.)
+    u64 cur_prev = ~0ull;
+    bool first = true;
+    int looked = 0;                                                // the step of this wave's last look at the earlier masks
+    int step = 1;
+    auto resolve = [&](const u64 ext) {
+        const u64 fixed = ext | tailmask;                          // never leaders: taken by earlier super-blocks, or past the image's last rank
+        bool force = true;
         for (;;) {
             if (live) {                                            // (wave-uniform)
                 // did a block before mine change since I last looked?  (lane bb holds block bb's stamp)
-                const bool dirty = first || __ballot(lane < tb && bstamp[lane < kSB ? lane : 0] >= looked) != 0ull;
+                const bool dirty = force || __ballot(lane < tb && bstamp[lane < kSB ? lane : 0] >= looked) != 0ull;
                 if (dirty) {
                     looked = step;
                     unsigned vlo = 0u, vhi = 0u;
-                    if (!first) {                                  // (the first look finds every mask of the super-block still zero)
+                    if (!first) {                                  // (the very first look finds every mask of the super-block still zero)
 #pragma unroll
                         for (int bb = 0; bb < kSB - 1; ++bb) {      // (one batch of reads: behind a branch per group of blocks they serialise)
                             const u64 l = myL[bb];
@@ -1481,16 +1469,43 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
                     GNMS_RACC(23);
                 }
             }
+            force = false;
             lds_barrier();
             GNMS_RACC(24);
             const int last = *stamp;
             ++step;
             if (step - last > 1) break;                            // a whole step without a change (a faster wave may have stamped a later step: still <=)
         }
-#ifdef GNMS_TIMING
-        if (threadIdx.x == 0 && b == 0 && last_sb) ((long long*)I.gx)[20] += step;
-#endif
+    };
+    // ---- the earlier super-blocks, in ascending order: row segments requested, masks awaited, ANDed ----
+    int cl = -1;                                                   // rank of the first leader (of an earlier super-block) that overlaps it
+    for (int s = 0; s < j; ++s) {
+        const int s0 = s * kSB;
+        u64 wv[kSB];
+#pragma unroll
+        for (int bb = 0; bb < kSB; ++bb) wv[bb] = (live && kT < n) ? I.W[(size_t)(s0 + bb) * L.NC + kT] : 0ull;
+        if (wave == 0 && s >= have) {                              // the masks of super-block s (another workgroup's, not seen yet): 32 granules, lane g polls granule g
+            const u64* g = I.gran + (size_t)s * 32 + (lane & 31);
+            u64 v = gran_load(g);
+            while (__ballot((v & 0xffffffff00000000ull) != epoch) != 0ull) { __builtin_amdgcn_s_sleep(2); v = gran_load(g); }
+            reinterpret_cast<unsigned*>(lmask + s0)[lane & 31] = (unsigned)(v & 0xffffffffu);   // (lanes 32..63 write the same words again)
+        }
+        lds_barrier();
+        int c = -1;
+#pragma unroll
+        for (int bb = 0; bb < kSB; ++bb) {
+            const u64 m = wv[bb] & lmask[s0 + bb];
+            if (c < 0 && m != 0ull) c = ((s0 + bb) << 6) + __builtin_ctzll(m);
+        }
+        if (cl < 0) cl = c;
     }
+    if (j + 1 > have) have = j + 1;                                // (every super-block up to j is in lmask from here on: polled above, or this workgroup's own)
+    const u64 ext = __ballot(cl >= 0);                             // removed-word of the wave's block (earlier super-blocks' leaders)
+    GNMS_TACC_IF(b == 0 && last_sb, 1);
+    resolve(ext);
+#ifdef GNMS_TIMING
+    if (threadIdx.x == 0 && b == 0 && last_sb) gnms_tbuf()[20] += step;
+#endif
     // ---- publish the masks (the chain's critical path ends here), then rem[] ----
     if (!last_sb && wave == 0 && lane < 32) {
         const unsigned half = reinterpret_cast<const unsigned*>(lmask + kb0)[lane];
@@ -1513,12 +1528,11 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
         if (((mine >> lane) & 1ull) == 0ull) r = ((ext >> lane) & 1ull) ? cl : c;
         if constexpr (STAGE != kNoStage) {
             // the last workgroup's last super-block stays in LDS for fast_final_body (the table is dead: every wave has passed a barrier behind
-            // its last read of it): r2 by position, the input index by rank, a second copy of r2, head by rank -- finalize_body<E, true>'s layout
+            // its last read of it): r2, head and input index by rank
             const bool park = last_wg && j == j1 - 1;
-            float* stageL = reinterpret_cast<float*>(smem);
+            float* r2L = reinterpret_cast<float*>(smem);                             // (finalize_fast_body's layout)
             int* hdL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4);
             int* ordL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 8);
-            float* r2L = reinterpret_cast<float*>(smem + (size_t)Ppow2 * 12);
             if (live && k < n) {
                 const int lr = r;
                 float sl = st_sk, ov;
@@ -1539,7 +1553,7 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
                     else { pl = gnms_prune(ov, stage_thr, stage_temp, stage_prune); pre = st_sk - pl * sl; }
                 } else if (lr == k) complex_img = 1;               // a leader outside its own group (NaN / <= thr diagonal): K5 proper decides the heads
                 const float r2 = pre < 0.0f ? 0.0f : (pre > 1.0f ? 1.0f : pre);      // torch.clamp keeps NaN
-                if (park) { stageL[k] = r2; hdL[k] = hd; ordL[k] = st_ck; r2L[k] = r2; }
+                if (park) { r2L[k] = r2; hdL[k] = hd; ordL[k] = st_ck; }
                 rem_store(I.rem, k, r);
                 rem_store(I.head, k, hd);
                 __hip_atomic_store(I.plead + k, pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2109,8 +2123,7 @@ __global__ __launch_bounds__(1024) void groups_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // STAGED (behind groups_body<E, SRC, true>, masked groups): the clamped values already sit in `stage` and the input index of every
 // rank in LDS behind the key region (ordL); r2 is in global memory as well.
-// HEADS (the fast tail): the valid heads come in sorted order (see the sort below).
-template <int E, bool STAGED = false, bool HEADS = false>
+template <int E, bool STAGED = false>
 __device__ __forceinline__ void finalize_body(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                               int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
                                               long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
@@ -2297,7 +2310,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __rest
                                                         int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
                                                         long long* __restrict__ invalid, int* __restrict__ nvalid,
                                                         int* __restrict__ ninvalid) {
-    finalize_body<E, false, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, (int)blockIdx.x);
+    finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2314,8 +2327,171 @@ __global__ __launch_bounds__(1024) void finalize_kernel(int N, const int* __rest
 // dynamic LDS: the scan's structures, then cnt[N] (fast_final_body); csr_build_body: 4 arrays of Ppow2 ints
 __host__ __device__ __forceinline__ size_t fast_tail_cnt_offset(int NB) { return (leaders_lds_size(NB) + 15) & ~(size_t)15; }
 __host__ __device__ __forceinline__ size_t fast_tail_lds_size(int N, int Ppow2) {
-    const size_t a = fast_tail_cnt_offset((N + 63) / 64) + (size_t)N * 4, c = (size_t)Ppow2 * 16;
+    const size_t a = fast_tail_cnt_offset((N + 63) / 64) + (size_t)N * 4, c = (size_t)Ppow2 * 32;     // (finalize_fast_body: 3 arrays + 2 key lists + the bucket segments)
     return a > c ? a : c;
+}
+
+// K6 of the fast tail.  In: r2 / head / input index by rank in LDS (fast_final_body).  Same outputs as finalize_body, bit for bit; what
+// differs is how the valid boxes get into descending order.  A valid HEAD carries r = clamp(its own score), and the ranks ARE the scores in
+// descending order (clamp is monotone, ties keep their positions): the valid heads, compacted in rank order, are a sorted run as they
+// stand (list A; checked, one compare per element -- a violation sends everything through the sort).  Only the other valid boxes (members
+// whose rescored value stayed above the threshold: list B, typically a few dozen) are sorted, and the two lists are merged by rank
+// (position in the own list + binary search in the other).  For ~1 900 valid boxes of 4 096 that replaces a 2 048-key merge sort (9 us on
+// one CU) by a compaction, a small sort and 11 LDS probes per box.  No global load and no wait for a global store anywhere.
+template <int E>
+__device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
+                                                   int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
+                                                   long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
+                                                   const int b) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const float* r2L = reinterpret_cast<const float*>(smem);
+    const int* hdL = reinterpret_cast<const int*>(smem + (size_t)Ppow2 * 4);
+    const int* ordL = reinterpret_cast<const int*>(smem + (size_t)Ppow2 * 8);
+    u64* keyA = reinterpret_cast<u64*>(smem + (size_t)Ppow2 * 12);                   // [Ppow2] valid heads, in rank order
+    u64* keyB = reinterpret_cast<u64*>(smem + (size_t)Ppow2 * 20);                   // [Ppow2] the other valid boxes
+    __shared__ unsigned ff_tot[2][16];
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const float vthr = P.valid_box_prob_threshold;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float* pb = prob + (size_t)b * N;
+    GNMS_T0();
+    // classify, thread-contiguous positions (the compaction keeps the order)
+    u64 key[E];
+    int cls[E];                                                    // 0 nan, 1 valid head, 2 valid other, 3 invalid, 4 padding
+    unsigned w0 = 0u, w1 = 0u;                                     // nan | heads << 16,  others | invalid << 16  (each count <= 4096)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int q = t * E + e;
+        cls[e] = 4;
+        key[e] = ~0ull;
+        if (q < n) {
+            const float r2 = r2L[q];
+            const float rr = (r2 < vthr) ? 0.0f : r2;                              // :115
+            cls[e] = (rr != rr) ? 0 : ((rr >= vthr) ? (hdL[q] == q ? 1 : 2) : ((rr < vthr) ? 3 : 0));   // vthr NaN: neither list (:118-123)
+            key[e] = ((u64)gnms_desc_key(rr) << 32) | (unsigned)q;
+            w0 += (cls[e] == 0) ? 1u : (cls[e] == 1 ? (1u << 16) : 0u);
+            w1 += (cls[e] == 2) ? 1u : (cls[e] == 3 ? (1u << 16) : 0u);
+        }
+    }
+    const unsigned inc0 = gnms_add_scan32(w0), inc1 = gnms_add_scan32(w1);
+    if (lane == 63) { ff_tot[0][wave] = inc0; ff_tot[1][wave] = inc1; }
+    lds_barrier();
+    unsigned base0 = 0u, base1 = 0u, tot0 = 0u, tot1 = 0u;
+    for (int w = 0; w < 16; ++w) {
+        const unsigned a = ff_tot[0][w], c = ff_tot[1][w];
+        if (w < wave) { base0 += a; base1 += c; }
+        tot0 += a; tot1 += c;
+    }
+    const int n_nan = (int)(tot0 & 0xffffu), ni = (int)(tot1 >> 16);
+    int nA = (int)(tot0 >> 16), nB = (int)(tot1 & 0xffffu);
+    const int nv = nA + nB, n_ge = n_nan + nv;
+    if (!valid && !invalid && !P.return_sorted_prob) {
+        // the caller wants the probabilities only (training reads just the third return value, lib/loss/rpn_3d.py:791)
+        for (int j = t; j < N; j += 1024) { pb[j] = (j < n) ? r2L[j] : 0.0f; I.sidx[j] = j; }     // (grouped mode: the un-thresholded clone, :124-125)
+        if (t == 0) { if (nvalid) nvalid[b] = nv; if (ninvalid) ninvalid[b] = ni; }
+        return;
+    }
+    const bool sorted_out = P.return_sorted_prob != 0;
+    // (the bucket counters of the merge below live where the heads were: every thread has read its heads in front of the barrier above)
+    for (int i = t; i < Ppow2; i += 1024) reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4)[i] = 0;
+    // compaction.  sidx layout: [0, n_nan) NaN by position, [n_nan, n_ge) valid (merged below), [n_ge, n_ge + ni) invalid by position
+    {
+        unsigned run0 = base0 + inc0 - w0, run1 = base1 + inc1 - w1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int q = t * E + e;
+            if (cls[e] == 0) { const int p = (int)(run0 & 0xffffu); I.sidx[p] = q; if (sorted_out) pb[p] = r2L[q]; run0 += 1u; }
+            else if (cls[e] == 1) { keyA[run0 >> 16] = key[e]; run0 += 1u << 16; }
+            else if (cls[e] == 2) { keyB[run1 & 0xffffu] = key[e]; run1 += 1u; }
+            else if (cls[e] == 3) {
+                const int j = (int)(run1 >> 16);
+                I.sidx[n_ge + j] = q;
+                if (invalid) invalid[(size_t)b * N + j] = ordL[q];
+                if (sorted_out) pb[n_ge + j] = 0.0f;                               // (thresholded, :115-117)
+                run1 += 1u << 16;
+            }
+        }
+    }
+    lds_barrier();
+    GNMS_TACC(12);
+    // the heads must be a sorted run (they are, whenever the scores were finite and the ranks their descending order)
+    int viol = 0;
+    for (int i = t + 1; i < nA; i += 1024) viol |= keyA[i] <= keyA[i - 1];
+    viol = __syncthreads_or(viol);
+    auto emit = [&](const u64 k, const int p) {
+        const int q = (int)(k & 0xffffffffu);
+        I.sidx[n_nan + p] = q;
+        if (valid) valid[(size_t)b * N + p] = ordL[q];
+        if (sorted_out) pb[n_nan + p] = r2L[q];                    // (valid: >= the threshold, returned as it is)
+    };
+    if (viol) {                                                    // never seen; kept exact: everything through the sort
+        for (int i = t; i < nA; i += 1024) keyB[nB + i] = keyA[i];
+        nB += nA;
+        u64 r[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = (t * E + e < nB) ? keyB[t * E + e] : ~0ull;
+        lds_barrier();
+        block_sort<E, u64>(r, keyB, E * 1024);
+        for (int i = t; i < nB; i += 1024) emit(keyB[i], i);
+    } else if (nB == 0) {
+        for (int i = t; i < nA; i += 1024) emit(keyA[i], i);
+    } else {
+        // MERGE BY BUCKETS.  The sorted heads split the key space into nA + 1 buckets; a box of B lies in bucket g = number of heads in front
+        // of it (a binary search), and its final position is g + (boxes of B in earlier buckets) + (its rank among its bucket mates); head
+        // i ends up at i + (boxes of B in buckets <= i).  So B is never sorted: count per bucket (LDS atomics), prefix over the buckets,
+        // members scattered into their bucket's segment (the scatter's atomics turn the exclusive prefix into the inclusive one), rank inside
+        // the segment by comparison -- buckets hold a box or two.  (nB >= 1, hence nA + 1 <= n <= Ppow2 counters: the head array, dead by now.)
+        int* cntG = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4);              // [nA + 1] (zeroed during the compaction above)
+        int* seg = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 28);              // [nB] indices into keyB, bucket by bucket
+        int gB[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = t + e * 1024;
+            gB[e] = 0;
+            if (i < nB) { gB[e] = lower_bound_lds<u64>(keyA, nA, keyB[i]); atomicAdd(&cntG[gB[e]], 1); }
+        }
+        lds_barrier();
+        {   // exclusive prefix over the nA + 1 buckets, in place (thread t owns buckets t * E .. t * E + E - 1)
+            int c[E], sum = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int g = t * E + e; c[e] = (g <= nA) ? cntG[g] : 0; sum += c[e]; }
+            const unsigned inc = gnms_add_scan32((unsigned)sum);
+            if (lane == 63) ff_tot[0][wave] = inc;
+            lds_barrier();
+            unsigned base = 0u;
+            for (int w = 0; w < 16; ++w) if (w < wave) base += ff_tot[0][w];
+            int run = (int)(base + inc) - sum;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int g = t * E + e; if (g <= nA) cntG[g] = run; run += c[e]; }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const int i = t + e * 1024; if (i < nB) seg[atomicAdd(&cntG[gB[e]], 1)] = i; }
+        lds_barrier();                                             // cntG[g] is now the INCLUSIVE prefix: boxes of B in buckets <= g
+        for (int i = t; i < nA; i += 1024) emit(keyA[i], i + cntG[i]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = t + e * 1024;
+            if (i < nB) {
+                const int g = gB[e], s0 = g > 0 ? cntG[g - 1] : 0, s1 = cntG[g];
+                const u64 k = keyB[i];
+                int rank = 0;
+                for (int j = s0; j < s1; ++j) rank += keyB[seg[j]] < k ? 1 : 0;
+                emit(k, g + s0 + rank);
+            }
+        }
+    }
+    GNMS_TACC(13);
+    for (int j = t; j < N; j += 1024) {
+        if (j >= nv && valid) valid[(size_t)b * N + j] = -1;
+        if (j >= ni && invalid) invalid[(size_t)b * N + j] = -1;
+        if (j >= n) I.sidx[j] = j;
+        if (!sorted_out) pb[j] = (j < n) ? r2L[j] : 0.0f;          // (grouped mode: the un-thresholded clone, :124-125)
+        else if (j >= n) pb[j] = 0.0f;
+    }
+    GNMS_TACC(14);
+    if (t == 0) { if (nvalid) nvalid[b] = nv; if (ninvalid) ninvalid[b] = ni; }
 }
 
 template <int E, int SRC>
@@ -2324,11 +2500,10 @@ __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, i
                                                 long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
                                                 const int b, const int last) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* stageL = reinterpret_cast<float*>(smem);                                  // r2 by position (finalize_body<E, true>'s `stage`)
-    int* hdL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4);                     // head by rank (dead once the verdict is in)
+    float* r2L = reinterpret_cast<float*>(smem);                                     // r2 by rank (= position)
+    int* hdL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4);                     // head by rank
     int* ordL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 8);                    // input index by rank
-    float* r2L = reinterpret_cast<float*>(smem + (size_t)Ppow2 * 12);                // r2 once more (the key sort overwrites `stage`)
-    int* cnt = reinterpret_cast<int*>(smem + fast_tail_cnt_offset(L.NB));            // members per leader rank
+    int* cnt = reinterpret_cast<int*>(smem + fast_tail_cnt_offset(L.NB));            // members per leader rank (dead once the verdict is in)
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int tid = threadIdx.x;
@@ -2348,7 +2523,7 @@ __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, i
                 const int hd = rem_load(I.head, k);
                 const float r2 = __hip_atomic_load(I.r2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int ck = I.order[k];
-                stageL[k] = r2; hdL[k] = hd; ordL[k] = ck; r2L[k] = r2;
+                r2L[k] = r2; hdL[k] = hd; ordL[k] = ck;
             }
         }
         if (cap < (long long)n) {                                                    // (else no group can be longer than the cap)
@@ -2379,10 +2554,10 @@ __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, i
         __syncthreads();
         groups_body<E, SRC, true>(src, N, ld, counts, P, ws, L, Ppow2, b);
         lds_barrier();
-        finalize_body<E, true, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+        finalize_body<E, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
         return;
     }
-    finalize_body<E, true, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+    finalize_fast_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
 }
 
 template <int E>
@@ -2481,6 +2656,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
                                                     long long* __restrict__ valid, long long* __restrict__ invalid, int* __restrict__ nvalid,
                                                     int* __restrict__ ninvalid, int sym_arg, int B, int spw, int fast) {
     int b;
+    GNMS_TINIT();
     if constexpr (E <= 4) {
         if (fast) {
             if ((int)blockIdx.x >= B * spw) {                            // the image's CSR workgroup
@@ -2491,14 +2667,14 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
             }
             const int last = leaders_chain<SRC>(N, counts, ws, L, B, spw, (int)blockIdx.x, sym_arg, &b, src, ld, P.nms_threshold, P.temperature,
                                                 P.pruning_method, Ppow2);
-            if (!last) return;
-            if (last != 3) { fast_final_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b, last); return; }
+            if (!last) { GNMS_TFLUSH(ws, L, b); return; }
+            if (last != 3) { fast_final_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b, last); GNMS_TFLUSH(ws, L, b); return; }
             __syncthreads();                                             // general scan: K4..K6 as before
             attribute_image<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, 0);
             __syncthreads();
             groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
             __syncthreads();
-            finalize_body<E, false, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+            finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
             return;
         }
     }
@@ -2509,7 +2685,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
         if constexpr (E <= 4) {
             groups_body<E, SRC, true>(src, N, ld, counts, P, ws, L, Ppow2, b);
             lds_barrier();
-            finalize_body<E, true, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+            finalize_body<E, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
         }
         return;
     }
@@ -2517,7 +2693,7 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     __syncthreads();
     groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
     __syncthreads();
-    finalize_body<E, false, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+    finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
 }
 
 }  // namespace

@@ -830,9 +830,10 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
     const int cwg = spw + (fast ? 1 : 0);                             // + the fast tail's CSR workgroup (csr_build_body)
     if ((int)blockIdx.x < nimg * cwg) {
         int b;
+        GNMS_TINIT();
 #ifdef GNMS_TIMING
         long long tt__ = (long long)__builtin_amdgcn_s_memtime();
-#define GNMS_TW_ACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && b == 0) ((long long*)img_ptrs(ws, L, 0).gx)[slot] += n__ - tt__; tt__ = n__; } while (0)
+#define GNMS_TW_ACC(slot) do { long long n__ = (long long)__builtin_amdgcn_s_memtime(); if (threadIdx.x == 0 && b == 0) gnms::gnms_tbuf()[slot] += n__ - tt__; tt__ = n__; } while (0)
 #else
 #define GNMS_TW_ACC(slot) do {} while (0)
 #endif
@@ -841,9 +842,8 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
                 if ((int)blockIdx.x >= nimg * spw) { csr_build_body<E>(N, counts, ws, L, (int)blockIdx.x - nimg * spw); return; }
                 const int last = leaders_chain<SRC>(N, counts, ws, L, nimg, spw, (int)blockIdx.x, 1, &b, chain_src, (long)N, P.nms_threshold,
                                                     P.temperature, P.pruning_method, Ppow2);
-                GNMS_TW_ACC(5);
-                if (last) fast_final_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b, last);
-                GNMS_TW_ACC(15);
+                if (last) { GNMS_TW_ACC(5); fast_final_body<E, SRC>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b, last); GNMS_TW_ACC(15); }
+                GNMS_TFLUSH(ws, L, b);
                 return;
             }
         }
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
                 groups_body<E, SRC, true>(chain_src, N, (long)N, counts, P, ws, L, Ppow2, b);
                 gnms::lds_barrier();
                 GNMS_TW_ACC(7);
-                finalize_body<E, true, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+                finalize_body<E, true>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
                 GNMS_TW_ACC(15);
             }
             return;
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
         if (!P.mask_group_boxes) return;                              // unmasked groups: the solves (a launch of their own) come before K6
         __syncthreads();
         GNMS_TW_ACC(7);
-        finalize_body<E, false, false>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
+        finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
         GNMS_TW_ACC(15);
         return;
     }

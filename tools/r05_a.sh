@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-5 session script A: GPU tests, phase ticks of the chain (timing build), a few bench shapes
 export TMPDIR=/tmp
-O=gpurun_out/r05a
+O=gpurun_out/r05b
 mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; echo "pytest rc $?" >> $O/pytest.txt
 tail -5 $O/pytest.txt
@@ -19,7 +19,7 @@ for a in "--batch 1" "--batch 4" "--batch 8" "--boxes 1024" "--boxes 256" "--box
 done
 python - <<'PY'
 import json
-for l in open('gpurun_out/r05a/shapes.jsonl'):
+for l in open('gpurun_out/r05b/shapes.jsonl'):
     if l.strip():
         d=json.loads(l); r=d.get('roofline') or {}
         print(d['config']['workload'][:50], 'graph' if d['config'].get('hip_graph_replay') else '', d['ms_per_step'], r.get('kernel'), r.get('kernel_ms'), r.get('frac'))
