@@ -276,11 +276,17 @@ def main():
     heartbeat = gdist.StepHeartbeat(dev)
     # a short run (the driver's K = 20 is 3 ms of GPU time) would otherwise be timed on clocks that are still ramping and on first-launch
     # work (module load, allocator growth): run untimed steps up to a fixed total before the W warm-up steps the contract asks for
-    prewarm = max(0, 100 - args.warmup)
+    prewarm = int(os.environ.get("GNMS_BENCH_PREWARM", max(0, 100 - args.warmup)))    # (the env override: tests of the launcher path on big shapes)
     for _ in range(prewarm):
         step()
     torch.cuda.synchronize()
     dt = gdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, heartbeat)
+    # `spread`: the contract's window above is ONE sample of K steps; four more windows of the same K steps right behind it say how far such
+    # a sample moves on this box (1 GPU only; `value` is and stays the first window)
+    windows = [dt]
+    if world == 1 and not args.no_extras:
+        for _ in range(4):
+            windows.append(gdist.timed_steps(step, args.steps, 0, torch.cuda.synchronize, heartbeat))
 
     out = None
     if rank == 0:
@@ -403,6 +409,11 @@ def main():
                                      "note": "reference lib/groomed_nms.py + lib/core.py iou on torch CPU, 8 threads, uniform N=4096, measured in the "
                                              "survey container (BASELINE.md section 2); not a published number, hence vs_baseline null"},
         }
+        if len(windows) > 1:
+            wm = sorted(w_ / args.steps * 1e3 for w_ in windows)
+            out["spread"] = {"windows": len(wm), "steps_per_window": args.steps, "min_ms": round(wm[0], 4), "median_ms": round(wm[len(wm) // 2], 4),
+                             "max_ms": round(wm[-1], 4), "first_window_ms": round(dt / args.steps * 1e3, 4),
+                             "what": "ms per step of %d consecutive windows of --steps steps in this run; `value` is the first" % len(wm)}
         if gdist.share_gpu() and world > 1:
             out["debug_shared_gpu"] = "GNMS_SHARE_GPU=1: %d ranks share %d GPU(s), gloo collectives -- launcher-path check, not a scaling number" % (
                 world, torch.cuda.device_count())
@@ -470,9 +481,35 @@ def main():
                     one()
                 torch.cuda.synchronize()
                 dts = gdist.timed_steps(one, steps, warmup, torch.cuda.synchronize)
+                # roofline brief of this shape's HBM-bound launches: the same events the headline's roofline is made of (slot 0 = the launch
+                # that writes the matrix, slot 1 = bitmask_kernel, the one full read of the matrix-in layer), over kr more steps
+                kr = max(5, min(steps, 20))
+                collect(0); collect(1)
+                check(lib.gnms_profile_events(1), "profile_events")
+                for _ in range(kr):
+                    one()
+                torch.cuda.synchronize()
+                check(lib.gnms_profile_events(0), "profile_events")
+                (msw, nw_), (msr, nr_) = collect(0), collect(1)
                 del bufs
-                return {"value": round(b_ * n_ * steps / dts, 1), "unit": "boxes/s", "ms_per_step": round(dts / steps * 1e3, 4), "steps": steps,
-                        "workload": "%d images x %d %s %dD boxes%s" % (b_, n_, args.kind, dim, ", reference call sequence" if (two_calls or ref_3d) else "")}
+                bytes_w = b_ * (4.0 * n_ * n_ + (16.0 if dim == 2 else 28.0) * n_)
+                bytes_r = b_ * (4.0 * n_ * n_ + 16.0 * n_)
+                wn = (lib.gnms_profile_write_kernel_name(dim, b_, n_).decode() if not (two_calls or ref_3d) else
+                      ("iou2d_self_kernel" if dim == 2 and not ref_3d else "iou3d_kernel"))
+
+                def brief(ms_sum, launches, nbytes, kname):
+                    if not launches or ms_sum <= 0:
+                        return None
+                    per = ms_sum / kr
+                    return {"kernel": kname, "kernel_ms": round(per, 4), "launches_per_step": round(launches / kr, 2), "algorithmic_bytes": round(nbytes),
+                            "achieved": round(nbytes / (per * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(nbytes / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                res = {"value": round(b_ * n_ * steps / dts, 1), "unit": "boxes/s", "ms_per_step": round(dts / steps * 1e3, 4), "steps": steps,
+                       "workload": "%d images x %d %s %dD boxes%s" % (b_, n_, args.kind, dim, ", reference call sequence" if (two_calls or ref_3d) else ""),
+                       "whole_step_frac": round((bytes_w + (bytes_r if (two_calls or ref_3d) else 0.0)) / (dts / steps) / 1e9 / HBM_PEAK_GBS, 4),
+                       "roofline": brief(msw, nw_, bytes_w * (2.0 if ref_3d else 1.0), wn)}
+                if two_calls or ref_3d:
+                    res["roofline_matrix_in"] = brief(msr, nr_, bytes_r, "bitmask_kernel")
+                return res
 
             # (60 steps where a step is a fraction of a millisecond: at 20 the 3D step read 0.203-0.207 ms where 100 steps give 0.185-0.188)
             for key, kw in (("two_calls", dict(dim=2, b_=B, n_=N, two_calls=True, steps=40)),

@@ -23,6 +23,11 @@ def _device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+def _binding():
+    from .groomed_nms import _binding as b
+    return b()
+
+
 def _launch(logits2d, targets2d, counts, positive_label, negative_label):
     """logits2d/targets2d: contiguous fp32 [B][N] on the GPU -> (loss [B], grad [B][N])."""
     lib = _lib.load()
@@ -98,6 +103,14 @@ def ap_loss_batched(logits, targets, active=None, counts=None, positive_label=1,
         tg = torch.where(active.to(logits.device), tg, torch.full_like(tg, ignore))
     if counts is not None:
         counts = counts.to(device=logits.device, dtype=torch.int32).contiguous()
+    ext = _binding()
+    if ext:                                              # the C++ autograd node (csrc/torch_binding.cpp); below: the ctypes path, same C ABI
+        try:
+            return ext.aploss(logits, tg, counts, float(positive_label), float(negative_label))
+        except RuntimeError as e:
+            if isinstance(e, torch.cuda.OutOfMemoryError) or not str(e).startswith("GNMS:"):
+                raise
+            raise _lib.GnmsError(str(e)) from None
     return _APLossBatched.apply(logits, tg, counts, positive_label, negative_label)
 
 

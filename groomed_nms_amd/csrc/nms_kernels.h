@@ -667,37 +667,58 @@ __device__ __forceinline__ u64 transpose64(u64 x, int lane) {            // lane
 
 // (round 4: no density gate any more -- with the scan on one workgroup per super-block the symmetric path is the faster one for dense
 // images too)
-constexpr int kSymPairsPerWave = 1;                          // (four pairs per wave, eight loads in flight, measured slower: 13.0 against 10.7 us at B = 8, N = 4096)
+// one pair (kb <= jb) of 64 x 64 bit blocks, pair index pr row-major over the upper triangle, by one wave: true = not each other's transpose
+__device__ __forceinline__ bool wsym_pair_bad(const ImgPtrs& I, const gnms_ws_layout& L, const int n, const int nb, const int pr, const int lane) {
+    auto rows_of = [&](int blk) { const int r = min(64, n - blk * 64); return r >= 64 ? ~0ull : ((1ull << r) - 1ull); };
+    // pr -> (kb, jb): pairs before row kb = kb * nb - kb (kb - 1) / 2
+    const float a = (float)(2 * nb + 1);
+    int kb = (int)((a - sqrtf(a * a - 8.0f * (float)pr)) * 0.5f);
+    kb = kb < 0 ? 0 : (kb >= nb ? nb - 1 : kb);
+    while (kb > 0 && kb * nb - kb * (kb - 1) / 2 > pr) --kb;
+    while ((kb + 1) * nb - (kb + 1) * kb / 2 <= pr) ++kb;
+    const int jb = kb + (pr - (kb * nb - kb * (kb - 1) / 2));
+    // A: rows = ranks of block kb (bits), columns = ranks of block jb (lanes); Bm the other way round
+    const u64 A = (jb * 64 + lane < n) ? (I.W[(size_t)kb * L.NC + jb * 64 + lane] & rows_of(kb)) : 0ull;
+    const u64 Bm = (kb * 64 + lane < n) ? (I.W[(size_t)jb * L.NC + kb * 64 + lane] & rows_of(jb)) : 0ull;
+    return A != transpose64(Bm, lane);
+}
+
+// (four pairs per wave, eight loads in flight, measured slower in round 3: 13.0 against 10.7 us at B = 8, N = 4096)
 __global__ __launch_bounds__(256) void wsym_check_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L) {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int nb = (n + 63) >> 6;
     const int pairs = nb * (nb + 1) / 2;
-    const int pr0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kSymPairsPerWave;      // pair index, row-major over kb <= jb
+    const int pr0 = blockIdx.x * 4 + (threadIdx.x >> 6);                         // pair index, row-major over kb <= jb
     if (pr0 >= pairs) return;
     if (I.misc[2] != 0) { if (pr0 == 0 && lane == 0) I.misc[3] = 1; return; }   // pre-sorted scores: W holds the triangle only
-    auto rows_of = [&](int blk) { const int r = min(64, n - blk * 64); return r >= 64 ? ~0ull : ((1ull << r) - 1ull); };
-    // pr -> (kb, jb): pairs before row kb = kb * nb - kb (kb - 1) / 2
-    const float a = (float)(2 * nb + 1);
-    int kb = (int)((a - sqrtf(a * a - 8.0f * (float)pr0)) * 0.5f);
-    kb = kb < 0 ? 0 : (kb >= nb ? nb - 1 : kb);
-    while (kb > 0 && kb * nb - kb * (kb - 1) / 2 > pr0) --kb;
-    while ((kb + 1) * nb - (kb + 1) * kb / 2 <= pr0) ++kb;
-    int jb = kb + (pr0 - (kb * nb - kb * (kb - 1) / 2));
-    u64 A[kSymPairsPerWave], Bm[kSymPairsPerWave];
-#pragma unroll
-    for (int q = 0; q < kSymPairsPerWave; ++q) {
-        const bool have = pr0 + q < pairs;
-        // A: rows = ranks of block kb (bits), columns = ranks of block jb (lanes); Bm the other way round
-        A[q] = (have && jb * 64 + lane < n) ? (I.W[(size_t)kb * L.NC + jb * 64 + lane] & rows_of(kb)) : 0ull;
-        Bm[q] = (have && kb * 64 + lane < n) ? (I.W[(size_t)jb * L.NC + kb * 64 + lane] & rows_of(jb)) : 0ull;
-        if (++jb >= nb) { ++kb; jb = kb; }                                  // the next pair in row-major order
-    }
-    bool bad = false;
-#pragma unroll
-    for (int q = 0; q < kSymPairsPerWave; ++q) bad |= A[q] != transpose64(Bm[q], lane);
+    const bool bad = wsym_pair_bad(I, L, n, nb, pr0, lane);
     if (__any(bad) && lane == 0) I.misc[3] = 1;                          // (every writer stores 1; the sort zeroed it)
+}
+
+// The same check as a ROLE of the tail launch (round 5, the matrix-in layer with the fast tail): workgroup `wg` of `nwg` checker workgroups
+// (the FIRST workgroups of the grid: they wait for nobody) takes every nwg-th group of 16 pairs of every image, while the chain workgroups
+// already run the symmetric scan on the assumption that the check will pass; the image's last chain workgroup waits for the verdict --
+// misc[7] == nwg workgroups done, misc[3] != 0: some pair failed -- before anything is final, and falls back to the general scan if it has to.
+// (As a launch of its own the check cost 9.9 us in front of the tail, B = 8, N = 4096.)  Images whose scores came in sorted (misc[2]: W
+// holds the triangle only) are not checked at all: everybody reads misc[2] and takes the general scan.
+__device__ __forceinline__ void wsym_check_in_launch(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int B, const int wg,
+                                                     const int nwg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int b = 0; b < B; ++b) {
+        const int n = gnms_count(counts, b, N);
+        ImgPtrs I = img_ptrs(ws, L, b);
+        if (I.misc[2] != 0) continue;
+        const int nb = (n + 63) >> 6;
+        const int pairs = nb * (nb + 1) / 2;
+        bool bad = false;
+        for (int pr = wg * nw + wave; pr < pairs; pr += nwg * nw) bad |= wsym_pair_bad(I, L, n, nb, pr, lane);
+        if (__any(bad) && lane == 0) __hip_atomic_store(I.misc + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0f70);                              // vmcnt(0): the flag is out before this workgroup counts as done
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(I.misc + 7, 1);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1759,7 +1780,8 @@ __device__ __forceinline__ int leaders_chain(int N, const int* __restrict__ coun
                                              const int stage_prune = 0, const int Ppow2 = 0) {
     const int jw = c / B, b = c - jw * B;
     *image = b;
-    const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;
+    // sym_arg: 0 general, 1 symmetric, 2 as wsym_check_kernel found, 3 symmetric on trust (the check runs in this launch: wsym_check_in_launch)
+    const int sym = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : (sym_arg == 3 ? (img_ptrs(ws, L, b).misc[2] == 0 ? 1 : 0) : sym_arg);
     if (!sym) {
         if (jw != spw - 1) return 0;
         leaders_body(N, counts, ws, L, b);
@@ -2388,7 +2410,7 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     const int nv = nA + nB, n_ge = n_nan + nv;
     if (!valid && !invalid && !P.return_sorted_prob) {
         // the caller wants the probabilities only (training reads just the third return value, lib/loss/rpn_3d.py:791)
-        for (int j = t; j < N; j += 1024) { pb[j] = (j < n) ? r2L[j] : 0.0f; I.sidx[j] = j; }     // (grouped mode: the un-thresholded clone, :124-125)
+        for (int j = t; j < N; j += 1024) pb[j] = (j < n) ? r2L[j] : 0.0f;                    // (grouped mode: the un-thresholded clone, :124-125)
         if (t == 0) { if (nvalid) nvalid[b] = nv; if (ninvalid) ninvalid[b] = ni; }
         return;
     }
@@ -2396,19 +2418,19 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     // (the bucket counters of the merge below live where the heads were: every thread has read its heads in front of the barrier above)
     for (int i = t; i < Ppow2; i += 1024) reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4)[i] = 0;
     // compaction.  sidx layout: [0, n_nan) NaN by position, [n_nan, n_ge) valid (merged below), [n_ge, n_ge + ni) invalid by position
+    // (sidx is the backward's map for the SORTED output only, bwd_gx_kernel: written only then)
     {
         unsigned run0 = base0 + inc0 - w0, run1 = base1 + inc1 - w1;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int q = t * E + e;
-            if (cls[e] == 0) { const int p = (int)(run0 & 0xffffu); I.sidx[p] = q; if (sorted_out) pb[p] = r2L[q]; run0 += 1u; }
+            if (cls[e] == 0) { const int p = (int)(run0 & 0xffffu); if (sorted_out) { I.sidx[p] = q; pb[p] = r2L[q]; } run0 += 1u; }
             else if (cls[e] == 1) { keyA[run0 >> 16] = key[e]; run0 += 1u << 16; }
             else if (cls[e] == 2) { keyB[run1 & 0xffffu] = key[e]; run1 += 1u; }
             else if (cls[e] == 3) {
                 const int j = (int)(run1 >> 16);
-                I.sidx[n_ge + j] = q;
                 if (invalid) invalid[(size_t)b * N + j] = ordL[q];
-                if (sorted_out) pb[n_ge + j] = 0.0f;                               // (thresholded, :115-117)
+                if (sorted_out) { I.sidx[n_ge + j] = q; pb[n_ge + j] = 0.0f; }     // (thresholded, :115-117)
                 run1 += 1u << 16;
             }
         }
@@ -2421,9 +2443,8 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     viol = __syncthreads_or(viol);
     auto emit = [&](const u64 k, const int p) {
         const int q = (int)(k & 0xffffffffu);
-        I.sidx[n_nan + p] = q;
         if (valid) valid[(size_t)b * N + p] = ordL[q];
-        if (sorted_out) pb[n_nan + p] = r2L[q];                    // (valid: >= the threshold, returned as it is)
+        if (sorted_out) { I.sidx[n_nan + p] = q; pb[n_nan + p] = r2L[q]; }   // (valid: >= the threshold, returned as it is)
     };
     if (viol) {                                                    // never seen; kept exact: everything through the sort
         for (int i = t; i < nA; i += 1024) keyB[nB + i] = keyA[i];
@@ -2486,7 +2507,7 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     for (int j = t; j < N; j += 1024) {
         if (j >= nv && valid) valid[(size_t)b * N + j] = -1;
         if (j >= ni && invalid) invalid[(size_t)b * N + j] = -1;
-        if (j >= n) I.sidx[j] = j;
+        if (sorted_out && j >= n) I.sidx[j] = j;
         if (!sorted_out) pb[j] = (j < n) ? r2L[j] : 0.0f;          // (grouped mode: the un-thresholded clone, :124-125)
         else if (j >= n) pb[j] = 0.0f;
     }
@@ -2654,20 +2675,36 @@ template <int E, int SRC>
 __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
                                                     char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob,
                                                     long long* __restrict__ valid, long long* __restrict__ invalid, int* __restrict__ nvalid,
-                                                    int* __restrict__ ninvalid, int sym_arg, int B, int spw, int fast) {
+                                                    int* __restrict__ ninvalid, int sym_arg, int B, int spw, int fast, int nchk) {
     int b;
     GNMS_TINIT();
     if constexpr (E <= 4) {
         if (fast) {
-            if ((int)blockIdx.x >= B * spw) {                            // the image's CSR workgroup
-                b = (int)blockIdx.x - B * spw;
-                const int symb = sym_arg == 2 ? (img_ptrs(ws, L, b).misc[3] == 0 ? 1 : 0) : sym_arg;
+            // grid: [nchk symmetry checkers (sym_arg 3)] [B * spw scan workgroups] [B CSR workgroups]
+            const int bx = (int)blockIdx.x - nchk;
+            if (bx < 0) { wsym_check_in_launch(N, counts, ws, L, B, (int)blockIdx.x, nchk); return; }
+            if (bx >= B * spw) {                                         // the image's CSR workgroup
+                b = bx - B * spw;
+                const int* misc = img_ptrs(ws, L, b).misc;
+                const int symb = sym_arg == 2 ? (misc[3] == 0 ? 1 : 0) : (sym_arg == 3 ? (misc[2] == 0 ? 1 : 0) : sym_arg);
                 if (symb) csr_build_body<E>(N, counts, ws, L, b);
                 return;
             }
-            const int last = leaders_chain<SRC>(N, counts, ws, L, B, spw, (int)blockIdx.x, sym_arg, &b, src, ld, P.nms_threshold, P.temperature,
-                                                P.pruning_method, Ppow2);
+            int last = leaders_chain<SRC>(N, counts, ws, L, B, spw, bx, sym_arg, &b, src, ld, P.nms_threshold, P.temperature, P.pruning_method, Ppow2);
             if (!last) { GNMS_TFLUSH(ws, L, b); return; }
+            if (last != 3 && sym_arg == 3) {                             // the scan ran on trust: the checkers' verdict before anything is final
+                ImgPtrs I = img_ptrs(ws, L, b);
+                int asym = 0;
+                if (threadIdx.x < 64) {
+                    while (__hip_atomic_load(I.misc + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nchk) __builtin_amdgcn_s_sleep(4);
+                    asym = __hip_atomic_load(I.misc + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                }
+                if (__syncthreads_or(asym)) {                            // not symmetric after all: the general scan, K4..K6 proper; nothing for the CSR workgroup
+                    if (threadIdx.x == 0) gran_store(I.gran + (size_t)16 * 32 + kGranVerdict, ((u64)(unsigned)I.misc[8] << 32) | 2ull);
+                    leaders_body(N, counts, ws, L, b);
+                    last = 3;
+                }
+            }
             if (last != 3) { fast_final_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b, last); GNMS_TFLUSH(ws, L, b); return; }
             __syncthreads();                                             // general scan: K4..K6 as before
             attribute_image<SRC>(src, ld, N, counts, P.nms_threshold, ws, L, b, 0);

@@ -369,6 +369,7 @@ bool matrix_sym_detection(int N) {
     static const int forced = [] { const char* e = getenv("GNMS_MATRIX_SYM"); return e ? atoi(e) : -1; }();
     return forced >= 0 ? forced != 0 : N >= 256;
 }
+// full: 0 = only the words a leader scan reads; 1 = whole rows + wsym_check_kernel behind; 2 = whole rows, the check rides in the tail launch
 int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st, int full = 0) {
     // (measured at B = 8, N = 4096, three interleaved repetitions: 16 waves 91.6-91.8 us = 0.733 of the HBM peak, 8 waves 95.2-95.7 us;
     // 16 loads in flight per wave change nothing either way)
@@ -380,9 +381,9 @@ int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* co
     else GNMS_BITMASK(true, 8, 8);
 #undef GNMS_BITMASK
     GNMS_CHECK_LAUNCH();
-    if (full) {
+    if (full == 1) {
         const int nb = (N + 63) / 64;
-        wsym_check_kernel<<<dim3(gnms_div_up(nb * (nb + 1) / 2, 4 * kSymPairsPerWave), B), 256, 0, st>>>(N, counts, ws, L);
+        wsym_check_kernel<<<dim3(gnms_div_up(nb * (nb + 1) / 2, 4), B), 256, 0, st>>>(N, counts, ws, L);
         GNMS_CHECK_LAUNCH();
     }
     return GNMS_OK;
@@ -980,12 +981,21 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     size_t lds = llds > glds ? llds : glds;
     const int fast = (fast_tail_enabled() && fast_tail_ok(N, P, sym, chain_cap)) ? 1 : 0;
     if (fast && lds < fast_tail_lds_size(N, P2)) lds = fast_tail_lds_size(N, P2);
+    GNMS_CHECK_ARG(sym != 3 || fast, "launch_tail: the in-launch symmetry check needs the fast tail");
     int rc;
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(tail_kernel<E, BOXES>, lds))) return rc;
         const int spw = leaders_chain_wgs(N, sym, chain_cap);
-        tail_kernel<E, BOXES><<<B * (spw + fast), 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
-                                                          ninvalid, sym, B, spw, fast);
+        // sym 3: symmetry checkers in front of the chain (one 16-wave workgroup per 64 pairs of 64 x 64 bit blocks, at most the CUs the chain leaves)
+        int nchk = 0;
+        if (sym == 3) {
+            const long nb = (N + 63) / 64, pairs = (long)B * nb * (nb + 1) / 2;
+            const int room = device_cu_count() - B * (spw + fast);
+            nchk = (int)std::min<long>(std::max(room, 8), (pairs + 63) / 64);
+            if (nchk < 1) nchk = 1;
+        }
+        tail_kernel<E, BOXES><<<nchk + B * (spw + fast), 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
+                                                          ninvalid, sym, B, spw, fast, nchk);
     });
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
@@ -1082,8 +1092,9 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     if (!scores_already_sorted && (rc = launch_sorts(scores, permute_from_boxes ? boxes2d : nullptr, B, N, counts, ws, L, P2, order, st))) return rc;
 
     if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N, matrix_sym_detection(N) ? 2 : 0)) {
-        const int sym = matrix_sym_detection(N) ? 2 : 0;
-        if ((rc = launch_bitmask(iou, B, N, ld, counts, P.nms_threshold, ws, L, st, sym ? 1 : 0))) return rc;
+        // (with the fast tail the symmetry check is a role of the tail launch and the scan runs on trust beside it: sym 3)
+        const int sym = matrix_sym_detection(N) ? ((fast_tail_enabled() && fast_tail_ok(N, P, 2)) ? 3 : 2) : 0;
+        if ((rc = launch_bitmask(iou, B, N, ld, counts, P.nms_threshold, ws, L, st, sym == 3 ? 2 : (sym ? 1 : 0)))) return rc;
         return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);
     }
     if (P.group_boxes) {

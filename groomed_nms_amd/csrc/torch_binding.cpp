@@ -197,11 +197,114 @@ Tensor iou2d(const Tensor& a, const Tensor& b, const c10::optional<Tensor>& out_
     return out;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The layer's neighbours on the same host path as the layer itself (round 5; they were Python autograd.Functions over ctypes:
+// 0.12-0.13 ms per AP-loss step at every size against 17-57 us of kernel time).
+// ------------------------------------------------------------------------------------------------
+// lib/loss/aploss.py:14-87 for a batch: logits / targets [B, N] -> loss [B]; d loss / d logits comes out of the forward pass (as in the
+// reference, :69-78) and the backward node only scales it (:80-85)
+struct APLossNode : public torch::autograd::Function<APLossNode> {
+    static Tensor forward(AutogradContext* ctx, const Tensor& logits, const Tensor& targets, const c10::optional<Tensor>& counts_, double pos, double neg) {
+        TORCH_CHECK(logits.is_cuda() && logits.dim() == 2 && targets.is_cuda() && targets.sizes() == logits.sizes(), "GNMS: aploss takes CUDA [B, N] logits and targets");
+        DeviceGuard guard(logits.device());
+        Tensor lg = logits.detach().to(at::kFloat).contiguous(), tg = targets.detach().to(at::kFloat).contiguous();
+        Tensor counts = counts_.has_value() ? *counts_ : Tensor();
+        const int64_t B = lg.size(0), N = lg.size(1);
+        Tensor loss = at::empty({B}, lg.options()), grad = at::empty({B, N}, lg.options());
+        check(gnms_aploss((const float*)cptr(lg), (const float*)cptr(tg), (int)B, (int)N, (const int32_t*)cptr(counts), (float)pos, (float)neg,
+                          (float*)mptr(loss), (float*)mptr(grad), current_stream(lg)), "gnms_aploss");
+        ctx->save_for_backward({grad});
+        ctx->saved_data["dtype"] = (int64_t)logits.scalar_type();
+        return loss;
+    }
+    static variable_list backward(AutogradContext* ctx, variable_list grads) {
+        variable_list out(5);
+        if (!grads[0].defined()) return out;
+        const Tensor grad = ctx->get_saved_variables()[0];
+        out[0] = (grad * grads[0].reshape({-1, 1})).to((at::ScalarType)ctx->saved_data["dtype"].toInt());
+        return out;
+    }
+};
+Tensor aploss(const Tensor& logits, const Tensor& targets, const c10::optional<Tensor>& counts, double pos, double neg) {
+    return APLossNode::apply(logits, targets, counts, pos, neg);
+}
+
+// lib/loss/rpn_3d.py:801-825 -> (targets [B, N] fp32, best_index [B, M] int64, best_score [B, M])
+std::vector<Tensor> best_targets(const Tensor& pred_params, const Tensor& pred_boxes, const Tensor& gt_params, const Tensor& gt_boxes, double beta,
+                                 const c10::optional<Tensor>& pred_counts, const c10::optional<Tensor>& gt_counts) {
+    TORCH_CHECK(pred_params.is_cuda() && pred_params.dim() == 3 && pred_params.size(2) == 7 && gt_params.dim() == 3 && gt_params.size(2) == 7,
+                "GNMS: best_targets takes CUDA [B, N, 7] / [B, M, 7] cuboid parameters");
+    DeviceGuard guard(pred_params.device());
+    Tensor pp = pred_params.detach().to(at::kFloat).contiguous(), pb = pred_boxes.detach().to(at::kFloat).slice(-1, 0, 4).contiguous();
+    Tensor gp = gt_params.detach().to(at::kFloat).contiguous(), gb = gt_boxes.detach().to(at::kFloat).slice(-1, 0, 4).contiguous();
+    const int64_t B = pp.size(0), N = pp.size(1), M = gp.size(1);
+    Tensor pc = pred_counts.has_value() ? *pred_counts : Tensor(), gc = gt_counts.has_value() ? *gt_counts : Tensor();
+    Tensor targets = at::empty({B, N}, pp.options()), idx = at::empty({B, M}, pp.options().dtype(at::kLong)), score = at::empty({B, M}, pp.options());
+    check(gnms_best_targets((const float*)cptr(pp), (const float*)cptr(pb), (const float*)cptr(gp), (const float*)cptr(gb), (int)B, (int)N, (int)M,
+                            (const int32_t*)cptr(pc), (const int32_t*)cptr(gc), (float)beta, (int64_t*)mptr(idx), (float*)mptr(score), (float*)mptr(targets),
+                            current_stream(pp)), "gnms_best_targets");
+    return {targets, idx, score};
+}
+
+// lib/loss/rpn_3d.py:731-737 / lib/rpn_util.py:1258-1266 -> (index [B, K] int64, count [B] int32, scores [B, K], boxes [B, K, 4] | undefined)
+std::vector<c10::optional<Tensor>> select_topk(const Tensor& scores, int64_t K, const c10::optional<Tensor>& candidates, const c10::optional<Tensor>& candidate_counts,
+                                               const c10::optional<Tensor>& boxes) {
+    TORCH_CHECK(scores.is_cuda() && scores.dim() == 2, "GNMS: select_topk takes CUDA [B, A] scores");
+    DeviceGuard guard(scores.device());
+    Tensor s = scores.detach().to(at::kFloat).contiguous();
+    const int64_t B = s.size(0), A = s.size(1);
+    Tensor cand = candidates.has_value() ? candidates->to(at::kInt).contiguous() : Tensor();
+    Tensor cnt = (candidates.has_value() && candidate_counts.has_value()) ? candidate_counts->to(at::kInt).contiguous() : Tensor();
+    const int64_t F = cand.defined() ? cand.size(1) : A;
+    Tensor bx = boxes.has_value() ? boxes->detach().to(at::kFloat).slice(-1, 0, 4).contiguous() : Tensor();
+    Tensor idx = at::empty({B, K}, s.options().dtype(at::kLong)), num = at::empty({B}, s.options().dtype(at::kInt)), ssel = at::empty({B, K}, s.options());
+    Tensor bsel = bx.defined() ? at::empty({B, K, 4}, s.options()) : Tensor();
+    check(gnms_select_topk((const float*)cptr(s), (int)B, (int)A, (const int32_t*)cptr(cand), (int)F, (const int32_t*)cptr(cnt), (int)K, (const float*)cptr(bx),
+                           (int64_t*)mptr(idx), (int32_t*)mptr(num), (float*)mptr(ssel), (float*)mptr(bsel), current_stream(s)), "gnms_select_topk");
+    std::vector<c10::optional<Tensor>> r(4);
+    r[0] = idx; r[1] = num; r[2] = ssel;
+    if (bsel.defined()) r[3] = bsel;
+    return r;
+}
+
+// lib/rpn_util.py:872-934: anchors [A, 4], deltas [B, A, 4] -> [B, A, 4]; means / stds: 4 host floats each (or empty)
+Tensor bbox_transform_inv(const Tensor& anchors, const Tensor& deltas, const std::vector<double>& means, const std::vector<double>& stds) {
+    TORCH_CHECK(deltas.is_cuda() && deltas.dim() == 3 && deltas.size(2) == 4 && anchors.dim() == 2 && anchors.size(1) == 4 && anchors.size(0) == deltas.size(1),
+                "GNMS: bbox_transform_inv takes anchors [A, 4] and CUDA deltas [B, A, 4]");
+    DeviceGuard guard(deltas.device());
+    Tensor d = deltas.detach().to(at::kFloat).contiguous(), a = anchors.detach().to(deltas.device(), at::kFloat).contiguous();
+    float m[4], sd[4];
+    for (int i = 0; i < 4; ++i) { m[i] = means.size() == 4 ? (float)means[i] : 0.0f; sd[i] = stds.size() == 4 ? (float)stds[i] : 1.0f; }
+    Tensor out = at::empty_like(d);
+    check(gnms_bbox_transform_inv((const float*)cptr(a), (const float*)cptr(d), (int)d.size(0), (int)d.size(1), means.size() == 4 ? m : nullptr,
+                                  stds.size() == 4 ? sd : nullptr, (float*)mptr(out), current_stream(d)), "gnms_bbox_transform_inv");
+    return out;
+}
+
+// The training tail of lib/loss/rpn_3d.py:772-825 + :1117-1131 as ONE host call, nothing but stream-ordered launches (HIP-graph capturable):
+// scores [B, N] already in descending order per image (as the loss sorts them, :731-737), boxes2d [B, N, 4], params3d [B, N, 7], ground truth
+// [B, M, 7] / [B, M, 4]:   GrooMeD-NMS on the 2D overlaps (:772-793) -> best box per ground truth (:801-825) -> after-NMS AP loss on the
+// rescored probabilities against those targets (:1123-1128).  -> (loss [B], prob [B, N], targets [B, N])
+std::vector<Tensor> training_tail(const Tensor& scores, const Tensor& boxes2d, const Tensor& params3d, const Tensor& gt_params, const Tensor& gt_boxes, double beta,
+                                  const c10::optional<Tensor>& counts, const c10::optional<Tensor>& gt_counts, double thr, double temp, double vthr,
+                                  int64_t prune, int64_t gsize) {
+    const variable_list o = Layer::apply(scores, boxes2d, counts, c10::nullopt, (int64_t)kWithIou2d, thr, temp, vthr, prune, false, true, true, gsize, false, false);
+    const std::vector<Tensor> bt = best_targets(params3d, boxes2d, gt_params, gt_boxes, beta, counts, gt_counts);
+    // (the scores came in sorted, so rank order == input order and the targets line up with prob as they are)
+    Tensor loss = APLossNode::apply(o[0], bt[0], counts, 1.0, 0.0);
+    return {loss, o[0], bt[0]};
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "GrooMeD-NMS layer: C++ autograd binding of libgroomed_nms_hip.so";
     m.def("layer", &layer, "forward entry + autograd node (mode 0 matrix in, 1 boxes -> matrix + layer, 2 cuboids -> matrix + layer, 3 from boxes)");
     m.def("iou2d", &iou2d, "pairwise 2D IoU matrices");
+    m.def("aploss", &aploss, "after-NMS AP loss of a batch, autograd node (lib/loss/aploss.py)");
+    m.def("best_targets", &best_targets, "best box per ground truth after the NMS (lib/loss/rpn_3d.py:801-825)");
+    m.def("select_topk", &select_topk, "per image the K best-scoring candidates (lib/loss/rpn_3d.py:731-737)");
+    m.def("bbox_transform_inv", &bbox_transform_inv, "lib/rpn_util.py:872-934");
+    m.def("training_tail", &training_tail, "layer -> best targets -> AP loss in one host call");
     m.def("abi_version", [] { return gnms_abi_version(); });
 }

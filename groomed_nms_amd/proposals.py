@@ -15,13 +15,43 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr, on_device
 
-__all__ = ["bbox_transform_inv", "select_topk", "projected_boxes_2d", "best_targets"]
+__all__ = ["bbox_transform_inv", "select_topk", "projected_boxes_2d", "best_targets", "training_tail"]
 
 
 def _device():
     if not torch.cuda.is_available():
         raise _lib.GnmsError("needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
     return torch.device("cuda", torch.cuda.current_device())
+
+
+def _binding():
+    from .groomed_nms import _binding as b
+    return b()
+
+
+def _gnms(fn, *args):
+    """a call into the C++ binding: the library's own failures (raised there as "GNMS: ...") become GnmsError, torch's stay what they are"""
+    try:
+        return fn(*args)
+    except RuntimeError as e:
+        if isinstance(e, torch.cuda.OutOfMemoryError) or not str(e).startswith("GNMS:"):
+            raise
+        raise _lib.GnmsError(str(e)) from None
+
+
+def training_tail(scores, boxes2d, params3d, gt_params, gt_boxes, beta, counts=None, gt_counts=None, nms_threshold=0.4, temperature=0.01,
+                  valid_box_prob_threshold=0.3, pruning_method="linear", group_size=100):
+    """lib/loss/rpn_3d.py:772-825 + :1117-1131 in ONE host call (C++ binding; stream-ordered launches only, HIP-graph capturable): scores
+    [B,N] sorted descending per image (:731-737), their boxes2d [B,N,4] / params3d [B,N,7], the ground truth [B,M,7] / [B,M,4] ->
+    GrooMeD-NMS on the 2D overlaps -> best box per ground truth (beta) -> after-NMS AP loss.  Returns (loss [B], prob [B,N], targets [B,N])."""
+    ext = _binding()
+    if not ext:
+        raise _lib.GnmsError("training_tail needs the C++ binding (groomed_nms_amd/gnms_torch*.so)")
+    prune = {"linear": 0, "sigmoidal": 1, "soft_nms": 2}[pruning_method]
+    c = counts.to(device=scores.device, dtype=torch.int32).contiguous() if counts is not None else None
+    g = gt_counts.to(device=scores.device, dtype=torch.int32).contiguous() if gt_counts is not None else None
+    return tuple(_gnms(ext.training_tail, scores.float(), boxes2d.float(), params3d, gt_params, gt_boxes, float(beta), c, g, float(nms_threshold),
+                       float(temperature), float(valid_box_prob_threshold), prune, int(min(int(group_size), 2 ** 31 - 2))))
 
 
 def _f4(v):
@@ -58,6 +88,13 @@ def select_topk(scores, k, candidates=None, candidate_counts=None, boxes=None):
     `candidate_counts` [B] restrict the choice (the foreground boxes of lib/loss/rpn_3d.py:731); None = every box."""
     if not scores.is_cuda:
         raise _lib.GnmsError("select_topk expects GPU tensors")
+    ext = _binding()
+    if ext:                                              # the C++ host path (csrc/torch_binding.cpp); below: ctypes, the same C ABI
+        dev = scores.device
+        cand = candidates.to(dev) if candidates is not None else None
+        cnt = candidate_counts.to(dev) if (candidates is not None and candidate_counts is not None) else None
+        idx, num, ssel, bsel = _gnms(ext.select_topk, scores, int(k), cand, cnt, boxes.to(dev) if boxes is not None else None)
+        return idx, num, ssel, bsel
     lib = _lib.load()
     dev = scores.device
     s = scores.detach().to(torch.float32).contiguous()
@@ -106,6 +143,12 @@ def best_targets(pred_params, pred_boxes, gt_params, gt_boxes, beta, pred_counts
     (GPU) -> (targets [B,N] fp32 in {0,1}, best_index [B,M] int64 with -1 where no box scores above beta, best_score [B,M])."""
     if not pred_params.is_cuda:
         raise _lib.GnmsError("best_targets expects GPU tensors")
+    ext = _binding()
+    if ext:
+        pc = pred_counts.to(device=pred_params.device, dtype=torch.int32).contiguous() if pred_counts is not None else None
+        gc = gt_counts.to(device=pred_params.device, dtype=torch.int32).contiguous() if gt_counts is not None else None
+        return tuple(_gnms(ext.best_targets, pred_params, pred_boxes.to(pred_params.device), gt_params.to(pred_params.device),
+                           gt_boxes.to(pred_params.device), float(beta), pc, gc))
     lib = _lib.load()
     dev = pred_params.device
     pp = pred_params.detach().to(torch.float32).contiguous()

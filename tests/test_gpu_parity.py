@@ -1663,6 +1663,14 @@ def test_n_rank_launcher_end_to_end():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and "debug_shared_gpu" in d
     assert "asynchronous" in d["config"]["collective"] and d["config"]["parallelism"].endswith("dp2") and d["roofline"]["frac"] > 0
     assert "cpu_baseline" not in d                                           # rank 0 at N = 1 only
+    # C5's shape exactly as the driver's 8-GPU run would start it: 8 ranks x 8 images x 16384 cuboids, folded onto this GPU
+    r5 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dim", "3", "--boxes", "16384", "--batch", "8", "--steps", "2",
+                         "--warmup", "1"], env=dict(env, GNMS_BENCH_PREWARM="2"), capture_output=True, text=True, timeout=1500)
+    d5 = one_json_line(r5)
+    waits5 = [float(x) for x in re.findall(r"rank \d+ waited ([0-9.]+) s in the final barrier", r5.stderr)]
+    assert len(waits5) == 8 and max(waits5) < 60.0, r5.stderr[-2000:]
+    assert d5["n_gpus"] == 8 and d5["config"]["boxes_per_image"] == 16384 and d5["config"]["images_per_gpu"] == 8 and d5["value"] > 0
+    assert d5["config"]["parallelism"].endswith("dp8") and "3D" in d5["config"]["workload"]
     e = one_json_line(subprocess.run([sys.executable, os.path.join(root, "tools", "e2e_bench.py"), "--mode", "train", "--gpus", "2", "--steps", "2",
                                       "--warmup", "1", "--batch", "1", "--topk", "512", "--height", "128", "--width", "320"], env=env,
                                      capture_output=True, text=True, timeout=900))
@@ -2375,3 +2383,163 @@ def test_empty_images_and_the_fast_tail_on_poisoned_outputs(G, O):
                     np.testing.assert_allclose(pb[:n], ref["prob"], atol=TOL, err_msg=str(tag))
                     np.testing.assert_allclose(grad[b, :n].cpu().numpy(), ref["grad_scores"], atol=TOL, rtol=1e-4, err_msg=str(tag))
                     check_index_lists(valid[b, :k].cpu().numpy(), invalid[b, :j].cpu().numpy(), ref["valid"], ref["invalid"])
+
+
+@pytest.mark.gpu
+def test_fuzz_3d_one_call_against_the_oracle(G, O):
+    """the 3D one-call entry against the ORACLE (not against its own matrix): seeded cuboid sets -- clustered and uniform,
+    flat and narrow scenes, ragged counts, thresholds around the cull's limit, box counts on both sides of 64 / 1024 / 2048 -- through
+    records -> column sort -> slot-culled bit matrix -> scan / fast tail, compared with corners -> iou3d_approximate(generalized) ->
+    0.5 (1 + giou) -> differentiable_nms of the CPU restatement: probabilities and gradients within TOL (the guard band of the 3D overlap,
+    iou3d_pair.h), valid / invalid as sets; an image is skipped when an overlap sits within 2e-6 of the threshold (the two sides may then
+    legitimately differ by a whole box: SURVEY 8-a6) -- counted, and it must stay the exception."""
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(20261001)
+    checked = skipped = 0
+    for trial in range(36):
+        B = int(rng.integers(1, 4))
+        N = int(rng.choice([5, 63, 64, 65, 257, 700, 1024, 1025, 1500, 2049, 2300]))
+        clustered = bool(rng.uniform() < 0.5)
+        par, scores = synthetic.batch_3d(int(rng.integers(1 << 30)), B, N, clustered=clustered, per=int(rng.choice([4, 32, 120])))
+        style = rng.uniform()
+        if style < 0.2:
+            par[:, :, 2] = 20.0                                              # every cuboid at one depth
+        elif style < 0.4:
+            par[:, :, 0] *= 0.05                                             # a narrow scene
+        thr = float(rng.choice([0.2, 0.4, 0.55, 0.75]))
+        gs = int(rng.choice([100, 100, 3]))
+        counts = [N] + [int(rng.integers(1, N + 1)) for _ in range(B - 1)]
+        ct = torch.tensor(counts, dtype=torch.int32).cuda()
+        pt = torch.from_numpy(par).cuda()
+        st = torch.from_numpy(scores).cuda().requires_grad_(True)
+        w = torch.from_numpy(rng.uniform(-1, 2, (B, N)).astype(np.float32)).cuda()
+        out = G.differentiable_nms_with_iou3d_batched(st, pt, counts=ct, nms_threshold=thr, group_size=gs)
+        (out[0] * w).sum().backward()
+        tag = (trial, B, N, clustered, thr, gs, counts)
+        for b in range(B):
+            n = counts[b]
+            m = _oracle_overlap3d(O, O.corners_of_cuboid(par[b, :n]))
+            if np.any(np.abs(m - np.float32(thr)) < 2e-6):
+                skipped += 1
+                continue
+            ref = O.differentiable_nms(scores[b, :n], m, grad_prob=w[b, :n].cpu().numpy(), nms_threshold=thr, group_size=gs)
+            np.testing.assert_allclose(out[0][b, :n].detach().cpu().numpy(), ref["prob"], atol=TOL, err_msg=str(tag))
+            np.testing.assert_allclose(st.grad[b, :n].cpu().numpy(), ref["grad_scores"], atol=TOL, rtol=1e-4, err_msg=str(tag))
+            nv, ni = int(out[4][b]), int(out[5][b])
+            check_index_lists(out[2][b, :nv].cpu().numpy(), out[3][b, :ni].cpu().numpy(), ref["valid"], ref["invalid"])
+            np.testing.assert_allclose(out[6][b, :n, :n].cpu().numpy(), m, atol=TOL, err_msg=str(tag))
+            checked += 1
+    assert checked >= 40 and skipped <= checked // 4, (checked, skipped)
+
+
+@pytest.mark.gpu
+def test_indices_copy_on_device_tensors(golden_misc):
+    """a9 (lib/groomed_nms.py:272-337) on the GPU box: the golden case and the layer's own use of it in the reference -- scattering a group's
+    block into the N x N inversion matrix (:108) -- with every tensor on the device; results against the reference's golden output and
+    against plain indexing."""
+    from groomed_nms_amd import indices_copy
+    g = golden_misc
+    dev = torch.device("cuda")
+    A = torch.from_numpy(g["indices_copy/A"].copy()).to(dev)
+    out = indices_copy(A, torch.from_numpy(g["indices_copy/B"]).to(dev), torch.from_numpy(g["indices_copy/ind"]).to(dev))
+    assert out.is_cuda and np.array_equal(out.cpu().numpy(), g["indices_copy/out"])
+    assert out.data_ptr() == A.data_ptr()                                          # in place, as the reference (:331-337)
+    rng = np.random.default_rng(5)
+    n = 300
+    M = torch.zeros((n, n), device=dev)
+    grp = torch.from_numpy(np.sort(rng.choice(n, 37, replace=False))).to(dev)
+    blk = torch.from_numpy(rng.standard_normal((37, 37)).astype(np.float32)).to(dev)
+    ref = M.clone()
+    ref[grp[:, None], grp[None, :]] = blk
+    got = indices_copy(M, blk, grp)
+    assert torch.equal(got, ref)
+    keep = M.clone()
+    got2 = indices_copy(M, 2 * blk, grp, inplace=False)
+    assert torch.equal(M, keep) and torch.equal(got2[grp[:, None], grp[None, :]], 2 * blk)
+
+
+@pytest.mark.gpu
+def test_inference_tail_nms_to_kitti_text(G, O):
+    """f4 on the GPU box: the reference's inference tail, lib/rpn_util.py:1295-1319 + :1385-1487 -- float64 proposals ->
+    iou(aboxes, aboxes) (NumPy in: the float64 HIP kernel) -> differentiable_nms on NumPy inputs -> `[0].numpy()` keep list -> the kept rows
+    through kitti_io -- on the golden KITTI cases: the keep list equals the oracle's on the same float64 overlaps, and every line written for
+    a kept box is, byte for byte, the line the REFERENCE wrote for that box (tests/golden/kitti_io.npz holds its text for all boxes)."""
+    from conftest import Golden
+    from groomed_nms_amd import kitti_io as K, overlaps
+    g = Golden("kitti_io.npz")
+
+    class Conf(dict):
+        __getattr__ = dict.__getitem__
+    for tag in ("k12", "k40_un"):
+        conf = Conf(lbls=["Car", "Pedestrian", "Cyclist"], has_un=bool(g[f"{tag}/has_un"]), use_un_for_score=bool(g[f"{tag}/has_un"]))
+        aboxes = g[f"{tag}/boxes"]                                                 # float64 [n, 14]: x1 y1 x2 y2 score cls ...
+        m = overlaps.iou(aboxes[:, 0:4], aboxes[:, 0:4])                           # lib/rpn_util.py:1295-1300 (NumPy float64 in and out)
+        assert isinstance(m, np.ndarray) and m.dtype == np.float64
+        keep = G.differentiable_nms(aboxes[:, 4], m, nms_threshold=0.4)[0].numpy()  # :1319-1320
+        ref = O.differentiable_nms(aboxes[:, 4].astype(np.float32), O.iou2d_f64(aboxes[:, 0:4], aboxes[:, 0:4]).astype(np.float32), nms_threshold=0.4)
+        assert keep.tolist() == [int(i) for i in ref["valid"]], tag
+        assert 0 < len(keep) < len(aboxes), tag                                    # (the case suppresses something and keeps something)
+        kept = aboxes[keep]
+        conv = K.convert_image_predictions_to_correct_entries(kept, conf, g[f"{tag}/p2"])
+        text = K.get_text_to_write_in_kitti_format(conv, conf)
+        golden_lines = g[f"{tag}/text"].tobytes().decode().split("\n")
+        lines = text.split("\n")
+        assert lines[-1] == "" and len(lines) - 1 == len(keep), tag
+        for line, i in zip(lines[:-1], keep.tolist()):
+            assert line == golden_lines[i], (tag, i)
+
+
+@pytest.mark.gpu
+def test_training_tail_in_one_host_call(G):
+    """Round 5 (VERDICT r4 #4a): the layer's neighbours on the C++ host path and the training tail of lib/loss/rpn_3d.py:772-825 + :1117-1131
+    as ONE call (proposals.training_tail: layer -> best box per ground truth -> after-NMS AP loss).  Against the same chain made of the
+    separate entries (each of which is held to the oracle / the reference's vectors by its own test): loss, probabilities, targets and
+    dL/dscores bit for bit; ragged counts; and captured into a HIP graph and replayed on new inputs (nothing but stream-ordered launches)."""
+    from groomed_nms_amd import proposals as PR, synthetic
+    from groomed_nms_amd.aploss import ap_loss_batched
+    rng = np.random.default_rng(99)
+    B, N, M = 3, 700, 6
+    dev = torch.device("cuda")
+
+    def draw(seed):
+        b2, sc = synthetic.batch_2d(seed, B, N, "clustered", per=24)
+        p3, _ = synthetic.batch_3d(seed + 1, B, N, clustered=True, per=24)
+        o = np.argsort(-sc, axis=1, kind="stable")                                 # the loss sorts by score first (:731-737)
+        sc, b2, p3 = np.take_along_axis(sc, o, 1), np.take_along_axis(b2, o[:, :, None], 1), np.take_along_axis(p3, o[:, :, None], 1)
+        pick = np.stack([np.random.default_rng(seed + b).choice(N // 2, M, replace=False) for b in range(B)])
+        return sc, b2, p3, np.take_along_axis(p3, pick[:, :, None], 1).copy(), np.take_along_axis(b2, pick[:, :, None], 1).copy()
+    counts = torch.tensor([N, 431, 64], dtype=torch.int32, device=dev)
+    gtc = torch.tensor([M, 3, 1], dtype=torch.int32, device=dev)
+    sc, b2, p3, gp, gb = draw(5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    s1, s2 = t(sc).requires_grad_(True), t(sc).requires_grad_(True)
+    loss, prob, targets = PR.training_tail(s1, t(b2), t(p3), t(gp), t(gb), 0.3, counts=counts, gt_counts=gtc)
+    prob2 = G.differentiable_nms_with_iou2d_batched(s2, t(b2), counts=counts, index_lists=False)[0]
+    targets2 = PR.best_targets(t(p3), t(b2), t(gp), t(gb), 0.3, pred_counts=counts, gt_counts=gtc)[0]
+    loss2 = ap_loss_batched(prob2, targets2, counts=counts)
+    assert torch.equal(prob, prob2) and torch.equal(targets, targets2) and torch.equal(loss, loss2)
+    assert float(targets.sum()) >= 3 and torch.all(loss >= 0)
+    wl = torch.tensor([1.0, 0.5, 2.0], device=dev)
+    (loss * wl).sum().backward()
+    (loss2 * wl).sum().backward()
+    assert torch.equal(s1.grad, s2.grad) and float(s1.grad.abs().sum()) > 0
+    # captured and replayed on new inputs
+    bufs = [torch.empty_like(t(x)) for x in (sc, b2, p3, gp, gb)]
+    for dst, src in zip(bufs, (sc, b2, p3, gp, gb)):
+        dst.copy_(t(src))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            PR.training_tail(*bufs, 0.3, counts=counts, gt_counts=gtc)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        g_loss, g_prob, g_tg = PR.training_tail(*bufs, 0.3, counts=counts, gt_counts=gtc)
+    for seed in (6, 7):
+        new = draw(seed)
+        for dst, src in zip(bufs, new):
+            dst.copy_(t(src))
+        graph.replay()
+        e_loss, e_prob, e_tg = PR.training_tail(*[t(x) for x in new], 0.3, counts=counts, gt_counts=gtc)
+        assert torch.equal(g_loss, e_loss) and torch.equal(g_prob, e_prob) and torch.equal(g_tg, e_tg), seed

@@ -36,3 +36,5 @@ for l in open(sys.argv[1]):
         d=json.loads(l); r=d.get('roofline') or {}
         print(d['config']['workload'][:50], 'graph' if d['config'].get('hip_graph_replay') else '', d['ms_per_step'], r.get('kernel'), r.get('kernel_ms'), r.get('frac'))
 PY
+python tools/tail_time.py > $O/tail_times.jsonl 2>/dev/null; cat $O/tail_times.jsonl
+python tools/aploss_time.py > $O/aploss_times.jsonl 2>/dev/null; cat $O/aploss_times.jsonl
