@@ -594,16 +594,15 @@ __device__ __forceinline__ void writers_staged_2d(const float* __restrict__ boxe
 // 16-wave workgroup claims 128 x 128 macro tiles (upper triangle of every image, image-major) one claim ahead and alternates between
 // TWO LDS tiles, so that ONE barrier per macro tile suffices: it publishes the tile for the mirrored pass AND the next claim, and the
 // waves that finish their mirrored stores early already compute the next tile into the other buffer.
-// tile0: the macro tiles [0, tile0) of every image are somebody else's (round 5: written on the side stream beside the bit-matrix kernel)
 template <bool NT>
 __device__ __forceinline__ void writers_sym_persistent(const float* __restrict__ rec, int N, float* __restrict__ out, long ld, int nimg, float thr,
-                                                       int* counter, const int tile0 = 0) {
+                                                       int* counter) {
     using namespace gnms_iou3d;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* const tileL = reinterpret_cast<float*>(smem);           // two LDS macro tiles, kSymTileBytes apart
+    float* const tile0 = reinterpret_cast<float*>(smem);           // two LDS macro tiles, kSymTileBytes apart
     __shared__ int s_next[2];
     const int nt = (N + kSymT - 1) / kSymT;
-    const int tpi = sym_tiles_per_image(N) - tile0, total = tpi * nimg;
+    const int tpi = sym_tiles_per_image(N), total = tpi * nimg;
     if (threadIdx.x == 0) s_next[0] = atomicAdd(counter, 1);
     __syncthreads();
     int cur = s_next[0], ph = 0;
@@ -612,10 +611,10 @@ __device__ __forceinline__ void writers_sym_persistent(const float* __restrict__
         if (threadIdx.x == 0) nx = atomicAdd(counter, 1);          // the claim after this one, in flight during the tile
         const int img = cur / tpi;
         int I, J;
-        sym_tile_of(tile0 + cur - img * tpi, nt, &I, &J);
+        sym_tile_of(cur - img * tpi, nt, &I, &J);
         const float* r = rec + (size_t)img * N * kRec;
         float* o = out + (size_t)img * N * ld;
-        float* const tile = tileL + (size_t)ph * (kSymTileBytes / sizeof(float));
+        float* const tile = tile0 + (size_t)ph * (kSymTileBytes / sizeof(float));
         sym_tile_compute<16, NT>(r, N, o, ld, I, J, thr, tile);
         if (threadIdx.x == 0) s_next[ph ^ 1] = nx;
         __syncthreads();                                            // the tile is in LDS, the next claim is known; buffer ph ^ 1 is free
@@ -877,7 +876,7 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
     }
     const int first_writer = nimg * cwg;
     if (SRC == kFromBoxes && staged) { writers_staged_2d<VEC>(write_src, N, out, ld, nimg, img_ptrs(ws, L, 0).misc + 5, L.per_image / sizeof(int), first_writer); return; }
-    if (SRC == kFromRecords && staged == 2) { writers_sym_persistent<true>(write_src, N, out, ld, nimg, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5, row0); return; }   // (row0: the first macro tile)
+    if (SRC == kFromRecords && staged == 2) { writers_sym_persistent<true>(write_src, N, out, ld, nimg, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5); return; }
     writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
 }
 
@@ -987,12 +986,12 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(tail_kernel<E, BOXES>, lds))) return rc;
         const int spw = leaders_chain_wgs(N, sym, chain_cap);
-        // sym 3: symmetry checkers in front of the chain (one 16-wave workgroup per 128 pairs of 64 x 64 bit blocks: fewer, so that the chain workgroups behind them in the grid start sooner, at most the CUs the chain leaves)
+        // sym 3: symmetry checkers in front of the chain (one 16-wave workgroup per 64 pairs of 64 x 64 bit blocks, at most the CUs the chain leaves)
         int nchk = 0;
         if (sym == 3) {
             const long nb = (N + 63) / 64, pairs = (long)B * nb * (nb + 1) / 2;
             const int room = device_cu_count() - B * (spw + fast);
-            nchk = (int)std::min<long>(std::max(room, 8), (pairs + 127) / 128);
+            nchk = (int)std::min<long>(std::max(room, 8), (pairs + 63) / 64);
             if (nchk < 1) nchk = 1;
         }
         tail_kernel<E, BOXES><<<nchk + B * (spw + fast), 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
@@ -1017,7 +1016,7 @@ bool sym_writers_in_tail_launch(int N, int64_t ld, const float* out) {
 template <int SRC>
 int launch_tail_write(const float* chain_src, const float* write_src, int B, int N, const int32_t* counts, const gnms_params& P, char* ws,
                       const gnms_ws_layout& L, float* prob, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, float* out,
-                      int64_t ld, hipStream_t st, int sym_tile0 = 0) {
+                      int64_t ld, hipStream_t st) {
     int P2 = next_pow2(N);
     if (P2 < 1024) P2 = 1024;
     // (the fused K5 -> K6 hand-off, E <= 4, parks order[] and a copy of r2 behind the key region: 16 bytes per key)
@@ -1030,7 +1029,7 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     if (SRC == kFromRecords && sym_writers_in_tail_launch(N, ld, out)) {   // writers_sym_persistent: two LDS macro tiles
         staged = 2;
         if (lds < 2 * gnms_iou3d::kSymTileBytes) lds = 2 * gnms_iou3d::kSymTileBytes;
-        writers = (long)(gnms_iou3d::sym_tiles_per_image(N) - sym_tile0) * B;
+        writers = (long)gnms_iou3d::sym_tiles_per_image(N) * B;
     }
     const int fast = (fast_tail_enabled() && fast_tail_ok(N, P, 1)) ? 1 : 0;
     if (fast && lds < fast_tail_lds_size(N, P2)) lds = fast_tail_lds_size(N, P2);
@@ -1054,11 +1053,11 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
         if (vec) {
             if ((rc = allow_lds(tail_write_kernel<true, E, SRC>, lds))) return rc;
             gnms_launch_prof(kProfMatrixWrite, tail_write_kernel<true, E, SRC>, grid, dim3(1024), lds, st, chain_src, write_src, N, counts, P, ws,
-                             L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, staged == 2 ? sym_tile0 : 0, N, staged, fast);
+                             L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, staged, fast);
         } else {
             if ((rc = allow_lds(tail_write_kernel<false, E, SRC>, lds))) return rc;
             gnms_launch_prof(kProfMatrixWrite, tail_write_kernel<false, E, SRC>, grid, dim3(1024), lds, st, chain_src, write_src, N, counts, P,
-                             ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, staged == 2 ? sym_tile0 : 0, N, staged, fast);
+                             ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, out, (long)ld, tr, 0, N, staged, fast);
         }
     });
     GNMS_CHECK_LAUNCH();
@@ -1317,20 +1316,6 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
     const int bands = std::max(1, std::min(8, N / 512));
     if ((rc = launch_sorts(scores, xkeys, B, N, counts, ws, L, P2, order, st, bands))) return rc;
     SideScope scope(st);
-    // Large images inside the symmetric writers' launch (round 5): the bit-matrix kernel is VALU-bound (0.32 ms at B = 8, N = 16384) and ran
-    // alone in front of a store-bound write that does not depend on it.  The first `pct` percent of every image's macro tiles now leave from
-    // the one-tile-per-workgroup symmetric writer on the side stream WHILE the bit-matrix kernel runs (512-thread workgroups at 44 VGPRs and
-    // 66 KiB of LDS leave room for its 256-thread workgroups on every CU: arithmetic on one side, stores on the other); the launch that carries
-    // the chain writes the rest.  GNMS_3D_SPLIT_PCT overrides (0: off).
-    static const int split_env = [] { const char* e = getenv("GNMS_3D_SPLIT_PCT"); return e ? atoi(e) : -1; }();
-    const int split_pct = (sym_tail && chain_in_write && N > 4096 && use_side_stream(B, N, ld)) ? (split_env >= 0 ? std::min(split_env, 90) : 15) : 0;
-    int sym_tile0 = 0;
-    if (split_pct > 0) {
-        hipStream_t side = nullptr;
-        if ((rc = scope.fork(&side, 0))) return rc;
-        if ((rc = gnms_internal_nms_overlap3d_sym(rec, B, N, iou_out, ld, side, P.nms_threshold, 0, split_pct))) return rc;
-        sym_tile0 = (int)((long long)gnms_iou3d::sym_tiles_per_image(N) * split_pct / 100);       // (gnms_internal_nms_overlap3d_sym's own rounding)
-    }
     // the part of the write that runs beside the bit-matrix kernel: rows [0, r1) of the all-pairs kernel
     const int r1 = beside ? split_rows(N, 20) : 0;
     if (r1 > 0) {                                                 // first part of the write beside the bit-matrix kernel
@@ -1354,10 +1339,8 @@ int forward_with_iou3d_on(float* rec, const float* params3d, const float* scores
             bitmask_rec3d_culled_kernel<1><<<dim3(gx, 1, B), 256, 0, st>>>(N, counts, P.nms_threshold, ws, L, pinned);
     }
     GNMS_CHECK_LAUNCH();
-    if (chain_in_write) {                                         // K3..K6 and the matrix in one launch, like the 2D entry
-        if ((rc = launch_tail_write<kFromRecords>(nullptr, rec, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, iou_out, ld, st, sym_tile0))) return rc;
-        return split_pct > 0 ? scope.join() : GNMS_OK;
-    }
+    if (chain_in_write)                                           // K3..K6 and the matrix in one launch, like the 2D entry
+        return launch_tail_write<kFromRecords>(nullptr, rec, B, N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, iou_out, ld, st);
     if (beside) {                                                 // see forward_boxes_impl for why the fork sits exactly here
         hipStream_t side = nullptr;
         if ((rc = scope.fork(&side, 1))) return rc;
