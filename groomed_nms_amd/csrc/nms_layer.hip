@@ -986,12 +986,12 @@ int launch_tail(const float* src, int B, int N, int64_t ld, const int32_t* count
     GNMS_DISPATCH_SORT(P2, {
         if ((rc = allow_lds(tail_kernel<E, BOXES>, lds))) return rc;
         const int spw = leaders_chain_wgs(N, sym, chain_cap);
-        // sym 3: symmetry checkers in front of the chain (one 16-wave workgroup per 64 pairs of 64 x 64 bit blocks, at most the CUs the chain leaves)
+        // sym 3: symmetry checkers in front of the chain (one 16-wave workgroup per 128 pairs of 64 x 64 bit blocks: fewer, so that the chain workgroups behind them in the grid start sooner, at most the CUs the chain leaves)
         int nchk = 0;
         if (sym == 3) {
             const long nb = (N + 63) / 64, pairs = (long)B * nb * (nb + 1) / 2;
             const int room = device_cu_count() - B * (spw + fast);
-            nchk = (int)std::min<long>(std::max(room, 8), (pairs + 63) / 64);
+            nchk = (int)std::min<long>(std::max(room, 8), (pairs + 127) / 128);
             if (nchk < 1) nchk = 1;
         }
         tail_kernel<E, BOXES><<<nchk + B * (spw + fast), 1024, lds, st>>>(src, N, (long)ld, counts, P, ws, L, P2, prob, (long long*)valid, (long long*)invalid, nvalid,
