@@ -1960,6 +1960,24 @@ def test_select_topk_among_all_anchors(G):
         want = PO.select_topk(sc[b], cand[b, :counts[b]], K)
         assert int(num[b]) == len(want) and idx[b, :len(want)].cpu().tolist() == want.tolist(), b
         assert (idx[b, len(want):] == -1).all()
+    # round 5, the cooperative launch (several workgroups per image from 4096 candidates on): candidate counts on both sides of its chunk
+    # (8192) and run (1024) boundaries, K above the count, ALL scores equal (every key ties at the threshold: candidate order decides),
+    # batches of one image and of sixteen
+    for Bq, Aq, K in ((1, 126720, 4096), (16, 20000, 3000), (2, 8193, 8192), (3, 5000, 6000), (1, 4097, 1025)):
+        sq = rng.random((Bq, Aq), dtype=np.float32)
+        sq[0, : Aq // 2] = 0.5                                             # half of image 0 ties
+        if Bq > 1:
+            sq[1] = 0.25                                                   # image 1: one value
+        bq = rng.random((Bq, Aq, 4), dtype=np.float32)
+        cq = rng.integers(1, Aq + 1, size=Bq).astype(np.int32)
+        cq[0] = Aq
+        idx, num, ssel, bsel = PR.select_topk(torch.from_numpy(sq).cuda(), K, torch.arange(Aq, dtype=torch.int32).repeat(Bq, 1).cuda(),
+                                              torch.from_numpy(cq).cuda(), torch.from_numpy(bq).cuda())
+        for b in range(Bq):
+            want = PO.select_topk(sq[b], np.arange(cq[b]), K)
+            assert int(num[b]) == len(want) and idx[b, :len(want)].cpu().tolist() == want.tolist(), (Bq, Aq, K, b)
+            assert (idx[b, len(want):] == -1).all() and (ssel[b, len(want):] == 0).all()
+            assert np.array_equal(ssel[b, :len(want)].cpu().numpy(), sq[b][want]) and np.array_equal(bsel[b, :len(want)].cpu().numpy(), bq[b][want])
 
 
 def test_self_iou_in_the_writers_geometry_and_negative_zero(G, O):

@@ -41,6 +41,10 @@ def main():
     for K in (500, 4096):                               # among ALL anchors: radix pre-selection + the sort of the K survivors
         t = timed(lambda: PR.select_topk(scores, K, None, None, boxes))
         print(json.dumps({"kernel": "select_topk among all anchors (+ gathers)", "B": B, "candidates": A, "K": K, "us": round(t, 1)}))
+    for Bq, K in ((1, 4096), (1, 500), (4, 4096)):   # C3 / C4's shapes: one (four) image(s), all anchors
+        sq, bq = scores[:Bq].contiguous(), boxes[:Bq].contiguous()
+        t = timed(lambda: PR.select_topk(sq, K, None, None, bq))
+        print(json.dumps({"kernel": "select_topk among all anchors (+ gathers)", "B": Bq, "candidates": A, "K": K, "us": round(t, 1)}))
     N = 4096
     par = torch.from_numpy(np.stack([rng.uniform(-20, 20, (B, N)), rng.uniform(0.5, 2.5, (B, N)), rng.uniform(4, 60, (B, N)),
                                      rng.uniform(1.4, 2, (B, N)), rng.uniform(1.3, 2, (B, N)), rng.uniform(3, 5, (B, N)),
