@@ -1339,6 +1339,7 @@ __device__ __forceinline__ void rem_store(int* rem, int k, int v) { __hip_atomic
 // probabilities -- and the groups' CSR the backward reads is built beside K6 by one more workgroup (csr_build_body).
 // Returns 0 in the workgroups that are done, 1 in the image's last one (2: STAGE and some leader is outside its own group).
 constexpr int kNoStage = -1;
+constexpr int kFastGroupMax = 256;   // longest group the fast tail handles (default cap: 101)
 constexpr int kGranVerdict = 30;     // gran[16][30]: the last workgroup's verdict for csr_build_body (payload 1 = fast tail, 2 = K5 ran, nothing to do)
 
 template <int STAGE = kNoStage>
@@ -2460,9 +2461,13 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     } else {
         // MERGE BY BUCKETS.  The sorted heads split the key space into nA + 1 buckets; a box of B lies in bucket g = number of heads in front
         // of it (a binary search), and its final position is g + (boxes of B in earlier buckets) + (its rank among its bucket mates); head
-        // i ends up at i + (boxes of B in buckets <= i).  So B is never sorted: count per bucket (LDS atomics), prefix over the buckets,
-        // members scattered into their bucket's segment (the scatter's atomics turn the exclusive prefix into the inclusive one), rank inside
-        // the segment by comparison -- buckets hold a box or two.  (nB >= 1, hence nA + 1 <= n <= Ppow2 counters: the head array, dead by now.)
+        // i ends up at i + (boxes of B in buckets <= i).  So B is not sorted as long as the buckets are small (a box or two on detector-like
+        // scores): count per bucket (LDS atomics), prefix over the buckets, members scattered into their bucket's segment (the scatter's
+        // atomics turn the exclusive prefix into the inclusive one), rank inside the segment by comparison.  A bucket of more than
+        // kBucketMax boxes -- scores that nearly tie put every rescored member behind the last head: the C3 harness's random-init network
+        // does exactly that, 2 281 boxes in one bucket, and ranking them by comparison took 0.5 ms -- sends B through the sort instead.
+        // (nB >= 1, hence nA + 1 <= n <= Ppow2 counters: the head array, dead by now.)
+        constexpr int kBucketMax = 32;
         int* cntG = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4);              // [nA + 1] (zeroed during the compaction above)
         int* seg = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 28);              // [nB] indices into keyB, bucket by bucket
         int gB[E];
@@ -2473,13 +2478,14 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
             if (i < nB) { gB[e] = lower_bound_lds<u64>(keyA, nA, keyB[i]); atomicAdd(&cntG[gB[e]], 1); }
         }
         lds_barrier();
-        {   // exclusive prefix over the nA + 1 buckets, in place (thread t owns buckets t * E .. t * E + E - 1)
-            int c[E], sum = 0;
+        int big;
+        {   // exclusive prefix over the nA + 1 buckets, in place (thread t owns buckets t * E .. t * E + E - 1); the largest bucket on the way
+            int c[E], sum = 0, mx = 0;
 #pragma unroll
-            for (int e = 0; e < E; ++e) { const int g = t * E + e; c[e] = (g <= nA) ? cntG[g] : 0; sum += c[e]; }
+            for (int e = 0; e < E; ++e) { const int g = t * E + e; c[e] = (g <= nA) ? cntG[g] : 0; sum += c[e]; mx = max(mx, c[e]); }
             const unsigned inc = gnms_add_scan32((unsigned)sum);
             if (lane == 63) ff_tot[0][wave] = inc;
-            lds_barrier();
+            big = __syncthreads_or(mx > kBucketMax);
             unsigned base = 0u;
             for (int w = 0; w < 16; ++w) if (w < wave) base += ff_tot[0][w];
             int run = (int)(base + inc) - sum;
@@ -2487,20 +2493,39 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
             for (int e = 0; e < E; ++e) { const int g = t * E + e; if (g <= nA) cntG[g] = run; run += c[e]; }
         }
         lds_barrier();
+        if (!big) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) { const int i = t + e * 1024; if (i < nB) seg[atomicAdd(&cntG[gB[e]], 1)] = i; }
-        lds_barrier();                                             // cntG[g] is now the INCLUSIVE prefix: boxes of B in buckets <= g
-        for (int i = t; i < nA; i += 1024) emit(keyA[i], i + cntG[i]);
+            for (int e = 0; e < E; ++e) { const int i = t + e * 1024; if (i < nB) seg[atomicAdd(&cntG[gB[e]], 1)] = i; }
+            lds_barrier();                                         // cntG[g] is now the INCLUSIVE prefix: boxes of B in buckets <= g
+            for (int i = t; i < nA; i += 1024) emit(keyA[i], i + cntG[i]);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int i = t + e * 1024;
-            if (i < nB) {
-                const int g = gB[e], s0 = g > 0 ? cntG[g - 1] : 0, s1 = cntG[g];
-                const u64 k = keyB[i];
-                int rank = 0;
-                for (int j = s0; j < s1; ++j) rank += keyB[seg[j]] < k ? 1 : 0;
-                emit(k, g + s0 + rank);
+            for (int e = 0; e < E; ++e) {
+                const int i = t + e * 1024;
+                if (i < nB) {
+                    const int g = gB[e], s0 = g > 0 ? cntG[g - 1] : 0, s1 = cntG[g];
+                    const u64 k = keyB[i];
+                    int rank = 0;
+                    for (int j = s0; j < s1; ++j) rank += keyB[seg[j]] < k ? 1 : 0;
+                    emit(k, g + s0 + rank);
+                }
             }
+        } else {
+            // B through the sort; a head's position still comes from the bucket prefix (cntG[i + 1]: boxes of B in buckets <= i)
+            for (int i = t; i < nA; i += 1024) emit(keyA[i], i + cntG[i + 1]);
+            if (nB <= 1024) {
+                u64 r1[1] = {t < nB ? keyB[t] : ~0ull};
+                lds_barrier();
+                int pe = 64;
+                while (pe < nB) pe <<= 1;
+                block_sort<1, u64>(r1, keyB, pe);
+            } else {
+                u64 r[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) r[e] = (t * E + e < nB) ? keyB[t * E + e] : ~0ull;
+                lds_barrier();
+                block_sort<E, u64>(r, keyB, E * 1024);
+            }
+            for (int j = t; j < nB; j += 1024) { const u64 k = keyB[j]; emit(k, j + lower_bound_lds<u64>(keyA, nA, k)); }
         }
     }
     GNMS_TACC(13);
@@ -2547,7 +2572,9 @@ __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, i
                 r2L[k] = r2; hdL[k] = hd; ordL[k] = ck;
             }
         }
-        if (cap < (long long)n) {                                                    // (else no group can be longer than the cap)
+        // (a group above kFastGroupMax members also takes K5 proper: csr_build_body ranks the members of a run by comparison, quadratic in its length)
+        const long long lim = cap < kFastGroupMax ? cap : kFastGroupMax;
+        if (lim < (long long)n) {                                                    // (else no group can be longer than the limit)
             for (int i = tid; i < n; i += 1024) cnt[i] = 0;
             lds_barrier();
 #pragma unroll
@@ -2558,7 +2585,7 @@ __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, i
             }
             lds_barrier();
             int over = 0;
-            for (int i = tid; i < n; i += 1024) over |= (long long)cnt[i] > cap;
+            for (int i = tid; i < n; i += 1024) over |= (long long)cnt[i] > lim;
             slow = __syncthreads_or(over);
         }
     }

@@ -2561,3 +2561,36 @@ def test_training_tail_in_one_host_call(G):
         graph.replay()
         e_loss, e_prob, e_tg = PR.training_tail(*[t(x) for x in new], 0.3, counts=counts, gt_counts=gtc)
         assert torch.equal(g_loss, e_loss) and torch.equal(g_prob, e_prob) and torch.equal(g_tg, e_tg), seed
+
+
+@pytest.mark.gpu
+def test_fast_tail_corner_cases_against_oracle(G, O):
+    """The fast tail's fallbacks (round 5), each against the oracle, bit for bit, with gradients:
+    * scores that nearly TIE (what a randomly initialised RPN emits -- the C3 harness: 4096 scores within 3e-3 of 0.76): every rescored
+      member lands behind the last head, i.e. in ONE bucket of K6's merge -> B goes through the sort;
+    * a cap far above the group lengths with one dense cluster of more than 256 boxes -> K5 proper (the CSR workgroup would rank the
+      run's members by comparison);
+    * a few heads and many valid members; no valid box at all; every box valid."""
+    from groomed_nms_amd import synthetic
+    rng = np.random.default_rng(31)
+    cases = []
+    bx, _ = synthetic.batch_2d(1, 1, 4096, "clustered", per=3)
+    cases.append(("near ties", bx[0], (0.76 - 1e-7 * rng.permutation(4096)).astype(np.float32), {}))
+    bx, sc = synthetic.batch_2d(2, 1, 3000, "clustered", per=600)
+    cases.append(("long groups", bx[0], sc[0], dict(group_size=5000)))
+    bx, sc = synthetic.batch_2d(3, 1, 2500, "clustered", per=90)
+    cases.append(("few heads", bx[0], (0.9 + 0.1 * sc[0]).astype(np.float32), dict(valid_box_prob_threshold=0.2)))
+    bx, sc = synthetic.batch_2d(4, 1, 1500, "uniform")
+    cases.append(("none valid", bx[0], (0.2 * sc[0]).astype(np.float32), {}))
+    cases.append(("all valid", bx[0], (0.5 + 0.5 * sc[0]).astype(np.float32), dict(valid_box_prob_threshold=0.0)))
+    for tag, boxes, scores, kw in cases:
+        n = len(scores)
+        st = torch.from_numpy(scores[None]).cuda().requires_grad_(True)
+        w = torch.from_numpy(rng.uniform(-1, 2, (1, n)).astype(np.float32)).cuda()
+        out = G.differentiable_nms_with_iou2d_batched(st, torch.from_numpy(boxes[None]).cuda(), **kw)
+        (out[0] * w).sum().backward()
+        ref = O.differentiable_nms(scores, O.iou2d(boxes, boxes), grad_prob=w[0].cpu().numpy(), **kw)
+        assert np.array_equal(out[0][0].detach().cpu().numpy(), ref["prob"]), tag
+        nv, ni = int(out[4][0]), int(out[5][0])
+        assert out[2][0, :nv].tolist() == list(ref["valid"]) and out[3][0, :ni].tolist() == list(ref["invalid"]), tag
+        assert np.array_equal(st.grad[0].cpu().numpy(), ref["grad_scores"]), tag

@@ -204,6 +204,8 @@ def main():
                 out[0].sum().backward()
         torch.cuda.synchronize()
         phase["nms_path"] = (time.perf_counter() - t1) / args.steps
+        if os.environ.get("GNMS_E2E_DUMP"):                         # (developer: the proposals the layer saw, for offline analysis)
+            np.savez(os.environ["GNMS_E2E_DUMP"], scores=s_sel.detach().cpu().numpy(), boxes=b_sel.cpu().numpy(), num=num.cpu().numpy())
     if rank == 0:
         imgs = world * B * args.steps
         print(json.dumps({
