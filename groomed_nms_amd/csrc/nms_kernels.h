@@ -528,6 +528,80 @@ __global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restric
 
 
 // ------------------------------------------------------------------------------------------------
+// K1 for N <= 2048 (round 5): the same two sorts by COUNTING, spread over the machine.  Up to 1024 keys one workgroup per (image, role)
+// sorted them in LDS: 4-5 us of merge passes on one CU inside a 9-12-us launch that left 240 CUs idle -- the longest launch in front of the
+// chain at the reference's own sizes.  A key's position in the sorted order is the number of keys below it (keys are distinct: the index is
+// in the low bits), and that needs no sort at all: workgroup (block, image, role) takes 64 keys, every workgroup holds ALL keys of its
+// image in LDS, thread (key, segment) counts the keys of one sixteenth of the image below its own, an LDS atomic adds the sixteen counts,
+// and the 64 results leave exactly as the merge kernel's do.  N / 64 workgroups per image and role: 256 at B = 8, N = 1024.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sort_count_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                          const int* __restrict__ counts, char* ws, gnms_ws_layout L,
+                                                          long long* __restrict__ order_out, int mode3d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* keys = reinterpret_cast<u64*>(smem);                          // [NP] all keys of the image (padding ~0: behind everything)
+    __shared__ int rk[64];
+    const int blk = blockIdx.x, b = blockIdx.y, role = blockIdx.z;
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int t = threadIdx.x, lane = t & 63, seg = t >> 6;
+    const int NP = (N + 63) & ~63;
+    const float* s = scores + (size_t)b * N;
+    const float* bx = boxes ? boxes + (size_t)b * N * 4 : nullptr;
+    float zlo = 0.0f, zscale = 0.0f;
+    if (role == 1 && mode3d > 1) block_z_bands(reinterpret_cast<const float4*>(bx), n, mode3d, &zlo, &zscale);
+    for (int i = t; i < NP; i += 1024) keys[i] = (i < n) ? sort_key_of(role, s, bx, i, mode3d, zlo, zscale) : ~0ull;
+    if (t < 64) rk[t] = 0;
+    __syncthreads();
+    const int k = blk * 64 + lane;                                     // (k < NP)
+    const u64 mine = keys[k];
+    {
+        const int per = NP >> 4;                                       // a multiple of 4
+        const u64* p = keys + seg * per;
+        int c = 0;
+        for (int j = 0; j < per; j += 4) c += (p[j] < mine ? 1 : 0) + (p[j + 1] < mine ? 1 : 0) + (p[j + 2] < mine ? 1 : 0) + (p[j + 3] < mine ? 1 : 0);
+        if (c) atomicAdd(&rk[lane], c);
+    }
+    // what only one workgroup per image and role does: the "already sorted" / "every box is plain" flags (every workgroup holds every key,
+    // so the first one decides alone), the counters, the call counter, the hand-off granules
+    int flag = 1;
+    if (blk == 0) {
+        if (role == 0) {
+            for (int i = t; i + 1 < n; i += 1024) flag &= keys[i] < keys[i + 1];      // ascending keys in index order = the scores came in sorted
+        } else {
+            for (int i = t; i < n; i += 1024) flag &= box_orders_plainly(reinterpret_cast<const float4*>(bx)[i]) ? 1 : 0;
+        }
+    }
+    const int all = __syncthreads_and(flag);                           // (also: every count has landed in rk)
+    if (blk == 0) {
+        if (role == 0) {
+            if (t < 8 && !(boxes && t == 6)) I.misc[t] = (t == 2) ? all : 0;           // ([6]: the x sort's)
+            if (t == 8) I.misc[8] = gnms_next_epoch(I.misc[8]);
+            for (int i = t; i < 17 * 32; i += 1024) I.gran[i] = 0ull;
+        } else if (t == 0) {
+            I.misc[6] = all ? 0 : 1;
+        }
+    }
+    if (seg != 0) return;
+    if (k < n) {
+        const int rank = rk[lane];
+        const int idx = (int)((unsigned)mine & (role == 0 ? 0xffffffffu : kColIdxMask));
+        if (role == 0) {
+            I.order[rank] = idx;
+            I.rankof[idx] = rank;
+            I.sscore[rank] = s[idx];
+            if (boxes) I.rbox[rank] = reinterpret_cast<const float4*>(bx)[idx];
+            if (order_out) order_out[(size_t)b * N + rank] = idx;
+        } else {
+            column_store(I, rank, idx, reinterpret_cast<const float4*>(bx)[idx], mode3d);
+        }
+    } else if (k < N && role == 0) {                                   // padding ranks map to themselves (order is a permutation of [0, N))
+        I.order[k] = k; I.rankof[k] = k; I.sscore[k] = 0.0f;
+        if (order_out) order_out[(size_t)b * N + k] = k;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: threshold bit matrix -- the ONE full read of the N x N fp32 matrix (HBM-read bound).
 // One wave = 64 rank-rows x 256 input columns.  Rows order[64*kb + r] are contiguous 4N-byte streams
 // whatever the permutation, so the row gather is free; lane t accumulates, for each of its 4 columns c,

@@ -922,6 +922,14 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
                  int64_t* order, hipStream_t st, int mode3d = 0) {
     int rc;
     const int roles = boxes ? 2 : 1;
+    // up to 2048 keys: by counting, N / 64 workgroups per image and role (sort_count_kernel); GNMS_COUNT_SORT=0: the LDS sorts below (developer A/B)
+    static const bool count_sort = [] { const char* e = getenv("GNMS_COUNT_SORT"); return !(e && e[0] == '0'); }();
+    if (count_sort && N <= 2048) {
+        const int NP = (N + 63) & ~63;
+        sort_count_kernel<<<dim3(NP / 64, B, roles), 1024, (size_t)NP * 8, st>>>(scores, boxes, N, counts, ws, L, (long long*)order, mode3d);
+        GNMS_CHECK_LAUNCH();
+        return GNMS_OK;
+    }
     if (P2 <= 1024) {
         sort_scores_kernel<1><<<dim3(B, roles), P2, (size_t)P2 * 8, st>>>(scores, N, counts, ws, L, P2, (long long*)order, boxes, mode3d);
         GNMS_CHECK_LAUNCH();
