@@ -368,24 +368,55 @@ __global__ __launch_bounds__(kApThreads) void ap_prepare_kernel(const float* __r
     if (t == 0) { S.meta[0] = F; S.meta[1] = G; S.meta[2] = 1; }
 }
 
+// (round 5: kRankPPW positives per wave -- every value loaded once for all of them; one positive per wave streamed 64 KiB through the L2 for each
+// of 4096 positives at N = 16384 and was bound by that.  The terms are summed in fp32 for 32 trips at a time -- at most 32 terms of [0, 1] per
+// lane: exact to 2^-19 -- and carried on in double.)
+constexpr int kRankPPW = 4;
 __global__ __launch_bounds__(1024) void ap_rank_kernel(int N, float* __restrict__ scratch) {
     const int b = blockIdx.y;
     ApScratch S = ap_scratch(scratch, N, b);
     const int F = S.meta[0], G = S.meta[1];
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 16 + (threadIdx.x >> 6);
-    if (p >= F) return;
-    const float x = asc_key_decode(S.keys[p]);
-    double sa = 0.0, sb = 0.0;
-    for (int k = lane; k < F; k += 64) sa += (double)rank_term(asc_key_decode(S.keys[k]), x, 2.0f);
-    for (int j = lane; j < G; j += 64) sb += (double)rank_term(S.bgv[j], x, 2.0f);
+    const int p0 = (blockIdx.x * 16 + (threadIdx.x >> 6)) * kRankPPW;
+    if (p0 >= F) return;
+    float x[kRankPPW];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { sa += __shfl_xor(sa, off, 64); sb += __shfl_xor(sb, off, 64); }
-    if (lane == 0) {
-        const float a = (float)sa + 0.5f;
-        const float bsum = (float)sb;
-        S.denom[p] = a + bsum;
-        S.mprec[p] = a / (a + bsum);
+    for (int u = 0; u < kRankPPW; ++u) x[u] = asc_key_decode(S.keys[min(p0 + u, F - 1)]);
+    double sa[kRankPPW], sb[kRankPPW];
+#pragma unroll
+    for (int u = 0; u < kRankPPW; ++u) { sa[u] = 0.0; sb[u] = 0.0; }
+    for (int k0 = 0; k0 < F; k0 += 64 * 32) {
+        float acc[kRankPPW] = {0.f, 0.f, 0.f, 0.f};
+        const int kend = min(F, k0 + 64 * 32);
+        for (int k = k0 + lane; k < kend; k += 64) {
+            const float v = asc_key_decode(S.keys[k]);
+#pragma unroll
+            for (int u = 0; u < kRankPPW; ++u) acc[u] += rank_term(v, x[u], 2.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < kRankPPW; ++u) sa[u] += (double)acc[u];
+    }
+    for (int j0 = 0; j0 < G; j0 += 64 * 32) {
+        float acc[kRankPPW] = {0.f, 0.f, 0.f, 0.f};
+        const int jend = min(G, j0 + 64 * 32);
+        for (int j = j0 + lane; j < jend; j += 64) {
+            const float v = S.bgv[j];
+#pragma unroll
+            for (int u = 0; u < kRankPPW; ++u) acc[u] += rank_term(v, x[u], 2.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < kRankPPW; ++u) sb[u] += (double)acc[u];
+    }
+#pragma unroll
+    for (int u = 0; u < kRankPPW; ++u) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { sa[u] += __shfl_xor(sa[u], off, 64); sb[u] += __shfl_xor(sb[u], off, 64); }
+        if (lane == 0 && p0 + u < F) {
+            const float a = (float)sa[u] + 0.5f;
+            const float bsum = (float)sb[u];
+            S.denom[p0 + u] = a + bsum;
+            S.mprec[p0 + u] = a / (a + bsum);
+        }
     }
 }
 
@@ -511,7 +542,7 @@ extern "C" int gnms_aploss(const float* logits, const float* targets, int B, int
         switch (E) { case 1: GNMS_AP_PREP(1); break; case 2: GNMS_AP_PREP(2); break; case 4: GNMS_AP_PREP(4); break; case 8: GNMS_AP_PREP(8); break;
                      default: GNMS_AP_PREP(16); break; }
 #undef GNMS_AP_PREP
-        ap_rank_kernel<<<dim3(gnms_div_up(N, 16), B), 1024, 0, st>>>(N, scratch);
+        ap_rank_kernel<<<dim3(gnms_div_up(N, 16 * kRankPPW), B), 1024, 0, st>>>(N, scratch);
         switch (E) { case 1: ap_scan_kernel<1><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
                      case 2: ap_scan_kernel<2><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
                      case 4: ap_scan_kernel<4><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
