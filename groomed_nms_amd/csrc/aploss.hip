@@ -371,11 +371,9 @@ __global__ __launch_bounds__(kApThreads) void ap_prepare_kernel(const float* __r
 // (round 5: kRankPPW positives per wave -- every value loaded once for all of them; one positive per wave streamed 64 KiB through the L2 for each
 // of 4096 positives at N = 16384 and was bound by that.  The terms are summed in fp32 for 32 trips at a time -- at most 32 terms of [0, 1] per
 // lane: exact to 2^-19 -- and carried on in double.)
-constexpr int kRankPPW = 4;
-__global__ __launch_bounds__(1024) void ap_rank_kernel(int N, float* __restrict__ scratch) {
-    const int b = blockIdx.y;
-    ApScratch S = ap_scratch(scratch, N, b);
-    const int F = S.meta[0], G = S.meta[1];
+// (with few positives -- fewer than a wave per SIMD of the machine -- one positive per wave keeps more waves in flight: kRankPPW = 1 below 2048)
+template <int kRankPPW>
+__device__ __forceinline__ void ap_rank_body(const ApScratch& S, const int F, const int G) {
     const int lane = threadIdx.x & 63;
     const int p0 = (blockIdx.x * 16 + (threadIdx.x >> 6)) * kRankPPW;
     if (p0 >= F) return;
@@ -386,7 +384,9 @@ __global__ __launch_bounds__(1024) void ap_rank_kernel(int N, float* __restrict_
 #pragma unroll
     for (int u = 0; u < kRankPPW; ++u) { sa[u] = 0.0; sb[u] = 0.0; }
     for (int k0 = 0; k0 < F; k0 += 64 * 32) {
-        float acc[kRankPPW] = {0.f, 0.f, 0.f, 0.f};
+        float acc[kRankPPW];
+#pragma unroll
+        for (int u = 0; u < kRankPPW; ++u) acc[u] = 0.0f;
         const int kend = min(F, k0 + 64 * 32);
         for (int k = k0 + lane; k < kend; k += 64) {
             const float v = asc_key_decode(S.keys[k]);
@@ -397,7 +397,9 @@ __global__ __launch_bounds__(1024) void ap_rank_kernel(int N, float* __restrict_
         for (int u = 0; u < kRankPPW; ++u) sa[u] += (double)acc[u];
     }
     for (int j0 = 0; j0 < G; j0 += 64 * 32) {
-        float acc[kRankPPW] = {0.f, 0.f, 0.f, 0.f};
+        float acc[kRankPPW];
+#pragma unroll
+        for (int u = 0; u < kRankPPW; ++u) acc[u] = 0.0f;
         const int jend = min(G, j0 + 64 * 32);
         for (int j = j0 + lane; j < jend; j += 64) {
             const float v = S.bgv[j];
@@ -418,6 +420,12 @@ __global__ __launch_bounds__(1024) void ap_rank_kernel(int N, float* __restrict_
             S.mprec[p0 + u] = a / (a + bsum);
         }
     }
+}
+__global__ __launch_bounds__(1024) void ap_rank_kernel(int N, float* __restrict__ scratch) {
+    const ApScratch S = ap_scratch(scratch, N, blockIdx.y);
+    const int F = S.meta[0], G = S.meta[1];
+    if (F >= 2048) ap_rank_body<4>(S, F, G);
+    else ap_rank_body<1>(S, F, G);
 }
 
 template <int kApE>
@@ -542,7 +550,7 @@ extern "C" int gnms_aploss(const float* logits, const float* targets, int B, int
         switch (E) { case 1: GNMS_AP_PREP(1); break; case 2: GNMS_AP_PREP(2); break; case 4: GNMS_AP_PREP(4); break; case 8: GNMS_AP_PREP(8); break;
                      default: GNMS_AP_PREP(16); break; }
 #undef GNMS_AP_PREP
-        ap_rank_kernel<<<dim3(gnms_div_up(N, 16 * kRankPPW), B), 1024, 0, st>>>(N, scratch);
+        ap_rank_kernel<<<dim3(gnms_div_up(N, 16), B), 1024, 0, st>>>(N, scratch);
         switch (E) { case 1: ap_scan_kernel<1><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
                      case 2: ap_scan_kernel<2><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
                      case 4: ap_scan_kernel<4><<<B, kApThreads, 0, st>>>(N, scratch, loss, grad); break;
