@@ -486,6 +486,10 @@ def main():
                 kr = max(5, min(steps, 20))
                 collect(0); collect(1)
                 check(lib.gnms_profile_events(1), "profile_events")
+                # (small shapes are host-bound: on an idle GPU the start marker of a bracket runs when it is enqueued and the launch behind it
+                # arrives microseconds later, so the bracket would time the host.  A spin kernel in front lets the host run kr steps ahead:
+                # markers and launches then execute back to back)
+                torch.cuda._sleep(int(4e6) + int(2.5e5) * kr)
                 for _ in range(kr):
                     one()
                 torch.cuda.synchronize()

@@ -60,6 +60,13 @@ python tools/host_overhead.py --boxes 512 --steps 1500 2>/dev/null | head -12 > 
 python tools/aploss_time.py > $O/${T}_aploss_times.jsonl 2>/dev/null
 python tools/e2e_bench.py --mode infer --steps 10 2>/dev/null | tail -1 > $O/${T}_e2e.jsonl
 python tools/e2e_bench.py --mode train --steps 10 2>/dev/null | tail -1 >> $O/${T}_e2e.jsonl
+python tools/proposals_time.py 2>/dev/null | grep "^{" > $O/${T}_proposals_times.jsonl
+PYTHONPATH=$PWD bash tools/prof_cmd.sh ${T}_prop python $PWD/tools/proposals_time.py > $O/prof_prop.txt 2>&1
+cp gpurun_out/prof_${T}_prop/run_kernel_stats.csv $O/${T}_proposals_kernel_stats.csv
+PYTHONPATH=$PWD bash tools/prof_cmd.sh ${T}_ap python $PWD/tools/aploss_time.py > $O/prof_ap.txt 2>&1
+cp gpurun_out/prof_${T}_ap/run_kernel_stats.csv $O/${T}_aploss_kernel_stats.csv
+python tools/tail_time.py 2>/dev/null | grep "^{" > $O/${T}_training_tail.jsonl
+for cfg in "1 4096 uniform" "8 4096 uniform" "8 1024 uniform" "8 512 uniform"; do set -- $cfg; echo "== B=$1 N=$2 $3 (lists)" >> $O/${T}_phase_ticks.txt; GNMS_LIB_PATH=build/timing/libgroomed_nms_hip.so GNMS_BINDING=ctypes timeout 300 python tools/phase_ticks.py --batch $1 --boxes $2 --kind $3 --lists 2>&1 | grep -v amdgpu.ids >> $O/${T}_phase_ticks.txt; done
 cat $O/${T}_bench.json; echo; cat $O/${T}_grid.jsonl | python -c "
 import json,sys
 for l in sys.stdin:
