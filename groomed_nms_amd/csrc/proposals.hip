@@ -428,7 +428,13 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
     {
         const int Kc = K < F ? K : F;
         const int G = std::max(gnms_div_up(F, kCoopChunk), gnms_div_up(Kc, 1024));
-        if (F > 4096 && K <= GNMS_MAX_BOXES && (long)B * G <= (long)gnms_device_cu_count() && B <= 65535) {
+        // Its grid barriers need every workgroup resident at the same time.  B * G <= CUs is not enough when ANOTHER launch of the same kind runs
+        // beside it on another stream (each could hold half the machine and wait for the rest for ever), so the launch is a COOPERATIVE one
+        // (hipLaunchCooperativeKernel: the runtime admits it only if the whole grid fits and runs one cooperative grid at a time); not while
+        // the stream is being captured, and if the runtime says no, the one-workgroup kernels below serve the call.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        if (!capturing && F > 4096 && K <= GNMS_MAX_BOXES && (long)B * G <= (long)gnms_device_cu_count() && B <= 65535) {
             const int Kpad = gnms_div_up(Kc, 1024) * 1024;
             const size_t per = coop_scratch_bytes(G, Kpad);
             gnms_async_buffer sc_buf;
@@ -438,12 +444,21 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
             if (lds < kCoopBins * sizeof(unsigned)) lds = kCoopBins * sizeof(unsigned);
             int rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(topk_coop_kernel), lds);
             if (rc) return rc;
-            topk_coop_kernel<<<dim3(G, B), 1024, lds, st>>>(scores, A, candidates, F, candidate_counts, K, Kpad, G, sc_buf.as<char>(),
-                                                            reinterpret_cast<const float4*>(boxes), (long long*)sel_index, sel_count, sel_scores,
-                                                            reinterpret_cast<float4*>(sel_boxes));
-            GNMS_CHECK_LAUNCH();
+            char* scp = sc_buf.as<char>();
+            const float4* bx4 = reinterpret_cast<const float4*>(boxes);
+            long long* sidx = (long long*)sel_index;
+            float4* sbx4 = reinterpret_cast<float4*>(sel_boxes);
+            int Gv = G;
+            void* args[] = {(void*)&scores, (void*)&A, (void*)&candidates, (void*)&F, (void*)&candidate_counts, (void*)&K, (void*)&Kpad, (void*)&Gv, (void*)&scp,
+                            (void*)&bx4, (void*)&sidx, (void*)&sel_count, (void*)&sel_scores, (void*)&sbx4};
+            const hipError_t le = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(topk_coop_kernel), dim3(G, B), dim3(1024), args, (unsigned)lds, st);
+            if (le == hipSuccess) {
+                GNMS_CHECK_LAUNCH();
+                GNMS_CHECK_HIP(sc_buf.release());
+                return GNMS_OK;
+            }
+            (void)hipGetLastError();                                  // (not admitted: the kernels below)
             GNMS_CHECK_HIP(sc_buf.release());
-            return GNMS_OK;
         }
     }
     gnms_async_buffer pre_buf;                                        // [B][K] pre-selected candidates + [B] counts (large F only)

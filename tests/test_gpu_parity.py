@@ -1978,6 +1978,27 @@ def test_select_topk_among_all_anchors(G):
             assert int(num[b]) == len(want) and idx[b, :len(want)].cpu().tolist() == want.tolist(), (Bq, Aq, K, b)
             assert (idx[b, len(want):] == -1).all() and (ssel[b, len(want):] == 0).all()
             assert np.array_equal(ssel[b, :len(want)].cpu().numpy(), sq[b][want]) and np.array_equal(bsel[b, :len(want)].cpu().numpy(), bq[b][want])
+    # two host threads on two streams at once: the cooperative launches must not wait for each other's workgroups for ever
+    import threading
+    big = torch.from_numpy(rng.random((12, 126720), dtype=np.float32)).cuda()          # 12 x 16 workgroups: three quarters of the machine per launch
+    want0 = PO.select_topk(big[0].cpu().numpy(), None, 4096)
+    errs = []
+
+    def worker():
+        try:
+            st_ = torch.cuda.Stream()
+            with torch.cuda.stream(st_):
+                for _ in range(20):
+                    idx_, _, _, _ = PR.select_topk(big, 4096)
+                st_.synchronize()
+            assert idx_[0].cpu().tolist() == want0.tolist()
+        except Exception as e:                                             # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=worker) for _ in range(2)]
+    [t_.start() for t_ in th]
+    [t_.join(timeout=120) for t_ in th]
+    assert not any(t_.is_alive() for t_ in th), "concurrent cooperative top-K launches hang"
+    assert not errs, errs
 
 
 def test_self_iou_in_the_writers_geometry_and_negative_zero(G, O):
