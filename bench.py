@@ -380,10 +380,7 @@ def main():
             self_ok = N <= 4096 and B <= 127 and B * ((N + 7) // 8) >= 8 * 256
             wname = ("iou2d_self_kernel" if self_ok else ("write_staged_kernel" if N > 4096 and N % 4 == 0 else "iou2d_kernel")) if args.dim == 2 else "iou3d_sym_kernel"
         r_write = roof(ms_write, n_write, alg_write, wname, fill_gbs, fill_what)
-        # (round 5: up to N = 4096 the one full read of the matrix-in layer is a ROLE of tail_pipe_kernel, whose launch also carries the symmetry
-        # check and the chain -- its duration is the read plus the chain's last super-block)
-        r_read = roof(ms_read, n_read, alg_read, "tail_pipe_kernel" if (N <= 4096 and B * ((N + 1023) // 1024 + 1) <= 128) else "bitmask_kernel", read_gbs,
-                      "plain non-temporal float4 load stream (gnms_profile_read)")
+        r_read = roof(ms_read, n_read, alg_read, "bitmask_kernel", read_gbs, "plain non-temporal float4 load stream (gnms_profile_read)")
 
         total_boxes = world * B * N * args.steps
         value = total_boxes / dt
@@ -515,7 +512,7 @@ def main():
                        "whole_step_frac": round((bytes_w + (bytes_r if (two_calls or ref_3d) else 0.0)) / (dts / steps) / 1e9 / HBM_PEAK_GBS, 4),
                        "roofline": brief(msw, nw_, bytes_w * (2.0 if ref_3d else 1.0), wn)}
                 if two_calls or ref_3d:
-                    res["roofline_matrix_in"] = brief(msr, nr_, bytes_r, "tail_pipe_kernel (read + symmetry check + chain)" if n_ <= 4096 else "bitmask_kernel")
+                    res["roofline_matrix_in"] = brief(msr, nr_, bytes_r, "bitmask_kernel")
                 return res
 
             # (60 steps where a step is a fraction of a millisecond: at 20 the 3D step read 0.203-0.207 ms where 100 steps give 0.185-0.188)

@@ -624,22 +624,23 @@ __device__ __forceinline__ float4 load_nt_f4(const float* p) {
     return v;
 }
 
-// (rank block kb of image b, column-chunk workgroup bxi of gx; rowbuf: 4096 words of LDS when WAVES == 16.  PIPE: the row leaves through
-// write-through stores -- the chain workgroups of the SAME launch read it, tail_pipe_kernel)
-template <bool VEC, int WAVES, int RB, bool PIPE>
-__device__ __forceinline__ void bitmask_body(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts, float thr, char* ws,
-                                             gnms_ws_layout L, int full, const int b, const int kb, const int bxi, const int gx, u64* rowbuf) {
+template <bool VEC, int WAVES = kMaskWaves, int RB = kMaskRB>
+__global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                                                  float thr, char* ws, gnms_ws_layout L, int full) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int kb = blockIdx.y;
     const int n = gnms_count(counts, b, N);
     const int k0 = kb * 64;
     // column chunk rotated by the row block: with pre-sorted scores half the tiles exit below, and an un-rotated grid
     // would leave that work on every other XCD (blocks are dealt round-robin to the 8 XCDs)
-    const int bx = (bxi + kb) % gx;
+    const int bx = (blockIdx.x + kb) % gridDim.x;
     const int c0 = (bx * WAVES + wave) * 256;
     // `full` with ONE 16-wave workgroup per rank block (N <= 4096): the row of W is collected in LDS, by column rank, and leaves as
     // one coalesced write -- N scattered 8-byte stores per row block otherwise (the triangle alone is half of them)
-    const bool rowbuffered = WAVES == 16 && full && gx == 1 && L.NC <= 4096;
+    __shared__ u64 rowbuf[(WAVES == 16) ? 4096 : 1];
+    const bool rowbuffered = WAVES == 16 && full && gridDim.x == 1 && L.NC <= 4096;
     if (k0 >= n) return;                                                 // (workgroup-uniform)
     ImgPtrs I = img_ptrs(ws, L, b);
     const bool ident = I.misc[2] != 0;                                   // scores were already sorted: rank == input index
@@ -707,10 +708,7 @@ __device__ __forceinline__ void bitmask_body(const float* __restrict__ iou, int 
             if (col[j] < L.NC && rk[j] >= 0 && rk[j] < L.NC) rowbuf[rk[j]] = w;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < L.NC; i += WAVES * 64) {
-            if (PIPE) __hip_atomic_store(reinterpret_cast<unsigned long long*>(Wk + i), (unsigned long long)rowbuf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else Wk[i] = rowbuf[i];
-        }
+        for (int i = threadIdx.x; i < L.NC; i += WAVES * 64) Wk[i] = rowbuf[i];
         return;
     }
 #pragma unroll
@@ -719,13 +717,6 @@ __device__ __forceinline__ void bitmask_body(const float* __restrict__ iou, int 
         // `full`, the whole row: wsym_check_kernel then decides whether the thresholded matrix is symmetric and the scan may pull
         if (col[j] < n && (full || rk[j] < k0 + 64)) Wk[rk[j]] = (((u64)wd[1][j] << 32) | wd[0][j]) & rowmask;
     }
-}
-
-template <bool VEC, int WAVES = kMaskWaves, int RB = kMaskRB>
-__global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
-                                                                  float thr, char* ws, gnms_ws_layout L, int full) {
-    __shared__ u64 rowbuf[(WAVES == 16) ? 4096 : 1];
-    bitmask_body<VEC, WAVES, RB, false>(iou, N, ld, counts, thr, ws, L, full, (int)blockIdx.z, (int)blockIdx.y, (int)blockIdx.x, (int)gridDim.x, rowbuf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2841,92 +2832,6 @@ __global__ __launch_bounds__(1024) void tail_kernel(const float* __restrict__ sr
     groups_body<E, SRC>(src, N, ld, counts, P, ws, L, Ppow2, b);
     __syncthreads();
     finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The matrix-in layer as ONE launch (round 5): the read of the matrix, the symmetry check, the chain and the groups' runs.
-// As launches of their own the chain (41 us at B = 8, N = 4096) ran strictly behind bitmask_kernel (88 us), although the scan of super-block j
-// needs only the bit rows of the rank blocks up to 16 j + 15.  Here the grid is ordered by super-block:
-//     [bit rows of blocks 0..15 of every image][chain workgroups of super-block 0][bit rows 16..31][chain 1] ... [checkers][CSR]
-// (a workgroup only ever waits for workgroups in front of it in the grid).  A bit-row workgroup is bitmask_kernel's body with the row leaving
-// through write-through stores and a count per (image, super-block) behind it; chain workgroup (j, b) waits for the counts 0..j of its image,
-// then runs as in tail_kernel; the checkers wait for every count, the last chain workgroup for the checkers.  When the read ends, what is left
-// of the chain is its last super-block: resolve, Stage B, K6.
-// ------------------------------------------------------------------------------------------------
-constexpr int kGranBits = 20;                     // gran[16][20 + j]: bit-row workgroups of super-block j that are done (a count, not a tagged granule: the sorts zero it)
-__device__ __forceinline__ unsigned* pipe_counter(const ImgPtrs& I, int j) { return reinterpret_cast<unsigned*>(I.gran + (size_t)16 * 32 + kGranBits + j); }
-
-template <int E>
-__global__ __launch_bounds__(1024) void tail_pipe_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts, gnms_params P,
-                                                         char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
-                                                         long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid, int B,
-                                                         int spw, int nchk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(E <= 4, "the fast tail");
-    const int NB = L.NB;
-    // which role, which super-block, which image (the decode is a loop of its own: with the role bodies inside it the kernel spilled)
-    int role = -1, j = 0, x = (int)blockIdx.x;
-    for (int jj = 0; jj < spw; ++jj) {
-        const int seg_bits = min(kSB, NB - jj * kSB) * B;
-        if (x < seg_bits) { role = 0; j = jj; break; }
-        x -= seg_bits;
-        if (x < B) { role = 1; j = jj; break; }
-        x -= B;
-    }
-    if (role < 0) { if (x < nchk) role = 2; else { role = 3; x -= nchk; } }
-    if (role == 0) {                                                     // ---- a bit row: rank block 16 j + t of image b ----
-        const int t = x / B, b = x - t * B;
-        bitmask_body<true, 16, kMaskRB, true>(iou, N, ld, counts, P.nms_threshold, ws, L, 2, b, j * kSB + t, 0, 1, reinterpret_cast<u64*>(smem));
-        __builtin_amdgcn_s_waitcnt(0x0f70);                              // vmcnt(0): the row is out ...
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(pipe_counter(img_ptrs(ws, L, b), j), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before it counts
-        return;
-    }
-    if (role == 1) {                                                     // ---- chain workgroup of super-block j, image x ----
-        const int b0 = x;
-        ImgPtrs I0 = img_ptrs(ws, L, b0);
-        if ((int)threadIdx.x <= j) {
-            const unsigned want = (unsigned)min(kSB, NB - (int)threadIdx.x * kSB);
-            while (__hip_atomic_load(pipe_counter(I0, (int)threadIdx.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(4);
-        }
-        __syncthreads();
-        int b;
-        int last = leaders_chain<kFromMatrix>(N, counts, ws, L, B, spw, j * B + b0, 3, &b, iou, ld, P.nms_threshold, P.temperature, P.pruning_method, Ppow2);
-        if (!last) return;
-        if (last != 3) {                                                 // the scan ran on trust: the checkers' verdict before anything is final
-            int asym = 0;
-            if (threadIdx.x < 64) {
-                while (__hip_atomic_load(I0.misc + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nchk) __builtin_amdgcn_s_sleep(4);
-                asym = __hip_atomic_load(I0.misc + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-            }
-            if (__syncthreads_or(asym)) {                                // not symmetric after all: the general scan, K4..K6 proper; nothing for the CSR workgroup
-                if (threadIdx.x == 0) gran_store(I0.gran + (size_t)16 * 32 + kGranVerdict, ((u64)(unsigned)I0.misc[8] << 32) | 2ull);
-                leaders_body(N, counts, ws, L, b);
-                last = 3;
-            }
-        }
-        if (last != 3) { fast_final_body<E, kFromMatrix>(iou, N, ld, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b, last); return; }
-        __syncthreads();                                                 // general scan: K4..K6 as before
-        attribute_image<kFromMatrix>(iou, ld, N, counts, P.nms_threshold, ws, L, b, 0);
-        __syncthreads();
-        groups_body<E, kFromMatrix>(iou, N, ld, counts, P, ws, L, Ppow2, b);
-        __syncthreads();
-        finalize_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
-        return;
-    }
-    if (role == 2) {                                                     // ---- symmetry checkers: every bit row of every image first ----
-        for (int i = (int)threadIdx.x; i < B * spw; i += 1024) {
-            const int b = i / spw, jj = i - b * spw;
-            const unsigned want = (unsigned)min(kSB, NB - jj * kSB);
-            const ImgPtrs I = img_ptrs(ws, L, b);
-            if (I.misc[2] == 0)                                          // (images with pre-sorted scores are not checked)
-                while (__hip_atomic_load(pipe_counter(I, jj), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(8);
-        }
-        __syncthreads();
-        wsym_check_in_launch(N, counts, ws, L, B, x, nchk);
-        return;
-    }
-    if (img_ptrs(ws, L, x).misc[2] == 0) csr_build_body<E>(N, counts, ws, L, x);   // ---- the image's CSR workgroup ----
 }
 
 }  // namespace

@@ -1102,28 +1102,6 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     if (P.group_boxes && P.mask_group_boxes && use_tail_kernel(N, matrix_sym_detection(N) ? 2 : 0)) {
         // (with the fast tail the symmetry check is a role of the tail launch and the scan runs on trust beside it: sym 3)
         const int sym = matrix_sym_detection(N) ? ((fast_tail_enabled() && fast_tail_ok(N, P, 2)) ? 3 : 2) : 0;
-        // ... and, for aligned matrices and batches whose waiting workgroups cannot fill the machine, the READ is a role of that launch too,
-        // the chain consuming the bit rows super-block by super-block (tail_pipe_kernel).  GNMS_PIPE=0: the two launches (developer A/B).
-        static const bool pipe_on = [] { const char* e = getenv("GNMS_PIPE"); return !(e && e[0] == '0'); }();
-        const int spw_p = leaders_chain_wgs(N, 3);
-        if (sym == 3 && pipe_on && (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0) && L.NC <= 4096 && B * (spw_p + 1) <= device_cu_count() / 2) {
-            int P2p = next_pow2(N);
-            if (P2p < 1024) P2p = 1024;
-            size_t lds = fast_tail_lds_size(N, P2p);
-            if (lds < 32 * 1024) lds = 32 * 1024;                       // (the bit rows' LDS copy of a row of W)
-            const long nb = L.NB, pairs = (long)B * nb * (nb + 1) / 2;
-            const int nchk = (int)std::max<long>(1, std::min<long>(std::max(device_cu_count() - B * (spw_p + 1), 8), (pairs + 127) / 128));
-            const unsigned grid = (unsigned)(L.NB * B + B * spw_p + nchk + B);
-            GNMS_DISPATCH_SORT(P2p, {
-                if constexpr (E <= 4) {
-                    if ((rc = allow_lds(tail_pipe_kernel<E>, lds))) return rc;
-                    gnms_launch_prof(kProfMatrixRead, tail_pipe_kernel<E>, dim3(grid), dim3(1024), lds, st, iou, N, (long)ld, counts, P, ws, L, P2p, prob,
-                                     (long long*)valid, (long long*)invalid, nvalid, ninvalid, B, spw_p, nchk);
-                }
-            });
-            GNMS_CHECK_LAUNCH();
-            return GNMS_OK;
-        }
         if ((rc = launch_bitmask(iou, B, N, ld, counts, P.nms_threshold, ws, L, st, sym == 3 ? 2 : (sym ? 1 : 0)))) return rc;
         return launch_tail<false>(iou, B, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, st, sym);
     }

@@ -2106,7 +2106,7 @@ def test_leader_scan_across_workgroups(G, O):
 
 def test_library_switches():
     """The five environment switches the shipped library still reads, each against the default run of the
-    same inputs: GNMS_PIPE=0 (round 5: the matrix-in layer's read and its tail as two launches instead of tail_pipe_kernel), GNMS_FAST_TAIL=0 (round 5: K5 proper -- the sort of the groups -- instead of the fast tail; probabilities, lists AND gradients,
+    same inputs: GNMS_FAST_TAIL=0 (round 5: K5 proper -- the sort of the groups -- instead of the fast tail; probabilities, lists AND gradients,
     i.e. the groups' runs the backward reads, must be the same bit for bit), GNMS_TWO_STREAMS=0 (large images: every launch on the caller's stream instead of the library's side stream),
     GNMS_MATRIX_SYM=0 (matrix-in layer: the general scan also for symmetric matrices), GNMS_TAIL_WRITERS=n (CUs that write the matrix
     beside the per-image chain) and GNMS_TRACE_LAUNCH=1 (developer: launch sites printed, device synchronised behind each)."""
@@ -2147,8 +2147,7 @@ print("ok")
 """
     runs = {}
     for tag, env in (("default", {}), ("one_stream", {"GNMS_TWO_STREAMS": "0"}), ("general_scan", {"GNMS_MATRIX_SYM": "0"}),
-                     ("few_writers", {"GNMS_TAIL_WRITERS": "40"}), ("trace", {"GNMS_TRACE_LAUNCH": "1"}), ("k5_proper", {"GNMS_FAST_TAIL": "0"}),
-                     ("two_launches", {"GNMS_PIPE": "0"})):
+                     ("few_writers", {"GNMS_TAIL_WRITERS": "40"}), ("trace", {"GNMS_TRACE_LAUNCH": "1"}), ("k5_proper", {"GNMS_FAST_TAIL": "0"})):
         path = "/tmp/gnms_switch_%s.npz" % tag
         r = _run_py(code, env, argv=(path,))
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stderr[-2000:])
