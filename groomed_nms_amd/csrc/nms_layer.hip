@@ -924,7 +924,9 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
     const int roles = boxes ? 2 : 1;
     // up to 2048 keys: by counting, N / 64 workgroups per image and role (sort_count_kernel); GNMS_COUNT_SORT=0: the LDS sorts below (developer A/B)
     static const bool count_sort = [] { const char* e = getenv("GNMS_COUNT_SORT"); return !(e && e[0] == '0'); }();
-    if (count_sort && N <= 2048) {
+    // (... and up to 4096 keys where its N / 64 workgroups per image and role are ONE round of the machine -- B <= 2: 256 compares per thread,
+    // ~8 us in one launch against 14 us of runs + merge; from two rounds on the merge sort wins, LABNOTES R5.6)
+    if (count_sort && (N <= 2048 || (N <= 4096 && (long)B * ((N + 63) / 64) * roles <= (long)device_cu_count()))) {
         const int NP = (N + 63) & ~63;
         sort_count_kernel<<<dim3(NP / 64, B, roles), 1024, (size_t)NP * 8, st>>>(scores, boxes, N, counts, ws, L, (long long*)order, mode3d);
         GNMS_CHECK_LAUNCH();
