@@ -2102,6 +2102,10 @@ def test_leader_scan_across_workgroups(G, O):
         ref = O.differentiable_nms(scores[b], O.iou2d(boxes[b], boxes[b]))
         for rep in (b, b + 4, B - 4 + b):
             assert np.array_equal(out[0][rep].cpu().numpy(), ref["prob"]), rep
+    # the same batch through the matrix-in layer (round 5: symmetry checkers in FRONT of 480 chain / CSR workgroups that wait for them)
+    two = G.differentiable_nms_batched(stt, out[6])
+    torch.cuda.synchronize()
+    assert torch.equal(two[0], out[0]) and torch.equal(two[2], out[2]) and torch.equal(two[4], out[4])
 
 
 def test_library_switches():
