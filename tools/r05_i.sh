@@ -1,8 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q -k "n4096 or scale or leader_scan or recycled or empty or fuzz_layer" 2>&1 | tail -2
-for cs in 1 0; do for a in "--batch 1 --graph" "--batch 2 --graph" "--batch 1"; do
-GNMS_COUNT_SORT=$cs timeout 300 python bench.py $a --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind 2>/dev/null | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('count_sort=$cs', d['config']['workload'][:40], 'graph' if d['config'].get('hip_graph_replay') else 'eager', d['ms_per_step'])"
-done; done
+timeout 900 python -m pytest tests -m gpu -x -q -k "from_boxes or adversarial or n4096 or fuzz_layer or scale or one_call" 2>&1 | tail -2
+GNMS_LIB_PATH=build/timing/libgroomed_nms_hip.so GNMS_BINDING=ctypes python tools/bits_ticks.py 2>&1 | grep -v amdgpu
+bash tools/prof.sh r05l_b8 --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind 2>&1 | head -6
+bash tools/prof.sh r05l_b4 --batch 4 --steps 200 --warmup 20 --no-cpu-baseline --no-other-kind 2>&1 | head -4
