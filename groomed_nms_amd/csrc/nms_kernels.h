@@ -833,12 +833,20 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* rowbuf = reinterpret_cast<u64*>(smem);                       // ROWBUF: [NC] words of row kb, by column rank
     ImgPtrs I = img_ptrs(ws, L, b);
+#ifdef GNMS_TIMING   // developer (tools/bits_ticks.py): phase ticks of wave 0 / wave 15 of rank block 32 of image 0, into xsol
+    long long bt__[6]; int bti__ = 0;
+#define GNMS_BT() do { bt__[bti__++] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GNMS_BT() do {} while (0)
+#endif
+    GNMS_BT();
     if (ROWBUF) {
         const int kbr = bx;                                   // one rank block per workgroup, wave w = column chunk w
         if (kbr * 64 >= n) return;
         for (int i = threadIdx.x; i < L.NC; i += blockDim.x) rowbuf[i] = 0ull;
         __syncthreads();
     }
+    GNMS_BT();
     const int nwaves = blockDim.x >> 6;
     for (int cq = 0; cq < (CHUNKLOOP ? (nchunk + nwaves - 1) / nwaves : 1); ++cq) {
     const int tile = ROWBUF ? bx * nchunk + wave : bx * 4 + wave;
@@ -885,6 +893,7 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     for (int j = 1; j < CPL; ++j) { hx0 = fminf(hx0, cb[j].x); hx1 = fmaxf(hx1, cb[j].z); hy0 = fminf(hy0, cb[j].y); hy1 = fmaxf(hy1, cb[j].w); }
     hx0 = wave_min_f(hx0); hy0 = wave_min_f(hy0); hx1 = wave_max_f(hx1); hy1 = wave_max_f(hy1);
     const bool cull = cols_ok && (thr >= 0.0f);
+    GNMS_BT();
 #pragma unroll 1
     for (int kw = 0; kw < KBW; ++kw) {
         const int kb = kbg * KBW + kw;
@@ -1023,11 +1032,20 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     }
     }   // !idle
     }   // chunks of this wave
+    GNMS_BT();
     if (ROWBUF) {
         __syncthreads();
+        GNMS_BT();
         u64* Wk = I.W + (size_t)bx * L.NC;
         for (int i = threadIdx.x; i < L.NC; i += blockDim.x) Wk[i] = rowbuf[i];      // the whole row, coalesced
     }
+    GNMS_BT();
+#ifdef GNMS_TIMING
+    if (ROWBUF && !CHUNKLOOP && b == 0 && bx == 32 && (threadIdx.x == 0 || threadIdx.x == 960)) {
+        long long* o = reinterpret_cast<long long*>(I.xsol) + (threadIdx.x ? 8 : 0);
+        for (int q = 1; q < 6; ++q) o[q] += bt__[q] - bt__[q - 1];
+    }
+#endif
 }
 
 // (ROWBUF without the chunk loop: two 16-wave workgroups per CU = 8 waves per SIMD, i.e. at most 64 VGPRs -- asked for explicitly)
