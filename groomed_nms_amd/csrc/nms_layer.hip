@@ -1129,7 +1129,8 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
         if (permute_from_boxes) ungrouped_permute_boxes_kernel<<<dim3(gnms_div_up(N, kPermuteRows), B), 256, 0, st>>>(N, counts, P, ws, L, Ps);
         else ungrouped_permute_kernel<<<dim3(N, B), 256, plds, st>>>(iou, N, (long)ld, counts, P, ws, L, Ps);
         GNMS_CHECK_LAUNCH();
-        ungrouped_solve_forward_kernel<<<dim3(L.NB, B), 256, 0, st>>>(scores, N, counts, P, ws, L, Ps);
+        if ((rc = allow_lds(ungrouped_solve_forward_kernel, kUngroupedFwdLds))) return rc;
+        ungrouped_solve_forward_kernel<<<dim3(gnms_div_up(N, kUB), B), kUThreads, kUngroupedFwdLds, st>>>(scores, N, counts, P, ws, L, Ps);
         GNMS_CHECK_LAUNCH();
     }
     GNMS_DISPATCH_SORT(P2, {
@@ -1456,7 +1457,8 @@ extern "C" int gnms_backward(const float* grad_prob, const float* scores, const 
         const float* Ps = reinterpret_cast<const float*>(ws + (size_t)B * L.per_image);   // written by the forward pass
         ungrouped_backward_prepare_kernel<<<dim3(gnms_div_up(N, 1024), B), 1024, 0, st>>>(N, ws, L);
         GNMS_CHECK_LAUNCH();
-        ungrouped_solve_backward_kernel<<<dim3(L.NB, B), 256, 0, st>>>(N, counts, P, ws, L, Ps, grad_scores);
+        if ((rc = allow_lds(ungrouped_solve_backward_kernel, kUngroupedBwdLds))) return rc;
+        ungrouped_solve_backward_kernel<<<dim3(gnms_div_up(N, kUB), B), kUThreads, kUngroupedBwdLds, st>>>(N, counts, P, ws, L, Ps, grad_scores);
         GNMS_CHECK_LAUNCH();
         if (grad_iou) {
             ungrouped_grad_iou_kernel<<<dim3(gnms_div_up(N, 256), N, B), 256, 0, st>>>(iou, N, (long)ld, counts, P, ws, L, grad_iou);

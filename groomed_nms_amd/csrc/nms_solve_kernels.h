@@ -222,10 +222,10 @@ __global__ __launch_bounds__(1024) void solve_groups_kernel(const float* __restr
 //   U1  ungrouped_permute_kernel   Ps[i][j] = f(iou[order[i]][order[j]]) for j < i, into a scratch matrix in NMS-position
 //       space (the reference makes the same copy, :48).  One workgroup per row: the input row is read coalesced into LDS,
 //       the column permutation is an LDS gather, the stores are coalesced.  4N^2 bytes in, 2N^2 out.
-//   U2  ungrouped_solve_forward_kernel   one workgroup per block of 64 positions, ALL blocks in flight: block b streams
-//       its 64 x 64b strip of Ps tile by tile (next tile prefetched into registers), and consumes x of block c as soon as
+//   U2  ungrouped_solve_forward_kernel   one workgroup per block of 128 positions, ALL blocks in flight: block b streams
+//       its 128 x 128b strip of Ps tile by tile (next tile prefetched into registers), and consumes x of block c as soon as
 //       block c publishes it (mailbox in global memory, decoupled look-back: a block only waits for lower-numbered blocks,
-//       which are dispatched first).  The sequential part is 64 dependent steps inside a 64 x 64 diagonal tile.
+//       which are dispatched first).  The diagonal tile is inverted ahead of the chain, so a block's own part is a product.
 //   U3  ungrouped_solve_backward_kernel  the same with the transpose, blocks published from the last to the first.
 // `rem` (unused by this mode) carries pos_of[input index] = NMS position; the bit-matrix region `W` holds the two mailboxes;
 // `xsol` the backward solution by position.  (The first version did all of this in ONE workgroup per image, row by
@@ -238,14 +238,25 @@ __global__ __launch_bounds__(1024) void solve_groups_kernel(const float* __restr
 __device__ __forceinline__ void mail_put(u64* slot, float v) {
     __hip_atomic_store(slot, (1ull << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float mail_get(const u64* slot) {
-    u64 w;
-    while (((w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0) __builtin_amdgcn_s_sleep(1);
-    return __uint_as_float((unsigned)(w & 0xffffffffu));
+// two consecutive slots by one lane; a slot at or past `n` counts as present with the value 0
+__device__ __forceinline__ u64 mail_peek(const u64* mail, int p, int n) {
+    return p < n ? __hip_atomic_load(mail + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 32);
 }
-// row pitch of the scratch matrix: whole 64-column tiles, because the solves load the diagonal tile of the last row block in full
-// (columns i0 .. i0+63; the entries past N are never used, but they must lie inside the allocation)
-__host__ __device__ inline size_t ungrouped_ld(int N) { return (size_t)((N + 63) & ~63); }
+__device__ __forceinline__ float2 mail_finish2(const u64* mail, int p, int n, u64 w0, u64 w1) {   // w0, w1: a first attempt already made
+    while ((w0 >> 32) == 0 || (w1 >> 32) == 0) {
+        __builtin_amdgcn_s_sleep(1);
+        w0 = mail_peek(mail, p, n);
+        w1 = mail_peek(mail, p + 1, n);
+    }
+    return make_float2(__uint_as_float((unsigned)(w0 & 0xffffffffu)), __uint_as_float((unsigned)(w1 & 0xffffffffu)));
+}
+__device__ __forceinline__ float2 mail_get2(const u64* mail, int p, int n) {
+    const u64 w0 = mail_peek(mail, p, n), w1 = mail_peek(mail, p + 1, n);
+    return mail_finish2(mail, p, n, w0, w1);
+}
+// row pitch of the scratch matrix: whole 128-column tiles, because the solves load the diagonal tile of the last row block in full
+// (columns i0 .. i0+127; the entries past N are never used, but they must lie inside the allocation)
+__host__ __device__ inline size_t ungrouped_ld(int N) { return (size_t)((N + 127) & ~127); }
 __host__ __device__ inline size_t ungrouped_scratch_bytes(int B, int N) { return (size_t)B * N * ungrouped_ld(N) * sizeof(float); }
 
 __global__ __launch_bounds__(1024) void ungrouped_prepare_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws,
@@ -307,69 +318,200 @@ __global__ __launch_bounds__(256) void ungrouped_permute_boxes_kernel(int N, con
     }
 }
 
-// 256 threads: thread t owns row t>>2 of the block and 16 consecutive columns (t&3)*16.. of every 64-column tile
-__device__ __forceinline__ void ungrouped_load_tile(const float* __restrict__ p, bool live, float4 (&dst)[4]) {
+// ---- the two solves on blocks of 128 positions (round 5) -----------------------------------------------------------------
+// A block's workgroup (512 threads; thread t owns row t>>2 and the 32 consecutive columns (t&3)*32.. of every 128-column tile)
+// inverts its own diagonal tile while the lower blocks are still solving: D = (I + T)^-1 of the unit lower triangular 128 x 128
+// tile from the inverses of its two 64 x 64 diagonal sub-tiles (one wave each, lane = column, forward substitution on the identity:
+// no cross-lane step) and D21 = -D22 T21 D11 (two 64^3 products out of LDS).  The block's solve is then a product,
+// x = D (s - sum_c P[blk][c] x_c): behind the LAST source block there are two 128 x 128 matrix-vector products of register-resident
+// tiles (32 fused multiply-adds per thread and a quad reduction each) where the 64-position version had a tile product and 63
+// dependent cross-lane steps, and there are half as many hand-offs.  D^T goes into the (otherwise unused) upper triangle of the
+// diagonal tile of Ps for the backward solve -- written after the block has published x.  Round 4: 200 / 221 us at B = 8, N = 4096.
+constexpr int kUB = 128;                  // positions per block
+constexpr int kUP = 132;                  // LDS row pitch in floats: 16-byte aligned rows, consecutive rows four banks apart
+// eight waves compute; a ninth polls the mailbox (a wave's loads return in order: a poll issued behind the prefetch of a 64-KiB tile
+// could not complete before the tile had landed)
+constexpr int kUThreads = 576;
+constexpr size_t kUngroupedFwdLds = (size_t)(2 * kUB * kUP + 3 * kUB) * sizeof(float);
+constexpr size_t kUngroupedBwdLds = (size_t)(kUB * kUP + 3 * kUB) * sizeof(float);
+
+// eight 16-byte loads, unconditional: the callers clamp the row to one that exists and never use what a dead row produced, so that
+// the compiler sees straight-line loads and counts them (a load under a branch made it wait for ALL outstanding loads, vmcnt(0))
+__device__ __forceinline__ void ungrouped_load_tile(const float* __restrict__ p, float4 (&dst)[8]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = live ? reinterpret_cast<const float4*>(p)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 8; ++q) dst[q] = reinterpret_cast<const float4*>(p)[q];
+}
+// sum over the four lanes of a quad, in every lane (two DPP quad_perm moves; __shfl_xor compiles to two ds_bpermute round trips)
+__device__ __forceinline__ float ungrouped_quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+// 64 x 64 product out of LDS, 512 threads, two rows x four columns per thread: C[i][j] = sign * sum_k A[i][k] B[k][j]
+__device__ __forceinline__ void ungrouped_mm64(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, float sign, int t) {
+    const int ti = (t >> 4) * 2, tj = (t & 15) * 4;
+    float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+        const float4 a0 = *reinterpret_cast<const float4*>(A + ti * kUP + k);
+        const float4 a1 = *reinterpret_cast<const float4*>(A + (ti + 1) * kUP + k);
+        const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 bv = *reinterpret_cast<const float4*>(Bm + (k + kk) * kUP + tj);
+            c0[0] = __builtin_fmaf(a0v[kk], bv.x, c0[0]); c0[1] = __builtin_fmaf(a0v[kk], bv.y, c0[1]);
+            c0[2] = __builtin_fmaf(a0v[kk], bv.z, c0[2]); c0[3] = __builtin_fmaf(a0v[kk], bv.w, c0[3]);
+            c1[0] = __builtin_fmaf(a1v[kk], bv.x, c1[0]); c1[1] = __builtin_fmaf(a1v[kk], bv.y, c1[1]);
+            c1[2] = __builtin_fmaf(a1v[kk], bv.z, c1[2]); c1[3] = __builtin_fmaf(a1v[kk], bv.w, c1[3]);
+        }
+    }
+    *reinterpret_cast<float4*>(C + ti * kUP + tj) = make_float4(sign * c0[0], sign * c0[1], sign * c0[2], sign * c0[3]);
+    *reinterpret_cast<float4*>(C + (ti + 1) * kUP + tj) = make_float4(sign * c1[0], sign * c1[1], sign * c1[2], sign * c1[3]);
+}
+// dot product of 32 register values with 32 consecutive LDS floats, four partial sums
+__device__ __forceinline__ float ungrouped_dot32(const float (&a)[32], const float* __restrict__ v) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 bv = *reinterpret_cast<const float4*>(v + 4 * q);
+        s0 = __builtin_fmaf(a[4 * q], bv.x, s0); s1 = __builtin_fmaf(a[4 * q + 1], bv.y, s1);
+        s2 = __builtin_fmaf(a[4 * q + 2], bv.z, s2); s3 = __builtin_fmaf(a[4 * q + 3], bv.w, s3);
+    }
+    return (s0 + s1) + (s2 + s3);
 }
 
-__global__ __launch_bounds__(256) void ungrouped_solve_forward_kernel(const float* __restrict__ scores, int N, const int* __restrict__ counts,
-                                                                      gnms_params P, char* ws, gnms_ws_layout L,
-                                                                      const float* __restrict__ Ps_all) {
-    __shared__ float xc[64];
-    __shared__ float tb[64];
+// The strip's tiles go through three register buffers, two loads ahead of the use; the stage count is padded to a multiple of three
+// with null stages IN FRONT (x = 0 from the poller, the tile index clamped).  No load is issued that is not used: the registers of a
+// redundant prefetch are the ones the code behind the loop reuses, and it then waits a tile fetch for them on the path of the hand-off.
+__global__ __launch_bounds__(kUThreads) void ungrouped_solve_forward_kernel(const float* __restrict__ scores, int N, const int* __restrict__ counts,
+                                                                      gnms_params P, char* ws, gnms_ws_layout L, float* __restrict__ Ps_all) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Tl = reinterpret_cast<float*>(smem);          // the diagonal tile T (strictly lower); its upper right quadrant: T21 D11
+    float* Dl = Tl + kUB * kUP;                            // D = (I + T)^-1
+    float* xc = Dl + kUB * kUP;                            // two buffers: the poller fills one while the other is read
+    float* rb = xc + 2 * kUB;
     const int b = blockIdx.y, blk = blockIdx.x;
     const int n = gnms_count(counts, b, N);
-    const int i0 = blk * 64;
+    const int i0 = blk * kUB;
     if (i0 >= n) return;                                       // nobody waits for a block past the end
-    const int rows = min(64, n - i0);
-    const int nblk = (n + 63) >> 6;
+    const int rows = min(kUB, n - i0);
+    const int nblk = (n + kUB - 1) / kUB;
     ImgPtrs I = img_ptrs(ws, L, b);
     const size_t ldp = ungrouped_ld(N);
-    const float* Ps = Ps_all + (size_t)b * N * ldp;
-    const float* s = scores + (size_t)b * N;
+    float* Ps = Ps_all + (size_t)b * N * ldp;
     u64* mail = I.W;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int r = t >> 2, cg = (t & 3) * 16;
+    const int pad = (3 - blk % 3) % 3;
+    if (wave == 8) {   // the poller
+        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();        // the four barriers of the inverse
+        for (int c = -pad; c < blk; ++c) {
+            const float2 v = c < 0 ? make_float2(0.f, 0.f) : mail_get2(mail, c * kUB + 2 * lane, n);
+            *reinterpret_cast<float2*>(xc + ((c + 4) & 1) * kUB + 2 * lane) = v;
+            __syncthreads();
+        }
+        __syncthreads();                                       // rb
+        return;
+    }
+    const int r = t >> 2, cg = (t & 3) * 32;
     const bool live = r < rows;
-    const float* strip = Ps + (size_t)(i0 + r) * ldp + cg;
-    // wave 0: row `lane` of the diagonal tile in registers (independent of every x); entries on/above the diagonal are not used
-    float4 trow[16];
-    if (wave == 0) {
-        const float4* p = reinterpret_cast<const float4*>(Ps + (size_t)(i0 + min(lane, rows - 1)) * ldp + i0);
+    const float* strip = Ps + (size_t)min(i0 + r, n - 1) * ldp + cg;   // (a dead row reads the image's last row: finite, never used)
+    {   // the diagonal tile: strictly lower part of the live rows, zero elsewhere
+        float4 d[8];
+        ungrouped_load_tile(strip + i0, d);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) trow[q] = p[q];
-    }
-    float acc = 0.0f;
-    float4 cur[4], nxt[4];
-    if (blk > 0) ungrouped_load_tile(strip, live, cur);
-    for (int c = 0; c < blk; ++c) {
-        if (c + 1 < blk) ungrouped_load_tile(strip + (size_t)(c + 1) * 64, live, nxt);
-        __syncthreads();                                       // xc of the previous tile is consumed
-        if (t < 64) xc[t] = mail_get(mail + c * 64 + t);
-        __syncthreads();
+        for (int q = 0; q < 8; ++q) {
+            const int c = cg + 4 * q;
+            *reinterpret_cast<float4*>(Tl + r * kUP + c) = make_float4((live && c < r) ? d[q].x : 0.f, (live && c + 1 < r) ? d[q].y : 0.f,
+                                                                       (live && c + 2 < r) ? d[q].z : 0.f, (live && c + 3 < r) ? d[q].w : 0.f);
+        }
+        if (r < 64 && cg >= 64) {                              // the upper right quadrant of D: zero (nothing else writes it)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc += cur[q].x * xc[cg + 4 * q] + cur[q].y * xc[cg + 4 * q + 1] + cur[q].z * xc[cg + 4 * q + 2] + cur[q].w * xc[cg + 4 * q + 3];
-            cur[q] = nxt[q];
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(Dl + r * kUP + cg + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    if ((t & 3) == 0 && live) tb[r] = s[P.presorted ? (i0 + r) : I.order[i0 + r]] - acc;
     __syncthreads();
-    if (wave == 0) {
-        float x = (lane < rows) ? tb[lane] : 0.0f;
-        const float* tr = reinterpret_cast<const float*>(trow);
+    if (wave < 2) {   // D11 / D22: column `lane` of the inverse of a 64 x 64 unit lower triangular tile, row by row
+        const int h0 = wave * 64;
+        float X[64];
 #pragma unroll
-        for (int bb = 0; bb < 63; ++bb) {                       // 63 dependent steps: v_readlane + multiply + subtract, no LDS
-            const float xbb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), bb));
-            const float upd = x - tr[bb] * xbb;
-            x = (lane > bb && lane < rows) ? upd : x;
+        for (int i = 0; i < 64; ++i) {
+            const float* Ti = Tl + (h0 + i) * kUP + h0;        // (wave-uniform address: LDS broadcast)
+            float v = (i == lane) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int k4 = 0; k4 < i; k4 += 4) {
+                const float4 tv = *reinterpret_cast<const float4*>(Ti + k4);
+                v = __builtin_fmaf(-tv.x, X[k4], v);
+                if (k4 + 1 < i) v = __builtin_fmaf(-tv.y, X[k4 + 1], v);
+                if (k4 + 2 < i) v = __builtin_fmaf(-tv.z, X[k4 + 2], v);
+                if (k4 + 3 < i) v = __builtin_fmaf(-tv.w, X[k4 + 3], v);
+            }
+            X[i] = v;
+            Dl[(h0 + i) * kUP + h0 + lane] = v;
         }
-        if (lane < rows) {
-            I.pre[i0 + lane] = x;
-            if (blk + 1 < nblk) mail_put(mail + i0 + lane, x);
+    }
+    __syncthreads();
+    // the row's score IN FRONT of the tile loads: a wave's loads return in order, and behind the two (redundant) prefetches of the last
+    // stages the wait for it was a tile fetch long -- on the path of every hand-off
+    const float sr = scores[(size_t)b * N + (P.presorted ? min(i0 + r, n - 1) : I.order[min(i0 + r, n - 1)])];
+    const int last_tile = max(blk - 1, 0);
+    float4 ta[8], tb[8], tc[8];
+    ungrouped_load_tile(strip + (size_t)min(max(-pad, 0), last_tile) * kUB, ta);
+    ungrouped_load_tile(strip + (size_t)min(max(-pad + 1, 0), last_tile) * kUB, tb);
+    ungrouped_mm64(Tl + 64 * kUP, Dl, Tl + 64, 1.0f, t);                       // T21 D11 -> Tl[0..63][64..127]
+    __syncthreads();
+    ungrouped_mm64(Dl + 64 * kUP + 64, Tl + 64, Dl + 64 * kUP, -1.0f, t);      // D21 = -D22 (T21 D11)
+    __syncthreads();
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+#define GNMS_U_STAGE(C, USE, FILL, LOAD)                                                                                   \
+    {                                                                                                                      \
+        if (LOAD) ungrouped_load_tile(strip + (size_t)max((C) + 2, 0) * kUB, FILL);                                        \
+        __syncthreads();                                       /* x of block C (zeros for C < 0) is in xc[(C + 4) & 1] */  \
+        const float* xs = xc + (((C) + 4) & 1) * kUB + cg;                                                                 \
+        _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                                    \
+            const float4 xv = *reinterpret_cast<const float4*>(xs + 4 * q);                                                \
+            acc0 = __builtin_fmaf(USE[q].x, xv.x, acc0); acc1 = __builtin_fmaf(USE[q].y, xv.y, acc1);                      \
+            acc2 = __builtin_fmaf(USE[q].z, xv.z, acc2); acc3 = __builtin_fmaf(USE[q].w, xv.w, acc3);                      \
+        }                                                                                                                  \
+    }
+    if (blk > 0) {   // pad + blk stages, a multiple of three; the last two issue no load (LOAD is a literal: no branch)
+        int c = -pad;
+        for (; c + 3 < blk; c += 3) {
+            GNMS_U_STAGE(c, ta, tc, true)
+            GNMS_U_STAGE(c + 1, tb, ta, true)
+            GNMS_U_STAGE(c + 2, tc, tb, true)
+        }
+        GNMS_U_STAGE(c, ta, tc, true)
+        GNMS_U_STAGE(c + 1, tb, ta, false)
+        GNMS_U_STAGE(c + 2, tc, tb, false)
+    }
+#undef GNMS_U_STAGE
+    // row r of D out of LDS (D is zero right of its diagonal).  Read here, not in front of the loop: held across the loop the 32 values
+    // were spilled to scratch and came back behind the last barrier
+    float dv[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(Dl + r * kUP + cg + 4 * q);
+        dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+    }
+    const float acc = ungrouped_quad_sum((acc0 + acc1) + (acc2 + acc3));
+    if ((t & 3) == 0) rb[r] = live ? sr - acc : 0.0f;
+    __syncthreads();
+    const float x = ungrouped_quad_sum(ungrouped_dot32(dv, rb + cg));
+    if ((t & 3) == 0 && live) {
+        if (blk + 1 < nblk) mail_put(mail + i0 + r, x);
+        I.pre[i0 + r] = x;
+    }
+    if (live) {   // D^T over the diagonal tile of Ps (row r: 0 left of the diagonal, 1 on it, D[c][r] right of it), for the backward solve
+        float* drow = Ps + (size_t)(i0 + r) * ldp + i0 + cg;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = cg + 4 * q + u;
+                v[u] = c > r ? Dl[c * kUP + r] : (c == r ? 1.0f : 0.0f);
+            }
+            *reinterpret_cast<float4*>(drow + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -379,78 +521,137 @@ __global__ __launch_bounds__(1024) void ungrouped_backward_prepare_kernel(int N,
     if (k < N && L.NB >= 2) img_ptrs(ws, L, blockIdx.y).W[N + k] = 0ull;       // backward mailbox
 }
 
-__global__ __launch_bounds__(256) void ungrouped_solve_backward_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws,
+// y = D^T (g - sum_{c > blk} P[c][blk]^T y_c), blocks published from the last to the first.  The sources c >= blk + 2 are accumulated per
+// thread (four rows of the source tile x eight columns) and reduced over the rows through LDS once, BEFORE the nearest source arrives;
+// the nearest source's tile waits transposed in registers (thread = column, 32 interleaved rows), so that behind y_{blk+1} there are, as
+// in the forward solve, two register-resident matrix-vector products.
+__global__ __launch_bounds__(kUThreads) void ungrouped_solve_backward_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws,
                                                                        gnms_ws_layout L, const float* __restrict__ Ps_all,
                                                                        float* __restrict__ grad_scores) {
-    __shared__ float red[64 * 65];
-    __shared__ float yc[64];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    float* yc = red + kUB * kUP;                           // two buffers
+    float* rb = yc + 2 * kUB;
     const int b = blockIdx.y;
     const int n = gnms_count(counts, b, N);
-    const int nblk = (n + 63) >> 6;
+    const int nblk = (n + kUB - 1) / kUB;
     ImgPtrs I = img_ptrs(ws, L, b);
     float* gs = grad_scores + (size_t)b * N;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x;
     if ((int)blockIdx.x >= nblk) {                              // padding positions get no gradient
-        for (int k = (int)blockIdx.x * 64 + t; k < min(N, ((int)blockIdx.x + 1) * 64); k += blockDim.x)
+        for (int k = (int)blockIdx.x * kUB + t; k < min(N, ((int)blockIdx.x + 1) * kUB); k += blockDim.x)
             if (k >= n) gs[P.presorted ? k : I.order[k]] = 0.0f;
         return;
     }
     const int blk = nblk - 1 - (int)blockIdx.x;                 // the LAST block has no dependency: it is dispatched first
-    const int i0 = blk * 64;
-    const int rows = min(64, n - i0);
+    const int i0 = blk * kUB;
+    const int rows = min(kUB, n - i0);
     const size_t ldp = ungrouped_ld(N);
     const float* Ps = Ps_all + (size_t)b * N * ldp;
     u64* mail = I.W + N;
-    const int r = t >> 2, cg = (t & 3) * 16;
-    // wave 0: column `lane` of the diagonal tile in registers (tcol[a] = T[a][lane], used for a > lane)
-    float tcol[64];
-    if (wave == 0) {
-#pragma unroll
-        for (int a = 0; a < 64; ++a) tcol[a] = Ps[(size_t)(i0 + min(a, rows - 1)) * ldp + i0 + lane];
+    const bool has_near = blk + 1 < nblk, has_far = blk + 2 < nblk;
+    if (t >= 512) {   // the poller
+        const int lane = t & 63;
+        if (has_near) __syncthreads();
+        for (int c = nblk - 1; c >= blk + 1; --c) {
+            const int p0 = c * kUB + 2 * lane;
+            const u64 w0 = mail_peek(mail, p0, n), w1 = mail_peek(mail, p0 + 1, n);
+            if (c == blk + 1 && has_far) { __syncthreads(); __syncthreads(); }   // the reduction of the far part (the first attempt is in flight)
+            const float2 v = mail_finish2(mail, p0, n, w0, w1);
+            *reinterpret_cast<float2*>(yc + (c & 1) * kUB + 2 * lane) = v;
+            __syncthreads();
+        }
+        __syncthreads();                                       // rb
+        return;
     }
-    float part[16];
+    const int r = t >> 2, qd = t & 3, cg = qd * 32;
+    const bool live = r < rows;
+    float dv[32];                                               // row r of D^T (the forward solve left it over the diagonal tile)
+    {
+        float4 d[8];
+        ungrouped_load_tile(Ps + (size_t)min(i0 + r, n - 1) * ldp + i0 + cg, d);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) part[q] = 0.0f;
-    float4 cur[4], nxt[4];
-    // tile (c, blk): rows 64c + r, columns i0 + cg ..
-    const float* colstrip = Ps + (size_t)r * ldp + i0 + cg;
-    if (nblk - 1 > blk) ungrouped_load_tile(colstrip + (size_t)(nblk - 1) * 64 * ldp, (nblk - 1) * 64 + r < n, cur);
-    for (int c = nblk - 1; c > blk; --c) {
-        if (c - 1 > blk) ungrouped_load_tile(colstrip + (size_t)(c - 1) * 64 * ldp, true, nxt);
-        __syncthreads();
-        if (t < 64) yc[t] = (c * 64 + t < n) ? mail_get(mail + c * 64 + t) : 0.0f;
-        __syncthreads();
-        const float y = yc[r];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            part[4 * q] += cur[q].x * y; part[4 * q + 1] += cur[q].y * y; part[4 * q + 2] += cur[q].z * y; part[4 * q + 3] += cur[q].w * y;
-            cur[q] = nxt[q];
+        for (int q = 0; q < 8; ++q) {
+            const int c = cg + 4 * q;
+            dv[4 * q] = (live && c >= r && c < rows) ? d[q].x : 0.f; dv[4 * q + 1] = (live && c + 1 >= r && c + 1 < rows) ? d[q].y : 0.f;
+            dv[4 * q + 2] = (live && c + 2 >= r && c + 2 < rows) ? d[q].z : 0.f; dv[4 * q + 3] = (live && c + 3 >= r && c + 3 < rows) ? d[q].w : 0.f;
         }
     }
+    float nt[32];                                               // nt[k] = P[(blk+1) * 128 + qd + 4k][i0 + r]
+    if (has_near) {
+        float4 d[8];
+        ungrouped_load_tile(Ps + (size_t)min((blk + 1) * kUB + r, n - 1) * ldp + i0 + cg, d);   // (a dead row: finite values against y = 0)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) red[r * 65 + cg + q] = part[q];
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(red + r * kUP + cg + 4 * q) = d[q];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 32; ++k) nt[k] = red[(qd + 4 * k) * kUP + r];
+    }
+    // far tiles: thread = rows 4 * (t >> 4) .. + 3 of the source tile, columns 8 * (t & 15) .. + 7
+    const int rg = (t >> 4) * 4, cq = (t & 15) * 8;
+    float part[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) part[k] = 0.0f;
+    if (has_far) {
+        // (rows past the image read its last row against y = 0)
+        float4 cur[8], nxt[8];
+#define GNMS_U_FAR_LOAD(C, DST)                                                                                            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+            const float* p = Ps + (size_t)min((C) * kUB + rg + j, n - 1) * ldp + i0 + cq;                                  \
+            DST[2 * j] = reinterpret_cast<const float4*>(p)[0]; DST[2 * j + 1] = reinterpret_cast<const float4*>(p)[1];    \
+        }
+        GNMS_U_FAR_LOAD(nblk - 1, cur)
+        for (int c = nblk - 1; c >= blk + 2; --c) {
+            if (c - 1 >= blk + 2) { GNMS_U_FAR_LOAD(c - 1, nxt) }   // (a redundant load here would be waited for by the copy below)
+            __syncthreads();                                   // y of block c is in yc[c & 1]
+            const float4 yv = *reinterpret_cast<const float4*>(yc + (c & 1) * kUB + rg);
+            const float yj[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part[0] = __builtin_fmaf(cur[2 * j].x, yj[j], part[0]); part[1] = __builtin_fmaf(cur[2 * j].y, yj[j], part[1]);
+                part[2] = __builtin_fmaf(cur[2 * j].z, yj[j], part[2]); part[3] = __builtin_fmaf(cur[2 * j].w, yj[j], part[3]);
+                part[4] = __builtin_fmaf(cur[2 * j + 1].x, yj[j], part[4]); part[5] = __builtin_fmaf(cur[2 * j + 1].y, yj[j], part[5]);
+                part[6] = __builtin_fmaf(cur[2 * j + 1].z, yj[j], part[6]); part[7] = __builtin_fmaf(cur[2 * j + 1].w, yj[j], part[7]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cur[q] = nxt[q];
+        }
+#undef GNMS_U_FAR_LOAD
+    }
+    float far = 0.0f;
+    if (has_far) {
+        __syncthreads();                                       // (the near tile's transposed reads of red are done)
+        *reinterpret_cast<float4*>(red + (t >> 4) * kUP + cq) = make_float4(part[0], part[1], part[2], part[3]);
+        *reinterpret_cast<float4*>(red + (t >> 4) * kUP + cq + 4) = make_float4(part[4], part[5], part[6], part[7]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) far += red[(qd + 4 * k) * kUP + r];    // 32 row groups: this lane takes eight, the quad all of them
+        far = ungrouped_quad_sum(far);
+    }
+    const float gxr = I.gx[min(i0 + r, n - 1)];
+    const int ci = P.presorted ? min(i0 + r, n - 1) : I.order[min(i0 + r, n - 1)];
+    float near = 0.0f;
+    if (has_near) {
+        __syncthreads();                                       // y of block blk + 1
+        const float* yn = yc + ((blk + 1) & 1) * kUB + qd;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            s0 = __builtin_fmaf(nt[k], yn[4 * k], s0); s1 = __builtin_fmaf(nt[k + 1], yn[4 * k + 4], s1);
+            s2 = __builtin_fmaf(nt[k + 2], yn[4 * k + 8], s2); s3 = __builtin_fmaf(nt[k + 3], yn[4 * k + 12], s3);
+        }
+        near = ungrouped_quad_sum((s0 + s1) + (s2 + s3));
+    }
+    if (qd == 0) rb[r] = live ? (gxr - far) - near : 0.0f;
     __syncthreads();
-    if (wave == 0) {
-        float sum = 0.0f;
-        for (int rr = 0; rr < 64; ++rr) sum += red[rr * 65 + lane];
-        int ci = 0;
-        float y = 0.0f;
-        if (lane < rows) {
-            ci = P.presorted ? (i0 + lane) : I.order[i0 + lane];
-            y = I.gx[i0 + lane] - sum;
-        }
-#pragma unroll
-        for (int a = 63; a > 0; --a) {
-            const float ya = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), a));
-            const float upd = y - tcol[a] * ya;
-            y = (lane < a && a < rows) ? upd : y;
-        }
-        if (lane < rows) {
-            I.xsol[i0 + lane] = y;
+    const float y = ungrouped_quad_sum(ungrouped_dot32(dv, rb + cg));
+    if (qd == 0) {
+        if (live) {
+            if (blk > 0) mail_put(mail + i0 + r, y);
+            I.xsol[i0 + r] = y;
             gs[ci] = y;
-            if (blk > 0) mail_put(mail + i0 + lane, y);
-        } else if (i0 + lane < N) {
-            gs[i0 + lane] = 0.0f;                               // padding behind a ragged image (order is the identity there)
+        } else if (i0 + r < N) {
+            gs[i0 + r] = 0.0f;                                  // padding behind a ragged image (order is the identity there)
         }
     }
 }

@@ -1395,6 +1395,42 @@ def test_overwritten_matrix_buffer_is_caught(G):
         assert torch.isfinite(s2.grad).all() and torch.equal(out[0], ref[0]) and torch.equal(s2.grad, s3.grad), kw
 
 
+def test_ungrouped_block_solves_against_oracle(G, O):
+    """group_boxes=False (lib/groomed_nms.py:110-111: inverse(I + P) @ scores): the two triangular solves on blocks of 128 positions
+    with the diagonal tiles' inverses (csrc/nms_solve_kernels.h), ragged batches whose counts sit on, beside and far from the block
+    edges, against the oracle's inverse in double.  Tolerances: TOL on the probabilities (north_star), 5e-4 / 1e-3 on the gradients
+    as in test_random_vs_oracle."""
+    from groomed_nms_amd import synthetic, overlaps
+    rng = np.random.default_rng(2024)
+    for N, counts, kind in ((300, [300, 129, 128, 127, 1, 0, 257, 256], "clustered"), (1000, [1000, 897, 896, 641], "uniform"),
+                            (2048, [2048, 1500], "clustered")):
+        B = len(counts)
+        boxes = np.stack([(synthetic.clustered_boxes_2d(rng, N, 24) if kind == "clustered" else synthetic.uniform_boxes_2d(rng, N))
+                          for _ in range(B)])
+        scores = np.stack([synthetic.tie_free_scores(rng, N) for _ in range(B)])
+        w = rng.uniform(-1, 2, size=(B, N)).astype(np.float32)
+        ct = torch.from_numpy(np.array(counts, np.int32)).cuda()
+        for mode in ("un_lin", "un_sig"):
+            st = torch.from_numpy(scores).cuda().requires_grad_(True)
+            iou = overlaps.iou_batched(torch.from_numpy(boxes).cuda()).requires_grad_(N <= 300)
+            prob, order, valid, invalid, nv, ni = G.differentiable_nms_batched(st, iou, counts=ct, **MODES[mode])
+            (prob * torch.from_numpy(w).cuda()).sum().backward()
+            for b in range(B):
+                n = counts[b]
+                tag = f"N={N} n={n} {mode}"
+                assert torch.all(st.grad[b, n:] == 0) and torch.all(prob[b, n:] == 0), tag
+                if n == 0:
+                    assert int(nv[b]) == 0 and int(ni[b]) == 0, tag
+                    continue
+                m = O.iou2d(boxes[b, :n], boxes[b, :n])
+                ref = O.differentiable_nms(scores[b, :n], m, grad_prob=w[b, :n], want_grad_iou=(N <= 300), **MODES[mode])
+                np.testing.assert_allclose(prob[b, :n].detach().cpu().numpy(), ref["prob"], atol=TOL, err_msg=tag)
+                np.testing.assert_allclose(st.grad[b, :n].cpu().numpy(), ref["grad_scores"], atol=5e-4, rtol=1e-3, err_msg=tag)
+                check_index_lists(valid[b, :int(nv[b])].cpu().numpy(), invalid[b, :int(ni[b])].cpu().numpy(), ref["valid"], ref["invalid"])
+                if N <= 300:
+                    np.testing.assert_allclose(iou.grad[b, :n, :n].cpu().numpy(), ref["grad_iou"], atol=5e-4, rtol=1e-3, err_msg=tag)
+
+
 def test_ungrouped_mode_with_a_tight_workspace(G, O):
     """Ungrouped mode at sizes that are not multiples of 64, through the C ABI with a workspace of EXACTLY gnms_workspace_bytes that
     ends at the end of its allocation (the diagonal-tile loads of the last row block stay inside the scratch pitch)."""
