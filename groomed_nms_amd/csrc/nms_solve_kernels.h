@@ -380,6 +380,88 @@ __device__ __forceinline__ float ungrouped_dot32(const float (&a)[32], const flo
     return (s0 + s1) + (s2 + s3);
 }
 
+#ifndef GNMS_UTICK
+#define GNMS_UTICK(i) do {} while (0)                          // (tools/usolve_ticks.hip: phase ticks of the inversion)
+#endif
+#ifndef GNMS_UHOP
+#define GNMS_UHOP(blk, slot) do {} while (0)                   // (tools/usolve_ticks.hip: when a block of image 0 sees / publishes what)
+#endif
+// The inverse of the unit lower triangular 128 x 128 tile I + T (T in Tl, strictly lower, zero elsewhere) into Dl (zero on entry), 512
+// threads, kUInvertBarriers barriers.  Bottom-up: the four 32 x 32 diagonal sub-tiles (one wave each, lane = column, forward substitution
+// on the identity: no cross-lane step; the next row of T is fetched while the current one is used -- with one wait per LDS read the
+// 64 x 64 version of this step was 12.4 us of a 17.5-us inversion), then D21 = -D22 T21 D11 at 32 and at 64.
+constexpr int kUInvertBarriers = 5;
+__device__ __forceinline__ void ungrouped_invert_diag32(const float* __restrict__ Tl, float* __restrict__ Dl, int t) {
+    const int lane = t & 63, wave = t >> 6;
+    if (wave < 4 && lane < 32) {
+        const int h0 = wave * 32;
+        float X[32];
+        float4 tr[8], tn[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tr[q] = tn[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i + 1 < 32) {                                  // row i + 1 (wave-uniform address: LDS broadcast)
+                const float* Tn = Tl + (h0 + i + 1) * kUP + h0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (4 * q < i + 1) tn[q] = *reinterpret_cast<const float4*>(Tn + 4 * q);
+            }
+            float s0 = (i == lane) ? 1.0f : 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (4 * q < i) s0 = __builtin_fmaf(-tr[q].x, X[4 * q], s0);
+                if (4 * q + 1 < i) s1 = __builtin_fmaf(-tr[q].y, X[4 * q + 1], s1);
+                if (4 * q + 2 < i) s2 = __builtin_fmaf(-tr[q].z, X[4 * q + 2], s2);
+                if (4 * q + 3 < i) s3 = __builtin_fmaf(-tr[q].w, X[4 * q + 3], s3);
+            }
+            const float v = (s0 + s1) + (s2 + s3);
+            X[i] = v;
+            Dl[(h0 + i) * kUP + h0 + lane] = v;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tr[q] = tn[q];
+        }
+    }
+    GNMS_UTICK(1);
+    __syncthreads();
+    GNMS_UTICK(2);
+}
+// 32 x 32 products out of LDS for the two 64 x 64 diagonal sub-tiles at once (pair p = t >> 8), one row x four columns per thread:
+// C_p[i][j] = sign * sum_k A_p[i][k] B_p[k][j]; the operands of pair p start 64 rows and 64 columns behind those of pair 0
+__device__ __forceinline__ void ungrouped_mm32x2(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ C, float sign, int t) {
+    const int off = (t >> 8) * (64 * kUP + 64);
+    const int ti = (t & 255) >> 3, tj = (t & 7) * 4;
+    A += off; Bm += off; C += off;
+    float c0[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+        const float4 a0 = *reinterpret_cast<const float4*>(A + ti * kUP + k);
+        const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float4 bv = *reinterpret_cast<const float4*>(Bm + (k + kk) * kUP + tj);
+            c0[0] = __builtin_fmaf(a0v[kk], bv.x, c0[0]); c0[1] = __builtin_fmaf(a0v[kk], bv.y, c0[1]);
+            c0[2] = __builtin_fmaf(a0v[kk], bv.z, c0[2]); c0[3] = __builtin_fmaf(a0v[kk], bv.w, c0[3]);
+        }
+    }
+    *reinterpret_cast<float4*>(C + ti * kUP + tj) = make_float4(sign * c0[0], sign * c0[1], sign * c0[2], sign * c0[3]);
+}
+// D21 = -D22 T21 D11 at 32 and at 64 (the first product of each level goes through an unused upper right part of Tl)
+__device__ __forceinline__ void ungrouped_invert_offdiag(float* __restrict__ Tl, float* __restrict__ Dl, int t) {
+    // 32 -> 64, both halves: T21 D11 goes through the (zero, unused) upper right 32 x 32 of each 64 x 64 diagonal sub-tile of Tl
+    ungrouped_mm32x2(Tl + 32 * kUP, Dl, Tl + 32, 1.0f, t);
+    __syncthreads();
+    ungrouped_mm32x2(Dl + 32 * kUP + 32, Tl + 32, Dl + 32 * kUP, -1.0f, t);
+    GNMS_UTICK(6);
+    __syncthreads();
+    ungrouped_mm64(Tl + 64 * kUP, Dl, Tl + 64, 1.0f, t);                       // T21 D11 -> Tl[0..63][64..127]
+    GNMS_UTICK(3);
+    __syncthreads();
+    ungrouped_mm64(Dl + 64 * kUP + 64, Tl + 64, Dl + 64 * kUP, -1.0f, t);      // D21 = -D22 (T21 D11)
+    GNMS_UTICK(4);
+    __syncthreads();
+    GNMS_UTICK(5);
+}
+
 // The strip's tiles go through three register buffers, two loads ahead of the use; the stage count is padded to a multiple of three
 // with null stages IN FRONT (x = 0 from the poller, the tile index clamped).  No load is issued that is not used: the registers of a
 // redundant prefetch are the ones the code behind the loop reuses, and it then waits a tile fetch for them on the path of the hand-off.
@@ -403,10 +485,11 @@ __global__ __launch_bounds__(kUThreads) void ungrouped_solve_forward_kernel(cons
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int pad = (3 - blk % 3) % 3;
     if (wave == 8) {   // the poller
-        __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();        // the four barriers of the inverse
+        for (int k = 0; k < 1 + kUInvertBarriers; ++k) __syncthreads();            // the diagonal tile and its inverse
         for (int c = -pad; c < blk; ++c) {
             const float2 v = c < 0 ? make_float2(0.f, 0.f) : mail_get2(mail, c * kUB + 2 * lane, n);
             *reinterpret_cast<float2*>(xc + ((c + 4) & 1) * kUB + 2 * lane) = v;
+            if (c == blk - 1) GNMS_UHOP(blk, 0);
             __syncthreads();
         }
         __syncthreads();                                       // rb
@@ -424,32 +507,11 @@ __global__ __launch_bounds__(kUThreads) void ungrouped_solve_forward_kernel(cons
             *reinterpret_cast<float4*>(Tl + r * kUP + c) = make_float4((live && c < r) ? d[q].x : 0.f, (live && c + 1 < r) ? d[q].y : 0.f,
                                                                        (live && c + 2 < r) ? d[q].z : 0.f, (live && c + 3 < r) ? d[q].w : 0.f);
         }
-        if (r < 64 && cg >= 64) {                              // the upper right quadrant of D: zero (nothing else writes it)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(Dl + r * kUP + cg + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(Dl + r * kUP + cg + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);   // (D is zero right of its diagonal)
     }
     __syncthreads();
-    if (wave < 2) {   // D11 / D22: column `lane` of the inverse of a 64 x 64 unit lower triangular tile, row by row
-        const int h0 = wave * 64;
-        float X[64];
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-            const float* Ti = Tl + (h0 + i) * kUP + h0;        // (wave-uniform address: LDS broadcast)
-            float v = (i == lane) ? 1.0f : 0.0f;
-#pragma unroll
-            for (int k4 = 0; k4 < i; k4 += 4) {
-                const float4 tv = *reinterpret_cast<const float4*>(Ti + k4);
-                v = __builtin_fmaf(-tv.x, X[k4], v);
-                if (k4 + 1 < i) v = __builtin_fmaf(-tv.y, X[k4 + 1], v);
-                if (k4 + 2 < i) v = __builtin_fmaf(-tv.z, X[k4 + 2], v);
-                if (k4 + 3 < i) v = __builtin_fmaf(-tv.w, X[k4 + 3], v);
-            }
-            X[i] = v;
-            Dl[(h0 + i) * kUP + h0 + lane] = v;
-        }
-    }
-    __syncthreads();
+    ungrouped_invert_diag32(Tl, Dl, t);
     // the row's score IN FRONT of the tile loads: a wave's loads return in order, and behind the two (redundant) prefetches of the last
     // stages the wait for it was a tile fetch long -- on the path of every hand-off
     const float sr = scores[(size_t)b * N + (P.presorted ? min(i0 + r, n - 1) : I.order[min(i0 + r, n - 1)])];
@@ -457,10 +519,7 @@ __global__ __launch_bounds__(kUThreads) void ungrouped_solve_forward_kernel(cons
     float4 ta[8], tb[8], tc[8];
     ungrouped_load_tile(strip + (size_t)min(max(-pad, 0), last_tile) * kUB, ta);
     ungrouped_load_tile(strip + (size_t)min(max(-pad + 1, 0), last_tile) * kUB, tb);
-    ungrouped_mm64(Tl + 64 * kUP, Dl, Tl + 64, 1.0f, t);                       // T21 D11 -> Tl[0..63][64..127]
-    __syncthreads();
-    ungrouped_mm64(Dl + 64 * kUP + 64, Tl + 64, Dl + 64 * kUP, -1.0f, t);      // D21 = -D22 (T21 D11)
-    __syncthreads();
+    ungrouped_invert_offdiag(Tl, Dl, t);
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
 #define GNMS_U_STAGE(C, USE, FILL, LOAD)                                                                                   \
     {                                                                                                                      \
@@ -494,13 +553,16 @@ __global__ __launch_bounds__(kUThreads) void ungrouped_solve_forward_kernel(cons
         dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
     }
     const float acc = ungrouped_quad_sum((acc0 + acc1) + (acc2 + acc3));
+    GNMS_UHOP(blk, 1);
     if ((t & 3) == 0) rb[r] = live ? sr - acc : 0.0f;
     __syncthreads();
+    GNMS_UHOP(blk, 2);
     const float x = ungrouped_quad_sum(ungrouped_dot32(dv, rb + cg));
     if ((t & 3) == 0 && live) {
         if (blk + 1 < nblk) mail_put(mail + i0 + r, x);
         I.pre[i0 + r] = x;
     }
+    GNMS_UHOP(blk, 3);
     if (live) {   // D^T over the diagonal tile of Ps (row r: 0 left of the diagonal, 1 on it, D[c][r] right of it), for the backward solve
         float* drow = Ps + (size_t)(i0 + r) * ldp + i0 + cg;
 #pragma unroll
