@@ -8,6 +8,7 @@
 #   <tag>_dim3_n16384_kernel_stats.csv                   kernel stats of the 3D N=16384 run
 #   <tag>_store_geometry.jsonl, _small_n.jsonl, _sgemm_mfma.txt   store-pattern ceilings, host cost of the small-N regime, the fp32 MFMA GEMM
 #   <tag>_sgemm_kernel_stats.csv, _mode_times.jsonl, _host_overhead_n512.txt   GEMM kernel times at 1024^3 / 2048^3, every mode of the layer, cProfile of the eager step
+#   <tag>_{ungrouped,unmasked}_uniform_kernel_stats.csv   kernel stats of the two non-default modes (tools/mode_prof.py)
 export TMPDIR=/tmp
 T=$1
 O=gpurun_out/profiles_$T
@@ -56,6 +57,10 @@ bash tools/sgemm_pmc.sh 4096 >> $O/${T}_sgemm_mfma.txt 2>/dev/null
 PYTHONPATH=$PWD bash tools/prof_cmd.sh ${T}_sgemm python $PWD/tools/sgemm_time.py 1024 2048 > $O/prof_sgemm.txt 2>&1
 cp gpurun_out/prof_${T}_sgemm/run_kernel_stats.csv $O/${T}_sgemm_kernel_stats.csv
 python tools/mode_times.py > $O/${T}_mode_times.jsonl 2>/dev/null
+for m in ungrouped unmasked; do
+  PYTHONPATH=$PWD bash tools/prof_cmd.sh ${T}_$m python $PWD/tools/mode_prof.py $m > $O/prof_$m.txt 2>&1
+  cp gpurun_out/prof_${T}_$m/run_kernel_stats.csv $O/${T}_${m}_uniform_kernel_stats.csv
+done
 python tools/host_overhead.py --boxes 512 --steps 1500 2>/dev/null | head -12 > $O/${T}_host_overhead_n512.txt
 python tools/aploss_time.py > $O/${T}_aploss_times.jsonl 2>/dev/null
 python tools/e2e_bench.py --mode infer --steps 10 2>/dev/null | tail -1 > $O/${T}_e2e.jsonl
