@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void ungrouped_permute_kernel(const float* __r
 // U1 straight from the boxes (gnms_forward_with_iou2d, round 4b): Ps[i][j] = f(iou(box at position i, box at position j)), j < i, with the
 // matrix kernel's own arithmetic (pair_iou: bit-identical entries) from the boxes in rank order the score sort leaves in rbox -- no read
 // of the 4 N^2-byte matrix (it is written beside, by gnms_iou2d's writers), 2 N^2 bytes out in 16-byte stores.  Hard-sorted scores only.
-// B = 8, N = 4096: 258 -> 95 us (one workgroup per row: 161 -- 32 768 workgroups of at most four vectors per thread).
+// B = 8, N = 4096: 258 -> 95 us (one workgroup per row: 161 -- 32 768 workgroups of at most four vectors per thread); round 5, the packed
+// plain row body: 77 us (every row of the workgroup for every vector, so that the row's box is a hoistable scalar load: 96).
 constexpr int kPermuteRows = 16;      // rows per workgroup of ungrouped_permute_boxes_kernel: the column boxes are loaded once for all of them
 __global__ __launch_bounds__(256) void ungrouped_permute_boxes_kernel(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                                                       float* __restrict__ Ps_all) {
@@ -304,15 +305,46 @@ __global__ __launch_bounds__(256) void ungrouped_permute_boxes_kernel(int N, con
     const int iend = min(i0 + kPermuteRows, n);                      // rows [i0, iend); row i has the columns j < i
     const size_t ldp = ungrouped_ld(N);
     float* out0 = Ps_all + ((size_t)b * N + i0) * ldp;
+    // Boxes that "divide plainly" (iou_tile.h: finite, no negative zero, x2 >= x1, y2 >= y1, magnitudes inside 2^-13 .. 2^20 -- pixel boxes
+    // always are) take the matrix writers' packed row body: the intersection as med3(min3(..)), the division as rcp + six packed fma steps,
+    // bit for bit the quotient pair_iou's IEEE division gives.  18 + 30 VALU slots per row of four entries instead of 40 + 44.
+    bool rows_plain = true;
+    for (int i = i0; i < iend; ++i) rows_plain &= gnms_iou::box_divides_plainly(I.rbox[i]);   // (workgroup-uniform)
     for (int j = threadIdx.x * 4; j < iend - 1; j += 1024) {        // (entries on / above the diagonal inside a row's last vector: never read)
         float4 cb[4];
+        gnms_iou::ColPairs cp;
+        bool cok = true;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cb[u] = I.rbox[min(j + u, n - 1)];
+        for (int u = 0; u < 4; ++u) {
+            cb[u] = I.rbox[min(j + u, n - 1)];
+            gnms_iou::colpairs_set(cp, u, cb[u]);
+            cok &= gnms_iou::box_divides_plainly(cb[u]);
+        }
+        const bool plain = rows_plain && __all(cok);                  // (wave-uniform)
         for (int i = max(i0, j + 1); i < iend; ++i) {
-            const float4 a = I.rbox[i];                                // (workgroup-uniform address)
+            const float4 a = I.rbox[i];                                // (uniform except in the vectors that cross the diagonal: no SGPR operands)
             float v[4];
+            if (plain) {
+                using namespace gnms_iou;
+                const float aw = a.z - a.x, ah = a.w - a.y;
+                const float aarea = aw * ah;
+                const gnms_f2 sx1 = {a.x, a.x}, sy1 = {a.y, a.y}, sx2 = {a.z, a.z}, sy2 = {a.w, a.w}, sa = {aarea, aarea};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = gnms_prune(pair_iou(a, cb[u]), P.nms_threshold, P.temperature, P.pruning_method);
+                for (int p = 0; p < 2; ++p) {
+                    const gnms_f2 dx1 = sx2 - cp.x1[p], dx2 = cp.x2[p] - sx1;
+                    const gnms_f2 dy1 = sy2 - cp.y1[p], dy2 = cp.y2[p] - sy1;
+                    const gnms_f2 w = {__builtin_amdgcn_fmed3f(hw_min3(dx1.x, dx2.x, cp.w[p].x), 0.0f, aw), __builtin_amdgcn_fmed3f(hw_min3(dx1.y, dx2.y, cp.w[p].y), 0.0f, aw)};
+                    const gnms_f2 h = {__builtin_amdgcn_fmed3f(hw_min3(dy1.x, dy2.x, cp.h[p].x), 0.0f, ah), __builtin_amdgcn_fmed3f(hw_min3(dy1.y, dy2.y, cp.h[p].y), 0.0f, ah)};
+                    const gnms_f2 inter = w * h;
+                    const gnms_f2 uni = (sa + cp.area[p]) - inter;
+                    const gnms_f2 q = div2_plain(inter, uni);
+                    v[2 * p] = gnms_prune(q.x, P.nms_threshold, P.temperature, P.pruning_method);
+                    v[2 * p + 1] = gnms_prune(q.y, P.nms_threshold, P.temperature, P.pruning_method);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = gnms_prune(pair_iou(a, cb[u]), P.nms_threshold, P.temperature, P.pruning_method);
+            }
             *reinterpret_cast<float4*>(out0 + (size_t)(i - i0) * ldp + j) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
