@@ -28,6 +28,9 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
                       and whether the valid-index sets agree -- the "max-|dscore| vs ref" half of BASELINE.json's metric
   other_kind          the same step on the other box generator (uniform <-> clustered), 1 GPU only
   hip_graph_replay    the same step as a replayed HIP graph of the C-ABI calls (no host cost per step), 1 GPU only
+  two_calls, dim3_*, N*, B*_N4096   the other shapes of the path (default line only), each with ms_per_step (eager, host included), its own
+                      roofline brief and device_ms_per_step: the step's time on the device when the host has run ahead (the same
+                      eager calls enqueued behind a spin kernel; small shapes are host-bound and hosts differ by 2x between boxes)
 """
 import argparse
 import ctypes
@@ -495,6 +498,17 @@ def main():
                 torch.cuda.synchronize()
                 check(lib.gnms_profile_events(0), "profile_events")
                 (msw, nw_), (msr, nr_) = collect(0), collect(1)
+                # the same kr steps once more behind a spin kernel, no per-launch events: what the GPU alone takes per step when the host has
+                # run ahead (the eager figure below includes the host's launch cost, which is all of it at the small shapes and differs
+                # between boxes by 2x)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(int(4e6) + int(2.5e5) * kr)
+                ev0.record()
+                for _ in range(kr):
+                    one()
+                ev1.record()
+                torch.cuda.synchronize()
+                dev_ms = ev0.elapsed_time(ev1) / kr
                 del bufs
                 bytes_w = b_ * (4.0 * n_ * n_ + (16.0 if dim == 2 else 28.0) * n_)
                 bytes_r = b_ * (4.0 * n_ * n_ + 16.0 * n_)
@@ -508,6 +522,7 @@ def main():
                     return {"kernel": kname, "kernel_ms": round(per, 4), "launches_per_step": round(launches / kr, 2), "algorithmic_bytes": round(nbytes),
                             "achieved": round(nbytes / (per * 1e-3) / 1e9, 1), "unit": "GB/s", "frac": round(nbytes / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 res = {"value": round(b_ * n_ * steps / dts, 1), "unit": "boxes/s", "ms_per_step": round(dts / steps * 1e3, 4), "steps": steps,
+                       "device_ms_per_step": round(dev_ms, 4),
                        "workload": "%d images x %d %s %dD boxes%s" % (b_, n_, args.kind, dim, ", reference call sequence" if (two_calls or ref_3d) else ""),
                        "whole_step_frac": round((bytes_w + (bytes_r if (two_calls or ref_3d) else 0.0)) / (dts / steps) / 1e9 / HBM_PEAK_GBS, 4),
                        "roofline": brief(msw, nw_, bytes_w * (2.0 if ref_3d else 1.0), wn)}
