@@ -535,6 +535,7 @@ __global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restric
 // image in LDS, thread (key, segment) counts the keys of one sixteenth of the image below its own, an LDS atomic adds the sixteen counts,
 // and the 64 results leave exactly as the merge kernel's do.  N / 64 workgroups per image and role: 256 at B = 8, N = 1024.
 // ------------------------------------------------------------------------------------------------
+template <int KPW>   // keys per workgroup: 64, or 32 where that still is one round of the machine (B = 1, N = 4096: 10.5 -> ? us)
 __global__ __launch_bounds__(1024) void sort_count_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
                                                           const int* __restrict__ counts, char* ws, gnms_ws_layout L,
                                                           long long* __restrict__ order_out, int mode3d) {
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(1024) void sort_count_kernel(const float* __restric
     const int blk = blockIdx.x, b = blockIdx.y, role = blockIdx.z;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
-    const int t = threadIdx.x, lane = t & 63, seg = t >> 6;
+    const int t = threadIdx.x, lane = t & (KPW - 1), seg = t / KPW;
     const int NP = (N + 63) & ~63;
     const float* s = scores + (size_t)b * N;
     const float* bx = boxes ? boxes + (size_t)b * N * 4 : nullptr;
@@ -553,10 +554,10 @@ __global__ __launch_bounds__(1024) void sort_count_kernel(const float* __restric
     for (int i = t; i < NP; i += 1024) keys[i] = (i < n) ? sort_key_of(role, s, bx, i, mode3d, zlo, zscale) : ~0ull;
     if (t < 64) rk[t] = 0;
     __syncthreads();
-    const int k = blk * 64 + lane;                                     // (k < NP)
+    const int k = blk * KPW + lane;                                    // (k < NP)
     const u64 mine = keys[k];
     {
-        const int per = NP >> 4;                                       // a multiple of 4
+        const int per = NP / (1024 / KPW);                             // a multiple of 4 (KPW = 32: the launcher asks for NP % 128 == 0)
         const u64* p = keys + seg * per;
         int c = 0;
         for (int j = 0; j < per; j += 4) c += (p[j] < mine ? 1 : 0) + (p[j + 1] < mine ? 1 : 0) + (p[j + 2] < mine ? 1 : 0) + (p[j + 3] < mine ? 1 : 0);

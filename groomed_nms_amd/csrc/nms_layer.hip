@@ -928,7 +928,10 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
     // ~8 us in one launch against 14 us of runs + merge; from two rounds on the merge sort wins, LABNOTES R5.6)
     if (count_sort && (N <= 2048 || (N <= 4096 && (long)B * ((N + 63) / 64) * roles <= (long)device_cu_count()))) {
         const int NP = (N + 63) & ~63;
-        sort_count_kernel<<<dim3(NP / 64, B, roles), 1024, (size_t)NP * 8, st>>>(scores, boxes, N, counts, ws, L, (long long*)order, mode3d);
+        if (NP % 128 == 0 && (long)B * (NP / 32) * roles <= (long)device_cu_count())   // half the compares per thread while the grid is one round
+            sort_count_kernel<32><<<dim3(NP / 32, B, roles), 1024, (size_t)NP * 8, st>>>(scores, boxes, N, counts, ws, L, (long long*)order, mode3d);
+        else
+            sort_count_kernel<64><<<dim3(NP / 64, B, roles), 1024, (size_t)NP * 8, st>>>(scores, boxes, N, counts, ws, L, (long long*)order, mode3d);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
