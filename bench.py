@@ -492,7 +492,12 @@ def main():
                 # (small shapes are host-bound: on an idle GPU the start marker of a bracket runs when it is enqueued and the launch behind it
                 # arrives microseconds later, so the bracket would time the host.  A spin kernel in front lets the host run kr steps ahead:
                 # markers and launches then execute back to back)
-                torch.cuda._sleep(int(4e6) + int(2.5e5) * kr)
+                # (the spin lasts at least three times what the host needed for kr eager steps, at 2.5 cycles per ns: on the pool's slowest
+                # hosts the fixed spin of round 4 ended before the steps were enqueued and the bracket of B = 1 read the host, 0.088 ms for 38.7 us)
+                spin = int(4e6) + int(2.5e5) * kr
+                if dts / steps < 1e-4:                      # (only the shapes a host can bind: behind 8 ms of spinning the 2-ms steps ran 8 % slower)
+                    spin = max(spin, min(int(3 * kr * (dts / steps) * 2.5e9), int(2e7)))
+                torch.cuda._sleep(spin)
                 for _ in range(kr):
                     one()
                 torch.cuda.synchronize()
@@ -502,7 +507,8 @@ def main():
                 # run ahead (the eager figure below includes the host's launch cost, which is all of it at the small shapes and differs
                 # between boxes by 2x)
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda._sleep(int(4e6) + int(2.5e5) * kr)
+                if dts / steps < 1e-4:                      # (a GPU-bound shape needs no head start, and the spin would cost it clock)
+                    torch.cuda._sleep(spin)
                 ev0.record()
                 for _ in range(kr):
                     one()
