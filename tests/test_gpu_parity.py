@@ -1431,6 +1431,32 @@ def test_ungrouped_block_solves_against_oracle(G, O):
                     np.testing.assert_allclose(iou.grad[b, :n, :n].cpu().numpy(), ref["grad_iou"], atol=5e-4, rtol=1e-3, err_msg=tag)
 
 
+def test_ungrouped_matrix_from_boxes_plain_and_other_boxes(G):
+    """ungrouped_permute_boxes_kernel takes the matrix writers' packed row body when every box of a wave's work "divides plainly"
+    (csrc/iou_tile.h) and pair_iou's IEEE division otherwise; either way the pruned triangular matrix must equal, bit for bit, what the
+    matrix-in entry permutes out of gnms_iou2d's matrix (lib/core.py:480-508).  Pixel boxes (plain), the same boxes scaled beyond 2^20
+    (not plain), a batch with one box moved to a negative-zero corner and one zero-area box (NaN self-overlap is never read: j < i)."""
+    from groomed_nms_amd import synthetic, overlaps
+    rng = np.random.default_rng(4242)
+    for N, scale, poke in ((333, 1.0, False), (333, 4.0e6, False), (260, 1.0, True), (700, 3.0e-5, False)):
+        boxes, scores = synthetic.batch_2d(int(rng.integers(1 << 30)), 2, N, "clustered", per=6)
+        boxes = (boxes * np.float32(scale)).astype(np.float32)
+        if poke:
+            boxes[0, 5, 0] = -0.0
+            boxes[1, 7] = boxes[1, 7, [0, 1, 0, 1]]                       # zero area
+        bt = torch.from_numpy(boxes).cuda()
+        w = torch.from_numpy(rng.uniform(-1, 2, (2, N)).astype(np.float32)).cuda()
+        s1 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        s2 = torch.from_numpy(scores).cuda().requires_grad_(True)
+        one = G.differentiable_nms_with_iou2d_batched(s1, bt, group_boxes=False)
+        two = G.differentiable_nms_batched(s2, overlaps.iou_batched(bt), group_boxes=False)
+        (one[0] * w).sum().backward()
+        (two[0] * w).sum().backward()
+        tag = (N, scale, poke)
+        assert torch.equal(one[0], two[0]) or torch.allclose(one[0], two[0], atol=0, rtol=0, equal_nan=True), tag
+        assert torch.equal(s1.grad, s2.grad) or torch.allclose(s1.grad, s2.grad, atol=0, rtol=0, equal_nan=True), tag
+
+
 def test_ungrouped_mode_with_a_tight_workspace(G, O):
     """Ungrouped mode at sizes that are not multiples of 64, through the C ABI with a workspace of EXACTLY gnms_workspace_bytes that
     ends at the end of its allocation (the diagonal-tile loads of the last row block stay inside the scratch pitch)."""
