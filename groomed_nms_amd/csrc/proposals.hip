@@ -197,15 +197,21 @@ __global__ __launch_bounds__(1024) void topk_preselect_kernel(const float* __res
 constexpr int kCoopKPT = 8;                       // keys per thread
 constexpr int kCoopChunk = 1024 * kCoopKPT;       // candidates per workgroup
 constexpr int kCoopBins = 2048;
-struct CoopScratch {                              // per image, in a stream-ordered temporary that the launch finds zeroed
+struct CoopScratch {                              // the part of an image's scratch that every launch must FIND ZEROED
     unsigned hist[3][kCoopBins];
     unsigned bar[8];
     unsigned sel_count;
-    unsigned pad[7];
-    // then: unsigned cnt[G][2]; u64 sel[Kpad]; u64 runs[Kpad]
+    unsigned exits;                               // workgroups of the image that are done: the last one zeroes this struct again
+    unsigned pad[6];
 };
-__host__ __device__ inline size_t coop_scratch_bytes(int G, int Kpad) {
-    return (sizeof(CoopScratch) + (size_t)G * 2 * sizeof(unsigned) + 15) / 16 * 16 + (size_t)Kpad * 16;
+// One scratch per device, kept between the calls (launches of this kernel are chained across streams, see gnms_select_topk: never two at
+// once): kCoopMaxImages headers first -- at the same place whatever G and K a call has, each left zeroed by the image's last workgroup --
+// then per image  unsigned cnt[G][2]; u64 sel[Kpad]; u64 runs[Kpad]  (written before they are read: any content will do).
+// Round 5, first version: a stream-ordered temporary + a memset per call, 5 us on the device and three more API calls on the host.
+constexpr int kCoopMaxImages = 512;
+__host__ __device__ inline size_t coop_rest_bytes(int G, int Kpad) { return ((size_t)G * 2 * sizeof(unsigned) + 15) / 16 * 16 + (size_t)Kpad * 16; }
+__host__ __device__ inline size_t coop_scratch_bytes(int B, int G, int Kpad) {
+    return (size_t)kCoopMaxImages * sizeof(CoopScratch) + (size_t)B * coop_rest_bytes(G, Kpad);
 }
 
 __device__ __forceinline__ void coop_grid_barrier(unsigned* counter, const unsigned G) {
@@ -254,10 +260,10 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
     const int f = gnms_count(cand_counts, b, F);
     const float* s = scores + (size_t)b * A;
     const int* cd = cand ? cand + (size_t)b * F : nullptr;
-    char* sp = scratch_all + (size_t)b * coop_scratch_bytes(G, Kpad);
-    CoopScratch* S = reinterpret_cast<CoopScratch*>(sp);
-    unsigned* cnt = reinterpret_cast<unsigned*>(sp + sizeof(CoopScratch));                     // [G][2]: keys below / equal to the threshold
-    u64* sel = reinterpret_cast<u64*>(sp + (sizeof(CoopScratch) + (size_t)G * 2 * sizeof(unsigned) + 15) / 16 * 16);   // [Kpad]
+    CoopScratch* S = reinterpret_cast<CoopScratch*>(scratch_all) + b;
+    char* sp = scratch_all + (size_t)kCoopMaxImages * sizeof(CoopScratch) + (size_t)b * coop_rest_bytes(G, Kpad);
+    unsigned* cnt = reinterpret_cast<unsigned*>(sp);                                           // [G][2]: keys below / equal to the threshold
+    u64* sel = reinterpret_cast<u64*>(sp + ((size_t)G * 2 * sizeof(unsigned) + 15) / 16 * 16);   // [Kpad]
     u64* runs = sel + Kpad;                                                                   // [Kpad] sorted runs of 1024
     const int m = f < K ? f : K;                                       // boxes selected
     auto index_of = [&](int i) { int a = cd ? cd[i] : i; return a < 0 ? 0 : (a >= A ? A - 1 : a); };   // (a bad index must not read out of bounds)
@@ -295,6 +301,7 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
     }
     // ---- which keys equal to T belong: per-workgroup counts, prefix over the workgroups before mine ----
     unsigned eq_before = 0u;                                           // keys == T in the workgroups before mine (candidate order)
+    unsigned eq_mine = 0u;                                             // ... and in this workgroup
     {
         unsigned nlt = 0u, neq = 0u;
 #pragma unroll
@@ -312,6 +319,7 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
         __syncthreads();
         unsigned weq = 0u;
         for (int w = 0; w < 16; ++w) weq += wtot[w];
+        eq_mine = weq;
         if (t == 0) {
             __hip_atomic_store(cnt + 2 * g, wlt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(cnt + 2 * g + 1, weq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -320,31 +328,48 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
         for (int w = 0; w < g; ++w) eq_before += __hip_atomic_load(cnt + 2 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- the selected pairs (key << 32 | candidate position) into sel[], any order: the sort below orders them ----
+    // Two passes: which of the thread's keys are taken (LDS only), then ONE device-scope fetch-add per workgroup for its range of sel[]
+    // and the stores.  (Round 5, first version: a returning fetch-add per wave and round of keys -- eight dependent memory round trips.)
     {
+        unsigned takemask = 0u, wave_take = 0u;
         unsigned eq_run = eq_before;                                   // keys == T in front of (e, wave 0 lane 0), candidate order
-#pragma unroll 1
+#pragma unroll
         for (int e = 0; e < kCoopKPT; ++e) {
             const int i = i0 + e * 1024;
             const bool v = i < f;
-            const bool is_eq = v && !all && key[e] == T;
-            const u64 beq = __ballot(is_eq);
-            // candidate order inside the workgroup is (e, t): the equal keys of the waves before mine in this round, then the lanes before me
-            if (lane == 0) wtot[wave] = (unsigned)__builtin_popcountll(beq);
-            __syncthreads();
-            unsigned wbefore = 0u, wall = 0u;
-            for (int w = 0; w < 16; ++w) { const unsigned c = wtot[w]; if (w < wave) wbefore += c; wall += c; }
-            __syncthreads();
-            const unsigned my_eq = eq_run + wbefore + (unsigned)__builtin_popcountll(beq & ((1ull << lane) - 1ull));
-            const bool take = v && (all || key[e] < T || (is_eq && my_eq < need_eq));
-            const u64 bt = __ballot(take);
-            if (bt) {
-                unsigned pos = 0u;
-                if (lane == __builtin_ctzll(bt)) pos = __hip_atomic_fetch_add(&S->sel_count, (unsigned)__builtin_popcountll(bt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pos = __builtin_amdgcn_readlane(pos, __builtin_ctzll(bt)) + (unsigned)__builtin_popcountll(bt & ((1ull << lane) - 1ull));
-                if (take && pos < (unsigned)Kpad)
-                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(sel + pos), ((unsigned long long)key[e] << 32) | (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool take = v && (all || key[e] < T);
+            if (eq_mine != 0u) {                                       // (workgroup-uniform: keys equal to the threshold are rare)
+                const bool is_eq = v && !all && key[e] == T;
+                const u64 beq = __ballot(is_eq);
+                // candidate order inside the workgroup is (e, t): the equal keys of the waves before mine in this round, then the lanes before me
+                if (lane == 0) wtot[wave] = (unsigned)__builtin_popcountll(beq);
+                __syncthreads();
+                unsigned wbefore = 0u, wall = 0u;
+                for (int w = 0; w < 16; ++w) { const unsigned c = wtot[w]; if (w < wave) wbefore += c; wall += c; }
+                __syncthreads();
+                const unsigned my_eq = eq_run + wbefore + (unsigned)__builtin_popcountll(beq & ((1ull << lane) - 1ull));
+                take = take || (is_eq && my_eq < need_eq);
+                eq_run += wall;
             }
-            eq_run += wall;
+            takemask |= take ? (1u << e) : 0u;
+            wave_take += (unsigned)__builtin_popcountll(__ballot(take));
+        }
+        if (lane == 0) wtot[wave] = wave_take;
+        __syncthreads();
+        unsigned run = 0u, wg_take = 0u;
+        for (int w = 0; w < 16; ++w) { const unsigned c = wtot[w]; if (w < wave) run += c; wg_take += c; }
+        if (t == 0) out2[0] = wg_take ? __hip_atomic_fetch_add(&S->sel_count, wg_take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        __syncthreads();
+        run += out2[0];
+#pragma unroll
+        for (int e = 0; e < kCoopKPT; ++e) {
+            const bool take = (takemask >> e) & 1u;
+            const u64 bt = __ballot(take);
+            const unsigned pos = run + (unsigned)__builtin_popcountll(bt & ((1ull << lane) - 1ull));
+            if (take && pos < (unsigned)Kpad)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(sel + pos), ((unsigned long long)key[e] << 32) | (unsigned)(i0 + e * 1024),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            run += (unsigned)__builtin_popcountll(bt);
         }
     }
     coop_grid_barrier(&S->bar[4], (unsigned)G);
@@ -379,6 +404,16 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
         if (sel_idx) sel_idx[(size_t)b * K + k] = -1;
         if (sel_scores) sel_scores[(size_t)b * K + k] = 0.0f;
         if (sel_boxes) sel_boxes[(size_t)b * K + k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // the image's last workgroup to get here leaves the header zeroed for the next call (every other one is behind its last barrier and its
+    // last read of the histograms: nobody looks at the header any more)
+    __shared__ unsigned last_one;
+    __syncthreads();
+    if (t == 0) last_one = __hip_atomic_fetch_add(&S->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(G - 1);
+    __syncthreads();
+    if (last_one) {
+        unsigned* z = reinterpret_cast<unsigned*>(S);
+        for (int i = t; i < (int)(sizeof(CoopScratch) / sizeof(unsigned)); i += 1024) __hip_atomic_store(z + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -437,17 +472,14 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
         // per call -- measured.)  Not while the stream is being captured: the one-workgroup kernels below serve a capture.
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-        if (!capturing && F > 4096 && K <= GNMS_MAX_BOXES && (long)B * G <= (long)gnms_device_cu_count() && B <= 65535) {
+        if (!capturing && F > 4096 && K <= GNMS_MAX_BOXES && (long)B * G <= (long)gnms_device_cu_count() && B <= kCoopMaxImages) {
             const int Kpad = gnms_div_up(Kc, 1024) * 1024;
-            const size_t per = coop_scratch_bytes(G, Kpad);
-            gnms_async_buffer sc_buf;
-            GNMS_CHECK_HIP(sc_buf.alloc(per * B, st));
-            GNMS_CHECK_HIP(hipMemsetAsync(sc_buf.p, 0, per * B, st));
+            const size_t need = coop_scratch_bytes(B, G, Kpad);
             size_t lds = (size_t)gnms_div_up(Kc, 1024) * 1024 * 8;
             if (lds < kCoopBins * sizeof(unsigned)) lds = kCoopBins * sizeof(unsigned);
             int rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(topk_coop_kernel), lds);
             if (rc) return rc;
-            struct Chain { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool any = false; };
+            struct Chain { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool any = false; char* scratch = nullptr; size_t cap = 0; };
             static std::mutex mu;
             static std::map<int, Chain> chains;
             int dev = 0;
@@ -456,8 +488,16 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
                 std::lock_guard<std::mutex> lock(mu);
                 Chain& C = chains[dev];
                 if (!C.ev) GNMS_CHECK_HIP(hipEventCreateWithFlags(&C.ev, hipEventDisableTiming));
+                if (need > C.cap) {                                    // (rare: the first call, or a bigger K; hipFree waits for the device)
+                    if (C.scratch) GNMS_CHECK_HIP(hipFree(C.scratch));
+                    C.scratch = nullptr; C.cap = 0;
+                    const size_t cap = need + (need >> 1);
+                    GNMS_CHECK_HIP(hipMalloc((void**)&C.scratch, cap));
+                    GNMS_CHECK_HIP(hipMemset(C.scratch, 0, (size_t)kCoopMaxImages * sizeof(CoopScratch)));
+                    C.cap = cap;
+                }
                 if (C.any && C.last != st) GNMS_CHECK_HIP(hipStreamWaitEvent(st, C.ev, 0));
-                topk_coop_kernel<<<dim3(G, B), 1024, lds, st>>>(scores, A, candidates, F, candidate_counts, K, Kpad, G, sc_buf.as<char>(),
+                topk_coop_kernel<<<dim3(G, B), 1024, lds, st>>>(scores, A, candidates, F, candidate_counts, K, Kpad, G, C.scratch,
                                                                 reinterpret_cast<const float4*>(boxes), (long long*)sel_index, sel_count, sel_scores,
                                                                 reinterpret_cast<float4*>(sel_boxes));
                 GNMS_CHECK_LAUNCH();
@@ -465,7 +505,6 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
                 C.last = st;
                 C.any = true;
             }
-            GNMS_CHECK_HIP(sc_buf.release());
             return GNMS_OK;
         }
     }
