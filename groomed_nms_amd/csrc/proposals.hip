@@ -226,7 +226,7 @@ __device__ __forceinline__ void coop_grid_barrier(unsigned* counter, const unsig
 
 // the digit of the (need)-th smallest key among the bins of one global histogram; every thread returns the same (digit, rest)
 __device__ __forceinline__ void coop_find_digit(const unsigned* hist, const int nbins, const unsigned need, unsigned* digit, unsigned* rest,
-                                                unsigned* wtot /* [16] LDS */, unsigned* out2 /* [2] LDS */) {
+                                                unsigned* binc, unsigned* wtot /* [16] LDS */, unsigned* out2 /* [3] LDS */) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     // thread t owns bins 2 t, 2 t + 1 (nbins <= 2048)
     const unsigned h0 = (2 * t < nbins) ? __hip_atomic_load(hist + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -239,13 +239,14 @@ __device__ __forceinline__ void coop_find_digit(const unsigned* hist, const int 
     for (int w = 0; w < wave; ++w) base += wtot[w];
     const unsigned before = base + inc - mine;                        // keys in bins < 2 t
     if (before < need && need <= before + mine) {                     // exactly one thread (need >= 1, need <= total)
-        unsigned d = 2u * t, r = need - before;
-        if (r > h0) { r -= h0; ++d; }
-        out2[0] = d; out2[1] = r;
+        unsigned d = 2u * t, r = need - before, c = h0;
+        if (r > h0) { r -= h0; ++d; c = h1; }
+        out2[0] = d; out2[1] = r; out2[2] = c;
     }
     __syncthreads();
     *digit = out2[0];
     *rest = out2[1];
+    *binc = out2[2];                                                  // keys in the chosen bin
     __syncthreads();
 }
 
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
                                                          int* __restrict__ sel_count, float* __restrict__ sel_scores, float4* __restrict__ sel_boxes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned* lh = reinterpret_cast<unsigned*>(smem);                  // [2048] LDS histogram; later the sort's keys
-    __shared__ unsigned wtot[16], out2[2];
+    __shared__ unsigned wtot[16], out2[4];
     const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int f = gnms_count(cand_counts, b, F);
     const float* s = scores + (size_t)b * A;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
         const int i = i0 + e * 1024;
         key[e] = (i < f) ? gnms_desc_key(s[index_of(i)]) : 0xffffffffu;          // (a real key can be 0xffffffff too: validity is i < f, not the key)
     }
+    unsigned eq_total = 0u;
     unsigned T = 0xffffffffu, need_eq = 0u;                            // keys < T are all selected; of the keys == T the first need_eq (candidate order)
     bool all = f <= K;                                                 // everything is selected
     if (!all) {
@@ -292,38 +294,29 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
             for (int i = t; i < nb; i += 1024) { const unsigned v = lh[i]; if (v) __hip_atomic_fetch_add(&S->hist[pass][i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             coop_grid_barrier(&S->bar[pass], (unsigned)G);
             unsigned d, rest;
-            coop_find_digit(S->hist[pass], nb, need, &d, &rest, wtot, out2);
+            coop_find_digit(S->hist[pass], nb, need, &d, &rest, &eq_total, wtot, out2);
             prefix |= d << shift;
             need = rest;
         }
         T = prefix;
-        need_eq = need;
+        need_eq = need;                                                // (eq_total: the last pass's bin is ONE key value: the keys equal to T)
     }
     // ---- which keys equal to T belong: per-workgroup counts, prefix over the workgroups before mine ----
+    // (only when SOME of the keys equal to T belong -- the same decision in every workgroup, from the same histogram: otherwise all of them
+    // are taken, nobody needs anybody's counts, and a grid barrier is saved: the common case, a threshold that one key holds)
+    const bool take_all_eq = !all && need_eq >= eq_total;
     unsigned eq_before = 0u;                                           // keys == T in the workgroups before mine (candidate order)
     unsigned eq_mine = 0u;                                             // ... and in this workgroup
-    {
-        unsigned nlt = 0u, neq = 0u;
+    if (!all && !take_all_eq) {
+        unsigned neq = 0u;
 #pragma unroll
-        for (int e = 0; e < kCoopKPT; ++e) {
-            const bool v = i0 + e * 1024 < f;
-            nlt += __builtin_popcountll(__ballot(v && (all || key[e] < T)));
-            neq += __builtin_popcountll(__ballot(v && !all && key[e] == T));
-        }
-        if (lane == 0) { wtot[wave] = nlt; }
-        __syncthreads();
-        unsigned wlt = 0u;
-        for (int w = 0; w < 16; ++w) wlt += wtot[w];
-        __syncthreads();
+        for (int e = 0; e < kCoopKPT; ++e) neq += __builtin_popcountll(__ballot(i0 + e * 1024 < f && key[e] == T));
         if (lane == 0) wtot[wave] = neq;
         __syncthreads();
         unsigned weq = 0u;
         for (int w = 0; w < 16; ++w) weq += wtot[w];
         eq_mine = weq;
-        if (t == 0) {
-            __hip_atomic_store(cnt + 2 * g, wlt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cnt + 2 * g + 1, weq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (t == 0) __hip_atomic_store(cnt + 2 * g + 1, weq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         coop_grid_barrier(&S->bar[3], (unsigned)G);
         for (int w = 0; w < g; ++w) eq_before += __hip_atomic_load(cnt + 2 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -337,7 +330,7 @@ __global__ __launch_bounds__(1024) void topk_coop_kernel(const float* __restrict
         for (int e = 0; e < kCoopKPT; ++e) {
             const int i = i0 + e * 1024;
             const bool v = i < f;
-            bool take = v && (all || key[e] < T);
+            bool take = v && (all || key[e] < T || (take_all_eq && key[e] == T));
             if (eq_mine != 0u) {                                       // (workgroup-uniform: keys equal to the threshold are rare)
                 const bool is_eq = v && !all && key[e] == T;
                 const u64 beq = __ballot(is_eq);
