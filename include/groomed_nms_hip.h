@@ -323,7 +323,7 @@ int gnms_bbox_transform_inv(const float* anchors, const float* deltas, int B, in
  * candidates (all ~127k anchors of an image at inference): a radix pre-selection first leaves exactly the K the stable sort would put
  * first (then K <= GNMS_MAX_BOXES; a stream-ordered temporary of B * (K + 1) ints).  From 4096 candidates on, while B * ceil(F / 8192)
  * workgroups fit the device and the stream is not being captured, several workgroups per image do the selection together: they use ONE
- * scratch per device that the library keeps between the calls (about 12.6 MiB + 16 bytes per selected box; grown with a blocking
+ * scratch per device that the library keeps between the calls (about 12 MiB + 16 bytes per selected box; grown with a blocking
  * hipFree / hipMalloc when a call needs more), and launches of that kind are ordered across streams by an event per device.
  * Outputs (any may be NULL), padded behind sel_count[b]: sel_index [B][K] int64 (-1), sel_scores [B][K] (0),
  * sel_boxes [B][K][4] gathered from boxes [B][A][4] (0) -- the padded layout gnms_forward_with_iou2d takes with counts. */
