@@ -50,6 +50,7 @@ _SIGNATURES = {
                                                c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, c_vp,
                                      ctypes.POINTER(GnmsParams), c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
+    "gnms_counts_to_host": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp]),
     "gnms_forward_from_boxes": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.POINTER(GnmsParams), c_vp, c_vp, c_vp,
                                                c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_backward_from_boxes": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.POINTER(GnmsParams), c_vp,

@@ -181,6 +181,42 @@ std::vector<c10::optional<Tensor>> layer(const Tensor& scores, const Tensor& src
     return r;
 }
 
+// the layer's two count vectors on the host (gnms_counts_to_host: tag-polled pinned mailbox, no device-to-host copy) -> nvalid[0..B) + ninvalid[0..B)
+std::vector<int64_t> counts_to_host(const Tensor& nvalid, const Tensor& ninvalid) {
+    TORCH_CHECK(nvalid.is_cuda() && ninvalid.is_cuda() && nvalid.scalar_type() == at::kInt && ninvalid.scalar_type() == at::kInt && nvalid.dim() == 1 &&
+                ninvalid.sizes() == nvalid.sizes() && nvalid.is_contiguous() && ninvalid.is_contiguous(), "GNMS: counts_to_host takes two contiguous CUDA int32 [B] tensors");
+    DeviceGuard guard(nvalid.device());
+    const int64_t B = nvalid.size(0);
+    std::vector<int32_t> h((size_t)(2 * B));
+    hipStream_t st = current_stream(nvalid);
+    int rc;
+    {
+        pybind11::gil_scoped_release nogil;
+        rc = gnms_counts_to_host((const int32_t*)cptr(nvalid), (const int32_t*)cptr(ninvalid), (int)B, h.data(), st);
+    }
+    check(rc, "gnms_counts_to_host");
+    return std::vector<int64_t>(h.begin(), h.end());
+}
+
+// lib/groomed_nms.py:10-129 for ONE image of GPU tensors in one host call: scores [N], iou [N, N] -> (valid, invalid, prob [N], nvalid [1], ninvalid [1]).
+// lists_now: the counts come to the host (gnms_counts_to_host) and valid / invalid are the reference's index tensors of K and N - K entries;
+// otherwise they are the padded [N] lists and the two counts stay on the device (LazyIndexList).  The unsqueeze / select / narrow views that
+// groomed_nms.py::differentiable_nms makes one torch call at a time from Python (~2 us a piece at N = 500, where the whole call is ~50 us).
+std::vector<Tensor> single(const Tensor& scores, const Tensor& iou, double thr, double temp, double vthr, int64_t prune, bool sorted_prob, bool group, bool mask,
+                           int64_t gsize, bool presorted, bool lists_now) {
+    TORCH_CHECK(scores.dim() == 1 && iou.dim() == 2 && iou.size(0) == scores.size(0) && iou.size(1) == scores.size(0),
+                "iou_unsorted must be (N, N) with N = len(scores_unsorted)");
+    const variable_list o = Layer::apply(scores.unsqueeze(0), iou.unsqueeze(0), c10::nullopt, c10::nullopt, (int64_t)kMatrixIn, thr, temp, vthr, prune, sorted_prob,
+                                         group, mask, gsize, presorted, true);
+    Tensor valid = o[4].select(0, 0), invalid = o[5].select(0, 0);
+    if (lists_now) {
+        const std::vector<int64_t> c = counts_to_host(o[2], o[3]);
+        valid = valid.narrow(0, 0, c[0]);
+        invalid = invalid.narrow(0, 0, c[1]);
+    }
+    return {valid, invalid, o[0].select(0, 0), o[2], o[3]};
+}
+
 // lib/core.py:480-508 iou(mode='combinations') for batches: boxes_a [B,M,4], boxes_b [B,N,4] -> [B,M,N]
 Tensor iou2d(const Tensor& a, const Tensor& b, const c10::optional<Tensor>& out_) {
     TORCH_CHECK(a.is_cuda() && b.is_cuda() && a.dim() == 3 && b.dim() == 3 && a.size(2) == 4 && b.size(2) == 4 && a.size(0) == b.size(0) &&
@@ -306,5 +342,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("select_topk", &select_topk, "per image the K best-scoring candidates (lib/loss/rpn_3d.py:731-737)");
     m.def("bbox_transform_inv", &bbox_transform_inv, "lib/rpn_util.py:872-934");
     m.def("training_tail", &training_tail, "layer -> best targets -> AP loss in one host call");
+    m.def("counts_to_host", &counts_to_host, "nvalid / ninvalid of a forward call on the host through the pinned mailbox (one blocking round trip, no copy)");
+    m.def("single", &single, "differentiable_nms of one image of GPU tensors: layer + host round trip + the reference's index tensors in one host call");
     m.def("abi_version", [] { return gnms_abi_version(); });
 }

@@ -479,6 +479,27 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
     if type(scores_unsorted) == np.ndarray:                                   # :34-36
         scores_unsorted = torch.from_numpy(scores_unsorted).float()
         iou_unsorted = torch.from_numpy(np.asarray(iou_unsorted)).float()
+    elif (sorting_method != "soft" and not debug and not _PLAIN_COUNTS and scores_unsorted.is_cuda and iou_unsorted.is_cuda
+          and scores_unsorted.dtype == torch.float32 and iou_unsorted.dtype == torch.float32 and scores_unsorted.dim() == 1
+          and scores_unsorted.shape[0] > 0 and iou_unsorted.device == scores_unsorted.device):
+        # GPU tensors in, hard sort (the training call site, lib/loss/rpn_3d.py:791): the whole call in the C++ binding
+        ext = _binding()
+        if ext and hasattr(ext, "single"):
+            p = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes, mask_group_boxes,
+                        group_size, False, True)
+            try:
+                o = ext.single(scores_unsorted, iou_unsorted, p.nms_threshold, p.temperature, p.valid_box_prob_threshold, p.pruning_method,
+                               bool(p.return_sorted_prob), bool(p.group_boxes), bool(p.mask_group_boxes), p.group_size, False, not LAZY_INDEX_LISTS)
+            except NotImplementedError:
+                raise
+            except RuntimeError as e:
+                if isinstance(e, torch.cuda.OutOfMemoryError) or not str(e).startswith("GNMS:"):
+                    raise
+                raise _lib.GnmsError(str(e)) from None
+            if not LAZY_INDEX_LISTS:
+                return o[0], o[1], o[2]
+            both = _LazyCounts(o[3], o[4])
+            return LazyIndexList(o[0], both, 0, None), LazyIndexList(o[1], both, 1, None), o[2]
     out_device = iou_unsorted.device
     dev = out_device if out_device.type == "cuda" else _device()
     scores = scores_unsorted.to(device=dev, dtype=torch.float32)
@@ -506,17 +527,13 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
     if debug:
         print("\nInside diff NMS... After sorting")
         print(non_suppression_prob)
-    # the two counts as ONE tensor without a kernel: nvalid / ninvalid are the two rows of one [2, B] allocation (_outputs, torch_binding.cpp)
-    base = getattr(nvalid, "_base", None)
-    pair = base[:, 0] if (base is not None and base.dim() == 2 and base.shape[0] == 2 and base.shape[1] == nvalid.shape[0]
-                          and ninvalid.data_ptr() == base[1].data_ptr()) else None
     if out_device == dev and LAZY_INDEX_LISTS and n > 0:
         # GPU tensors in: the two index lists have a data-dependent length K, which only the host can turn into a tensor shape.  They
         # come back as LazyIndexList objects that hold the padded device list and its device-side count and become real tensors on
         # first use -- training reads only the probabilities (lib/loss/rpn_3d.py:791 takes `[2]`), so its step never waits for the GPU.
-        both = pair if pair is not None else torch.stack([nvalid[0], ninvalid[0]])
+        both = _LazyCounts(nvalid, ninvalid)
         return (LazyIndexList(valid[0], both, 0, indices), LazyIndexList(invalid[0], both, 1, indices), non_suppression_prob)
-    counts = (pair if pair is not None else torch.stack([nvalid[0], ninvalid[0]])).tolist() if n > 0 else [0, 0]   # the one host sync: K is data dependent
+    counts = _counts_to_host(nvalid, ninvalid) if n > 0 else [0, 0]   # the one host round trip: K is data dependent (B = 1: [nvalid, ninvalid])
     valid_boxes_index = valid[0, :counts[0]]
     invalid_boxes_index = invalid[0, :counts[1]]
     if indices is not None:
@@ -529,10 +546,51 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
     return valid_boxes_index, invalid_boxes_index, non_suppression_prob
 
 
+_PLAIN_COUNTS = __import__("os").environ.get("GNMS_COUNTS_MAILBOX", "") == "0"
+
+
+def _counts_to_host(nvalid, ninvalid):
+    """[nvalid[0..B), ninvalid[0..B)] as Python ints: the one host round trip the reference's return convention needs
+    (lib/groomed_nms.py:120-127), through gnms_counts_to_host (a tag-polled slot of pinned memory, no device-to-host copy)."""
+    nv, ni = nvalid.contiguous(), ninvalid.contiguous()
+    if _PLAIN_COUNTS:                                              # GNMS_COUNTS_MAILBOX=0 (developer A/B): torch's device-to-host copy
+        return torch.cat([nv, ni]).tolist()
+    ext = _binding()
+    if ext and hasattr(ext, "counts_to_host"):
+        try:
+            return ext.counts_to_host(nv, ni)
+        except RuntimeError as e:
+            if not str(e).startswith("GNMS:"):
+                raise
+            raise _lib.GnmsError(str(e)) from None
+    import ctypes
+    lib = _lib.load()
+    b = nv.shape[0]
+    host = (ctypes.c_int32 * (2 * b))()
+    with _lib.on_device(nv.device):
+        _lib.check(lib.gnms_counts_to_host(nv.data_ptr(), ni.data_ptr(), b, ctypes.cast(host, ctypes.c_void_p), _lib.stream_ptr(nv.device)),
+                   "gnms_counts_to_host")
+    return list(host)
+
+
 # Module switch, OFF by default: differentiable_nms returns plain index tensors exactly like the reference (one host sync per call: their
 # length K is data dependent).  A training loop that reads only the probabilities (lib/loss/rpn_3d.py:791 takes `[2]`) may set it to
 # True: with GPU tensors in, the two lists then come back as LazyIndexList objects and the call never waits for the GPU.
 LAZY_INDEX_LISTS = False
+
+
+class _LazyCounts:
+    """the device-side counts of one call, fetched once (for both lists) on first use"""
+    __slots__ = ("_nv", "_ni", "_host")
+
+    def __init__(self, nvalid, ninvalid):
+        self._nv, self._ni, self._host = nvalid, ninvalid, None
+
+    def get(self, which):
+        if self._host is None:
+            self._host = _counts_to_host(self._nv, self._ni)          # [nvalid[0], ninvalid[0]] (B = 1)
+            self._nv = self._ni = None
+        return int(self._host[which])
 
 
 class LazyIndexList:
@@ -554,7 +612,7 @@ class LazyIndexList:
     @property
     def t(self):
         if self._t is None:
-            k = int(self._counts[self._which].item())
+            k = self._counts.get(self._which)
             t = self._padded[:k]
             if self._map is not None:
                 t = self._map[t]

@@ -163,6 +163,15 @@ int gnms_forward_with_iou3d(const float* params3d, const float* scores, int B, i
                             int64_t* invalid, int32_t* nvalid, int32_t* ninvalid, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* The two per-image counts of a forward call on the HOST: what the reference's return convention needs before it can shape
+ * `valid_boxes_index` / `invalid_boxes_index` (lib/groomed_nms.py:120-127; their length K is data dependent).  Blocking; ordered behind
+ * everything enqueued on `stream` before it.  nvalid / ninvalid: the DEVICE arrays [B] a gnms_forward* call wrote; host_out: HOST array
+ * [2 B] = nvalid[0..B) then ninvalid[0..B).  Not a device-to-host copy: a one-wave kernel stores the counts and a call tag into a slot of
+ * fine-grained pinned memory the library keeps per device (64 KiB, allocated by the first call) and the host polls the tag (one PCIe
+ * write instead of a copy submission + a stream synchronisation: ~20 us less per call at N = 500).  B > 127, or no tag within two
+ * seconds: a plain asynchronous copy + stream synchronisation.  Cannot be captured into a graph (GNMS_ERR_INVALID_ARGUMENT). */
+int gnms_counts_to_host(const int32_t* nvalid, const int32_t* ninvalid, int B, int32_t* host_out, void* stream);
+
 /* backward of L through prob.  grad_prob [B][N] = dL/dprob (same order as prob).
  *   grad_scores [B][N] (input order), overwritten.
  *   grad_iou    [B][N][ld] or NULL.  When given it is fully overwritten (zero fill + the sparse

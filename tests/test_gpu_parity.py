@@ -2681,3 +2681,95 @@ def test_fast_tail_corner_cases_against_oracle(G, O):
         nv, ni = int(out[4][0]), int(out[5][0])
         assert out[2][0, :nv].tolist() == list(ref["valid"]) and out[3][0, :ni].tolist() == list(ref["invalid"]), tag
         assert np.array_equal(st.grad[0].cpu().numpy(), ref["grad_scores"]), tag
+
+
+@pytest.mark.gpu
+def test_counts_to_host_mailbox(G):
+    """gnms_counts_to_host (the host round trip of lib/groomed_nms.py:120-127 as a tag-polled slot of pinned memory): the counts it hands
+    to the host equal a plain device-to-host copy -- every B up to the slot size, the copy path above it, both bindings, calls right behind
+    a long-running kernel (the tag must not be seen early), four host threads with streams of their own at once, and a refusal inside a
+    stream capture; differentiable_nms's index tensors go through it on every call (lengths against nvalid of the batched entry)."""
+    import ctypes
+    import threading
+    from groomed_nms_amd import _lib, groomed_nms as M, synthetic
+    from groomed_nms_amd.overlaps import iou as iou_fn
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(77)
+    ext = M._binding()
+    assert ext and hasattr(ext, "counts_to_host")
+
+    def via_ctypes(nv, ni):
+        b = nv.shape[0]
+        host = (ctypes.c_int32 * (2 * b))()
+        _lib.check(lib.gnms_counts_to_host(nv.data_ptr(), ni.data_ptr(), b, ctypes.cast(host, ctypes.c_void_p), _lib.stream_ptr(dev)), "counts")
+        return list(host)
+
+    for B in (1, 2, 8, 63, 64, 65, 127, 128, 300):          # 127 = the last B of the mailbox, from 128 on the copy path
+        for rep in range(3):
+            a = rng.integers(0, 1 << 30, B).astype(np.int32)
+            b = rng.integers(0, 1 << 30, B).astype(np.int32)
+            nv, ni = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+            want = a.tolist() + b.tolist()
+            assert list(ext.counts_to_host(nv, ni)) == want, (B, rep)
+            assert via_ctypes(nv, ni) == want, (B, rep)
+            assert M._counts_to_host(nv, ni) == want
+    # behind ~2 ms of queued work that produces the counts: the poll must wait for the producer
+    big = torch.zeros((1 << 24,), dtype=torch.int32, device=dev)
+    for rep in range(20):
+        big.add_(1)
+        big.add_(1)
+        nv = big[:4].clone()
+        ni = big[-4:].clone()
+        assert list(ext.counts_to_host(nv, ni)) == [2 * (rep + 1)] * 8
+    # more calls than slots (the slot of a tag is reused every 64 calls)
+    for rep in range(200):
+        nv = torch.full((3,), rep, dtype=torch.int32, device=dev)
+        assert list(ext.counts_to_host(nv, nv)) == [rep] * 6
+    # four host threads, a stream each
+    errs = []
+
+    def worker(t):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rep in range(150):
+                    nv = torch.full((5,), 1000 * t + rep, dtype=torch.int32, device=dev)
+                    ni = nv + 7
+                    got = list(ext.counts_to_host(nv, ni))
+                    if got != [1000 * t + rep] * 5 + [1000 * t + rep + 7] * 5:
+                        errs.append((t, rep, got))
+        except Exception as e:                                # noqa: BLE001
+            errs.append((t, repr(e)))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert not errs, errs[:3]
+    # no host round trip inside a capture
+    nv = torch.zeros((2,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g.capture_begin()
+        try:
+            with pytest.raises(_lib.GnmsError):
+                via_ctypes(nv, nv)
+        finally:
+            g.capture_end()
+    torch.cuda.synchronize()
+    # the reference entry: lengths of the two index tensors = the batched entry's device-side counts
+    for n in (1, 37, 500, 1500):
+        boxes, scores = synthetic.batch_2d(300 + n, 1, n, "clustered")
+        bt, s = torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev)
+        iou = iou_fn(bt[0], bt[0])
+        valid, invalid, prob = G.differentiable_nms(s[0], iou)
+        out = G.differentiable_nms_batched(s, iou.unsqueeze(0))
+        assert valid.shape[0] == int(out[4][0]) and invalid.shape[0] == int(out[5][0]) and valid.shape[0] + invalid.shape[0] == n
+        assert torch.equal(valid, out[2][0, :valid.shape[0]]) and torch.equal(invalid, out[3][0, :invalid.shape[0]])
+        M.LAZY_INDEX_LISTS = True
+        try:
+            lv, li, lp = G.differentiable_nms(s[0], iou)
+            assert isinstance(lv, M.LazyIndexList) and torch.equal(lv.t, valid) and torch.equal(li.t, invalid) and torch.equal(lp, prob)
+        finally:
+            M.LAZY_INDEX_LISTS = False

@@ -62,6 +62,7 @@ for lazy in (False, True):
         out[2].sum().backward()
 
     print(json.dumps({"what": "single call differentiable_nms(scores, iou), GPU tensors, N=500", "binding": binding, "lazy_index_lists": lazy,
+                      "counts_to_host": "torch copy (GNMS_COUNTS_MAILBOX=0)" if GN._PLAIN_COUNTS else "pinned mailbox (gnms_counts_to_host)",
                       "us_per_call": round(us, 1), "us_fwd_bwd": round(time_it(fwdbwd), 1)}))
 GN.LAZY_INDEX_LISTS = False
 print(json.dumps({"what": "iou(boxes, boxes) N=500", "binding": binding, "us_per_call": round(time_it(lambda: overlaps.iou(boxes, boxes)), 1)}))
