@@ -51,18 +51,8 @@ int plain_copy(const int32_t* nvalid, const int32_t* ninvalid, int B, int32_t* h
     return GNMS_OK;
 }
 
-}  // namespace
-
-extern "C" int gnms_counts_to_host(const int32_t* nvalid, const int32_t* ninvalid, int B, int32_t* host_out, void* stream) {
-    GNMS_CHECK_ARG(B >= 0 && (B == 0 || (nvalid && ninvalid && host_out)), "gnms_counts_to_host: null pointer");
-    if (B == 0) return GNMS_OK;
-    hipStream_t st = (hipStream_t)stream;
-    int dev = 0;
-    GNMS_CHECK_HIP(hipGetDevice(&dev));
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    GNMS_CHECK_HIP(hipStreamIsCapturing(st, &cap));
-    GNMS_CHECK_ARG(cap == hipStreamCaptureStatusNone, "gnms_counts_to_host: a host round trip cannot be captured into a graph");
-    if (B > kMaxImages || dev >= kMaxDevices) return plain_copy(nvalid, ninvalid, B, host_out, st);
+Mailbox* mailbox(int dev) {
+    if (dev < 0 || dev >= kMaxDevices) return nullptr;
     Mailbox& M = g_box[dev];
     std::call_once(M.once, [&M] {
         void* p = nullptr;
@@ -74,7 +64,24 @@ extern "C" int gnms_counts_to_host(const int32_t* nvalid, const int32_t* ninvali
         M.host = (int32_t*)p;
         M.dev = (int32_t*)d;
     });
-    if (M.err != hipSuccess || !M.dev) return plain_copy(nvalid, ninvalid, B, host_out, st);
+    return (M.err == hipSuccess && M.dev) ? &M : nullptr;
+}
+
+}  // namespace
+
+extern "C" int gnms_counts_to_host(const int32_t* nvalid, const int32_t* ninvalid, int B, int32_t* host_out, void* stream) {
+    GNMS_CHECK_ARG(B >= 0 && (B == 0 || (nvalid && ninvalid && host_out)), "gnms_counts_to_host: null pointer");
+    if (B == 0) return GNMS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0;
+    GNMS_CHECK_HIP(hipGetDevice(&dev));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    GNMS_CHECK_HIP(hipStreamIsCapturing(st, &cap));
+    GNMS_CHECK_ARG(cap == hipStreamCaptureStatusNone, "gnms_counts_to_host: a host round trip cannot be captured into a graph");
+    if (B > kMaxImages) return plain_copy(nvalid, ninvalid, B, host_out, st);
+    Mailbox* Mp = mailbox(dev);
+    if (!Mp) return plain_copy(nvalid, ninvalid, B, host_out, st);
+    Mailbox& M = *Mp;
     uint32_t s = M.seq.fetch_add(1, std::memory_order_relaxed) + 1;
     const int32_t tag = (int32_t)(s | 0x40000000u);                      // never 0, the slots' initial content
     const int slot = (int)(s % kSlots);
@@ -98,5 +105,59 @@ extern "C" int gnms_counts_to_host(const int32_t* nvalid, const int32_t* ninvali
         }
     }
     for (int i = 0; i < 2 * B; ++i) host_out[i] = h[2 + i];
+    return GNMS_OK;
+}
+
+// The same trip without the extra kernel: the forward call's `nvalid` / `ninvalid` arguments may point INTO a slot (the kernels only ever
+// store to them, once, at the end of an image's chain), preset to -1 by the host; the host then polls until every word is a count.
+extern "C" int gnms_host_counts_slot(int B, int32_t** device_view, const int32_t** host_view) {
+    GNMS_CHECK_ARG(B >= 1 && device_view && host_view, "gnms_host_counts_slot: bad arguments");
+    if (B > kMaxImages) {
+        gnms_set_error("gnms_host_counts_slot: B=%d exceeds %d images per slot", B, kMaxImages);
+        return GNMS_ERR_UNSUPPORTED;
+    }
+    int dev = 0;
+    GNMS_CHECK_HIP(hipGetDevice(&dev));
+    Mailbox* M = mailbox(dev);
+    if (!M) {
+        gnms_set_error("gnms_host_counts_slot: no fine-grained pinned memory on device %d", dev);
+        return GNMS_ERR_HIP;
+    }
+    const uint32_t s = M->seq.fetch_add(1, std::memory_order_relaxed) + 1;
+    const size_t off = (size_t)(s % kSlots) * kSlotWords + 2;
+    for (int i = 0; i < 2 * B; ++i) __atomic_store_n(M->host + off + i, -1, __ATOMIC_RELAXED);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);                               // the presets are out before any launch that follows
+    *device_view = M->dev + off;
+    *host_view = M->host + off;
+    return GNMS_OK;
+}
+
+extern "C" int gnms_host_counts_wait(const int32_t* host_view, int B, int32_t* host_out, void* stream) {
+    GNMS_CHECK_ARG(host_view && host_out && B >= 1 && B <= kMaxImages, "gnms_host_counts_wait: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    int i = 0;
+    bool synced = false;
+    for (unsigned spins = 0; i < 2 * B; ++spins) {
+        const int32_t v = __atomic_load_n(host_view + i, __ATOMIC_ACQUIRE);
+        if (v >= 0) { host_out[i++] = v; continue; }
+        if (synced) {
+            gnms_set_error("gnms_host_counts_wait: the stream is idle and count %d was never written (was the slot passed to the forward call?)", i);
+            return GNMS_ERR_INVALID_ARGUMENT;
+        }
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff) {
+            hipError_t q = hipStreamQuery(st);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+                gnms_set_error("gnms_host_counts_wait: %s", hipGetErrorString(q));
+                return GNMS_ERR_HIP;
+            }
+            if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                GNMS_CHECK_HIP(hipStreamSynchronize(st));                  // everything the stream held has been written by now
+                synced = true;
+                i = 0;
+            }
+        }
+    }
     return GNMS_OK;
 }

@@ -720,6 +720,60 @@ __global__ __launch_bounds__(WAVES * 64) void bitmask_kernel(const float* __rest
     }
 }
 
+// K2 for few, small images (round 5): the kernel above gives a wave 64 rows x 256 columns, eight batches of eight 1-KiB loads one after the
+// other -- at N = 500, B = 1 that is 16 busy waves on the whole machine and eight memory latencies in a row (8.8 us for 1 MB).  Here the 64
+// rows of a rank block are dealt to the eight waves of a workgroup, eight rows each: ONE batch of loads per wave.  A wave's eight rows
+// are eight consecutive bits = one BYTE of the column's word, so the partial results meet in LDS as the bytes of the words (byte stores),
+// and four of the waves scatter the finished words.  Stores exactly the words bitmask_kernel<true> stores.  Needs ld % 4 == 0 and a
+// 16-byte aligned matrix (VEC).
+__global__ __launch_bounds__(512) void bitmask_small_kernel(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
+                                                            float thr, char* ws, gnms_ws_layout L, int full) {
+    __shared__ u64 words[256];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int kb = blockIdx.y;
+    const int n = gnms_count(counts, b, N);
+    const int k0 = kb * 64;
+    if (k0 >= n) return;
+    const int c0 = (int)((blockIdx.x + kb) % gridDim.x) * 256;           // (rotated like bitmask_kernel's chunks)
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const bool ident = I.misc[2] != 0;
+    if (c0 >= n || (ident && c0 >= k0 + 64)) return;                     // (workgroup-uniform)
+    const float* m = iou + (size_t)b * N * ld;
+    const int myrank = k0 + lane;
+    const int myrow = (myrank < n) ? I.order[myrank] : I.order[k0];
+    const int nrows = min(64, n - k0);
+    const u64 rowmask = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
+    // the scatterers' ranks, asked for before the rows so that the two latencies overlap
+    const int mycol = c0 + (int)threadIdx.x;
+    int rk = mycol;
+    if (threadIdx.x < 256 && mycol < n && !ident) rk = I.rankof[mycol];
+    const int col0 = c0 + 4 * lane;
+    const bool active = col0 + 3 < ld;
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int row = __builtin_amdgcn_readlane(myrow, wave * 8 + u);
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) v[u] = load_nt_f4(m + (size_t)row * ld + col0);
+    }
+    unsigned by[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const unsigned bit = 1u << u;
+        by[0] |= !(v[u].x <= thr) ? bit : 0u;                            // lib/groomed_nms.py:250 (NaN -> removed)
+        by[1] |= !(v[u].y <= thr) ? bit : 0u;
+        by[2] |= !(v[u].z <= thr) ? bit : 0u;
+        by[3] |= !(v[u].w <= thr) ? bit : 0u;
+    }
+    unsigned char* bytes = reinterpret_cast<unsigned char*>(words);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bytes[(4 * lane + j) * 8 + wave] = (unsigned char)by[j];
+    __syncthreads();
+    if (threadIdx.x < 256 && mycol < n && (full || rk < k0 + 64)) (I.W + (size_t)kb * L.NC)[rk] = words[threadIdx.x] & rowmask;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2s: is the thresholded matrix SYMMETRIC?  (matrix-in layer, round 3.)  The callers of differentiable_nms(scores, iou) hand it
 // iou(boxes, boxes) -- symmetric -- but the interface does not say so, and the general scan (candidates push leader by leader: ~130

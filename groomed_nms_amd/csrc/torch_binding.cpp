@@ -48,6 +48,10 @@ std::pair<Tensor, int64_t> matrix_layout(const Tensor& iou) {
     return {iou.contiguous(), N};
 }
 
+// set by single() around Layer::apply (which runs forward() on the calling thread): the forward call then stores its two counts straight into
+// a slot of the library's pinned mailbox (gnms_host_counts_slot) instead of the `cnt` tensor, which stays unwritten
+thread_local int32_t* tl_counts_slot = nullptr;
+
 struct Layer : public torch::autograd::Function<Layer> {
     // src: the overlap matrix [B,N,N] (kMatrixIn), 2D boxes [B,N,4] (kWithIou2d, kFromBoxes) or cuboid parameters [B,N,7] (kWithIou3d)
     static variable_list forward(AutogradContext* ctx, const Tensor& scores, const Tensor& src, const c10::optional<Tensor>& counts_,
@@ -71,6 +75,8 @@ struct Layer : public torch::autograd::Function<Layer> {
         Tensor cnt = at::empty({2, B}, f32.dtype(at::kInt));
         Tensor order = lists[0], valid = index_lists ? lists[1] : Tensor(), invalid = index_lists ? lists[2] : Tensor();
         Tensor nvalid = cnt[0], ninvalid = cnt[1];
+        int32_t* const nv_out = tl_counts_slot ? tl_counts_slot : (int32_t*)mptr(nvalid);
+        int32_t* const ni_out = tl_counts_slot ? tl_counts_slot + B : (int32_t*)mptr(ninvalid);
         const size_t wsb = gnms_workspace_bytes((int)B, (int)N, &P);
         Tensor ws = at::empty({(int64_t)std::max<size_t>(wsb, 256)}, f32.dtype(at::kByte));
         Tensor kept, iou;                     // kept: what the backward reads besides the scores (matrix / boxes), if anything
@@ -82,14 +88,14 @@ struct Layer : public torch::autograd::Function<Layer> {
             kept = ml.first;
             ld = ml.second;
             check(gnms_forward((const float*)cptr(s), (const float*)cptr(kept), (int)B, (int)N, ld, (const int32_t*)cptr(counts), &P, (float*)mptr(prob),
-                               (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), (int32_t*)mptr(nvalid), (int32_t*)mptr(ninvalid),
+                               (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), nv_out, ni_out,
                                mptr(ws), (size_t)ws.numel(), st), "gnms_forward");
         } else if (mode == kFromBoxes) {
             TORCH_CHECK(src.size(2) == 4, "GNMS: boxes must be [B, N, 4]");
             kept = src.contiguous();
             check(gnms_forward_from_boxes((const float*)cptr(kept), (const float*)cptr(s), (int)B, (int)N, (const int32_t*)cptr(counts), &P, (float*)mptr(prob),
-                                          (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), (int32_t*)mptr(nvalid),
-                                          (int32_t*)mptr(ninvalid), mptr(ws), (size_t)ws.numel(), st), "gnms_forward_from_boxes");
+                                          (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), nv_out,
+                                          ni_out, mptr(ws), (size_t)ws.numel(), st), "gnms_forward_from_boxes");
         } else {
             const bool three_d = mode == kWithIou3d;
             TORCH_CHECK(src.size(2) == (three_d ? 7 : 4), "GNMS: expected [B, N, ", three_d ? 7 : 4, "] as the second argument");
@@ -98,8 +104,8 @@ struct Layer : public torch::autograd::Function<Layer> {
             TORCH_CHECK(iou.is_cuda() && iou.scalar_type() == at::kFloat && iou.is_contiguous() && iou.numel() == B * N * N, "GNMS: iou_out must be a contiguous CUDA float [B, N, N] tensor");
             auto entry = three_d ? gnms_forward_with_iou3d : gnms_forward_with_iou2d;
             check(entry((const float*)cptr(boxes), (const float*)cptr(s), (int)B, (int)N, ld, (const int32_t*)cptr(counts), &P, (float*)mptr(iou),
-                        (float*)mptr(prob), (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), (int32_t*)mptr(nvalid),
-                        (int32_t*)mptr(ninvalid), mptr(ws), (size_t)ws.numel(), st), three_d ? "gnms_forward_with_iou3d" : "gnms_forward_with_iou2d");
+                        (float*)mptr(prob), (int64_t*)mptr(order), (int64_t*)mptr(valid), (int64_t*)mptr(invalid), nv_out,
+                        ni_out, mptr(ws), (size_t)ws.numel(), st), three_d ? "gnms_forward_with_iou3d" : "gnms_forward_with_iou2d");
             // The masked-group backward (the default) never reads the overlaps, so the matrix is not kept at all.  The unmasked / ungrouped
             // backward does: there it is saved through autograd, whose version counter then catches a caller that overwrites the
             // (possibly caller-provided) buffer between forward and backward instead of silently producing wrong gradients.
@@ -206,13 +212,36 @@ std::vector<Tensor> single(const Tensor& scores, const Tensor& iou, double thr, 
                            int64_t gsize, bool presorted, bool lists_now) {
     TORCH_CHECK(scores.dim() == 1 && iou.dim() == 2 && iou.size(0) == scores.size(0) && iou.size(1) == scores.size(0),
                 "iou_unsorted must be (N, N) with N = len(scores_unsorted)");
+    TORCH_CHECK(scores.is_cuda() && scores.size(0) > 0, "GNMS: single takes a non-empty CUDA tensor");
+    DeviceGuard guard(scores.device());
+    int32_t* slot_dev = nullptr;
+    const int32_t* slot_host = nullptr;
+    // lists_now: the forward call writes its counts into a slot of pinned memory the host polls -- no kernel, no copy, no stream synchronisation
+    // behind the layer (gnms_host_counts_slot / _wait); no slot (no fine-grained memory): the counts tensor + gnms_counts_to_host
+    if (lists_now && gnms_host_counts_slot(1, &slot_dev, &slot_host) != GNMS_OK) slot_dev = nullptr;
+    struct Reset { ~Reset() { tl_counts_slot = nullptr; } } reset;
+    tl_counts_slot = slot_dev;
     const variable_list o = Layer::apply(scores.unsqueeze(0), iou.unsqueeze(0), c10::nullopt, c10::nullopt, (int64_t)kMatrixIn, thr, temp, vthr, prune, sorted_prob,
                                          group, mask, gsize, presorted, true);
+    tl_counts_slot = nullptr;
     Tensor valid = o[4].select(0, 0), invalid = o[5].select(0, 0);
     if (lists_now) {
-        const std::vector<int64_t> c = counts_to_host(o[2], o[3]);
-        valid = valid.narrow(0, 0, c[0]);
-        invalid = invalid.narrow(0, 0, c[1]);
+        int64_t k, m;
+        if (slot_dev) {
+            int32_t c[2];
+            int rc;
+            hipStream_t st = current_stream(scores);
+            {
+                pybind11::gil_scoped_release nogil;
+                rc = gnms_host_counts_wait(slot_host, 1, c, st);
+            }
+            check(rc, "gnms_host_counts_wait");
+            k = c[0]; m = c[1];
+        } else {
+            const std::vector<int64_t> c = counts_to_host(o[2], o[3]);
+            k = c[0]; m = c[1];
+        }
+        return {valid.narrow(0, 0, k), invalid.narrow(0, 0, m), o[0].select(0, 0)};
     }
     return {valid, invalid, o[0].select(0, 0), o[2], o[3]};
 }

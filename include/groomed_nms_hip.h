@@ -171,6 +171,14 @@ int gnms_forward_with_iou3d(const float* params3d, const float* scores, int B, i
  * write instead of a copy submission + a stream synchronisation: ~20 us less per call at N = 500).  B > 127, or no tag within two
  * seconds: a plain asynchronous copy + stream synchronisation.  Cannot be captured into a graph (GNMS_ERR_INVALID_ARGUMENT). */
 int gnms_counts_to_host(const int32_t* nvalid, const int32_t* ninvalid, int B, int32_t* host_out, void* stream);
+/* The same trip without any launch behind the layer: gnms_host_counts_slot hands out 2 B words of that pinned memory, preset to -1, as the
+ * device (`device_view`) and the host (`host_view`) address them; pass device_view as `nvalid` and device_view + B as `ninvalid` to ONE
+ * gnms_forward* call (the kernels store each count exactly once, at the end of the image's chain), then gnms_host_counts_wait polls
+ * host_view until all 2 B words are counts (>= 0) and copies them to host_out [2 B]; it falls back to a stream synchronisation when the
+ * stream runs empty first or after two seconds.  B <= 127 (GNMS_ERR_UNSUPPORTED above); a slot is recycled 64 gnms_host_counts_slot /
+ * gnms_counts_to_host calls later on the same device.  differentiable_nms at N = 500, index tensors included: 64 -> 46 us per call. */
+int gnms_host_counts_slot(int B, int32_t** device_view, const int32_t** host_view);
+int gnms_host_counts_wait(const int32_t* host_view, int B, int32_t* host_out, void* stream);
 
 /* backward of L through prob.  grad_prob [B][N] = dL/dprob (same order as prob).
  *   grad_scores [B][N] (input order), overwritten.

@@ -2758,6 +2758,33 @@ def test_counts_to_host_mailbox(G):
         finally:
             g.capture_end()
     torch.cuda.synchronize()
+    # the slot form (gnms_host_counts_slot / _wait): the forward call's own stores land in pinned memory
+    P = _lib.GnmsParams()
+    lib.gnms_default_params(ctypes.byref(P))
+    for B, n in ((1, 500), (3, 300), (8, 1024)):
+        boxes, scores = synthetic.batch_2d(900 + n, B, n, "uniform")
+        bt, sc = torch.from_numpy(boxes).to(dev), torch.from_numpy(scores).to(dev)
+        ref = G.differentiable_nms_with_iou2d_batched(sc, bt)
+        dv, hv = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.gnms_host_counts_slot(B, ctypes.byref(dv), ctypes.byref(hv)), "slot")
+        preset = (ctypes.c_int32 * (2 * B)).from_address(hv.value)
+        assert list(preset) == [-1] * (2 * B)
+        ws = torch.empty((lib.gnms_workspace_bytes(B, n, ctypes.byref(P)),), dtype=torch.uint8, device=dev)
+        prob = torch.empty((B, n), device=dev)
+        iou = torch.empty((B, n, n), device=dev)
+        _lib.check(lib.gnms_forward_with_iou2d(bt.data_ptr(), sc.data_ptr(), B, n, n, None, ctypes.byref(P), iou.data_ptr(), prob.data_ptr(), None, None, None,
+                                               dv.value, dv.value + 4 * B, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "fwd")
+        host = (ctypes.c_int32 * (2 * B))()
+        _lib.check(lib.gnms_host_counts_wait(hv.value, B, ctypes.cast(host, ctypes.c_void_p), _lib.stream_ptr(dev)), "wait")
+        assert list(host) == ref[4].tolist() + ref[5].tolist(), (B, n)
+        assert torch.equal(prob, ref[0])
+    dv, hv = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.gnms_host_counts_slot(2, ctypes.byref(dv), ctypes.byref(hv)), "slot")
+    host = (ctypes.c_int32 * 4)()
+    torch.cuda.synchronize()
+    assert lib.gnms_host_counts_wait(hv.value, 2, ctypes.cast(host, ctypes.c_void_p), _lib.stream_ptr(dev)) == -1        # nobody writes this slot
+    assert b"never written" in lib.gnms_last_error()
+    assert lib.gnms_host_counts_slot(128, ctypes.byref(dv), ctypes.byref(hv)) == -2
     # the reference entry: lengths of the two index tensors = the batched entry's device-side counts
     for n in (1, 37, 500, 1500):
         boxes, scores = synthetic.batch_2d(300 + n, 1, n, "clustered")
@@ -2773,3 +2800,82 @@ def test_counts_to_host_mailbox(G):
             assert isinstance(lv, M.LazyIndexList) and torch.equal(lv.t, valid) and torch.equal(li.t, invalid) and torch.equal(lp, prob)
         finally:
             M.LAZY_INDEX_LISTS = False
+
+
+@pytest.mark.gpu
+def test_bitmask_small_kernel_against_the_row_kernel(O):
+    """bitmask_small_kernel (K2 of few, small images: the 64 rows of a rank block dealt to eight waves, the words assembled from bytes in LDS)
+    stores exactly the words of bitmask_kernel: the matrix-in layer's probabilities, lists, counts and gradients with it (default) and
+    without it (GNMS_BITMASK_SMALL=0) are the same bit for bit -- sizes around the 64-row and 256-column edges, with and without the
+    symmetry detection (N >= 256), ragged batches with an empty image, already sorted scores (only the triangle is stored), an asymmetric
+    matrix, NaN entries (:250 removes them), a strided matrix view (ld > N) -- and the default run equals the oracle."""
+    code = """
+import sys, numpy as np, torch
+import groomed_nms_amd as G
+from groomed_nms_amd import synthetic, overlaps
+out = {}
+def run(tag, s, m, counts=None, **kw):
+    st = s.clone().requires_grad_(True)
+    o = G.differentiable_nms_batched(st, m, counts=counts, **kw)
+    w = torch.linspace(-1.0, 2.0, s.shape[1], device="cuda").repeat(s.shape[0], 1)
+    (o[0] * w).sum().backward()
+    for i, k in enumerate(("prob", "order", "valid", "invalid", "nvalid", "ninvalid")):
+        a = o[i].detach().cpu().numpy().copy()
+        if k in ("valid", "invalid"):                       # padded behind the counts
+            cnt = o[4 if k == "valid" else 5].cpu().numpy()
+            for b in range(a.shape[0]):
+                a[b, cnt[b]:] = -1
+        out[tag + "_" + k] = a
+    g = st.grad.cpu().numpy().copy()
+    if counts is not None:
+        c = counts.cpu().numpy()
+        for b in range(g.shape[0]):
+            g[b, c[b]:] = 0
+            out[tag + "_prob"][b, c[b]:] = 0
+            out[tag + "_order"][b, c[b]:] = -1
+    out[tag + "_grad"] = g
+for n in (1, 2, 63, 64, 65, 200, 255, 256, 257, 500, 511, 513, 777, 1000, 1024, 1500, 2048):
+    for kind in ("uniform", "clustered"):
+        b, s = synthetic.batch_2d(40 + n, 1, n, kind)
+        bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+        run("n%d_%s" % (n, kind), st, overlaps.iou_batched(bt))
+b, s = synthetic.batch_2d(5, 5, 700, "clustered")
+bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+m = overlaps.iou_batched(bt)
+run("ragged", st, m, counts=torch.tensor([700, 0, 1, 333, 65], dtype=torch.int32, device="cuda"))
+o = torch.sort(st, dim=1, descending=True, stable=True)[1]
+ss = torch.gather(st, 1, o)
+ms = torch.gather(torch.gather(m, 1, o[:, :, None].expand(-1, -1, 700)), 2, o[:, None, :].expand(-1, 700, -1)).contiguous()
+run("sorted", ss, ms)
+run("presorted", ss, ms, presorted=True)
+ma = m.clone(); ma[:, 3, 40:90] = 0.9; ma[:, 400:420, 7] = 0.0
+run("asym", st, ma)
+mn = m.clone(); mn[:, 10, 20] = float("nan"); mn[:, 20, 10] = float("nan"); mn[:, 5, 600] = float("nan")
+run("nan", st, mn)
+wide = torch.zeros((5, 700, 704), device="cuda"); wide[:, :, :700] = m
+run("strided", st, wide[:, :, :700])
+odd = torch.zeros((5, 700, 701), device="cuda"); odd[:, :, :700] = m
+run("odd_ld", st, odd[:, :, :700])                      # (ld % 4 != 0: the scalar row kernel either way)
+torch.cuda.synchronize()
+np.savez(sys.argv[1], **out)
+print("ok")
+"""
+    runs = {}
+    for tag, env in (("default", {}), ("row_kernel", {"GNMS_BITMASK_SMALL": "0"})):
+        path = "/tmp/gnms_bitmask_small_%s.npz" % tag
+        r = _run_py(code, env, argv=(path,))
+        assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stderr[-2000:])
+        runs[tag] = np.load(path)
+    for k in runs["default"].files:
+        assert np.array_equal(runs["row_kernel"][k], runs["default"][k], equal_nan=True), k
+    # and the default run against the oracle on a few of the cases
+    from groomed_nms_amd import synthetic
+    d = runs["default"]
+    for n, kind in ((65, "clustered"), (500, "uniform"), (777, "clustered"), (1024, "uniform")):
+        b, s = synthetic.batch_2d(40 + n, 1, n, kind)
+        m = O.iou2d(b[0], b[0])
+        ref = O.differentiable_nms(s[0], m)
+        tag = "n%d_%s" % (n, kind)
+        np.testing.assert_array_equal(d[tag + "_prob"][0], ref["prob"])
+        nv = int(d[tag + "_nvalid"][0])
+        np.testing.assert_array_equal(d[tag + "_valid"][0, :nv], ref["valid"])
