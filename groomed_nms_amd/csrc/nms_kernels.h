@@ -2508,6 +2508,7 @@ __host__ __device__ __forceinline__ size_t fast_tail_lds_size(int N, int Ppow2) 
 // whose rescored value stayed above the threshold: list B, typically a few dozen) are sorted, and the two lists are merged by rank
 // (position in the own list + binary search in the other).  For ~1 900 valid boxes of 4 096 that replaces a 2 048-key merge sort (9 us on
 // one CU) by a compaction, a small sort and 11 LDS probes per box.  No global load and no wait for a global store anywhere.
+constexpr int kDirectMergeMax = 256;     // boxes of list B up to which K6 of the fast tail places them by counting (finalize_fast_body)
 template <int E>
 __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
                                                    int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
@@ -2605,6 +2606,28 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
         for (int i = t; i < nB; i += 1024) emit(keyB[i], i);
     } else if (nB == 0) {
         for (int i = t; i < nA; i += 1024) emit(keyA[i], i);
+    } else if (nB <= kDirectMergeMax) {
+        // FEW other valid boxes (the usual case: a few dozen rescored members): no counters, no prefix, no scatter.  A box of B ends up at
+        // (heads in front of it: a binary search) + (boxes of B in front of it: counted, nB compares on the few waves that hold B); head i at
+        // i + (boxes of B whose bucket is <= i: counted over the nB bucket numbers).  One barrier instead of five, and the loops read LDS at
+        // one address per wave (a broadcast).  Same positions as the bucket merge below -- the keys are distinct, the order is total.
+        int* gL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 28);               // [nB] bucket of each box of B
+        for (int j = t; j < nB; j += 1024) {
+            const u64 k = keyB[j];
+            const int g = lower_bound_lds<u64>(keyA, nA, k);
+            gL[j] = g;
+            int c = 0, x = 0;
+            for (; x + 4 <= nB; x += 4) c += (keyB[x] < k ? 1 : 0) + (keyB[x + 1] < k ? 1 : 0) + (keyB[x + 2] < k ? 1 : 0) + (keyB[x + 3] < k ? 1 : 0);
+            for (; x < nB; ++x) c += keyB[x] < k ? 1 : 0;
+            emit(k, g + c);
+        }
+        lds_barrier();
+        for (int i = t; i < nA; i += 1024) {
+            int c = 0, x = 0;
+            for (; x + 4 <= nB; x += 4) c += (gL[x] <= i ? 1 : 0) + (gL[x + 1] <= i ? 1 : 0) + (gL[x + 2] <= i ? 1 : 0) + (gL[x + 3] <= i ? 1 : 0);
+            for (; x < nB; ++x) c += gL[x] <= i ? 1 : 0;
+            emit(keyA[i], i + c);
+        }
     } else {
         // MERGE BY BUCKETS.  The sorted heads split the key space into nA + 1 buckets; a box of B lies in bucket g = number of heads in front
         // of it (a binary search), and its final position is g + (boxes of B in earlier buckets) + (its rank among its bucket mates); head

@@ -379,7 +379,7 @@ int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* co
     // few, small images: one batch of loads per wave instead of eight in a row (bitmask_small_kernel); GNMS_BITMASK_SMALL=0: never (developer A/B)
     static const int small_wgs = [] { const char* e = getenv("GNMS_BITMASK_SMALL"); return e ? atoi(e) : 1024; }();
     if (!vec) GNMS_BITMASK(false, kMaskWaves, kMaskRB);
-    else if ((long)B * L.NB * gnms_div_up(N, 256) <= (long)small_wgs)
+    else if (N <= 2048 && (long)B * L.NB * gnms_div_up(N, 256) <= (long)small_wgs)        // (N = 4096, B = 1 keeps the row-buffered 16-wave kernel)
         gnms_launch_prof(kProfMatrixRead, bitmask_small_kernel, dim3(gnms_div_up(N, 256), L.NB, B), dim3(512), 0, st, iou, N, (long)ld, counts, thr, ws, L, full);
     else if (N >= 4096) GNMS_BITMASK(true, 16, 8);
     else GNMS_BITMASK(true, 8, 8);
