@@ -30,7 +30,9 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   hip_graph_replay    the same step as a replayed HIP graph of the C-ABI calls (no host cost per step), 1 GPU only
   two_calls, dim3_*, N*, B*_N4096   the other shapes of the path (default line only), each with ms_per_step (eager, host included), its own
                       roofline brief and device_ms_per_step: the step's time on the device when the host has run ahead (the same
-                      eager calls enqueued behind a spin kernel; small shapes are host-bound and hosts differ by 2x between boxes)
+                      eager calls enqueued behind a spin kernel; small shapes are host-bound and hosts differ by 2x between boxes);
+                      host-bound one-call shapes also carry c_abi_ms_per_step: the same step as the C-ABI call sequence of a compiled
+                      host (forward entry + gnms_backward through ctypes, eager, no autograd engine)
 """
 import argparse
 import ctypes
@@ -515,6 +517,26 @@ def main():
                 ev1.record()
                 torch.cuda.synchronize()
                 dev_ms = ev0.elapsed_time(ev1) / kr
+                # host-bound shapes: the same step as the C-ABI call sequence a compiled host makes (gnms_forward_with_iou2d/3d + gnms_backward
+                # on fixed buffers through ctypes, eager, no autograd engine) -- what of the eager figure is the library's and what PyTorch's
+                cabi_ms = None
+                if dts / steps < 1e-4 and not (two_calls or ref_3d):
+                    ws_c = torch.empty((lib.gnms_workspace_bytes(b_, n_, ctypes.byref(P)),), dtype=torch.uint8, device=dev)
+                    prob_c, grad_c, s_c = torch.empty((b_, n_), device=dev), torch.empty((b_, n_), device=dev), sc.detach()
+                    entry = lib.gnms_forward_with_iou2d if dim == 2 else lib.gnms_forward_with_iou3d
+
+                    def one_c():
+                        st_["i"] = (st_["i"] + 1) % nb_
+                        buf = bufs[st_["i"]]
+                        sp = stream_ptr(dev)
+                        check(entry(ptr(bx), ptr(s_c), b_, n_, n_, None, ctypes.byref(P), ptr(buf), ptr(prob_c), None, None, None, None, None, ptr(ws_c),
+                                    ws_c.numel(), sp), "fwd")
+                        check(lib.gnms_backward(ptr(ww), ptr(s_c), ptr(buf), b_, n_, n_, None, ctypes.byref(P), ptr(grad_c), None, ptr(ws_c), ws_c.numel(), sp), "bwd")
+                    for _ in range(10):
+                        one_c()
+                    torch.cuda.synchronize()
+                    cabi_ms = gdist.timed_steps(one_c, steps, warmup, torch.cuda.synchronize) / steps * 1e3
+                    del ws_c
                 del bufs
                 bytes_w = b_ * (4.0 * n_ * n_ + (16.0 if dim == 2 else 28.0) * n_)
                 bytes_r = b_ * (4.0 * n_ * n_ + 16.0 * n_)
@@ -534,6 +556,8 @@ def main():
                        "roofline": brief(msw, nw_, bytes_w * (2.0 if ref_3d else 1.0), wn)}
                 if two_calls or ref_3d:
                     res["roofline_matrix_in"] = brief(msr, nr_, bytes_r, "bitmask_kernel")
+                if cabi_ms is not None:
+                    res["c_abi_ms_per_step"] = round(cabi_ms, 4)
                 return res
 
             # (60 steps where a step is a fraction of a millisecond: at 20 the 3D step read 0.203-0.207 ms where 100 steps give 0.185-0.188)

@@ -216,6 +216,12 @@ std::vector<Tensor> single(const Tensor& scores, const Tensor& iou, double thr, 
     DeviceGuard guard(scores.device());
     int32_t* slot_dev = nullptr;
     const int32_t* slot_host = nullptr;
+    if (lists_now) {   // (a capture would bake this call's slot into the graph and then fail in the wait below, with launches already recorded)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        TORCH_CHECK(hipStreamIsCapturing(current_stream(scores), &cap) == hipSuccess && cap == hipStreamCaptureStatusNone,
+                    "GNMS: differentiable_nms returns index tensors of a data-dependent length -- a host round trip that cannot be captured into a graph; "
+                    "capture differentiable_nms_batched, or set groomed_nms.LAZY_INDEX_LISTS = True");
+    }
     // lists_now: the forward call writes its counts into a slot of pinned memory the host polls -- no kernel, no copy, no stream synchronisation
     // behind the layer (gnms_host_counts_slot / _wait); no slot (no fine-grained memory): the counts tensor + gnms_counts_to_host
     if (lists_now && gnms_host_counts_slot(1, &slot_dev, &slot_host) != GNMS_OK) slot_dev = nullptr;

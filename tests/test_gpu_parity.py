@@ -2747,6 +2747,9 @@ def test_counts_to_host_mailbox(G):
     assert not errs, errs[:3]
     # no host round trip inside a capture
     nv = torch.zeros((2,), dtype=torch.int32, device=dev)
+    cap_b, cap_sc = synthetic.batch_2d(3, 1, 300, "uniform")
+    cap_s = torch.from_numpy(cap_sc[0]).to(dev)
+    cap_iou = iou_fn(torch.from_numpy(cap_b[0]).to(dev), torch.from_numpy(cap_b[0]).to(dev))
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     st = torch.cuda.Stream()
@@ -2755,6 +2758,8 @@ def test_counts_to_host_mailbox(G):
         try:
             with pytest.raises(_lib.GnmsError):
                 via_ctypes(nv, nv)
+            with pytest.raises(RuntimeError, match="cannot be captured"):          # the reference entry says so before it launches anything
+                G.differentiable_nms(cap_s, cap_iou)
         finally:
             g.capture_end()
     torch.cuda.synchronize()
