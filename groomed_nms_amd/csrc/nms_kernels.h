@@ -2589,6 +2589,7 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     // the heads must be a sorted run (they are, whenever the scores were finite and the ranks their descending order)
     int viol = 0;
     for (int i = t + 1; i < nA; i += 1024) viol |= keyA[i] <= keyA[i - 1];
+    if (t < kDirectMergeMax) reinterpret_cast<int*>(smem + (size_t)Ppow2 * 28)[t] = 0;      // (the counting merge's ranks; nobody else is in that region yet)
     viol = __syncthreads_or(viol);
     auto emit = [&](const u64 k, const int p) {
         const int q = (int)(k & 0xffffffffu);
@@ -2607,26 +2608,39 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     } else if (nB == 0) {
         for (int i = t; i < nA; i += 1024) emit(keyA[i], i);
     } else if (nB <= kDirectMergeMax) {
-        // FEW other valid boxes (the usual case: a few dozen rescored members): no counters, no prefix, no scatter.  A box of B ends up at
-        // (heads in front of it: a binary search) + (boxes of B in front of it: counted, nB compares on the few waves that hold B); head i at
-        // i + (boxes of B whose bucket is <= i: counted over the nB bucket numbers).  One barrier instead of five, and the loops read LDS at
-        // one address per wave (a broadcast).  Same positions as the bucket merge below -- the keys are distinct, the order is total.
-        int* gL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 28);               // [nB] bucket of each box of B
-        for (int j = t; j < nB; j += 1024) {
-            const u64 k = keyB[j];
-            const int g = lower_bound_lds<u64>(keyA, nA, k);
-            gL[j] = g;
-            int c = 0, x = 0;
-            for (; x + 4 <= nB; x += 4) c += (keyB[x] < k ? 1 : 0) + (keyB[x + 1] < k ? 1 : 0) + (keyB[x + 2] < k ? 1 : 0) + (keyB[x + 3] < k ? 1 : 0);
-            for (; x < nB; ++x) c += keyB[x] < k ? 1 : 0;
-            emit(k, g + c);
+        // FEW other valid boxes (up to 256; ~100-200 of 4 096 uniform boxes): no bucket counters, no prefix over the heads, no scatter by
+        // atomics.  A box of B ends up at (heads in front of it: a binary search) + (boxes of B in front of it: its rank in B, counted --
+        // nB^2 compares spread over all 1024 threads, thread (box, segment), the reads of a wave at ONE LDS address); the bucket numbers g
+        // laid out by that rank are a sorted list, and head i ends up at i + (boxes of B whose bucket is <= i: a binary search in it).
+        // Two barriers, two binary searches and nB^2 / 1024 compares per thread where the bucket merge has five barriers, two rounds of
+        // LDS atomics and a scan.  Same positions -- the keys are distinct, the order is total.
+        int* cntB = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 28);             // [kDirectMergeMax] rank of each box of B (zeroed in front of the barrier above)
+        int* gS = cntB + kDirectMergeMax;                                          // [nB] bucket numbers in B's sorted order
+        {
+            int lgP = 6;
+            while ((1 << lgP) < nB) ++lgP;                                         // P = 64 .. 256 boxes side by side, S = 1024 / P segments
+            const int j = t & ((1 << lgP) - 1), sg = t >> lgP, S = 1024 >> lgP, per = (nB + S - 1) / S;
+            const int x0 = sg * per, x1 = min(nB, x0 + per);
+            if (j < nB && x0 < x1) {
+                const u64 k = keyB[j];
+                int c = 0, x = x0;
+                for (; x + 4 <= x1; x += 4) c += (keyB[x] < k ? 1 : 0) + (keyB[x + 1] < k ? 1 : 0) + (keyB[x + 2] < k ? 1 : 0) + (keyB[x + 3] < k ? 1 : 0);
+                for (; x < x1; ++x) c += keyB[x] < k ? 1 : 0;
+                if (c) atomicAdd(&cntB[j], c);
+            }
+        }
+        lds_barrier();
+        if (t < nB) {
+            const u64 k = keyB[t];
+            const int r = cntB[t], g = lower_bound_lds<u64>(keyA, nA, k);
+            gS[r] = g;
+            emit(k, g + r);
         }
         lds_barrier();
         for (int i = t; i < nA; i += 1024) {
-            int c = 0, x = 0;
-            for (; x + 4 <= nB; x += 4) c += (gL[x] <= i ? 1 : 0) + (gL[x + 1] <= i ? 1 : 0) + (gL[x + 2] <= i ? 1 : 0) + (gL[x + 3] <= i ? 1 : 0);
-            for (; x < nB; ++x) c += gL[x] <= i ? 1 : 0;
-            emit(keyA[i], i + c);
+            int lo = 0, hi = nB;                                                   // boxes of B with bucket <= i
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (gS[mid] <= i) lo = mid + 1; else hi = mid; }
+            emit(keyA[i], i + lo);
         }
     } else {
         // MERGE BY BUCKETS.  The sorted heads split the key space into nA + 1 buckets; a box of B lies in bucket g = number of heads in front
