@@ -573,6 +573,9 @@ def _counts_to_host(nvalid, ninvalid):
     return list(host)
 
 
+counts_to_host = _counts_to_host      # public name: the padded lists of the batched entries cut to size on the host, `valid[b, :counts_to_host(nvalid, ninvalid)[b]]`
+
+
 # Module switch, OFF by default: differentiable_nms returns plain index tensors exactly like the reference (one host sync per call: their
 # length K is data dependent).  A training loop that reads only the probabilities (lib/loss/rpn_3d.py:791 takes `[2]`) may set it to
 # True: with GPU tensors in, the two lists then come back as LazyIndexList objects and the call never waits for the GPU.
