@@ -9,6 +9,8 @@
 // the 64 rows of a rank block; no per-thread 64-iteration loop, no shared memory), only tiles that a
 // suppressor can reach are computed (suppressor index < end of the rank block), and the scan runs ON
 // the device (leaders_kernel), so only keep[] and the count cross PCIe.
+#include <algorithm>
+#include <mutex>
 #include <vector>
 #include <string.h>
 #include "nms_kernels.h"
@@ -24,19 +26,52 @@ __device__ __forceinline__ float bcastf(float v, int lane) {
 // boxes [n][dim] sorted by score; W[kb][c] bit r = devIoU(box[64 kb + r], box[c]) > thresh
 // shift: the pixel convention (x2 - x1 + shift): 1 in nms_kernel.cu:24-32, a parameter of lib/nms_others.py:119 girshick_nms.
 // keep_le: 0 = suppress when IoU > thresh (nms_kernel.cu:71); 1 = keep only IoU <= thresh (nms_others.py:146: a NaN overlap suppresses)
+// what the leader scan expects of a sort that never ran: boxes arrive sorted, rank == index.  The workgroups of the first row block do it on the side
+// (COLS columns each) -- the mask kernels read none of it, the scan runs a launch later
+template <int COLS>
+__device__ __forceinline__ void classic_init_part(int n, char* ws, const gnms_ws_layout& L) {
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    const int base = blockIdx.x * COLS, end = min(n, base + COLS);
+    for (int k = base + (int)threadIdx.x; k < end; k += 256) { I.order[k] = k; I.rankof[k] = k; }
+    if (blockIdx.x == 0 && threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;
+}
+
+// J columns per lane: a wave's tile is 64 rows x 64 J columns, ~25 VALU instructions per pair (one IEEE division) all on ONE SIMD -- 11 us for
+// J = 4.  Up to ~8000 boxes such tiles are fewer than the machine's SIMDs (n = 500: 16 busy waves, 21 us; n = 4096: 24 us), and J = 1 gives
+// four times the waves a quarter of the work each (n = 500: 22.5 -> 8.8 us; n = 4096: 24 -> 20 with the 1D grid below); above, J = 4 keeps the box loads amortised.
+template <int J>
 __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restrict__ boxes, int n, int dim, float thresh, float shift, int keep_le,
-                                                           char* ws, gnms_ws_layout L) {
+                                                           char* ws, gnms_ws_layout L, int init) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kb = blockIdx.y;
+    int kb, c0;
+    if (J == 1) {
+        // a 1D grid over the tiles a suppressor can reach only (column block <= row block: NB (NB + 1) / 2 of them, four per workgroup).  As a 2D
+        // grid the idle upper triangle and the busy lower one landed on different CUs -- workgroup id mod 256 keeps a CU in ONE column chunk --
+        // and the busiest CU ran four full workgroups: 24 us at n = 4096 where the arithmetic is 11.
+        if (init) {
+            ImgPtrs I0 = img_ptrs(ws, L, 0);
+            for (int k = blockIdx.x * 256 + (int)threadIdx.x; k < n; k += gridDim.x * 256) { I0.order[k] = k; I0.rankof[k] = k; }
+            if (blockIdx.x == 0 && threadIdx.x < 8) I0.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;
+        }
+        const int w = blockIdx.x * 4 + wave, nbk = (n + 63) >> 6;
+        if (w >= nbk * (nbk + 1) / 2) return;
+        kb = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+        while (kb * (kb + 1) / 2 > w) --kb;
+        while ((kb + 1) * (kb + 2) / 2 <= w) ++kb;
+        c0 = (w - kb * (kb + 1) / 2) * 64;
+    } else {
+        if (init && blockIdx.y == 0) classic_init_part<256 * J>(n, ws, L);
+        kb = blockIdx.y;
+        c0 = (blockIdx.x * 4 + wave) * (64 * J);
+    }
     const int k0 = kb * 64;
-    const int c0 = (blockIdx.x * 4 + wave) * 256;
     if (k0 >= n || c0 >= n || c0 >= k0 + 64) return;      // suppressors come from ranks < k0 + 64
     ImgPtrs I = img_ptrs(ws, L, 0);
-    float bx1[4], by1[4], bx2[4], by2[4], bs[4];
-    int col[4];
+    float bx1[J], by1[J], bx2[J], by2[J], bs[J];
+    int col[J];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        col[j] = c0 + 4 * lane + j;
+    for (int j = 0; j < J; ++j) {
+        col[j] = c0 + J * lane + j;
         const float* p = boxes + (size_t)(col[j] < n ? col[j] : n - 1) * dim;
         bx1[j] = p[0]; by1[j] = p[1]; bx2[j] = p[2]; by2[j] = p[3];
         bs[j] = (bx2[j] - bx1[j] + shift) * (by2[j] - by1[j] + shift);         // nms_kernel.cu:30
@@ -46,12 +81,14 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
     const float rx1 = q[0], ry1 = q[1], rx2 = q[2], ry2 = q[3];
     const float rs = (rx2 - rx1 + shift) * (ry2 - ry1 + shift);                // :29
     const int nrows = min(64, n - k0);
-    unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
+    unsigned lo[J], hi[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) lo[j] = hi[j] = 0u;
 #pragma unroll 8
     for (int r = 0; r < 64; ++r) {
         const float ax1 = bcastf(rx1, r), ay1 = bcastf(ry1, r), ax2 = bcastf(rx2, r), ay2 = bcastf(ry2, r), as = bcastf(rs, r);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < J; ++j) {
             // (v_max / v_min issued directly, the row coordinate from its SGPR: no canonicalising moves; iou3d_pair.h)
             const float left = gnms_iou3d::vmax_s(ax1, bx1[j]), right = gnms_iou3d::vmin_s(ax2, bx2[j]);   // :25
             const float top = gnms_iou3d::vmax_s(ay1, by1[j]), bottom = gnms_iou3d::vmin_s(ay2, by2[j]);   // :26
@@ -65,7 +102,7 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
     const unsigned long long rowmask = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
     u64* Wk = I.W + (size_t)kb * L.NC;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < J; ++j)
         if (col[j] < L.NC) Wk[col[j]] = ((((u64)hi[j]) << 32) | lo[j]) & rowmask;
 }
 
@@ -80,7 +117,8 @@ __device__ __forceinline__ double bcastd(double v, int lane) {
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 __global__ __launch_bounds__(256) void classic_mask_f64_kernel(const double* __restrict__ boxes, int n, int dim, double thresh, double shift, int keep_le,
-                                                               char* ws, gnms_ws_layout L) {
+                                                               char* ws, gnms_ws_layout L, int init) {
+    if (init && blockIdx.y == 0) classic_init_part<256>(n, ws, L);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kb = blockIdx.y;
     const int k0 = kb * 64;
@@ -108,19 +146,25 @@ __global__ __launch_bounds__(256) void classic_mask_f64_kernel(const double* __r
     if (col < L.NC) I.W[(size_t)kb * L.NC + col] = word;
 }
 
-__global__ void classic_init_kernel(int n, char* ws, gnms_ws_layout L) {
-    ImgPtrs I = img_ptrs(ws, L, 0);
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) { I.order[k] = k; I.rankof[k] = k; }
-    if (k < 8) I.misc[k] = (k == 2) ? 1 : 0;     // boxes arrive sorted: rank == index
-}
-
 __global__ void classic_export_kernel(int n, char* ws, gnms_ws_layout L, int* __restrict__ keep, int* __restrict__ num_out) {
     ImgPtrs I = img_ptrs(ws, L, 0);
     const int nl = I.misc[0];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) *num_out = nl;
     if (t < nl) keep[t] = I.leadr[t];                      // :131 keep_out[num_to_keep++] = i
+}
+
+// the same as ONE workgroup that ends with a tag for a polling host (`_nms`: keep / num_out / tag lie in fine-grained pinned memory): every
+// thread's stores are out (system scope) before the barrier, the tag leaves behind it
+__global__ __launch_bounds__(1024) void classic_export_tag_kernel(char* ws, gnms_ws_layout L, int* __restrict__ keep, int* __restrict__ num_out,
+                                                                  int* __restrict__ tag_ptr, int tag) {
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    const int nl = I.misc[0];
+    for (int t = threadIdx.x; t < nl; t += 1024) keep[t] = I.leadr[t];
+    if (threadIdx.x == 0) *num_out = nl;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(tag_ptr, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // LARGE inputs (n > GNMS_MAX_BOXES; the reference's `use_nms and synced` inference path hands gpu_nms every anchor, > 100k boxes,
@@ -132,7 +176,7 @@ __global__ void classic_export_kernel(int n, char* ws, gnms_ws_layout L, int* __
 // The mask is read once (its upper block triangle: n^2/16 bytes -- the reference copies all n^2/8 to the HOST and scans there).
 constexpr int kClassicLargeMax = 262144;            // remv: 4096 words of LDS; W: 8.6 GB
 __global__ __launch_bounds__(1024) void classic_scan_large_kernel(int n, const u64* __restrict__ W, long NC, int* __restrict__ keep,
-                                                                  int* __restrict__ num_out) {
+                                                                  int* __restrict__ num_out, int* __restrict__ tag_ptr, int tag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* remv = reinterpret_cast<u64*>(smem);
     __shared__ u64 s_kept;
@@ -172,6 +216,11 @@ __global__ __launch_bounds__(1024) void classic_scan_large_kernel(int n, const u
         __syncthreads();
     }
     if (tid == 0) *num_out = s_num;
+    if (tag_ptr) {                                                                   // (`_nms`: see classic_export_tag_kernel; wave 0 wrote keep[])
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(tag_ptr, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace
@@ -180,8 +229,9 @@ extern "C" size_t gnms_nms_workspace_bytes(int n) { return n > 0 ? gnms_make_lay
 
 namespace {
 // boxes: float [n][dim] (is_fp64 = 0) or double [n][dim] (is_fp64 = 1)
+// tag_ptr: a word of fine-grained pinned memory that receives `tag` behind the last store to keep / num_out (`_nms`), or null
 int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double thresh, double shift, int keep_le, int32_t* keep,
-                    int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream) {
+                    int32_t* num_out, void* workspace, size_t workspace_bytes, void* stream, int32_t* tag_ptr = nullptr, int32_t tag = 0) {
     GNMS_CHECK_ARG(n >= 0 && boxes_dim >= 4, "gnms_nms_sorted_shift: bad shape (n=%d dim=%d)", n, boxes_dim);
     GNMS_CHECK_ARG(num_out != nullptr, "gnms_nms_sorted: num_out is NULL");
     hipStream_t st = (hipStream_t)stream;
@@ -192,29 +242,33 @@ int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double
     if (workspace_bytes < L.per_image) { gnms_set_error("gnms_nms_sorted: workspace too small"); return GNMS_ERR_WORKSPACE; }
     char* ws = (char*)workspace;
     GNMS_CHECK_ARG(L.NB <= 65535, "gnms_nms_sorted: too many row blocks");
-    auto mask = [&]() {
+    // (init: the identity order and the counters the leader scan reads -- written by the first row block's workgroups, three launches instead of four)
+    auto mask = [&](int init) {
         if (is_fp64)
-            classic_mask_f64_kernel<<<dim3(gnms_div_up(n, 256), L.NB), 256, 0, st>>>((const double*)boxes, n, boxes_dim, thresh, shift, keep_le, ws, L);
+            classic_mask_f64_kernel<<<dim3(gnms_div_up(n, 256), L.NB), 256, 0, st>>>((const double*)boxes, n, boxes_dim, thresh, shift, keep_le, ws, L, init);
+        else if ((long)L.NB * gnms_div_up(n, 256) / 2 < 4096)      // fewer 64 x 256 tiles than four per SIMD: 64 x 64 tiles
+            classic_mask_kernel<1><<<dim3(gnms_div_up(((n + 63) / 64) * (((n + 63) / 64) + 1) / 2, 4)), 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
         else
-            classic_mask_kernel<<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L);
+            classic_mask_kernel<4><<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
     };
     if (n > GNMS_MAX_BOXES) {                                     // the reference's scan on the device (classic_scan_large_kernel)
-        mask();
+        mask(0);
         GNMS_CHECK_LAUNCH();
-        classic_scan_large_kernel<<<1, 1024, (size_t)L.NB * 8, st>>>(n, img_ptrs(ws, L, 0).W, (long)L.NC, keep, num_out);
+        classic_scan_large_kernel<<<1, 1024, (size_t)L.NB * 8, st>>>(n, img_ptrs(ws, L, 0).W, (long)L.NC, keep, num_out, tag_ptr, tag);
         GNMS_CHECK_LAUNCH();
         return GNMS_OK;
     }
-    classic_init_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L);
-    GNMS_CHECK_LAUNCH();
-    mask();
+    mask(1);
     GNMS_CHECK_LAUNCH();
     const size_t lds = leaders_lds_size(L.NB);
-    if (lds > 64 * 1024)
-        GNMS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(leaders_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) {
+        const int rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(leaders_kernel), lds);       // (remembered per device and kernel)
+        if (rc) return rc;
+    }
     leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L, 0, 1, 1);
     GNMS_CHECK_LAUNCH();
-    classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);
+    if (tag_ptr) classic_export_tag_kernel<<<1, 1024, 0, st>>>(ws, L, keep, num_out, tag_ptr, tag);
+    else classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);
     GNMS_CHECK_LAUNCH();
     return GNMS_OK;
 }
@@ -235,10 +289,41 @@ extern "C" int gnms_nms_sorted(const float* boxes, int n, int boxes_dim, float t
     return gnms_nms_sorted_shift(boxes, n, boxes_dim, thresh, 1.0f, 0, keep, num_out, workspace, workspace_bytes, stream);
 }
 
-// The reference's exact symbol (lib/nms/gpu_nms.hpp:1-2): host pointers, blocking, allocates per call
-// (nms_kernel.cu:100-108,142-143).  Errors cannot be returned through this signature; unlike the
-// reference (which prints and carries on, :12-19) a failure yields *num_out = 0 and the message is
-// kept for gnms_last_error().
+// The reference's exact symbol (lib/nms/gpu_nms.hpp:1-2): host pointers, blocking (nms_kernel.cu:100-108,142-143 allocate, copy in,
+// copy the whole bit matrix out and free per call).  Errors cannot be returned through this signature; unlike the
+// reference (which prints and carries on, :12-19) a failure yields *num_out = 0 and the message is kept for gnms_last_error().
+//
+// Round 5: neither copy is a blocking hipMemcpy of pageable memory any more.  One block of fine-grained (coherent, host-mapped) pinned
+// memory per device stays between the calls: the boxes go through it (a host memcpy, then an asynchronous copy to the device -- the bit-matrix
+// kernel reads every box n / 64 times, which must not cross PCIe), `keep[]` and the count are written INTO it by the kernels themselves
+// (classic_export_tag_kernel / classic_scan_large_kernel only ever store to them) and end with the call's tag, and
+// the host polls the tag: no device-to-host copy, no stream synchronisation.  Per call with the mask kernel's small tiles (tools/nms_host.py, old and new
+// library on one box, profiles/r05h_nms_host_ab.txt): n = 500 75 -> 40-50 us, n = 2000 100 -> 74-82, n = 4096 148 -> 125-128.
+namespace {
+struct NmsStage {
+    std::mutex mu;                 // a call holds it from its first byte in the block to its last out of it (calls on the null stream never overlapped anyway)
+    char* host = nullptr;          // [0, 256): the tag; then keep[n] + the count; then the boxes
+    char* dev = nullptr;           // the same block as the device addresses it
+    size_t bytes = 0;
+    uint32_t seq = 0;
+};
+NmsStage g_nms_stage[64];
+
+// blocks until the tag has arrived (or the null stream has run empty / failed); false: HIP error
+bool nms_wait_tag(const char* host, int32_t tag) {
+    const int32_t* h = reinterpret_cast<const int32_t*>(host);
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(h, __ATOMIC_ACQUIRE) == tag) return true;
+        __builtin_ia32_pause();
+        if ((spins & 0x3fff) == 0x3fff) {
+            const hipError_t q = hipStreamQuery(nullptr);
+            if (q == hipSuccess) return __atomic_load_n(h, __ATOMIC_ACQUIRE) == tag || hipStreamSynchronize(nullptr) == hipSuccess;
+            if (q != hipErrorNotReady) return false;
+        }
+    }
+}
+}  // namespace
+
 extern "C" void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
                      float nms_overlap_thresh, int device_id) {
     if (num_out) *num_out = 0;
@@ -249,25 +334,64 @@ extern "C" void _nms(int* keep_out, int* num_out, const float* boxes_host, int b
     if (cur != device_id && hipSetDevice(device_id) != hipSuccess) { gnms_set_error("_nms: hipSetDevice(%d) failed", device_id); return; }   // :80-89
     const size_t bbytes = (size_t)boxes_num * boxes_dim * sizeof(float);
     const size_t wbytes = gnms_nms_workspace_bytes(boxes_num);
+    const size_t off_ws = (bbytes + 255) / 256 * 256;
+    // the pinned block: tag | keep[] + count | boxes
+    const size_t st_keep = 256, st_boxes = st_keep + ((size_t)(boxes_num + 1) * 4 + 255) / 256 * 256, st_need = st_boxes + bbytes;
+    NmsStage* S = (device_id >= 0 && device_id < 64) ? &g_nms_stage[device_id] : nullptr;
+    std::unique_lock<std::mutex> lock;
+    if (S) {
+        lock = std::unique_lock<std::mutex>(S->mu);
+        if (S->bytes < st_need) {
+            if (S->host) { (void)hipDeviceSynchronize(); (void)hipHostFree(S->host); S->host = S->dev = nullptr; S->bytes = 0; }
+            const size_t want = std::max<size_t>((st_need + (1u << 20) - 1) >> 20 << 20, 4u << 20);
+            void *h = nullptr, *d = nullptr;
+            if (hipHostMalloc(&h, want, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+                memset(h, 0, 256);
+                S->host = (char*)h; S->dev = (char*)d; S->bytes = want;
+            } else {
+                if (h) (void)hipHostFree(h);
+                (void)hipGetLastError();
+                S = nullptr;                                       // no pinned block: the plain copies below
+                lock.unlock();
+            }
+        }
+    }
     char* dev = nullptr;
-    const size_t off_keep = (bbytes + 255) / 256 * 256;
-    const size_t off_ws = off_keep + ((size_t)(boxes_num + 1) * 4 + 255) / 256 * 256;
     // stream-ordered allocation on the null stream: the pool keeps the block between calls (the reference pays a cudaMalloc /
     // cudaFree per call, nms_kernel.cu:100-108,142-143; here that was two thirds of the call)
-    if (hipMallocAsync((void**)&dev, off_ws + wbytes, nullptr) != hipSuccess) { gnms_set_error("_nms: hipMallocAsync failed"); return; }
-    int32_t* keep_d = (int32_t*)(dev + off_keep);
-    int32_t* num_d = keep_d + boxes_num;                      // staged right behind keep[] on the device
+    const size_t off_keep_d = off_ws + wbytes;                    // (only the plain path keeps keep[] on the device)
+    if (hipMallocAsync((void**)&dev, off_keep_d + (S ? 0 : (size_t)(boxes_num + 1) * 4), nullptr) != hipSuccess) { gnms_set_error("_nms: hipMallocAsync failed"); return; }
     int rc = GNMS_OK;
-    hipError_t e = hipMemcpy(dev, boxes_host, bbytes, hipMemcpyHostToDevice);                        // :103-106
-    if (e == hipSuccess)
-        rc = gnms_nms_sorted((const float*)dev, boxes_num, boxes_dim, nms_overlap_thresh, keep_d, num_d, dev + off_ws, wbytes, nullptr);
-    // keep[] and the count come back in ONE blocking copy (it orders after the kernels): boxes_num + 1 ints
-    std::vector<int32_t> host((size_t)boxes_num + 1);
-    if (e == hipSuccess && rc == GNMS_OK) e = hipMemcpy(host.data(), keep_d, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && rc == GNMS_OK) {
-        const int num = host[boxes_num];
-        if (num > 0) memcpy(keep_out, host.data(), (size_t)num * sizeof(int));
-        *num_out = num;
+    hipError_t e;
+    if (S) {
+        memcpy(S->host + st_boxes, boxes_host, bbytes);
+        e = hipMemcpyAsync(dev, S->host + st_boxes, bbytes, hipMemcpyHostToDevice, nullptr);                 // :103-106 (pinned source: asynchronous)
+        int32_t* keep_p = reinterpret_cast<int32_t*>(S->dev + st_keep);
+        const int32_t tag = (int32_t)(++S->seq | 0x40000000u);
+        if (e == hipSuccess)
+            rc = nms_sorted_impl(dev, 0, boxes_num, boxes_dim, (double)nms_overlap_thresh, 1.0, 0, keep_p, keep_p + boxes_num, dev + off_ws, wbytes, nullptr,
+                                 reinterpret_cast<int32_t*>(S->dev), tag);
+        if (e == hipSuccess && rc == GNMS_OK && !nms_wait_tag(S->host, tag)) e = hipErrorUnknown;
+        if (e == hipSuccess && rc == GNMS_OK) {
+            const int32_t* hk = reinterpret_cast<const int32_t*>(S->host + st_keep);
+            const int num = hk[boxes_num];
+            if (num > 0) memcpy(keep_out, hk, (size_t)num * sizeof(int));
+            *num_out = num;
+        }
+    } else {
+        int32_t* keep_d = (int32_t*)(dev + off_keep_d);
+        int32_t* num_d = keep_d + boxes_num;                      // staged right behind keep[] on the device
+        e = hipMemcpy(dev, boxes_host, bbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess)
+            rc = gnms_nms_sorted((const float*)dev, boxes_num, boxes_dim, nms_overlap_thresh, keep_d, num_d, dev + off_ws, wbytes, nullptr);
+        // keep[] and the count come back in ONE blocking copy (it orders after the kernels): boxes_num + 1 ints
+        std::vector<int32_t> host((size_t)boxes_num + 1);
+        if (e == hipSuccess && rc == GNMS_OK) e = hipMemcpy(host.data(), keep_d, host.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && rc == GNMS_OK) {
+            const int num = host[boxes_num];
+            if (num > 0) memcpy(keep_out, host.data(), (size_t)num * sizeof(int));
+            *num_out = num;
+        }
     }
     (void)hipFreeAsync(dev, nullptr);
     if (e != hipSuccess) gnms_set_error("_nms: HIP copy failed");
