@@ -2884,3 +2884,47 @@ print("ok")
         np.testing.assert_array_equal(d[tag + "_prob"][0], ref["prob"])
         nv = int(d[tag + "_nvalid"][0])
         np.testing.assert_array_equal(d[tag + "_valid"][0, :nv], ref["valid"])
+
+
+@pytest.mark.gpu
+def test_classic_nms_pinned_staging(O):
+    """`_nms` keeps one block of pinned memory per device for the boxes, keep[] and the count (classic_nms.hip): a block that starts small
+    (GNMS_NMS_STAGE_MIN) and has to grow between calls, sizes on both sides of the bit-matrix kernel's tile switch (64 x 64 tiles in a
+    1D grid / 64 x 256 in a 2D grid), two host threads calling at once -- every keep list against the oracle."""
+    code = """
+import sys, threading, numpy as np
+from groomed_nms_amd import synthetic
+from groomed_nms_amd.nms import gpu_nms
+out = {}
+def dets_of(n, seed):
+    rng = np.random.default_rng(seed)
+    return np.concatenate([synthetic.clustered_boxes_2d(rng, n, 32), synthetic.tie_free_scores(rng, n)[:, None]], 1).astype(np.float32)
+for i, n in enumerate((500, 4096, 37, 9000, 500, 12000, 1)):
+    out["seq%d_n%d" % (i, n)] = np.asarray(gpu_nms(dets_of(n, 10 + i), 0.45), np.int64)
+res = {}
+def worker(t):
+    for rep in range(20):
+        n = (300, 777, 2000, 64)[(t + rep) % 4]
+        res[(t, rep)] = np.asarray(gpu_nms(dets_of(n, 1000 * t + rep), 0.5), np.int64)
+th = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+[x.start() for x in th]; [x.join() for x in th]
+for (t, rep), v in res.items():
+    out["thr%d_%d" % (t, rep)] = v
+np.savez(sys.argv[1], **out)
+print("ok")
+"""
+    path = "/tmp/gnms_nms_stage.npz"
+    r = _run_py(code, {"GNMS_NMS_STAGE_MIN": "65536"}, argv=(path,))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+    d = np.load(path)
+    from groomed_nms_amd import synthetic
+
+    def dets_of(n, seed):
+        rng = np.random.default_rng(seed)
+        return np.concatenate([synthetic.clustered_boxes_2d(rng, n, 32), synthetic.tie_free_scores(rng, n)[:, None]], 1).astype(np.float32)
+    for i, n in enumerate((500, 4096, 37, 9000, 500, 12000, 1)):
+        assert list(d["seq%d_n%d" % (i, n)]) == O.classic_nms(dets_of(n, 10 + i), 0.45, rule="gpu"), (i, n)
+    for t in range(3):
+        for rep in range(20):
+            n = (300, 777, 2000, 64)[(t + rep) % 4]
+            assert list(d["thr%d_%d" % (t, rep)]) == O.classic_nms(dets_of(n, 1000 * t + rep), 0.5, rule="gpu"), (t, rep)
