@@ -53,6 +53,8 @@ _SIGNATURES = {
     "gnms_counts_to_host": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_vp, c_vp]),
     "gnms_host_counts_slot": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
     "gnms_host_counts_wait": (ctypes.c_int, [c_vp, ctypes.c_int, c_vp, c_vp]),
+    "gnms_host_counts_release": (ctypes.c_int, [c_vp, c_vp]),
+    "gnms_test_mailbox_slots": (ctypes.c_int, [ctypes.c_int]),
     "gnms_forward_from_boxes": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.POINTER(GnmsParams), c_vp, c_vp, c_vp,
                                                c_vp, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_backward_from_boxes": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, c_vp, ctypes.POINTER(GnmsParams), c_vp,

@@ -10,6 +10,7 @@
 // suppressor can reach are computed (suppressor index < end of the rank block), and the scan runs ON
 // the device (leaders_kernel), so only keep[] and the count cross PCIe.
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <string.h>
@@ -309,16 +310,19 @@ struct NmsStage {
 };
 NmsStage g_nms_stage[64];
 
-// blocks until the tag has arrived (or the null stream has run empty / failed); false: HIP error
+// blocks until the tag has arrived (or the null stream has run empty / failed); false: HIP error.  Spin, yield, sleep (gnms_poll_backoff); after
+// two seconds without the tag the stream is synchronised instead (as the counts mailbox does) -- the caller holds the per-device mutex meanwhile
 bool nms_wait_tag(const char* host, int32_t tag) {
     const int32_t* h = reinterpret_cast<const int32_t*>(host);
-    for (unsigned spins = 0;; ++spins) {
+    const auto t0 = std::chrono::steady_clock::now();
+    gnms_poll_backoff bo;
+    for (;;) {
         if (__atomic_load_n(h, __ATOMIC_ACQUIRE) == tag) return true;
-        __builtin_ia32_pause();
-        if ((spins & 0x3fff) == 0x3fff) {
+        if (bo.wait()) {
             const hipError_t q = hipStreamQuery(nullptr);
-            if (q == hipSuccess) return __atomic_load_n(h, __ATOMIC_ACQUIRE) == tag || hipStreamSynchronize(nullptr) == hipSuccess;
-            if (q != hipErrorNotReady) return false;
+            if (q != hipSuccess && q != hipErrorNotReady) return false;
+            if (q == hipSuccess || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+                return __atomic_load_n(h, __ATOMIC_ACQUIRE) == tag || hipStreamSynchronize(nullptr) == hipSuccess;
         }
     }
 }

@@ -62,6 +62,25 @@ struct gnms_async_buffer {
 };
 
 
+// one step of a host-side poll loop: a spin hint on x86 / ARM, nothing elsewhere
+static inline void gnms_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    __asm__ __volatile__("yield" ::: "memory");
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
+// Bounded spin, then yield, then sleep (host_mailbox.hip, classic_nms.hip: the host polls a word of pinned memory the kernels store to).
+// ~4 k pauses cover a call at the reference's size without a system call; the next ~4 k polls give the core away between looks; from there
+// the poll sleeps 2, 4, ... 128 us.  wait() returns true every 1024 steps of the spin / yield phases and after every sleep: "look at the
+// stream now" (a failed or empty stream never delivers the word).
+struct gnms_poll_backoff {
+    unsigned n = 0, sleep_us = 2;
+    bool wait();
+};
+
 static inline int gnms_div_up(int a, int b) { return (a + b - 1) / b; }
 static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 

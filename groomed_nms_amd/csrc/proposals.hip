@@ -219,7 +219,16 @@ __device__ __forceinline__ void coop_grid_barrier(unsigned* counter, const unsig
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) __builtin_amdgcn_s_sleep(2);
+        // The host only launches this kernel when every workgroup of the grid is resident at once (gnms_select_topk: occupancy x CUs >= B * G,
+        // launches of this kind chained across streams).  What the host cannot see -- another PROCESS holding CUs, a CU-masked stream -- would
+        // make this wait for ever and hang the GPU; a wait of two seconds (s_memtime: 100 MHz) aborts the launch instead, which the next
+        // synchronisation reports as an error.
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        unsigned polls = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++polls & 0xfffu) == 0u && __builtin_amdgcn_s_memtime() - t0 > 200000000ull) __builtin_trap();
+        }
     }
     __syncthreads();
 }
@@ -472,12 +481,26 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
             if (lds < kCoopBins * sizeof(unsigned)) lds = kCoopBins * sizeof(unsigned);
             int rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(topk_coop_kernel), lds);
             if (rc) return rc;
-            struct Chain { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool any = false; char* scratch = nullptr; size_t cap = 0; };
+            struct Chain { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool any = false; char* scratch = nullptr; size_t cap = 0; std::map<size_t, int> per_cu; };
             static std::mutex mu;
             static std::map<int, Chain> chains;
             int dev = 0;
             GNMS_CHECK_HIP(hipGetDevice(&dev));
+            bool resident = true;
             {
+                std::lock_guard<std::mutex> lock(mu);
+                Chain& C = chains[dev];
+                // residency as the runtime computes it for THIS kernel, workgroup size and LDS request (remembered per LDS size): the grid
+                // barrier is only safe when occupancy x CUs covers the grid -- otherwise the one-workgroup kernels below
+                auto it = C.per_cu.find(lds);
+                if (it == C.per_cu.end()) {
+                    int nb = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(topk_coop_kernel), 1024, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+                    it = C.per_cu.emplace(lds, nb).first;
+                }
+                resident = (long)it->second * gnms_device_cu_count() >= (long)B * G;
+            }
+            if (resident) {
                 std::lock_guard<std::mutex> lock(mu);
                 Chain& C = chains[dev];
                 if (!C.ev) GNMS_CHECK_HIP(hipEventCreateWithFlags(&C.ev, hipEventDisableTiming));
@@ -497,8 +520,8 @@ extern "C" int gnms_select_topk(const float* scores, int B, int A, const int32_t
                 GNMS_CHECK_HIP(hipEventRecord(C.ev, st));
                 C.last = st;
                 C.any = true;
+                return GNMS_OK;
             }
-            return GNMS_OK;
         }
     }
     gnms_async_buffer pre_buf;                                        // [B][K] pre-selected candidates + [B] counts (large F only)

@@ -224,8 +224,15 @@ std::vector<Tensor> single(const Tensor& scores, const Tensor& iou, double thr, 
     }
     // lists_now: the forward call writes its counts into a slot of pinned memory the host polls -- no kernel, no copy, no stream synchronisation
     // behind the layer (gnms_host_counts_slot / _wait); no slot (no fine-grained memory): the counts tensor + gnms_counts_to_host
+    // (every slot owned -- more than 64 calls in flight on the device -- is GNMS_ERR_UNSUPPORTED: the plain path below)
     if (lists_now && gnms_host_counts_slot(1, &slot_dev, &slot_host) != GNMS_OK) slot_dev = nullptr;
-    struct Reset { ~Reset() { tl_counts_slot = nullptr; } } reset;
+    // the slot is this call's until the wait below has returned; a forward call that throws gives it back (behind the stream: the launches
+    // that did get enqueued may still store their counts)
+    struct Reset {
+        const int32_t* view;
+        hipStream_t st;
+        ~Reset() { tl_counts_slot = nullptr; if (view) (void)gnms_host_counts_release(view, st); }
+    } reset{slot_dev ? slot_host : nullptr, current_stream(scores)};
     tl_counts_slot = slot_dev;
     const variable_list o = Layer::apply(scores.unsqueeze(0), iou.unsqueeze(0), c10::nullopt, c10::nullopt, (int64_t)kMatrixIn, thr, temp, vthr, prune, sorted_prob,
                                          group, mask, gsize, presorted, true);
@@ -239,6 +246,7 @@ std::vector<Tensor> single(const Tensor& scores, const Tensor& iou, double thr, 
             hipStream_t st = current_stream(scores);
             {
                 pybind11::gil_scoped_release nogil;
+                reset.view = nullptr;                                    // the wait gives the slot back on every path
                 rc = gnms_host_counts_wait(slot_host, 1, c, st);
             }
             check(rc, "gnms_host_counts_wait");

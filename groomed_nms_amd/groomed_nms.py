@@ -483,6 +483,8 @@ def differentiable_nms(scores_unsorted, iou_unsorted, nms_threshold=0.4, pruning
           and scores_unsorted.dtype == torch.float32 and iou_unsorted.dtype == torch.float32 and scores_unsorted.dim() == 1
           and scores_unsorted.shape[0] > 0 and iou_unsorted.device == scores_unsorted.device):
         # GPU tensors in, hard sort (the training call site, lib/loss/rpn_3d.py:791): the whole call in the C++ binding
+        if iou_unsorted.dim() != 2 or iou_unsorted.shape[0] != scores_unsorted.shape[0] or iou_unsorted.shape[1] != scores_unsorted.shape[0]:
+            raise ValueError("iou_unsorted must be (N, N) with N = len(scores_unsorted)")       # (the same exception on every host path: ADVICE r5)
         ext = _binding()
         if ext and hasattr(ext, "single"):
             p = _params(nms_threshold, pruning_method, temperature, valid_box_prob_threshold, return_sorted_prob, group_boxes, mask_group_boxes,

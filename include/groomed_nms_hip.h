@@ -175,10 +175,19 @@ int gnms_counts_to_host(const int32_t* nvalid, const int32_t* ninvalid, int B, i
  * device (`device_view`) and the host (`host_view`) address them; pass device_view as `nvalid` and device_view + B as `ninvalid` to ONE
  * gnms_forward* call (the kernels store each count exactly once, at the end of the image's chain), then gnms_host_counts_wait polls
  * host_view until all 2 B words are counts (>= 0) and copies them to host_out [2 B]; it falls back to a stream synchronisation when the
- * stream runs empty first or after two seconds.  B <= 127 (GNMS_ERR_UNSUPPORTED above); a slot is recycled 64 gnms_host_counts_slot /
- * gnms_counts_to_host calls later on the same device.  differentiable_nms at N = 500, index tensors included: 64 -> 46 us per call. */
+ * stream runs empty first or after two seconds.  B <= 127 (GNMS_ERR_UNSUPPORTED above).
+ * OWNERSHIP: the slot belongs to the caller from gnms_host_counts_slot until gnms_host_counts_wait returns (whatever it returns) or
+ * gnms_host_counts_release is called -- exactly one of the two per slot; nobody else is handed the slot in between, however many calls other
+ * threads make on the device.  When all 64 slots of the device are owned, gnms_host_counts_slot returns GNMS_ERR_UNSUPPORTED and the caller
+ * takes the plain path (device counts + gnms_counts_to_host).  gnms_host_counts_release is for a caller that took a slot and will not wait
+ * (its forward call failed, or was never made): it synchronises `stream` first, so a forward call that was enqueued can no longer store
+ * into a slot somebody else owns by then.  A wait / release on a view that is not owned is GNMS_ERR_INVALID_ARGUMENT.
+ * differentiable_nms at N = 500, index tensors included: 64 -> 46 us per call. */
 int gnms_host_counts_slot(int B, int32_t** device_view, const int32_t** host_view);
 int gnms_host_counts_wait(const int32_t* host_view, int B, int32_t* host_out, void* stream);
+int gnms_host_counts_release(const int32_t* host_view, void* stream);
+/* test hook: the number of mailbox slots gnms_host_counts_slot / gnms_counts_to_host may use per device (1 .. 64); returns the previous value */
+int gnms_test_mailbox_slots(int n);
 
 /* backward of L through prob.  grad_prob [B][N] = dL/dprob (same order as prob).
  *   grad_scores [B][N] (input order), overwritten.

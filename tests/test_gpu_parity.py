@@ -2808,6 +2808,109 @@ def test_counts_to_host_mailbox(G):
 
 
 @pytest.mark.gpu
+def test_counts_slot_ownership_under_threads(G):
+    """VERDICT r5 #5 / ADVICE r5: a slot of the counts mailbox has ONE owner from gnms_host_counts_slot until its wait / release.  Eight host
+    threads (a stream each) make 500 differentiable_nms(scores, iou) calls of different N at once -- far more than 64 slot hand-outs while
+    any one thread sits between its slot and its wait; every call's index tensors must have the lengths AND contents of the batched
+    entry's padded lists.  Then the same with the mailbox cut to two slots (gnms_test_mailbox_slots): most calls find no free slot and take
+    the plain path, none may read another call's counts.  Then the protocol itself through the C ABI: a leaked slot is never handed out
+    again, release gives it back, a second wait on a view is refused."""
+    import ctypes
+    import threading
+    from groomed_nms_amd import _lib, groomed_nms as M, synthetic
+    from groomed_nms_amd.overlaps import iou as iou_fn
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    ext = M._binding()
+    assert ext and hasattr(ext, "single")
+    sizes = [3, 17, 64, 100, 129, 257, 300, 411, 500, 640, 777, 1024]
+    cases = []
+    for i, n in enumerate(sizes):
+        boxes, scores = synthetic.batch_2d(4000 + i, 1, n, "clustered" if i % 2 else "uniform")
+        bt, s = torch.from_numpy(boxes[0]).to(dev), torch.from_numpy(scores[0]).to(dev)
+        iou = iou_fn(bt, bt)
+        ref = G.differentiable_nms_batched(s.unsqueeze(0), iou.unsqueeze(0))
+        k, m = int(ref[4][0]), int(ref[5][0])
+        cases.append((s, iou, ref[2][0, :k].clone(), ref[3][0, :m].clone(), ref[0][0].clone()))
+    torch.cuda.synchronize()
+    assert len({c[2].shape[0] for c in cases}) >= 8           # the lengths differ from case to case: a stolen slot would show
+
+    def storm(threads, calls):
+        errs = []
+
+        def worker(t):
+            try:
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for rep in range(calls):
+                        s, iou, v, iv, pr = cases[(7 * t + rep) % len(cases)]
+                        valid, invalid, prob = G.differentiable_nms(s, iou)
+                        if valid.shape != v.shape or invalid.shape != iv.shape:
+                            errs.append((t, rep, "length", tuple(valid.shape), tuple(v.shape)))
+                        elif rep % 8 == 0 and not (torch.equal(valid, v) and torch.equal(invalid, iv) and torch.equal(prob, pr)):
+                            errs.append((t, rep, "content"))
+            except Exception as e:                            # noqa: BLE001
+                errs.append((t, repr(e)))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        return errs
+
+    assert M.LAZY_INDEX_LISTS is False
+    errs = storm(8, 500)
+    assert not errs, errs[:4]
+    old = lib.gnms_test_mailbox_slots(2)
+    try:
+        errs = storm(8, 500)
+        assert not errs, errs[:4]
+        # the protocol: two slots, both taken -> the third request is refused, not served with an owned slot
+        dv, hv = [ctypes.c_void_p() for _ in range(3)], [ctypes.c_void_p() for _ in range(3)]
+        assert lib.gnms_host_counts_slot(1, ctypes.byref(dv[0]), ctypes.byref(hv[0])) == 0
+        assert lib.gnms_host_counts_slot(1, ctypes.byref(dv[1]), ctypes.byref(hv[1])) == 0
+        assert hv[0].value != hv[1].value
+        assert lib.gnms_host_counts_slot(1, ctypes.byref(dv[2]), ctypes.byref(hv[2])) == -2 and b"owned" in lib.gnms_last_error()
+        # ... and the tagged path falls back to its copy while every slot is owned
+        nv = torch.tensor([41, 42], dtype=torch.int32, device=dev)
+        assert list(ext.counts_to_host(nv, nv + 1)) == [41, 42, 42, 43]
+        # a forward call into slot 0; its wait gives the slot back; a second wait on the same view is refused
+        s, iou, v, iv, pr = cases[8]
+        n = s.shape[0]
+        P = _lib.GnmsParams()
+        lib.gnms_default_params(ctypes.byref(P))
+        ws = torch.empty((lib.gnms_workspace_bytes(1, n, ctypes.byref(P)),), dtype=torch.uint8, device=dev)
+        prob = torch.empty((1, n), device=dev)
+        _lib.check(lib.gnms_forward(s.data_ptr(), iou.data_ptr(), 1, n, n, None, ctypes.byref(P), prob.data_ptr(), None, None, None,
+                                    dv[0].value, dv[0].value + 4, ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "fwd")
+        host = (ctypes.c_int32 * 2)()
+        _lib.check(lib.gnms_host_counts_wait(hv[0].value, 1, ctypes.cast(host, ctypes.c_void_p), _lib.stream_ptr(dev)), "wait")
+        assert list(host) == [v.shape[0], iv.shape[0]]
+        assert lib.gnms_host_counts_wait(hv[0].value, 1, ctypes.cast(host, ctypes.c_void_p), _lib.stream_ptr(dev)) == -1 and b"not owned" in lib.gnms_last_error()
+        assert lib.gnms_host_counts_wait(hv[0].value + 4, 1, ctypes.cast(host, ctypes.c_void_p), _lib.stream_ptr(dev)) == -1     # not a view
+        # slot 0 is free again, slot 1 still owned; release returns it
+        assert lib.gnms_host_counts_slot(1, ctypes.byref(dv[2]), ctypes.byref(hv[2])) == 0 and hv[2].value == hv[0].value
+        assert lib.gnms_host_counts_slot(1, ctypes.byref(dv[0]), ctypes.byref(hv[0])) == -2
+        _lib.check(lib.gnms_host_counts_release(hv[1].value, _lib.stream_ptr(dev)), "release")
+        assert lib.gnms_host_counts_release(hv[1].value, _lib.stream_ptr(dev)) == -1
+        _lib.check(lib.gnms_host_counts_release(hv[2].value, _lib.stream_ptr(dev)), "release")
+        # a forward call that raises inside differentiable_nms (refused parameters) must not leak its slot: with two slots, three failures
+        # in a row would leave none
+        bb, bs = synthetic.batch_2d(4100, 1, 2100, "uniform")          # N above the largest unmasked group the solves take: gnms_forward refuses
+        bbt = torch.from_numpy(bb[0]).to(dev)
+        big_s, big_iou = torch.from_numpy(bs[0]).to(dev), iou_fn(bbt, bbt)
+        for _ in range(3):
+            with pytest.raises(_lib.GnmsError, match="unmasked groups"):
+                G.differentiable_nms(big_s, big_iou, mask_group_boxes=False, group_size=1 << 20)
+        assert lib.gnms_host_counts_slot(1, ctypes.byref(dv[0]), ctypes.byref(hv[0])) == 0
+        assert lib.gnms_host_counts_slot(1, ctypes.byref(dv[1]), ctypes.byref(hv[1])) == 0
+        _lib.check(lib.gnms_host_counts_release(hv[0].value, _lib.stream_ptr(dev)), "release")
+        _lib.check(lib.gnms_host_counts_release(hv[1].value, _lib.stream_ptr(dev)), "release")
+    finally:
+        lib.gnms_test_mailbox_slots(old)
+    valid, invalid, prob = G.differentiable_nms(cases[8][0], cases[8][1])
+    assert torch.equal(valid, cases[8][2]) and torch.equal(invalid, cases[8][3])
+
+
+@pytest.mark.gpu
 def test_bitmask_small_kernel_against_the_row_kernel(O):
     """bitmask_small_kernel (K2 of few, small images: the 64 rows of a rank block dealt to eight waves, the words assembled from bytes in LDS)
     stores exactly the words of bitmask_kernel: the matrix-in layer's probabilities, lists, counts and gradients with it (default) and
