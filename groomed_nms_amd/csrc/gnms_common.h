@@ -123,6 +123,7 @@ static inline size_t gnms_align_up(size_t a, size_t b) { return (a + b - 1) / b 
 //     W          u64   [NB][NC] W[kb][k'] bit r set iff !(iou[order[64*kb+r]][order[k']] <= thr): the ranks of block kb that
 //                               rank k', were it a leader, takes out of `remaining` (:249-262).  Rank x rank space: the
 //                               bit-matrix kernel reads input columns and scatters each word to its rank position.
+//                               (one_launch_kernel, N <= 1024: the region holds the leader scan's triangular table instead, nms_one_launch.h)
 // ------------------------------------------------------------------------------------------------
 struct gnms_ws_layout {
     int N, NB, NC;
@@ -152,7 +153,12 @@ static inline gnms_ws_layout gnms_make_layout(int N) {
     L.off_rbox = take(n4 * 4);
     L.off_rec = take(n4 * 12);
     L.off_xrec = take(n4 * 12);
-    L.off_W = take((size_t)(L.NB > 0 ? L.NB : 1) * (size_t)(L.NC > 0 ? L.NC : 4) * 8);
+    {   // (up to one super-block the region also holds the image of the scan's triangular table, nms_one_launch.h: NB (NB + 1) / 2 pairs of 64 words)
+        size_t wbytes = (size_t)(L.NB > 0 ? L.NB : 1) * (size_t)(L.NC > 0 ? L.NC : 4) * 8;
+        const size_t tbytes = (size_t)L.NB * (L.NB + 1) / 2 * 64 * 8;
+        if (L.NB <= 16 && wbytes < tbytes) wbytes = tbytes;
+        L.off_W = take(wbytes);
+    }
     L.per_image = o;
     return L;
 }

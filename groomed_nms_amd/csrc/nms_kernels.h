@@ -27,6 +27,20 @@ namespace {   // internal linkage: the header is included by several translation
 
 typedef unsigned long long u64;
 
+// Data that one workgroup of a launch hands to another workgroup of the SAME launch (the leader scan's granules and rem[], everything in
+// one_launch_kernel): the L2s of the eight XCDs are not coherent with each other inside a kernel, so such data leaves through agent-scope
+// (write-through) stores and is read with agent-scope loads.
+template <typename T> __device__ __forceinline__ T coh_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void coh_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float4 coh_load_f4(const float4* p) {
+    const u64 a = coh_load(reinterpret_cast<const u64*>(p)), c = coh_load(reinterpret_cast<const u64*>(p) + 1);
+    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)c), __uint_as_float((unsigned)(c >> 32)));
+}
+__device__ __forceinline__ void coh_store_f4(float4* p, const float4 v) {
+    coh_store(reinterpret_cast<u64*>(p), ((u64)__float_as_uint(v.y) << 32) | __float_as_uint(v.x));
+    coh_store(reinterpret_cast<u64*>(p) + 1, ((u64)__float_as_uint(v.w) << 32) | __float_as_uint(v.z));
+}
+
 // ------------------------------------------------------------------------------------------------
 // Workgroup sort of P = blockDim.x * E 64-bit keys (P a power of two, blockDim.x a multiple of 64),
 // ascending.  Thread t owns elements t*E .. t*E+E-1 in registers.  A bitonic network whose stages run
@@ -535,14 +549,22 @@ __global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restric
 // image in LDS, thread (key, segment) counts the keys of one sixteenth of the image below its own, an LDS atomic adds the sixteen counts,
 // and the 64 results leave exactly as the merge kernel's do.  N / 64 workgroups per image and role: 256 at B = 8, N = 1024.
 // ------------------------------------------------------------------------------------------------
-template <int KPW>   // keys per workgroup: 64, or 32 where that still is one round of the machine (B = 1, N = 4096: 10.5 -> ? us)
-__global__ __launch_bounds__(1024) void sort_count_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
-                                                          const int* __restrict__ counts, char* ws, gnms_ws_layout L,
-                                                          long long* __restrict__ order_out, int mode3d) {
+// FUSED (round 6, one_launch_kernel): the same workgroup as a ROLE of the one launch of a small image.  Nothing of the workspace is
+// zeroed or counted here (the launch's tag comes from its caller and the flags are strong granules, see there); everything another
+// workgroup of the launch reads leaves through agent-scope stores, and the workgroup's last act is its "sorted" flag.
+__device__ __forceinline__ u64 strong_gran(unsigned tag, unsigned slot) { return ((u64)tag << 32) | (u64)(unsigned)(~tag ^ (0x9E3779B9u * (slot + 1u))); }
+constexpr unsigned kSlotSort = 0u;       // + 32 * role + workgroup of the sort          -> gran[1 + role][workgroup]
+constexpr unsigned kSlotBits = 64u;      // + workgroup of the bit table (<= 64)         -> gran[3 .. 4][workgroup]
+constexpr unsigned kSlotVerdict = 128u;  // + the verdict (1 fast tail, 2 K5 proper ran) -> gran[16][kGranVerdict]
+
+template <int KPW, bool FUSED = false>   // keys per workgroup: 64, or 32 where that still is one round of the machine (B = 1, N = 4096: 10.5 -> ? us)
+__device__ __forceinline__ void sort_count_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                const int* __restrict__ counts, char* ws, gnms_ws_layout L,
+                                                long long* __restrict__ order_out, int mode3d, const int blk, const int b, const int role,
+                                                const unsigned tag = 0u) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64* keys = reinterpret_cast<u64*>(smem);                          // [NP] all keys of the image (padding ~0: behind everything)
     __shared__ int rk[64];
-    const int blk = blockIdx.x, b = blockIdx.y, role = blockIdx.z;
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int t = threadIdx.x, lane = t & (KPW - 1), seg = t / KPW;
@@ -576,30 +598,60 @@ __global__ __launch_bounds__(1024) void sort_count_kernel(const float* __restric
     const int all = __syncthreads_and(flag);                           // (also: every count has landed in rk)
     if (blk == 0) {
         if (role == 0) {
-            if (t < 8 && !(boxes && t == 6)) I.misc[t] = (t == 2) ? all : 0;           // ([6]: the x sort's)
-            if (t == 8) I.misc[8] = gnms_next_epoch(I.misc[8]);
-            for (int i = t; i < 17 * 32; i += 1024) I.gran[i] = 0ull;
+            if constexpr (FUSED) {
+                if (t < 8 && !(boxes && t == 6)) coh_store(I.misc + t, (t == 2) ? all : 0);
+            } else {
+                if (t < 8 && !(boxes && t == 6)) I.misc[t] = (t == 2) ? all : 0;           // ([6]: the x sort's)
+                if (t == 8) I.misc[8] = gnms_next_epoch(I.misc[8]);
+                for (int i = t; i < 17 * 32; i += 1024) I.gran[i] = 0ull;
+            }
         } else if (t == 0) {
-            I.misc[6] = all ? 0 : 1;
+            if constexpr (FUSED) coh_store(I.misc + 6, all ? 0 : 1); else I.misc[6] = all ? 0 : 1;
         }
     }
-    if (seg != 0) return;
-    if (k < n) {
-        const int rank = rk[lane];
-        const int idx = (int)((unsigned)mine & (role == 0 ? 0xffffffffu : kColIdxMask));
-        if (role == 0) {
-            I.order[rank] = idx;
-            I.rankof[idx] = rank;
-            I.sscore[rank] = s[idx];
-            if (boxes) I.rbox[rank] = reinterpret_cast<const float4*>(bx)[idx];
-            if (order_out) order_out[(size_t)b * N + rank] = idx;
-        } else {
-            column_store(I, rank, idx, reinterpret_cast<const float4*>(bx)[idx], mode3d);
+    if (seg == 0) {
+        if (k < n) {
+            const int rank = rk[lane];
+            const int idx = (int)((unsigned)mine & (role == 0 ? 0xffffffffu : kColIdxMask));
+            if (role == 0) {
+                if constexpr (FUSED) {
+                    coh_store(I.order + rank, idx);
+                    coh_store(I.rankof + idx, rank);
+                    coh_store(I.sscore + rank, s[idx]);
+                    if (boxes) coh_store_f4(I.rbox + rank, reinterpret_cast<const float4*>(bx)[idx]);
+                } else {
+                    I.order[rank] = idx;
+                    I.rankof[idx] = rank;
+                    I.sscore[rank] = s[idx];
+                    if (boxes) I.rbox[rank] = reinterpret_cast<const float4*>(bx)[idx];
+                }
+                if (order_out) order_out[(size_t)b * N + rank] = idx;
+            } else {
+                if constexpr (FUSED) {
+                    coh_store(I.xidx + rank, idx);
+                    coh_store_f4(I.xbox + rank, reinterpret_cast<const float4*>(bx)[idx]);
+                } else {
+                    column_store(I, rank, idx, reinterpret_cast<const float4*>(bx)[idx], mode3d);
+                }
+            }
+        } else if (k < N && role == 0) {                               // padding ranks map to themselves (order is a permutation of [0, N))
+            if constexpr (FUSED) { coh_store(I.order + k, k); coh_store(I.rankof + k, k); coh_store(I.sscore + k, 0.0f); }
+            else { I.order[k] = k; I.rankof[k] = k; I.sscore[k] = 0.0f; }
+            if (order_out) order_out[(size_t)b * N + k] = k;
         }
-    } else if (k < N && role == 0) {                                   // padding ranks map to themselves (order is a permutation of [0, N))
-        I.order[k] = k; I.rankof[k] = k; I.sscore[k] = 0.0f;
-        if (order_out) order_out[(size_t)b * N + k] = k;
     }
+    if constexpr (FUSED) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);                            // vmcnt(0): this wave's stores are acknowledged ...
+        __syncthreads();                                               // ... every wave's are
+        if (t == 0) coh_store(I.gran + (size_t)(1 + role) * 32 + blk, strong_gran(tag, kSlotSort + 32u * (unsigned)role + (unsigned)blk));
+    }
+}
+
+template <int KPW>
+__global__ __launch_bounds__(1024) void sort_count_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                          const int* __restrict__ counts, char* ws, gnms_ws_layout L,
+                                                          long long* __restrict__ order_out, int mode3d) {
+    sort_count_body<KPW>(scores, boxes, N, counts, ws, L, order_out, mode3d, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1489,11 +1541,16 @@ constexpr int kNoStage = -1;
 constexpr int kFastGroupMax = 256;   // longest group the fast tail handles (default cap: 101)
 constexpr int kGranVerdict = 30;     // gran[16][30]: the last workgroup's verdict for csr_build_body (payload 1 = fast tail, 2 = K5 ran, nothing to do)
 
-template <int STAGE = kNoStage>
+// FUSED (round 6, one_launch_kernel; a single super-block: j0 = 0, j1 = 1): sort, bit table and this chain are workgroups of ONE launch.
+// The sort's outputs are read with agent-scope loads (the caller has waited for the sort's flags); the super-block's table is not
+// gathered from W but copied from the image the table workgroups leave where W lies (one_launch_bits_*: already in this layout, word
+// (source block bb <= target block tb, target lane) = the bits M[target][source] -- the reference's own orientation, :250, so no
+// symmetry is assumed and none is checked), behind a wait for their `nflags` flags; `tag` = the launch's call counter value.
+template <int STAGE = kNoStage, bool FUSED = false>
 __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int j0,
                                                const int j1, const int me, const float* __restrict__ stage_src = nullptr, long stage_ld = 0,
                                                const float stage_thr = 0.0f, const float stage_temp = 0.0f, const int stage_prune = 0,
-                                               const int Ppow2 = 0) {
+                                               const int Ppow2 = 0, const unsigned tag = 0u, const int nflags = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t oa, ol, oc, op;
     leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -1515,7 +1572,7 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
     const bool last_wg = j1 == nsb;                                // this workgroup ends with the image's last super-block
     int have = 0;                                                  // super-blocks [0, have) have their masks in lmask (workgroup-uniform)
     int complex_img = 0;                                           // STAGE: a leader of this workgroup's ranks is outside its own group
-    const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
+    const u64 epoch = FUSED ? ((u64)tag << 32) : ((u64)(unsigned)I.misc[8] << 32);
     GNMS_T0();
     // table layout: pair (source block bb <= target block tb) at tb (tb + 1) / 2 + bb -- a target's words are consecutive, so the wave
     // that owns it reads them at immediate offsets from one base (the general scan's layout needs the triangular index per word:
@@ -1534,9 +1591,15 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
     if constexpr (STAGE != kNoStage) {
         const int kk = ((kb0 + (wave < nblk ? wave : 0)) << 6) + lane;
         if (wave < nblk && kk < n) {
-            st_sk = I.sscore[kk];
-            st_ck = I.order[kk];
-            if (STAGE == kFromBoxes) st_bk = I.rbox[kk];
+            if constexpr (FUSED) {
+                st_sk = coh_load(I.sscore + kk);
+                st_ck = coh_load(I.order + kk);
+                if (STAGE == kFromBoxes) st_bk = coh_load_f4(I.rbox + kk);
+            } else {
+                st_sk = I.sscore[kk];
+                st_ck = I.order[kk];
+                if (STAGE == kFromBoxes) st_bk = I.rbox[kk];
+            }
         }
     }
     if (tid == 0) *stamp = 0;
@@ -1544,15 +1607,30 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
     {   // the own super-block's table: no dependence on anybody (in flight while the first masks are waited for)
         constexpr int kTabAll = (kSBPairs * 64 + 1023) / 1024;
         u64 tw[kTabAll];
+        if constexpr (FUSED) {                                     // the table workgroups' flags, then their image of the table as it stands
+            if (wave == 0) {
+                const u64 want = strong_gran(tag, kSlotBits + (unsigned)(lane < nflags ? lane : 0));
+                const u64* g = I.gran + (size_t)3 * 32 + (lane < nflags ? lane : 0);
+                while (__ballot(gran_load(g) != want) != 0ull) __builtin_amdgcn_s_sleep(1);
+            }
+            __syncthreads();
+            const int npw = (nb * (nb + 1) / 2) * 64;              // the image's pairs (target block < nb): what the table workgroups wrote
 #pragma unroll
-        for (int u = 0; u < kTabAll; ++u) {
-            const int e = tid + u * 1024;
-            tw[u] = 0ull;
-            if (e < kSBPairs * 64) {
-                const int pr = e >> 6;
-                const int bb = pair_b[pr], bp = pair_bp[pr];
-                const int k = (kb0 + bp) * 64 + (e & 63);          // row block = the SOURCE block bb, column = target rank (bp, lane)
-                if (bp < nblk && k < n) tw[u] = I.W[(size_t)(kb0 + bb) * L.NC + k];
+            for (int u = 0; u < kTabAll; ++u) {
+                const int e = tid + u * 1024;
+                tw[u] = (e < npw) ? coh_load(I.W + e) : 0ull;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kTabAll; ++u) {
+                const int e = tid + u * 1024;
+                tw[u] = 0ull;
+                if (e < kSBPairs * 64) {
+                    const int pr = e >> 6;
+                    const int bb = pair_b[pr], bp = pair_bp[pr];
+                    const int k = (kb0 + bp) * 64 + (e & 63);      // row block = the SOURCE block bb, column = target rank (bp, lane)
+                    if (bp < nblk && k < n) tw[u] = I.W[(size_t)(kb0 + bb) * L.NC + k];
+                }
             }
         }
 #pragma unroll
@@ -1707,11 +1785,17 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
                 float sl = st_sk, ov;
                 if (STAGE == kFromBoxes) {
                     float4 bl = st_bk;
-                    if (lr != k) { bl = I.rbox[lr]; sl = I.sscore[lr]; }
+                    if (lr != k) {
+                        if constexpr (FUSED) { bl = coh_load_f4(I.rbox + lr); sl = coh_load(I.sscore + lr); }
+                        else { bl = I.rbox[lr]; sl = I.sscore[lr]; }
+                    }
                     ov = pair_iou(st_bk, bl);
                 } else {
                     int cb = st_ck;
-                    if (lr != k) { cb = I.order[lr]; sl = I.sscore[lr]; }
+                    if (lr != k) {
+                        if constexpr (FUSED) { cb = coh_load(I.order + lr); sl = coh_load(I.sscore + lr); }
+                        else { cb = I.order[lr]; sl = I.sscore[lr]; }
+                    }
                     ov = overlap_at<STAGE>(overlap_src<STAGE>(stage_src, I, b, N, stage_ld), stage_ld, st_ck, cb, stage_thr);
                 }
                 float pre = 0.0f, pl = 0.0f;
@@ -2724,11 +2808,11 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     if (t == 0) { if (nvalid) nvalid[b] = nv; if (ninvalid) ninvalid[b] = ni; }
 }
 
-template <int E, int SRC>
+template <int E, int SRC, bool FUSED = false>
 __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
                                                 char* ws, gnms_ws_layout L, int Ppow2, float* __restrict__ prob, long long* __restrict__ valid,
                                                 long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
-                                                const int b, const int last) {
+                                                const int b, const int last, const unsigned tag = 0u) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* r2L = reinterpret_cast<float*>(smem);                                     // r2 by rank (= position)
     int* hdL = reinterpret_cast<int*>(smem + (size_t)Ppow2 * 4);                     // head by rank
@@ -2740,7 +2824,7 @@ __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, i
     const int nb = (n + 63) >> 6;
     const int nsb = max(1, (nb + kSB - 1) / kSB);
     const int own0 = (nsb - 1) * kSB * 64;                                           // the parked super-block: [own0, n)
-    const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
+    const u64 epoch = FUSED ? ((u64)tag << 32) : ((u64)(unsigned)I.misc[8] << 32);
     const long long cap = (long long)P.group_size + 1;
     int slow = last == 2;
     GNMS_T0();
@@ -2778,7 +2862,7 @@ __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, i
     __builtin_amdgcn_s_waitcnt(0x0f70);                                              // vmcnt(0)
     __syncthreads();
     GNMS_TACC(9);
-    if (tid == 0) gran_store(I.gran + (size_t)16 * 32 + kGranVerdict, epoch | (slow ? 2ull : 1ull));
+    if (tid == 0) gran_store(I.gran + (size_t)16 * 32 + kGranVerdict, FUSED ? strong_gran(tag, kSlotVerdict + (slow ? 2u : 1u)) : (epoch | (slow ? 2ull : 1ull)));
     if (slow) {
         size_t oa, ol, oc, op;
         leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -2792,8 +2876,8 @@ __device__ __forceinline__ void fast_final_body(const float* __restrict__ src, i
     finalize_fast_body<E>(N, counts, P, ws, L, Ppow2, prob, valid, invalid, nvalid, ninvalid, b);
 }
 
-template <int E>
-__device__ __forceinline__ void csr_build_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b) {
+template <int E, bool FUSED = false>
+__device__ __forceinline__ void csr_build_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const unsigned tag = 0u) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* cnt = reinterpret_cast<int*>(smem);                                         // members per leader rank
     int* fill = cnt + E * 1024;
@@ -2804,12 +2888,20 @@ __device__ __forceinline__ void csr_build_body(int N, const int* __restrict__ co
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
     if (wave == 0) {
         const u64* g = I.gran + (size_t)16 * 32 + kGranVerdict;
         u64 v = gran_load(g);
-        while ((v & 0xffffffff00000000ull) != epoch) { __builtin_amdgcn_s_sleep(8); v = gran_load(g); }
-        if (lane == 0) { s_cnt[0] = (int)(v & 3ull); s_cnt[1] = 0; s_cnt[2] = 0; }
+        int verdict;
+        if constexpr (FUSED) {                                                       // (strong granules: the launch zeroed nothing)
+            const u64 v1 = strong_gran(tag, kSlotVerdict + 1u), v2 = strong_gran(tag, kSlotVerdict + 2u);
+            while (v != v1 && v != v2) { __builtin_amdgcn_s_sleep(8); v = gran_load(g); }
+            verdict = v == v1 ? 1 : 2;
+        } else {
+            const u64 epoch = (u64)(unsigned)I.misc[8] << 32;
+            while ((v & 0xffffffff00000000ull) != epoch) { __builtin_amdgcn_s_sleep(8); v = gran_load(g); }
+            verdict = (int)(v & 3ull);
+        }
+        if (lane == 0) { s_cnt[0] = verdict; s_cnt[1] = 0; s_cnt[2] = 0; }
     }
     for (int i = tid; i < E * 1024; i += 1024) { cnt[i] = 0; fill[i] = 0; }
     __syncthreads();

@@ -14,6 +14,7 @@
 #include "iou3d_tile.h"
 #include "iou3d_sym.h"
 #include "nms_solve_kernels.h"
+#include "nms_one_launch.h"
 
 // defined in iou_kernels.hip
 bool gnms_internal_overlap3d_sym_ok(int N, int64_t ld, const float* out);
@@ -1081,6 +1082,38 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     return GNMS_OK;
 }
 
+// A small image's whole forward pass as ONE launch (nms_one_launch.h): masked groups, hard sort, N <= 1024 (one super-block), a 16-byte
+// aligned matrix with ld % 4 == 0, and no more workgroups than two rounds of the machine (every one asks for the chain's LDS, so a CU
+// holds one).  GNMS_ONE_LAUNCH=0: never (developer / test switch: the three-launch path stays reachable for A/B runs and the tests).
+bool one_launch_enabled() {
+    static const bool on = [] { const char* e = getenv("GNMS_ONE_LAUNCH"); return !(e && e[0] == '0'); }();
+    return on;
+}
+struct OneLaunchPlan { int kpw, split, grid; };
+bool one_launch_plan(int B, int N, const gnms_params& P, OneLaunchPlan* plan) {
+    if (!one_launch_enabled() || !fast_tail_enabled() || N > kOneLaunchMaxN || !fast_tail_ok(N, P, 1)) return false;
+    const int cus = device_cu_count();
+    const int NP = (N + 63) & ~63, NB = NP / 64;
+    const int kpw = (NP % 128 == 0 && (long)B * (NP / 32) <= (long)cus / 2) ? 32 : 64;
+    int split = 4;                                                // table workgroups: 16 rows each while that leaves the machine half empty
+    while (split > 1 && (long)B * NB * split > (long)cus / 2) split >>= 1;
+    const long grid = (long)B * (NP / kpw + NB * split + 2);
+    if (grid > 2L * cus) return false;
+    plan->kpw = kpw; plan->split = split; plan->grid = (int)grid;
+    return true;
+}
+int launch_one_matrix(const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts, const gnms_params& P, char* ws,
+                      const gnms_ws_layout& L, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid,
+                      hipStream_t st, const OneLaunchPlan& plan) {
+    const size_t lds = one_launch_lds_size(N);
+    int rc;
+    if ((rc = allow_lds(one_launch_kernel<kFromMatrix>, lds))) return rc;
+    one_launch_kernel<kFromMatrix><<<plan.grid, 1024, lds, st>>>(scores, iou, N, (long)ld, counts, P, ws, L, prob, (long long*)valid, (long long*)invalid,
+                                                                 nvalid, ninvalid, (long long*)order, B, plan.kpw, plan.split);
+    GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
 int forward_impl(const char* fn, const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts,
                  const gnms_params* params, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid,
                  int32_t* ninvalid, void* workspace, size_t workspace_bytes, void* stream, bool scores_already_sorted,
@@ -1104,6 +1137,11 @@ int forward_impl(const char* fn, const float* scores, const float* iou, int B, i
     const size_t sort_lds = (size_t)P2 * 8;
     const int sort_threads = P2 <= 1024 ? P2 : 1024;
 
+    {   // a small image: sort, threshold bits and chain as one launch
+        OneLaunchPlan plan;
+        if (!scores_already_sorted && (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0) && one_launch_plan(B, N, P, &plan))
+            return launch_one_matrix(scores, iou, B, N, ld, counts, P, ws, L, prob, order, valid, invalid, nvalid, ninvalid, st, plan);
+    }
     const bool permute_from_boxes = boxes2d && !P.group_boxes && !P.presorted && !scores_already_sorted;
     // (with the boxes the score sort also leaves them in rank order, rbox; its second role, the boxes by x centre, is not used here)
     if (!scores_already_sorted && (rc = launch_sorts(scores, permute_from_boxes ? boxes2d : nullptr, B, N, counts, ws, L, P2, order, st))) return rc;

@@ -2911,12 +2911,15 @@ def test_counts_slot_ownership_under_threads(G):
 
 
 @pytest.mark.gpu
-def test_bitmask_small_kernel_against_the_row_kernel(O):
-    """bitmask_small_kernel (K2 of few, small images: the 64 rows of a rank block dealt to eight waves, the words assembled from bytes in LDS)
-    stores exactly the words of bitmask_kernel: the matrix-in layer's probabilities, lists, counts and gradients with it (default) and
-    without it (GNMS_BITMASK_SMALL=0) are the same bit for bit -- sizes around the 64-row and 256-column edges, with and without the
-    symmetry detection (N >= 256), ragged batches with an empty image, already sorted scores (only the triangle is stored), an asymmetric
-    matrix, NaN entries (:250 removes them), a strided matrix view (ld > N) -- and the default run equals the oracle."""
+def test_one_launch_against_three_launches(O):
+    """Round 6: up to N = 1024 the matrix-in layer is ONE launch (one_launch_kernel: sort, the scan's table straight from the matrix, chain;
+    nms_one_launch.h); GNMS_ONE_LAUNCH=0 keeps the three launches (sort_count_kernel, bitmask_small_kernel, tail_kernel with the symmetry check).
+    Probabilities, order, lists, counts and gradients of the two are the same bit for bit -- sizes around the 64-row and 256-column edges,
+    batches (ragged, with an empty image), already sorted scores, the presorted mode (never the one launch), an asymmetric matrix (the one
+    launch reads the reference's own triangle, the three launches find the asymmetry and take the general scan), NaN entries (:250 removes
+    them), a strided matrix view (ld > N), an odd ld (never the one launch), groups above the cap (verdict "slow": K5 proper inside the launch),
+    negative thresholds, the same call repeated, single images through the reference's own signature -- and the default run equals the oracle
+    (the launch inside a captured graph: test_capturable_in_a_hip_graph, N = 1024)."""
     code = """
 import sys, numpy as np, torch
 import groomed_nms_amd as G
@@ -2964,13 +2967,31 @@ wide = torch.zeros((5, 700, 704), device="cuda"); wide[:, :, :700] = m
 run("strided", st, wide[:, :, :700])
 odd = torch.zeros((5, 700, 701), device="cuda"); odd[:, :, :700] = m
 run("odd_ld", st, odd[:, :, :700])                      # (ld % 4 != 0: the scalar row kernel either way)
+b8, s8 = synthetic.batch_2d(9, 8, 1024, "uniform")
+m8 = overlaps.iou_batched(torch.from_numpy(b8).cuda())
+run("b8_n1024", torch.from_numpy(s8).cuda(), m8)
+b3, s3 = synthetic.batch_2d(10, 3, 500, "clustered", per=25)
+m3 = overlaps.iou_batched(torch.from_numpy(b3).cuda())
+for gs in (2, 30, 100):
+    run("cap%d" % gs, torch.from_numpy(s3).cuda(), m3, group_size=gs)
+run("negthr", torch.from_numpy(s3).cuda(), m3, nms_threshold=-0.5)
+run("thr0", torch.from_numpy(s3).cuda(), m3, nms_threshold=0.0)
+run("sorted_prob", torch.from_numpy(s3).cuda(), m3, return_sorted_prob=True)
+for rep in range(3):                                     # the call counter moves on, stale flags never match
+    run("rep%d" % rep, torch.from_numpy(s3).cuda(), m3)
+# one image through the reference's own signature (index tensors through the pinned counts slot), twenty calls of alternating sizes
+for i in range(20):
+    n = (500, 130, 64, 1000)[i % 4]
+    bb, ss = synthetic.batch_2d(60 + i, 1, n, "clustered", per=20)
+    o = G.differentiable_nms(torch.from_numpy(ss[0]).cuda(), overlaps.iou(torch.from_numpy(bb[0]).cuda(), torch.from_numpy(bb[0]).cuda()))
+    out["single%d_prob" % i], out["single%d_valid" % i], out["single%d_invalid" % i] = o[2].cpu().numpy(), o[0].cpu().numpy(), o[1].cpu().numpy()
 torch.cuda.synchronize()
 np.savez(sys.argv[1], **out)
 print("ok")
 """
     runs = {}
-    for tag, env in (("default", {}), ("row_kernel", {"GNMS_BITMASK_SMALL": "0"})):
-        path = "/tmp/gnms_bitmask_small_%s.npz" % tag
+    for tag, env in (("default", {}), ("row_kernel", {"GNMS_ONE_LAUNCH": "0"})):
+        path = "/tmp/gnms_one_launch_%s.npz" % tag
         r = _run_py(code, env, argv=(path,))
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stderr[-2000:])
         runs[tag] = np.load(path)
