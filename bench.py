@@ -386,7 +386,7 @@ def main():
             self_ok = N <= 4096 and B <= 127 and B * ((N + 7) // 8) >= 8 * 256
             wname = ("iou2d_self_kernel" if self_ok else ("write_staged_kernel" if N > 4096 and N % 4 == 0 else "iou2d_kernel")) if args.dim == 2 else "iou3d_sym_kernel"
         r_write = roof(ms_write, n_write, alg_write, wname, fill_gbs, fill_what)
-        r_read = roof(ms_read, n_read, alg_read, "bitmask_kernel", read_gbs, "plain non-temporal float4 load stream (gnms_profile_read)")
+        r_read = roof(ms_read, n_read, alg_read, "one_launch_kernel" if N <= 1024 and os.environ.get("GNMS_ONE_LAUNCH", "1") != "0" else "bitmask_kernel", read_gbs, "plain non-temporal float4 load stream (gnms_profile_read)")
 
         total_boxes = world * B * N * args.steps
         value = total_boxes / dt
@@ -559,7 +559,7 @@ def main():
                        "whole_step_frac": round((bytes_w + (bytes_r if (two_calls or ref_3d) else 0.0)) / (dts / steps) / 1e9 / HBM_PEAK_GBS, 4),
                        "roofline": brief(msw, nw_, bytes_w * (2.0 if ref_3d else 1.0), wn)}
                 if two_calls or ref_3d:
-                    res["roofline_matrix_in"] = brief(msr, nr_, bytes_r, "bitmask_kernel")
+                    res["roofline_matrix_in"] = brief(msr, nr_, bytes_r, "one_launch_kernel" if n_ <= 1024 and os.environ.get("GNMS_ONE_LAUNCH", "1") != "0" else "bitmask_kernel")
                 if cabi_ms is not None:
                     res["c_abi_ms_per_step"] = round(cabi_ms, 4)
                 return res
@@ -586,6 +586,84 @@ def main():
                 out["two_calls_other_kind"] = {"error": str(e)[:300]}
             finally:
                 args.kind = keep
+
+        if world == 1 and not args.no_extras and not args.graph and not args.two_calls and args.dim == 2 and not args.sorted_scores:
+            # (round 6) the reference's OWN operating points, which it never exceeds: differentiable_nms on <= 500 boxes of one image, two images
+            # per batch (lib/loss/rpn_3d.py:732,772-793; scripts/config/groumd_nms.py:116), gpu_nms on <= nms_topN_pre = 3000 boxes
+            # (lib/rpn_util.py:1285-1334), the ablations' modes at N = 500 (scripts/config/: group_boxes / mask_group_boxes = False), and the
+            # soft sort (lib/groomed_nms.py:131-165, test-only) -- the one MFMA kernel of the path -- against torch.matmul on this box
+            def timed_us(fn, n, warm):
+                for _ in range(warm):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e6
+
+            def ref_call(lazy, **kw):
+                bx_np, sc_np = synthetic.batch_2d(1000, 2, 500, args.kind)
+                bxs = [torch.from_numpy(bx_np[i]).to(dev) for i in range(2)]
+                scs = [torch.from_numpy(sc_np[i]).to(dev).requires_grad_(True) for i in range(2)]
+                from groomed_nms_amd import groomed_nms as GN
+                keep = GN.LAZY_INDEX_LISTS
+                GN.LAZY_INDEX_LISTS = lazy
+
+                def fwd():
+                    for i in range(2):                                       # the per-image loop of rpn_3d.py:772-793
+                        ov = overlaps.iou(bxs[i], bxs[i])
+                        G.differentiable_nms(scs[i], ov, **kw)
+
+                def fwd_bwd():
+                    tot = None
+                    for i in range(2):
+                        ov = overlaps.iou(bxs[i], bxs[i])
+                        pr = G.differentiable_nms(scs[i], ov, **kw)[2]
+                        tot = pr.sum() if tot is None else tot + pr.sum()
+                    scs[0].grad = scs[1].grad = None
+                    tot.backward()
+                try:
+                    return {"us_forward": round(timed_us(fwd, 300, 30), 1), "us_forward_backward": round(timed_us(fwd_bwd, 200, 20), 1)}
+                finally:
+                    GN.LAZY_INDEX_LISTS = keep
+            try:
+                out["ref_call_N500_B2"] = {"workload": "per image of 2: iou(boxes, boxes) + differentiable_nms(scores, iou) on 500 %s boxes, GPU tensors "
+                                                       "(lib/loss/rpn_3d.py:772-793); host included" % args.kind,
+                                           "index_tensors": ref_call(False), "lazy_index_lists": ref_call(True),
+                                           "modes_us_forward_backward": {"grouped_unmasked": ref_call(False, mask_group_boxes=False)["us_forward_backward"],
+                                                                         "ungrouped": ref_call(False, group_boxes=False)["us_forward_backward"],
+                                                                         "sigmoidal": ref_call(False, pruning_method="sigmoidal", temperature=0.1)["us_forward_backward"]}}
+            except Exception as e:
+                out["ref_call_N500_B2"] = {"error": str(e)[:300]}
+            try:
+                from groomed_nms_amd.nms import gpu_nms
+                bx_np, sc_np = synthetic.batch_2d(1000, 1, 3000, args.kind)
+                dets = np.concatenate([bx_np[0], sc_np[0][:, None]], axis=1).astype(np.float32)
+                dets = dets[np.argsort(-dets[:, 4], kind="stable")]
+                us = timed_us(lambda: gpu_nms(dets, 0.4, device_id=0), 200, 20)
+                out["gpu_nms_N3000"] = {"workload": "gpu_nms(dets[3000, 5] on the host, 0.4) -> keep (lib/rpn_util.py:1285-1334; the C symbol _nms, both PCIe "
+                                                    "directions included)", "us_per_call": round(us, 1), "kept": int(len(gpu_nms(dets, 0.4, device_id=0)))}
+            except Exception as e:
+                out["gpu_nms_N3000"] = {"error": str(e)[:300]}
+            try:
+                n_ss = 4096
+                bx_np, sc_np = synthetic.batch_2d(1000, 1, n_ss, args.kind)
+                sc_t = torch.from_numpy(sc_np[0]).to(dev)
+                ov_t = overlaps.iou(torch.from_numpy(bx_np[0]).to(dev), torch.from_numpy(bx_np[0]).to(dev))
+                ms_ss = timed_us(lambda: G.soft_sort(sc_t, ov_t, temperature=1.0), 20, 3) / 1e3
+                a_t = torch.rand((n_ss, n_ss), device=dev)
+                ms_mm = timed_us(lambda: torch.matmul(a_t, ov_t), 20, 3) / 1e3
+                flops = 2.0 * n_ss ** 3
+                peak_tf = 157.3                                              # fp32 matrix peak, MI355X_MICROARCH.md
+                out["soft_sort_N4096"] = {"workload": "soft_sort(scores[4096], iou[4096, 4096]): P = softmax rows, P @ iou on v_mfma_f32_32x32x2_f32 "
+                                                      "(lib/groomed_nms.py:131-165)", "ms_per_call": round(ms_ss, 4),
+                                          "roofline": {"bound": "mfma", "achieved": round(flops / (ms_ss * 1e-3) / 1e12, 1), "peak": peak_tf, "unit": "TFLOP/s",
+                                                       "frac": round(flops / (ms_ss * 1e-3) / 1e12 / peak_tf, 4),
+                                                       "note": "whole call (row kernels + GEMM) over the GEMM's flops"},
+                                          "torch_matmul_same_box": {"ms": round(ms_mm, 4), "TFLOP/s": round(flops / (ms_mm * 1e-3) / 1e12, 1)}}
+            except Exception as e:
+                out["soft_sort_N4096"] = {"error": str(e)[:300]}
 
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O

@@ -347,8 +347,9 @@ extern "C" void _nms(int* keep_out, int* num_out, const float* boxes_host, int b
         lock = std::unique_lock<std::mutex>(S->mu);
         if (S->bytes < st_need) {
             if (S->host) { (void)hipDeviceSynchronize(); (void)hipHostFree(S->host); S->host = S->dev = nullptr; S->bytes = 0; }
-            // (GNMS_NMS_STAGE_MIN: the block's first size in bytes -- the test of its growth starts it small)
-            static const size_t min_bytes = [] { const char* e = getenv("GNMS_NMS_STAGE_MIN"); return e ? (size_t)atoll(e) : (size_t)(4u << 20); }();
+            // (the block starts at 64 KiB -- a call at the reference's sizes, <= 3000 boxes -- and grows to what the largest call needed: a
+            // device synchronisation and a re-allocation each time, a handful of times per process; test_classic_nms_pinned_staging walks it up)
+            constexpr size_t min_bytes = (size_t)64 << 10;
             const size_t want = std::max<size_t>((st_need + (1u << 16) - 1) >> 16 << 16, min_bytes);
             void *h = nullptr, *d = nullptr;
             if (hipHostMalloc(&h, want, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {

@@ -554,8 +554,8 @@ __global__ __launch_bounds__(1024) void sort_merge_kernel(const float* __restric
 // workgroup of the launch reads leaves through agent-scope stores, and the workgroup's last act is its "sorted" flag.
 __device__ __forceinline__ u64 strong_gran(unsigned tag, unsigned slot) { return ((u64)tag << 32) | (u64)(unsigned)(~tag ^ (0x9E3779B9u * (slot + 1u))); }
 constexpr unsigned kSlotSort = 0u;       // + 32 * role + workgroup of the sort          -> gran[1 + role][workgroup]
-constexpr unsigned kSlotBits = 64u;      // + workgroup of the bit table (<= 64)         -> gran[3 .. 4][workgroup]
-constexpr unsigned kSlotVerdict = 128u;  // + the verdict (1 fast tail, 2 K5 proper ran) -> gran[16][kGranVerdict]
+constexpr unsigned kSlotBits = 64u;      // + workgroup of the bit table (<= 416)        -> gran[3 .. 15][workgroup]
+constexpr unsigned kSlotVerdict = 512u;  // + the verdict (1 fast tail, 2 K5 proper ran) -> gran[16][kGranVerdict]
 
 template <int KPW, bool FUSED = false>   // keys per workgroup: 64, or 32 where that still is one round of the machine (B = 1, N = 4096: 10.5 -> ? us)
 __device__ __forceinline__ void sort_count_body(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
@@ -1550,7 +1550,7 @@ template <int STAGE = kNoStage, bool FUSED = false>
 __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int j0,
                                                const int j1, const int me, const float* __restrict__ stage_src = nullptr, long stage_ld = 0,
                                                const float stage_thr = 0.0f, const float stage_temp = 0.0f, const int stage_prune = 0,
-                                               const int Ppow2 = 0, const unsigned tag = 0u, const int nflags = 0) {
+                                               const int Ppow2 = 0, const unsigned tag = 0u, const int nflags = 0, const size_t lds_side = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t oa, ol, oc, op;
     leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -1590,16 +1590,21 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
     float4 st_bk = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (STAGE != kNoStage) {
         const int kk = ((kb0 + (wave < nblk ? wave : 0)) << 6) + lane;
-        if (wave < nblk && kk < n) {
-            if constexpr (FUSED) {
-                st_sk = coh_load(I.sscore + kk);
-                st_ck = coh_load(I.order + kk);
-                if (STAGE == kFromBoxes) st_bk = coh_load_f4(I.rbox + kk);
-            } else {
-                st_sk = I.sscore[kk];
-                st_ck = I.order[kk];
-                if (STAGE == kFromBoxes) st_bk = I.rbox[kk];
+        if constexpr (FUSED) {
+            // the whole image's order / scores (/ boxes) by rank into LDS, beside everything else (smem + lds_side): the rank's own values and,
+            // behind the resolve, its leader's come from there -- one gather level (the overlap entry) instead of two
+            int* ordA = reinterpret_cast<int*>(smem + lds_side);
+            float* sscA = reinterpret_cast<float*>(ordA + 1024);
+            float4* rbxA = reinterpret_cast<float4*>(smem + lds_side + 8192);
+            if (tid < n) {
+                ordA[tid] = coh_load(I.order + tid);
+                sscA[tid] = coh_load(I.sscore + tid);
+                if (STAGE == kFromBoxes) rbxA[tid] = coh_load_f4(I.rbox + tid);
             }
+        } else if (wave < nblk && kk < n) {
+            st_sk = I.sscore[kk];
+            st_ck = I.order[kk];
+            if (STAGE == kFromBoxes) st_bk = I.rbox[kk];
         }
     }
     if (tid == 0) *stamp = 0;
@@ -1609,11 +1614,22 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
         u64 tw[kTabAll];
         if constexpr (FUSED) {                                     // the table workgroups' flags, then their image of the table as it stands
             if (wave == 0) {
-                const u64 want = strong_gran(tag, kSlotBits + (unsigned)(lane < nflags ? lane : 0));
-                const u64* g = I.gran + (size_t)3 * 32 + (lane < nflags ? lane : 0);
-                while (__ballot(gran_load(g) != want) != 0ull) __builtin_amdgcn_s_sleep(1);
+                for (int f0 = 0; f0 < nflags; f0 += 64) {         // (<= 13 x 32 flags: gran[3 .. 15])
+                    const int f = f0 + lane < nflags ? f0 + lane : f0;
+                    const u64 want = strong_gran(tag, kSlotBits + (unsigned)f);
+                    const u64* g = I.gran + (size_t)3 * 32 + f;
+                    while (__ballot(gran_load(g) != want) != 0ull) __builtin_amdgcn_s_sleep(1);
+                }
             }
             __syncthreads();
+            if constexpr (STAGE != kNoStage) {
+                const int kk = ((kb0 + (wave < nblk ? wave : 0)) << 6) + lane;
+                if (wave < nblk && kk < n) {
+                    st_sk = reinterpret_cast<const float*>(smem + lds_side + 4096)[kk];
+                    st_ck = reinterpret_cast<const int*>(smem + lds_side)[kk];
+                    if (STAGE == kFromBoxes) st_bk = reinterpret_cast<const float4*>(smem + lds_side + 8192)[kk];
+                }
+            }
             const int npw = (nb * (nb + 1) / 2) * 64;              // the image's pairs (target block < nb): what the table workgroups wrote
 #pragma unroll
             for (int u = 0; u < kTabAll; ++u) {
@@ -1749,7 +1765,42 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
     if (j + 1 > have) have = j + 1;                                // (every super-block up to j is in lmask from here on: polled above, or this workgroup's own)
     const u64 ext = __ballot(cl >= 0);                             // removed-word of the wave's block (earlier super-blocks' leaders)
     GNMS_TACC_IF(b == 0 && last_sb, 1);
-    resolve(ext);
+    if constexpr (FUSED) {
+        // A single super-block with nobody to hand masks to: ONE wave walks the blocks in order -- lane = rank of the block, the table words of
+        // block t2 against the masks of the blocks before it (wave-uniform: scalar registers), then the in-block fixed point -- no barrier and no
+        // repeated steps: ~150-300 cycles per block where the sixteen-wave fixed point above takes 4-7 steps of ~1200 (N = 500: 4.3 -> ~1 us)
+        if (wave == 0) {
+            u64 m[kSB];
+#pragma unroll
+            for (int t2 = 0; t2 < kSB; ++t2) {
+                m[t2] = 0ull;
+                if (t2 < nblk) {                                   // (wave-uniform)
+                    const u64* X = Xs + (size_t)(t2 * (t2 + 1) / 2) * 64 + lane;
+                    u64 hit = 0ull;
+#pragma unroll
+                    for (int bb = 0; bb < t2; ++bb) hit |= X[bb * 64] & m[bb];
+                    const u64 csq = X[t2 * 64] & below;
+                    const int nr = min(64, n - ((kb0 + t2) << 6));
+                    const u64 cur = __ballot(hit != 0ull) | (nr < 64 ? ~((1ull << nr) - 1ull) : 0ull);
+                    u64 leaders = ~cur;
+                    if (leaders != 0ull) {
+                        const bool cand = ((cur >> lane) & 1ull) == 0ull;
+                        for (;;) {                                 // in-block fixed point: positions < t are final after t rounds
+                            const u64 nl = __ballot(cand && (csq & leaders) == 0ull);
+                            if (nl == leaders) break;
+                            leaders = nl;
+                        }
+                    }
+                    m[t2] = leaders;
+                    if (lane == 0) lmask[kb0 + t2] = leaders;
+                }
+            }
+        }
+        lds_barrier();
+        mine = live ? lmask[kb0 + tb] : 0ull;
+    } else {
+        resolve(ext);
+    }
 #ifdef GNMS_TIMING
     if (threadIdx.x == 0 && b == 0 && last_sb) gnms_tbuf()[20] += step;
 #endif
@@ -1786,14 +1837,14 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
                 if (STAGE == kFromBoxes) {
                     float4 bl = st_bk;
                     if (lr != k) {
-                        if constexpr (FUSED) { bl = coh_load_f4(I.rbox + lr); sl = coh_load(I.sscore + lr); }
+                        if constexpr (FUSED) { bl = reinterpret_cast<const float4*>(smem + lds_side + 8192)[lr]; sl = reinterpret_cast<const float*>(smem + lds_side + 4096)[lr]; }
                         else { bl = I.rbox[lr]; sl = I.sscore[lr]; }
                     }
                     ov = pair_iou(st_bk, bl);
                 } else {
                     int cb = st_ck;
                     if (lr != k) {
-                        if constexpr (FUSED) { cb = coh_load(I.order + lr); sl = coh_load(I.sscore + lr); }
+                        if constexpr (FUSED) { cb = reinterpret_cast<const int*>(smem + lds_side)[lr]; sl = reinterpret_cast<const float*>(smem + lds_side + 4096)[lr]; }
                         else { cb = I.order[lr]; sl = I.sscore[lr]; }
                     }
                     ov = overlap_at<STAGE>(overlap_src<STAGE>(stage_src, I, b, N, stage_ld), stage_ld, st_ck, cb, stage_thr);
@@ -2641,10 +2692,13 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
     const int n_nan = (int)(tot0 & 0xffffu), ni = (int)(tot1 >> 16);
     int nA = (int)(tot0 >> 16), nB = (int)(tot1 & 0xffffu);
     const int nv = nA + nB, n_ge = n_nan + nv;
+    // the two counts leave as soon as they are known: where they go to pinned host memory (gnms_host_counts_slot: the reference's index
+    // tensors have a data-dependent length) the host takes them ~3 us before the lists below are complete -- which it does not read; whatever
+    // it enqueues next is behind this launch on the stream
+    if (t == 0) { if (nvalid) nvalid[b] = nv; if (ninvalid) ninvalid[b] = ni; }
     if (!valid && !invalid && !P.return_sorted_prob) {
         // the caller wants the probabilities only (training reads just the third return value, lib/loss/rpn_3d.py:791)
         for (int j = t; j < N; j += 1024) pb[j] = (j < n) ? r2L[j] : 0.0f;                    // (grouped mode: the un-thresholded clone, :124-125)
-        if (t == 0) { if (nvalid) nvalid[b] = nv; if (ninvalid) ninvalid[b] = ni; }
         return;
     }
     const bool sorted_out = P.return_sorted_prob != 0;
@@ -2805,7 +2859,6 @@ __device__ __forceinline__ void finalize_fast_body(int N, const int* __restrict_
         else if (j >= n) pb[j] = 0.0f;
     }
     GNMS_TACC(14);
-    if (t == 0) { if (nvalid) nvalid[b] = nv; if (ninvalid) ninvalid[b] = ni; }
 }
 
 template <int E, int SRC, bool FUSED = false>

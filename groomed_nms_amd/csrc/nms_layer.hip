@@ -377,8 +377,8 @@ int launch_bitmask(const float* iou, int B, int N, int64_t ld, const int32_t* co
     const bool vec = (ld % 4 == 0) && ((uintptr_t)iou % 16 == 0);
 #define GNMS_BITMASK(V, W, R)                                                                                                         \
     gnms_launch_prof(kProfMatrixRead, bitmask_kernel<V, W, R>, dim3(gnms_div_up(N, W * 256), L.NB, B), dim3(W * 64), 0, st, iou, N, (long)ld, counts, thr, ws, L, full)
-    // few, small images: one batch of loads per wave instead of eight in a row (bitmask_small_kernel); GNMS_BITMASK_SMALL=0: never (developer A/B)
-    static const int small_wgs = [] { const char* e = getenv("GNMS_BITMASK_SMALL"); return e ? atoi(e) : 1024; }();
+    // few, small images: one batch of loads per wave instead of eight in a row (bitmask_small_kernel)
+    constexpr int small_wgs = 1024;
     if (!vec) GNMS_BITMASK(false, kMaskWaves, kMaskRB);
     else if (N <= 2048 && (long)B * L.NB * gnms_div_up(N, 256) <= (long)small_wgs)        // (N = 4096, B = 1 keeps the row-buffered 16-wave kernel)
         gnms_launch_prof(kProfMatrixRead, bitmask_small_kernel, dim3(gnms_div_up(N, 256), L.NB, B), dim3(512), 0, st, iou, N, (long)ld, counts, thr, ws, L, full);
@@ -885,6 +885,49 @@ __global__ __launch_bounds__(1024) void tail_write_kernel(const float* __restric
     writers_persistent<VEC, SRC>(write_src, N, out, ld, nimg, tile_rows, row0, row_end, P.nms_threshold, img_ptrs(ws, L, 0).misc + 5);
 }
 
+// gnms_forward_with_iou2d on small images as ONE launch (nms_one_launch.h): [matrix writers] [sort] [table from the boxes] [chain] [CSR].
+// The writers are writers_staged_2d with a slot of the claim ring (as iou2d_self_kernel: zero at the start, re-zeroed by the last writer
+// to leave).
+__global__ __launch_bounds__(1024) void one_launch_boxes_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, int N,
+                                                                const int* __restrict__ counts, gnms_params P, char* ws, gnms_ws_layout L,
+                                                                float* __restrict__ prob, long long* __restrict__ valid, long long* __restrict__ invalid,
+                                                                int* __restrict__ nvalid, int* __restrict__ ninvalid, long long* __restrict__ order_out,
+                                                                int B, int kpw, int tpw, float* __restrict__ out, long ld, int* __restrict__ claims,
+                                                                int nwriters) {
+    GNMS_TINIT();
+    const int NP = (N + 63) & ~63, nsort = NP / kpw, nbits = (L.NB * (L.NB + 1) / 2 + tpw - 1) / tpw;
+    int bx = (int)blockIdx.x, b;
+    if (bx < nwriters) {
+        // the writers FIRST in the grid: they wait for nobody and are the longest role at N = 1024 (every workgroup of the launch holds a CU
+        // to itself -- the chain's LDS -- so behind the sort and table workgroups they would only start when those retire: 36 us against 20)
+        writers_staged_2d<true>(boxes, N, out, ld, B, claims, 64, 0);
+        if (threadIdx.x == 0) {                                             // (thread 0 issued every claim of this workgroup and has consumed them all)
+            int* done = claims + (size_t)B * 64;
+            if (atomicAdd(done, 1) == nwriters - 1) {
+                for (int i = 0; i <= B; ++i) atomicExch(claims + (size_t)i * 64, 0);
+            }
+        }
+        return;
+    }
+    bx -= nwriters;
+    if (bx < B * nsort) {
+        b = bx / nsort;
+        const unsigned tag = (unsigned)gnms_next_epoch(coh_load(img_ptrs(ws, L, b).misc + 8));
+        if (kpw == 32) sort_count_body<32, true>(scores, boxes, N, counts, ws, L, order_out, 0, bx - b * nsort, b, 0, tag);
+        else sort_count_body<64, true>(scores, boxes, N, counts, ws, L, order_out, 0, bx - b * nsort, b, 0, tag);
+        return;
+    }
+    bx -= B * nsort;
+    if (bx < B * nbits) {
+        b = bx / nbits;
+        const unsigned tag = (unsigned)gnms_next_epoch(coh_load(img_ptrs(ws, L, b).misc + 8));
+        one_launch_bits_from_boxes(N, counts, P.nms_threshold, ws, L, b, bx - b * nbits, tpw, tag, nsort);
+        return;
+    }
+    bx -= B * nbits;
+    one_launch_chain_or_csr<kFromBoxes>(boxes, N, (long)N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, B, bx, nsort, nbits);
+}
+
 // bitmask_boxes_kernel: workgroups of 4 wave tiles, (row blocks) x (column chunks) tiles per image; 4 columns per lane
 // (64 x 256 tiles) when that already gives every SIMD a couple of waves, else 1 column per lane (64 x 64 tiles)
 int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts, float thr, char* ws, const gnms_ws_layout& L, hipStream_t st) {
@@ -927,8 +970,8 @@ int launch_sorts(const float* scores, const float* boxes, int B, int N, const in
                  int64_t* order, hipStream_t st, int mode3d = 0) {
     int rc;
     const int roles = boxes ? 2 : 1;
-    // up to 2048 keys: by counting, N / 64 workgroups per image and role (sort_count_kernel); GNMS_COUNT_SORT=0: the LDS sorts below (developer A/B)
-    static const bool count_sort = [] { const char* e = getenv("GNMS_COUNT_SORT"); return !(e && e[0] == '0'); }();
+    // up to 2048 keys: by counting, N / 64 workgroups per image and role (sort_count_kernel)
+    constexpr bool count_sort = true;
     // (... and up to 4096 keys where its N / 64 workgroups per image and role are ONE round of the machine -- B <= 2: 256 compares per thread,
     // ~8 us in one launch against 14 us of runs + merge; from two rounds on the merge sort wins, LABNOTES R5.6)
     if (count_sort && (N <= 2048 || (N <= 4096 && (long)B * ((N + 63) / 64) * roles <= (long)device_cu_count()))) {
@@ -1058,11 +1101,8 @@ int launch_tail_write(const float* chain_src, const float* write_src, int B, int
     // the stores.  B = 8, N = 4096, same box, ms per step clustered / uniform: 216 writers 0.140 / 0.160, 208 0.139 / 0.158,
     // 200 0.140 / 0.151, 192 0.142 / 0.142, 184 0.144 / 0.144 -- at 24 writers per XCD the chain of the uniform images (1890
     // leaders each) stops being the longer side of the launch, at the price of 1.5 % on clustered ones.  (A plain fill in this
-    // geometry: 6.2-6.4 TB/s from 64-128 workgroups, 5.8 from 248: profiles/r03*_store_geometry.jsonl.)  GNMS_TAIL_WRITERS overrides.
-    static const int writers_cap = [] { const char* e = getenv("GNMS_TAIL_WRITERS"); return e ? atoi(e) : 0; }();
-    // (round 4: the scan runs on nsb workgroups per image and the chain is no longer the longer side of the launch -- the cap is what the
-    // store stream itself likes, GNMS_TAIL_WRITERS)
-    const int cap = writers_cap > 0 ? writers_cap : (staged == 1 ? (cus * 208) / 256 : 0);
+    // geometry: 6.2-6.4 TB/s from 64-128 workgroups, 5.8 from 248: profiles/r03*_store_geometry.jsonl.)
+    const int cap = staged == 1 ? (cus * 208) / 256 : 0;
     if (cap > 0 && writers > cap) writers = cap;
     const dim3 grid((unsigned)(B * (leaders_chain_wgs(N, 1) + fast) + writers));
     const bool vec = (ld % 4 == 0) && ((uintptr_t)out % 16 == 0);
@@ -1105,12 +1145,54 @@ bool one_launch_plan(int B, int N, const gnms_params& P, OneLaunchPlan* plan) {
 int launch_one_matrix(const float* scores, const float* iou, int B, int N, int64_t ld, const int32_t* counts, const gnms_params& P, char* ws,
                       const gnms_ws_layout& L, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid,
                       hipStream_t st, const OneLaunchPlan& plan) {
-    const size_t lds = one_launch_lds_size(N);
+    const size_t lds = one_launch_lds_size(N, false);
     int rc;
     if ((rc = allow_lds(one_launch_kernel<kFromMatrix>, lds))) return rc;
-    one_launch_kernel<kFromMatrix><<<plan.grid, 1024, lds, st>>>(scores, iou, N, (long)ld, counts, P, ws, L, prob, (long long*)valid, (long long*)invalid,
-                                                                 nvalid, ninvalid, (long long*)order, B, plan.kpw, plan.split);
+    // (profile slot of the matrix READ: this launch holds the layer's one pass over the matrix -- bench.py's `roofline_matrix_in`)
+    gnms_launch_prof(kProfMatrixRead, one_launch_kernel<kFromMatrix>, dim3((unsigned)plan.grid), dim3(1024), lds, st, scores, iou, N, (long)ld, counts, P, ws, L, prob,
+                     (long long*)valid, (long long*)invalid, nvalid, ninvalid, (long long*)order, B, plan.kpw, plan.split);
     GNMS_CHECK_LAUNCH();
+    return GNMS_OK;
+}
+
+// the one-call entry (gnms_forward_with_iou2d, masked groups): the same with the table from the boxes and the matrix writers behind the chain
+int launch_one_boxes(const float* scores, const float* boxes, int B, int N, const int32_t* counts, const gnms_params& P, char* ws,
+                     const gnms_ws_layout& L, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid,
+                     float* out, int64_t ld, hipStream_t st, bool* launched) {
+    *launched = false;
+    if (!one_launch_enabled() || !fast_tail_enabled() || N > kOneLaunchMaxN || !fast_tail_ok(N, P, 1) || B > kClaimImgs) return GNMS_OK;
+    if (!((ld % 4 == 0) && ((uintptr_t)out % 16 == 0))) return GNMS_OK;
+    const int cus = device_cu_count();
+    const int NP = (N + 63) & ~63, NB = NP / 64, nbp = NB * (NB + 1) / 2;
+    const int kpw = (NP % 128 == 0 && (long)B * (NP / 32) <= (long)cus / 2) ? 32 : 64;
+    // One task (a 64 x 64 block of pair decisions on 16 waves) per table workgroup, and only while all of them are about one round of the
+    // machine: in rank space nothing can be culled, and where the tasks queue the three launches (x-sorted, culled bit matrix: 5-7 us) win.
+    // Kernel time of the launch against sort + bits + tail_write_kernel, us (profiles/r06g_*): B = 8 N = 256 18.3 / 25.0, B = 16 N = 256
+    // 17.5 / 24.9, B = 1 / 2 N = 500 18.1 / 20.5 and 18.2 / 21.9, B = 8 N = 512 22.8 / 23.4, B = 1 N = 1024 23.4 / 25.1 -- and with 2 / 4 / 8
+    // tasks per workgroup B = 2 / 4 / 8 at N = 1024: 28.0 / 25.9, 31.2 / 26.7, 37.9 / 33.5 (the one launch loses).
+    const int tpw = 1;
+    const int ntab = gnms_div_up(nbp, tpw);
+    if ((long)B * ntab > (long)cus * 5 / 4 || ntab > 13 * 32) return GNMS_OK;
+    const long front = (long)B * (NP / kpw + ntab + 2);
+    if (front > 3L * cus) return GNMS_OK;
+    int* claims = nullptr;
+    int rc = claim_slot_for(st, &claims);
+    if (rc == kNoClaimSlot) return GNMS_OK;
+    if (rc) return rc;
+    const int ncc = (N + gnms_iou::kWaveCols - 1) / gnms_iou::kWaveCols, nrt = (N + kStagedRows - 1) / kStagedRows;
+    long writers = (long)B * ((ncc * nrt + 15) >> 4);
+    // (3/8 of the CUs write: at ~29 GB/s per writer workgroup the 32 MB of B = 8, N = 1024 then take as long as sort -> table -> chain
+    // beside them on the other 5/8)
+    const long cap = (long)cus * 3 / 8;
+    if (writers > cap) writers = cap;
+    if (writers < 1) writers = 1;
+    size_t lds = one_launch_lds_size(N, true);
+    if (lds < (size_t)N * 16) lds = (size_t)N * 16;
+    if ((rc = allow_lds(one_launch_boxes_kernel, lds))) return rc;
+    gnms_launch_prof(kProfMatrixWrite, one_launch_boxes_kernel, dim3((unsigned)(front + writers)), dim3(1024), lds, st, scores, boxes, N, counts, P, ws, L, prob,
+                     (long long*)valid, (long long*)invalid, nvalid, ninvalid, (long long*)order, B, kpw, tpw, out, (long)ld, claims, (int)writers);
+    GNMS_CHECK_LAUNCH();
+    *launched = true;
     return GNMS_OK;
 }
 
@@ -1201,12 +1283,11 @@ namespace {
 // from-boxes layer reads it, so the write goes to a library-owned second stream and the layer's own kernels run beside it on the
 // caller's stream.  A fork and a join cost 7-25 us of idle queue each and the layer's latency-bound kernels run 1.3-3x slower
 // beside the write, which is why smaller problems stay on one stream (B=8, N=4096: 0.180-0.187 against 0.193 ms, not worth a
-// second code path; B=4: 0.152 against 0.138; N=8192, B=1: even; B=2: 0.246 against 0.306).  GNMS_TWO_STREAMS=0/1 forces.
+// second code path; B=4: 0.152 against 0.138; N=8192, B=1: even; B=2: 0.246 against 0.306).
 struct SideStream { hipStream_t s = nullptr; hipEvent_t fork[2] = {nullptr, nullptr}, join = nullptr; };
 std::mutex g_side_mu;
 bool use_side_stream(int B, int N, int64_t ld) {
-    static const int forced = [] { const char* e = getenv("GNMS_TWO_STREAMS"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-    return forced >= 0 ? forced == 1 : (N > 4096 && (long long)B * N * ld * 4 >= (384ll << 20));
+    return N > 4096 && (long long)B * N * ld * 4 >= (384ll << 20);
 }
 // the caller holds g_side_mu
 int side_stream(SideStream** out) {
@@ -1292,6 +1373,8 @@ extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (B <= 0 || N <= 0) return "";
     if (dim == 3 && chain_rides_in_write_launch(B, N) && sym_writers_in_tail_launch(N, N, nullptr)) return "tail_write_kernel";
     if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : (N % 4 == 0 ? "write_staged_kernel" : "iou2d_kernel");
+    if (dim == 2 && N <= kOneLaunchMaxN && one_launch_enabled() && fast_tail_enabled() &&
+        (long)B * (((N + 63) / 64) * ((N + 63) / 64 + 1) / 2) <= (long)device_cu_count() * 5 / 4) return "one_launch_boxes_kernel";   // (launch_one_boxes' rule)
     if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
     if (dim == 3) return "iou3d_nms_fast_kernel";
     return "iou2d_kernel";
@@ -1548,6 +1631,11 @@ int forward_boxes_impl(const float* boxes, const float* scores, int B, int N, co
     // VALU-heavy kernels share the SIMDs and the sum stays the same (write 1.97 ms, step 2.01); forked in front of the sorts as well,
     // those crawl (step 2.35).
     const bool persistent_write = mw && !mw->one_launch && (mw->ld % 4 == 0) && ((uintptr_t)mw->out % 16 == 0) && (N % 4 == 0);
+    if (mw && mw->one_launch && !scores_already_sorted) {            // a small image: sort, table, chain and the matrix write as ONE launch
+        bool launched = false;
+        if ((rc = launch_one_boxes(scores, boxes, B, N, counts, P, ws, L, prob, order, valid, invalid, nvalid, ninvalid, mw->out, mw->ld, st, &launched))) return rc;
+        if (launched) return GNMS_OK;
+    }
     if (!scores_already_sorted && (rc = launch_sorts(scores, boxes, B, N, counts, ws, L, P2, order, st))) return rc;
     if (persistent_write) {
         SideScope whole(st);

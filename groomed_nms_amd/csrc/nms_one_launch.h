@@ -8,13 +8,12 @@
 //
 //   sort    sort_count_body<KPW, FUSED>: the score sort by counting, exactly the workgroup of sort_count_kernel; outputs through agent-scope
 //           stores, then its flag.
-//   table   waits for the image's sort flags, then thresholds rows 64 tb + r of the matrix IN RANK ORDER and leaves -- not W, which nobody
-//           behind the fast tail reads -- the words of the scan's triangular table themselves: word (source block bb <= tb, target row r) =
-//           bits s of !(iou[order[64 tb + r]][order[64 bb + s]] <= thr), lib/groomed_nms.py:250.  A set entry is scattered to its bit by
-//           one LDS atomic (the thresholded matrix of an NMS input is sparse: a few entries per row), the columns' ranks come from an LDS
-//           copy of rankof; columns no row of the block can see (rank >= 64 (tb + 1)) are not even loaded.  The table has the reference's
-//           own orientation (row = the later box, column = the leader), so nothing is assumed about the matrix's symmetry and the
-//           symmetry check of the three-launch path has no counterpart here.
+//   table   thresholds a few INPUT rows of the matrix while the sort still runs, waits for the image's sort flags, and leaves -- not W, which
+//           nobody behind the fast tail reads -- the words of the scan's triangular table themselves: word (source block bb <= tb, target
+//           row r) = bits s of !(iou[order[64 tb + r]][order[64 bb + s]] <= thr), lib/groomed_nms.py:250.  A set entry is scattered to its
+//           bit by one LDS atomic (the thresholded matrix of an NMS input is sparse: a few entries per row), the ranks come from an LDS
+//           copy of rankof.  The table has the reference's own orientation (row = the later box, column = the leader), so nothing is
+//           assumed about the matrix's symmetry and the symmetry check of the three-launch path has no counterpart here.
 //   chain   leaders_sb_body<SRC, FUSED> (one super-block) -> fast_final_body: as in tail_kernel, the table copied from the image above.
 //   CSR     csr_build_body, and the launch's last act: the workspace's call counter moves on.
 //
@@ -38,76 +37,81 @@ __device__ __forceinline__ void one_launch_wait(const u64* g, const int count, c
 
 constexpr int kOneLaunchMaxN = 1024;     // one super-block
 
-// table workgroup w of image b (w = tb * split + part: rows [part * 64 / split, (part + 1) * 64 / split) of rank block tb); split in {1, 2, 4}
+// table workgroup w of image b: the 64 / split INPUT rows [w * 64 / split, ...) of the matrix, split in {1, 2, 4} (wave v: rows v * 4 / split + u).
+// Which rows those are does not depend on the sort, so the rows are requested and thresholded BEFORE the sort's flags are waited for -- the
+// one memory latency of the role that matters hides behind the sort; behind the flags only the ranks are fetched (LDS copy of rankof), the
+// set entries scattered to the words (target rank k = rankof[row], source block bb = rankof[column] >> 6) of an LDS table, and row k's
+// words for bb <= k >> 6 stored (every word of the table image has exactly one writer: the workgroup that holds its target's row).
 __device__ __forceinline__ void one_launch_bits_from_matrix(const float* __restrict__ iou, int N, long ld, const int* __restrict__ counts,
                                                             const float thr, char* ws, gnms_ws_layout L, const int b, const int w,
                                                             const int split, const unsigned tag, const int nsort) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NP = (N + 63) & ~63;
     int* rankL = reinterpret_cast<int*>(smem);                                   // [NP] rank of input column c
-    u64* tab = reinterpret_cast<u64*>(smem + (size_t)NP * 4);                    // [tb + 1][64]
-    __shared__ int rowL[64];                                                     // input row of rank 64 tb + r
+    u64* tab = reinterpret_cast<u64*>(smem + (size_t)NP * 4);                    // [rows of the workgroup][kSB source blocks]
+    __shared__ int krL[64];                                                      // rank of the workgroup's row
     const int n = gnms_count(counts, b, N);
     ImgPtrs I = img_ptrs(ws, L, b);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tb = w / split, part = w - tb * split;
-    const int k0 = tb * 64;
-    if (wave == 0) one_launch_wait(I.gran + 32, nsort, tag, kSlotSort);
-    __syncthreads();
-    if (k0 < n) {                                                                // (workgroup-uniform)
-        const int rpg = 64 / split, rpw = 4 / split;                             // rows per workgroup / per wave
-        const int rows0 = part * rpg;
-        const int lim = k0 + 64;                                                 // columns of rank >= lim: no row of the block looks at them
-        for (int i = tid; i < n; i += 1024) rankL[i] = coh_load(I.rankof + i);
-        if (tid < 64) rowL[tid] = (k0 + tid < n) ? coh_load(I.order + k0 + tid) : 0;
-        for (int i = tid; i < (tb + 1) * 64; i += 1024) tab[i] = 0ull;
-        __syncthreads();
-        const float* m = iou + (size_t)b * N * ld;
-        const int nchunks = (n + 255) >> 8;                                      // <= 4 chunks of 256 columns, lane l: columns 256 c + 4 l ..
-        int rk[4][4];
-        bool need[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int col0 = c * 256 + 4 * lane;
-            int lo = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                rk[c][j] = (c < nchunks && col0 + j < n) ? rankL[col0 + j] : 0x7fffffff;
-                lo = min(lo, rk[c][j]);
-            }
-            need[c] = lo < lim;                                                  // (col0 < n <= ld and both multiples of 4: the 16 bytes are inside the row)
-        }
+    const int rpg = 64 / split, rpw = 4 / split;                                 // rows per workgroup / per wave
+    const int i0 = w * rpg;                                                      // first input row
+    const int nb = (n + 63) >> 6;
+    const float* m = iou + (size_t)b * N * ld;
+    const int nchunks = (n + 255) >> 8;                                          // <= 4 chunks of 256 columns, lane l: columns 256 c + 4 l ..
+    unsigned bits[4] = {0u, 0u, 0u, 0u};                                         // row u: bit 4 c + j = !(iou[row][256 c + 4 l + j] <= thr)
+    if (i0 < n) {                                                                // (workgroup-uniform)
         float4 v[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int r = rows0 + wave * rpw + u;
-            const bool row_ok = u < rpw && k0 + r < n;
-            const float* p = m + (size_t)rowL[row_ok ? r : 0] * ld + 4 * lane;
+            const int i = i0 + wave * rpw + u;
+            const bool row_ok = u < rpw && i < n;
+            const float* p = m + (size_t)(row_ok ? i : i0) * ld + 4 * lane;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 4; ++c) {                                        // (4 l < n <= ld and both multiples of 4: the 16 bytes are inside the row)
                 v[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row_ok && need[c]) v[u][c] = load_nt_f4(p + c * 256);
+                if (row_ok && c < nchunks && c * 256 + 4 * lane < n) v[u][c] = load_nt_f4(p + c * 256);
             }
         }
+        for (int i = tid; i < rpg * kSB; i += 1024) tab[i] = 0ull;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int r = rows0 + wave * rpw + u;
-            const bool row_ok = u < rpw && k0 + r < n;
+            const bool row_ok = u < rpw && i0 + wave * rpw + u < n;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (!(row_ok && need[c])) continue;
+                const int col0 = c * 256 + 4 * lane;
+                if (!(row_ok && c < nchunks)) continue;
                 const float e[4] = {v[u][c].x, v[u][c].y, v[u][c].z, v[u][c].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (rk[c][j] < lim && !(e[j] <= thr))                        // lib/groomed_nms.py:250 (NaN -> removed)
-                        atomicOr(&tab[(rk[c][j] >> 6) * 64 + r], 1ull << (rk[c][j] & 63));
+                    if (col0 + j < n && !(e[j] <= thr)) bits[u] |= 1u << (4 * c + j);   // lib/groomed_nms.py:250 (NaN -> removed)
+            }
+        }
+    }
+    if (wave == 0) one_launch_wait(I.gran + 32, nsort, tag, kSlotSort);
+    __syncthreads();
+    if (i0 < nb * 64) {                                                          // (rows past the image's last rank block have no words in the table)
+        for (int i = tid; i < n; i += 1024) rankL[i] = coh_load(I.rankof + i);
+        if (tid < rpg) krL[tid] = (i0 + tid < n) ? coh_load(I.rankof + i0 + tid) : i0 + tid;   // (padding rows: rank = index, all-zero words)
+        if (i0 >= n) for (int i = tid; i < rpg * kSB; i += 1024) tab[i] = 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u >= rpw) continue;
+            const int rl = wave * rpw + u;
+            const int tbk = krL[rl] >> 6;                                        // the row's own rank block: sources beyond it are never looked at
+            unsigned todo = bits[u];
+            while (todo) {
+                const int q = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                const int rc = rankL[(q >> 2) * 256 + 4 * lane + (q & 3)];
+                if ((rc >> 6) <= tbk) atomicOr(&tab[rl * kSB + (rc >> 6)], 1ull << (rc & 63));
             }
         }
         __syncthreads();
-        u64* img = I.W + (size_t)(tb * (tb + 1) / 2) * 64;                       // the table's words of target block tb, source blocks 0 .. tb
-        for (int i = tid; i < (tb + 1) * rpg; i += 1024) {
-            const int bb = i / rpg, r = rows0 + (i - bb * rpg);
-            coh_store(img + bb * 64 + r, tab[bb * 64 + r]);
+        for (int i = tid; i < rpg * kSB; i += 1024) {
+            const int rl = i / kSB, bb = i - rl * kSB;
+            const int k = krL[rl], tb = k >> 6;
+            if (bb <= tb && tb < nb) coh_store(I.W + (size_t)(tb * (tb + 1) / 2 + bb) * 64 + (k & 63), tab[i]);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);                                          // vmcnt(0)
@@ -116,11 +120,107 @@ __device__ __forceinline__ void one_launch_bits_from_matrix(const float* __restr
 }
 
 // bytes of dynamic LDS the launch needs (every workgroup asks for the chain's)
-__host__ __device__ inline size_t one_launch_lds_size(int N) {
+// The table straight from the BOXES (gnms_forward_with_iou2d's one launch: the matrix is an output there).  In rank space nothing has to be
+// permuted: task (tb, bb <= tb) -- its number IS the table's pair index -- holds the 64 target boxes of rank block tb in its lanes, walks
+// the sources of block bb (wave-uniform, broadcast with v_readlane) and a lane's bits are its word, stored coalesced.  The decision is
+// bitmask_boxes_body's, operation for operation (sign of fma(-thr, uni, inter) outside a guard band of 8 ulp, the IEEE division inside it
+// and for boxes without a positive finite area), i.e. bit for bit `!(iou <= thr)` of the matrix the writers of the same launch store.
+// Workgroup w of an image: tasks [w * tpw, (w + 1) * tpw), each on 16 / tpw waves that share the 64 sources; tpw in {1, 2, 4, 8, 16}.
+__device__ __forceinline__ void one_launch_bits_from_boxes(int N, const int* __restrict__ counts, const float thr, char* ws, gnms_ws_layout L,
+                                                           const int b, const int w, const int tpw, const unsigned tag, const int nsort) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* wordsL = reinterpret_cast<u64*>(smem);                                  // [tpw][64]
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wpt = 16 / tpw, tl = wave / wpt, part = wave - tl * wpt;           // waves per task, the wave's task, its share of the sources
+    const int task = w * tpw + tl;
+    int tb = 0;
+    while ((tb + 1) * (tb + 2) / 2 <= task) ++tb;
+    const int bb = task - tb * (tb + 1) / 2;
+    const int nb = (n + 63) >> 6;
+    const bool live = tb < nb;                                                   // (wave-uniform; tasks past the image's last block: nothing to write)
+    if (wpt > 1) for (int i = tid; i < tpw * 64; i += 1024) wordsL[i] = 0ull;
+    if (wave == 0) one_launch_wait(I.gran + 32, nsort, tag, kSlotSort);
+    __syncthreads();
+    u64 word = 0ull;
+    if (live) {
+        const int kt = tb * 64 + lane, ks = bb * 64 + lane;
+        const float4 tbx = coh_load_f4(I.rbox + (kt < n ? kt : n - 1));
+        const float4 sbx = coh_load_f4(I.rbox + (ks < n ? ks : n - 1));
+        const float tarea = (tbx.z - tbx.x) * (tbx.w - tbx.y), sarea = (sbx.z - sbx.x) * (sbx.w - sbx.y);
+        const bool targets_ok = __all((tarea > 0.0f) && (tarea < INFINITY));
+        const u64 sources_ok = __ballot((sarea > 0.0f) && (sarea < INFINITY));
+        const float guard = fmaxf(fabsf(thr), 1.0f) * 9.6e-7f;                   // 8 ulp at the threshold's magnitude (bitmask_boxes_body)
+        const int spp = 64 / wpt, nsrc = min(64, n - bb * 64);
+        const int s1 = min(nsrc, (part + 1) * spp);
+        for (int s = part * spp; s < s1; ++s) {
+            const float ax1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbx.x), s));
+            const float ay1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbx.y), s));
+            const float ax2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbx.z), s));
+            const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sbx.w), s));
+            const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sarea), s));
+            const float wd = fmaxf(gnms_iou3d::vmin_s(ax2, tbx.z) - gnms_iou3d::vmax_s(ax1, tbx.x), 0.0f);
+            const float ht = fmaxf(gnms_iou3d::vmin_s(ay2, tbx.w) - gnms_iou3d::vmax_s(ay1, tbx.y), 0.0f);
+            const float inter = wd * ht;
+            const float uni = (aa + tarea) - inter;
+            const float d = __builtin_fmaf(-thr, uni, inter);
+            const bool unsure = !(fabsf(d) > guard * uni);                       // also true for NaN
+            bool bit;
+            if (!(targets_ok && ((sources_ok >> s) & 1ull)) || __any(unsure)) bit = !(inter / uni <= thr);
+            else bit = d > 0.0f;
+            word |= bit ? (1ull << s) : 0ull;
+        }
+        if (kt >= n) word = 0ull;
+        if (wpt > 1 && word != 0ull) atomicOr(&wordsL[tl * 64 + lane], word);
+    }
+    if (wpt > 1) {
+        __syncthreads();
+        if (live && part == 0) coh_store(I.W + (size_t)task * 64 + lane, wordsL[tl * 64 + lane]);
+    } else if (live) {
+        coh_store(I.W + (size_t)task * 64 + lane, word);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                          // vmcnt(0)
+    __syncthreads();
+    if (tid == 0) coh_store(I.gran + (size_t)3 * 32 + w, strong_gran(tag, kSlotBits + (unsigned)w));
+}
+
+// the chain's side region (the image's order / scores / boxes by rank, leaders_sb_body<.., FUSED>) lies behind everything else of the chain
+__host__ __device__ inline size_t one_launch_lds_side(int N) { return (fast_tail_lds_size(N, 1024) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t one_launch_lds_size(int N, bool boxes) {
     const size_t NP = (size_t)((N + 63) & ~63);
-    const size_t chain = fast_tail_lds_size(N, 1024), sort = NP * 8, bits = NP * 4 + (size_t)kSB * 64 * 8;
+    const size_t chain = one_launch_lds_side(N) + 8192 + (boxes ? 16384 : 0), sort = NP * 8, bits = NP * 4 + (size_t)64 * kSB * 8;
     size_t m = chain > sort ? chain : sort;
     return m > bits ? m : bits;
+}
+
+// the image's chain workgroup (c < B) or its CSR workgroup (B <= c < 2 B)
+template <int SRC>
+__device__ __forceinline__ void one_launch_chain_or_csr(const float* __restrict__ src, int N, long ld, const int* __restrict__ counts, gnms_params P,
+                                                        char* ws, gnms_ws_layout L, float* __restrict__ prob, long long* __restrict__ valid,
+                                                        long long* __restrict__ invalid, int* __restrict__ nvalid, int* __restrict__ ninvalid,
+                                                        const int B, const int c, const int nsort, const int nbits) {
+    int b;
+    if (c < B) {                                                                 // the image's chain
+        b = c;
+        ImgPtrs I = img_ptrs(ws, L, b);
+        const unsigned tag = (unsigned)gnms_next_epoch(coh_load(I.misc + 8));
+        GNMS_T0();
+        if (threadIdx.x < 64) one_launch_wait(I.gran + 32, nsort, tag, kSlotSort);
+        __syncthreads();
+        GNMS_TACC(16);                                                           // (developer build: the chain's wait for the sort)
+        const int last = leaders_sb_body<SRC, true>(N, counts, ws, L, b, 0, 1, 0, src, ld, P.nms_threshold, P.temperature, P.pruning_method, 1024,
+                                                    tag, nbits, one_launch_lds_side(N));
+        fast_final_body<1, SRC, true>(src, N, ld, counts, P, ws, L, 1024, prob, valid, invalid, nvalid, ninvalid, b, last, tag);
+        GNMS_TFLUSH(ws, L, b);
+        return;
+    }
+    b = c - B;                                                                   // the image's CSR workgroup
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const unsigned tag = (unsigned)gnms_next_epoch(coh_load(I.misc + 8));
+    csr_build_body<1, true>(N, counts, ws, L, b, tag);
+    __syncthreads();
+    if (threadIdx.x == 0) coh_store(I.misc + 8, (int)tag);                       // every other workgroup of the image has read the counter long ago
 }
 
 template <int SRC>
@@ -135,36 +235,25 @@ __global__ __launch_bounds__(1024) void one_launch_kernel(const float* __restric
     if (bx < B * nsort) {
         b = bx / nsort;
         const unsigned tag = (unsigned)gnms_next_epoch(coh_load(img_ptrs(ws, L, b).misc + 8));
+        GNMS_T0();
         if (kpw == 32) sort_count_body<32, true>(scores, nullptr, N, counts, ws, L, order_out, 0, bx - b * nsort, b, 0, tag);
         else sort_count_body<64, true>(scores, nullptr, N, counts, ws, L, order_out, 0, bx - b * nsort, b, 0, tag);
+        GNMS_TACC_IF(bx == 0, 17);                                               // (developer build: the first sort workgroup, start to flag)
+        GNMS_TFLUSH(ws, L, bx == 0 ? 0 : 1);
         return;
     }
     bx -= B * nsort;
     if (bx < B * nbits) {
         b = bx / nbits;
         const unsigned tag = (unsigned)gnms_next_epoch(coh_load(img_ptrs(ws, L, b).misc + 8));
+        GNMS_T0();
         one_launch_bits_from_matrix(src, N, ld, counts, P.nms_threshold, ws, L, b, bx - b * nbits, split, tag, nsort);
+        GNMS_TACC_IF(bx == nbits - 1, 18);                                       // (developer build: image 0's last table workgroup, start to flag)
+        GNMS_TFLUSH(ws, L, bx == nbits - 1 ? 0 : 1);
         return;
     }
     bx -= B * nbits;
-    if (bx < B) {                                                                // the image's chain
-        b = bx;
-        ImgPtrs I = img_ptrs(ws, L, b);
-        const unsigned tag = (unsigned)gnms_next_epoch(coh_load(I.misc + 8));
-        if (threadIdx.x < 64) one_launch_wait(I.gran + 32, nsort, tag, kSlotSort);
-        __syncthreads();
-        const int last = leaders_sb_body<SRC, true>(N, counts, ws, L, b, 0, 1, 0, src, ld, P.nms_threshold, P.temperature, P.pruning_method, 1024,
-                                                    tag, nbits);
-        fast_final_body<1, SRC, true>(src, N, ld, counts, P, ws, L, 1024, prob, valid, invalid, nvalid, ninvalid, b, last, tag);
-        GNMS_TFLUSH(ws, L, b);
-        return;
-    }
-    b = bx - B;                                                                  // the image's CSR workgroup
-    ImgPtrs I = img_ptrs(ws, L, b);
-    const unsigned tag = (unsigned)gnms_next_epoch(coh_load(I.misc + 8));
-    csr_build_body<1, true>(N, counts, ws, L, b, tag);
-    __syncthreads();
-    if (threadIdx.x == 0) coh_store(I.misc + 8, (int)tag);                       // every other workgroup of the image has read the counter long ago
+    one_launch_chain_or_csr<SRC>(src, N, ld, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, B, bx, nsort, nbits);
 }
 
 }  // namespace

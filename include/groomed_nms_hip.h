@@ -21,8 +21,7 @@
  *   - gnms_forward_with_iou2d / _iou3d on images of more than 4096 boxes issue the matrix write on a library-owned stream
  *     (one per device, lowest priority) that forks from `stream` and joins it again before the call returns control of the
  *     ordering to the caller: to the caller everything is still ordered on `stream` (earlier work happens before, later work
- *     after), also under stream capture (the fork/join is captured as a branch of the graph).  GNMS_TWO_STREAMS=0 in the
- *     environment keeps every launch on `stream`;
+ *     after), also under stream capture (the fork/join is captured as a branch of the graph);
  *   - a batch is B images of up to N boxes; image b uses the first counts[b] boxes (counts may be
  *     NULL: every image has N).  Scores are [B][N]; overlap matrices are [B][N][ld] row-major with
  *     row stride ld >= N elements (image stride N*ld);

@@ -2171,11 +2171,11 @@ def test_leader_scan_across_workgroups(G, O):
 
 
 def test_library_switches():
-    """The five environment switches the shipped library still reads, each against the default run of the
-    same inputs: GNMS_FAST_TAIL=0 (round 5: K5 proper -- the sort of the groups -- instead of the fast tail; probabilities, lists AND gradients,
-    i.e. the groups' runs the backward reads, must be the same bit for bit), GNMS_TWO_STREAMS=0 (large images: every launch on the caller's stream instead of the library's side stream),
-    GNMS_MATRIX_SYM=0 (matrix-in layer: the general scan also for symmetric matrices), GNMS_TAIL_WRITERS=n (CUs that write the matrix
-    beside the per-image chain) and GNMS_TRACE_LAUNCH=1 (developer: launch sites printed, device synchronised behind each)."""
+    """The environment switches the shipped library still reads (four since round 6), each against the default run
+    of the same inputs: GNMS_FAST_TAIL=0 (round 5: K5 proper -- the sort of the groups -- instead of the fast tail; probabilities, lists AND
+    gradients, i.e. the groups' runs the backward reads, must be the same bit for bit), GNMS_MATRIX_SYM=0 (matrix-in layer: the general scan
+    also for symmetric matrices), GNMS_TRACE_LAUNCH=1 (developer: launch sites printed, device synchronised behind each) and
+    GNMS_ONE_LAUNCH=0 (round 6: small images in three launches; its own cases: test_one_launch_against_three_launches)."""
     code = """
 import sys, numpy as np, torch
 import groomed_nms_amd as G
@@ -2212,8 +2212,8 @@ np.savez(sys.argv[1], **out)
 print("ok")
 """
     runs = {}
-    for tag, env in (("default", {}), ("one_stream", {"GNMS_TWO_STREAMS": "0"}), ("general_scan", {"GNMS_MATRIX_SYM": "0"}),
-                     ("few_writers", {"GNMS_TAIL_WRITERS": "40"}), ("trace", {"GNMS_TRACE_LAUNCH": "1"}), ("k5_proper", {"GNMS_FAST_TAIL": "0"})):
+    for tag, env in (("default", {}), ("general_scan", {"GNMS_MATRIX_SYM": "0"}), ("trace", {"GNMS_TRACE_LAUNCH": "1"}), ("k5_proper", {"GNMS_FAST_TAIL": "0"}),
+                     ("three_launches", {"GNMS_ONE_LAUNCH": "0"})):
         path = "/tmp/gnms_switch_%s.npz" % tag
         r = _run_py(code, env, argv=(path,))
         assert r.returncode == 0 and "ok" in r.stdout, (tag, r.stderr[-2000:])
@@ -2979,6 +2979,49 @@ run("thr0", torch.from_numpy(s3).cuda(), m3, nms_threshold=0.0)
 run("sorted_prob", torch.from_numpy(s3).cuda(), m3, return_sorted_prob=True)
 for rep in range(3):                                     # the call counter moves on, stale flags never match
     run("rep%d" % rep, torch.from_numpy(s3).cuda(), m3)
+# the one-call entry (boxes in, matrix + layer out): one_launch_boxes_kernel against sort + bits + tail_write_kernel
+def run_boxes(tag, bx, sc, counts=None, **kw):
+    st = sc.clone().requires_grad_(True)
+    o = G.differentiable_nms_with_iou2d_batched(st, bx, counts=counts, **kw)
+    w = torch.linspace(-1.0, 2.0, sc.shape[1], device="cuda").repeat(sc.shape[0], 1)
+    (o[0] * w).sum().backward()
+    out[tag + "_w"] = w.cpu().numpy()
+    c = counts.cpu().numpy() if counts is not None else None
+    for i, k in enumerate(("prob", "order", "valid", "invalid", "nvalid", "ninvalid", "iou")):
+        a = o[i].detach().cpu().numpy().copy()
+        if k in ("valid", "invalid"):
+            cnt = o[4 if k == "valid" else 5].cpu().numpy()
+            for b in range(a.shape[0]):
+                a[b, cnt[b]:] = -1
+        if c is not None and k in ("prob", "order", "iou"):
+            for b in range(a.shape[0]):
+                if k == "iou":
+                    a[b, c[b]:, :] = 0; a[b, :, c[b]:] = 0
+                else:
+                    a[b, c[b]:] = 0 if k == "prob" else -1
+        out[tag + "_" + k] = a
+    g = st.grad.cpu().numpy().copy()
+    if c is not None:
+        for b in range(g.shape[0]):
+            g[b, c[b]:] = 0
+    out[tag + "_grad"] = g
+for n in (1, 2, 63, 64, 65, 200, 256, 257, 500, 777, 1000, 1024):
+    for kind in ("uniform", "clustered"):
+        b, s = synthetic.batch_2d(140 + n, 2, n, kind)
+        run_boxes("box_n%d_%s" % (n, kind), torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda())
+b, s = synthetic.batch_2d(15, 8, 1024, "uniform")
+run_boxes("box_b8_n1024", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda())
+b, s = synthetic.batch_2d(16, 8, 256, "clustered")
+run_boxes("box_b8_n256", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda())
+b, s = synthetic.batch_2d(17, 5, 700, "clustered")
+run_boxes("box_ragged", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), counts=torch.tensor([700, 0, 1, 333, 65], dtype=torch.int32, device="cuda"))
+for gs in (2, 30):
+    run_boxes("box_cap%d" % gs, torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), group_size=gs)
+bd = b.copy(); bd[:, 5] = bd[:, 4]; bd[:, 9, 2] = bd[:, 9, 0]; bd[:, 11, 3] = np.float32("nan"); bd[:, 13] = np.float32(0.0)   # duplicates, an empty box, a NaN coordinate, an all-zero box
+run_boxes("box_degenerate", torch.from_numpy(bd).cuda(), torch.from_numpy(s).cuda())
+run_boxes("box_thr0", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), nms_threshold=0.0)
+for rep in range(3):
+    run_boxes("box_rep%d" % rep, torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda())
 # one image through the reference's own signature (index tensors through the pinned counts slot), twenty calls of alternating sizes
 for i in range(20):
     n = (500, 130, 64, 1000)[i % 4]
@@ -3000,6 +3043,16 @@ print("ok")
     # and the default run against the oracle on a few of the cases
     from groomed_nms_amd import synthetic
     d = runs["default"]
+    for n, kind in ((65, "uniform"), (500, "clustered"), (1024, "uniform")):
+        b, s = synthetic.batch_2d(140 + n, 2, n, kind)
+        tag = "box_n%d_%s" % (n, kind)
+        for img in range(2):
+            m = O.iou2d(b[img], b[img])
+            ref = O.differentiable_nms(s[img], m, grad_prob=d[tag + "_w"][img])
+            np.testing.assert_array_equal(d[tag + "_iou"][img], m)
+            np.testing.assert_array_equal(d[tag + "_prob"][img], ref["prob"])
+            np.testing.assert_array_equal(d[tag + "_valid"][img, :int(d[tag + "_nvalid"][img])], ref["valid"])
+            np.testing.assert_array_equal(d[tag + "_grad"][img], ref["grad_scores"])
     for n, kind in ((65, "clustered"), (500, "uniform"), (777, "clustered"), (1024, "uniform")):
         b, s = synthetic.batch_2d(40 + n, 1, n, kind)
         m = O.iou2d(b[0], b[0])
@@ -3013,7 +3066,7 @@ print("ok")
 @pytest.mark.gpu
 def test_classic_nms_pinned_staging(O):
     """`_nms` keeps one block of pinned memory per device for the boxes, keep[] and the count (classic_nms.hip): a block that starts small
-    (GNMS_NMS_STAGE_MIN) and has to grow between calls, sizes on both sides of the bit-matrix kernel's tile switch (64 x 64 tiles in a
+    (64 KiB) and has to grow between calls, sizes on both sides of the bit-matrix kernel's tile switch (64 x 64 tiles in a
     1D grid / 64 x 256 in a 2D grid), two host threads calling at once -- every keep list against the oracle."""
     code = """
 import sys, threading, numpy as np
@@ -3038,7 +3091,7 @@ np.savez(sys.argv[1], **out)
 print("ok")
 """
     path = "/tmp/gnms_nms_stage.npz"
-    r = _run_py(code, {"GNMS_NMS_STAGE_MIN": "65536"}, argv=(path,))
+    r = _run_py(code, {}, argv=(path,))
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
     d = np.load(path)
     from groomed_nms_amd import synthetic

@@ -19,6 +19,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--kind", default="clustered")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--lists", action="store_true", help="ask for the valid / invalid index lists (K6 then compacts and sorts)")
+ap.add_argument("--counts", type=int, default=0, help="boxes per image actually used (ragged: counts[b] = this; 0 = all)")
 ap.add_argument("--two-calls", action="store_true", help="gnms_iou2d, then the matrix-in layer gnms_forward: the chain kernels alone on the machine")
 a = ap.parse_args()
 lib = _lib.load()
@@ -38,7 +39,7 @@ ni = torch.empty((B,), dtype=torch.int32, device="cuda") if a.lists else None
 lp = lambda t: ptr(t) if t is not None else None
 n4 = (4 * N + 255) // 256 * 256
 off_gx = 15 * n4
-names = {21: "resolve (wave 15): table words to registers", 22: "resolve (wave 15): dirty check + AND pass", 23: "resolve (wave 15): in-block fixed point + publish", 24: "resolve (wave 15): barrier", 20: "leaders_sym resolve rounds (count)", 5: "CHAIN leaders total", 6: "CHAIN attribute total", 7: "CHAIN groups total", 15: "CHAIN finalize total", 0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store / sym scan: wait for the other workgroups",
+names = {16: "one launch: chain waits for the sort flags", 17: "one launch: sort workgroup 0, start to flag", 18: "one launch: last table workgroup, start to flag (incl. its wait for the sort)", 21: "resolve (wave 15): table words to registers", 22: "resolve (wave 15): dirty check + AND pass", 23: "resolve (wave 15): in-block fixed point + publish", 24: "resolve (wave 15): barrier", 20: "leaders_sym resolve rounds (count)", 5: "CHAIN leaders total", 6: "CHAIN attribute total", 7: "CHAIN groups total", 15: "CHAIN finalize total", 0: "leaders prologue (table 0)", 1: "leaders resolve / prefetch+far push", 2: "leaders barrier A", 3: "leaders near push + table store / sym scan: wait for the other workgroups",
          4: "leaders barrier B / sym scan: rem + fast-tail stage A", 8: "groups keys / fast tail: loads + cap check", 9: "groups radix / fast tail: store acks + barrier", 10: "groups runs", 11: "groups rescoring", 12: "finalize classify", 13: "finalize sort",
          14: "finalize output"}
 tot = np.zeros(28, np.int64)
