@@ -947,10 +947,18 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
 #define GNMS_BT() do {} while (0)
 #endif
     GNMS_BT();
+#ifdef GNMS_TIMING
+    const long long rt0__ = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+    // ROWBUF with KBW = 2 (round 6; B = 8, N = 4096): a workgroup takes TWO rank blocks, their rows of W side by side in LDS.  With one
+    // block per workgroup the launch was 512 workgroups, two per CU, each pulling all 4096 column boxes, their indices and ranks (96 KiB)
+    // through the CU for ~3 us of arithmetic: 48 MB of L2 -> CU traffic in the first microseconds, the late waves' loads 6-8 us behind, and
+    // the CU's second workgroup (younger waves) finishing 7-8 us after the first (profiles/r06j_bits_timeline.txt: image 0 done at 15 us,
+    // image 7 at 23).  256 workgroups of two blocks pull half the bytes and have their CU to themselves.
     if (ROWBUF) {
-        const int kbr = bx;                                   // one rank block per workgroup, wave w = column chunk w
+        const int kbr = bx * KBW;                             // KBW rank blocks per workgroup, wave w = column chunk w
         if (kbr * 64 >= n) return;
-        for (int i = threadIdx.x; i < L.NC; i += blockDim.x) rowbuf[i] = 0ull;
+        for (int i = threadIdx.x; i < KBW * L.NC; i += blockDim.x) rowbuf[i] = 0ull;
         __syncthreads();
     }
     GNMS_BT();
@@ -971,7 +979,11 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     bool cok = true;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        const int p = c0 + CPL * lane + j;
+        // (round 6: column 64 j + lane, not CPL lane + j.  With four CONSECUTIVE columns per lane the lanes of one load instruction sat 64 bytes
+        // apart -- 64 requests to the texture pipe per instruction, four instructions over the same lines -- and the sixteen waves' column
+        // phases queued behind each other at ~0.7 k ticks a wave (wave 0: 8 k, wave 15: 18 k, profiles/r06k_bits_timeline.txt); which lane
+        // holds which column is free: the word goes to the column's rank)
+        const int p = c0 + 64 * j + lane;
         const int pp = p < n ? p : n - 1;                             // clamped duplicates: harmless in the hull, never stored
         cb[j] = I.xbox[pp];
         crank[j] = (p < n) ? I.rankof[I.xidx[pp]] : 0x7fffffff;
@@ -986,7 +998,7 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     // column box and per row.  Rows/columns that fail, and the pairs inside the guard band, take the exact IEEE division.
     // (two workgroups per CU leave 64 VGPRs: the columns' ranks, not needed before the words are parked, wait in LDS meanwhile)
     constexpr bool STASH = ROWBUF && !CHUNKLOOP && CPL == 4;
-    int* const crank_lds = reinterpret_cast<int*>(smem + (size_t)L.NC * 8) + threadIdx.x;   // [CPL][1024]
+    int* const crank_lds = reinterpret_cast<int*>(smem + (size_t)KBW * L.NC * 8) + threadIdx.x;   // [CPL][1024] (behind the KBW rows)
     if (STASH) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) crank_lds[j * 1024] = crank[j];
@@ -1130,7 +1142,7 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
         }
         }   // !fast_rows
         // the FULL row of W: the overlap is symmetric, and with all columns present the leader scan can pull (leaders_body, sym)
-        u64* Wk = ROWBUF ? rowbuf : I.W + (size_t)kb * L.NC;
+        u64* Wk = ROWBUF ? rowbuf + (size_t)kw * L.NC : I.W + (size_t)kb * L.NC;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             const int cr = STASH ? crank_lds[j * 1024] : crank[j];
@@ -1143,21 +1155,31 @@ __device__ __forceinline__ void bitmask_boxes_body(const float* __restrict__ box
     if (ROWBUF) {
         __syncthreads();
         GNMS_BT();
-        u64* Wk = I.W + (size_t)bx * L.NC;
-        for (int i = threadIdx.x; i < L.NC; i += blockDim.x) Wk[i] = rowbuf[i];      // the whole row, coalesced
+        for (int kw = 0; kw < KBW; ++kw) {
+            const int kb = bx * KBW + kw;
+            if (kb >= L.NB || kb * 64 >= n) break;
+            u64* Wk = I.W + (size_t)kb * L.NC;
+            for (int i = threadIdx.x; i < L.NC; i += blockDim.x) Wk[i] = rowbuf[(size_t)kw * L.NC + i];   // the whole row, coalesced
+        }
     }
     GNMS_BT();
 #ifdef GNMS_TIMING
-    if (ROWBUF && !CHUNKLOOP && b == 0 && bx == 32 && (threadIdx.x == 0 || threadIdx.x == 960)) {
+    if (ROWBUF && !CHUNKLOOP && b == 0 && bx == (int)gridDim.x / 2 && (threadIdx.x == 0 || threadIdx.x == 960)) {
         long long* o = reinterpret_cast<long long*>(I.xsol) + (threadIdx.x ? 8 : 0);
         for (int q = 1; q < 6; ++q) o[q] += bt__[q] - bt__[q - 1];
+    }
+    // (round 6) the launch's timeline: every workgroup's start and end on the constant-rate clock (s_memrealtime, 100 MHz, one clock for all
+    // XCDs), last call only -- tools/bits_ticks.py
+    if (ROWBUF && !CHUNKLOOP && threadIdx.x == 0 && bx < 256) {
+        long long* o = reinterpret_cast<long long*>(I.xsol) + 32 + 2 * bx;
+        o[0] = rt0__; o[1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 #endif
 }
 
 // (ROWBUF without the chunk loop: two 16-wave workgroups per CU = 8 waves per SIMD, i.e. at most 64 VGPRs -- asked for explicitly)
 template <int CPL, int KBW, bool ROWBUF = false, bool CHUNKLOOP = false>
-__global__ __launch_bounds__(ROWBUF ? 1024 : 256, (ROWBUF && !CHUNKLOOP) ? 8 : 1) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
+__global__ __launch_bounds__(ROWBUF ? 1024 : 256, (ROWBUF && !CHUNKLOOP) ? (KBW > 1 ? 4 : 8) : 1) void bitmask_boxes_kernel(const float* __restrict__ boxes, int N, const int* __restrict__ counts,
                                                             float thr, char* ws, gnms_ws_layout L) {
     bitmask_boxes_body<CPL, KBW, ROWBUF, CHUNKLOOP>(boxes, N, counts, thr, ws, L, (int)blockIdx.z, (int)blockIdx.x);
 }

@@ -952,6 +952,13 @@ int launch_bitmask_boxes(const float* boxes, int B, int N, const int32_t* counts
         bitmask_boxes_kernel<4, 1, true, true><<<dim3(NB, 1, B), 1024, lds, st>>>(boxes, N, counts, thr, ws, L);
     } else if (tiles4 >= 2048 && (N + 255) / 256 <= 16) {
         // one 16-wave workgroup per rank block: words collected in an LDS copy of the row, written out coalesced
+        // (from two workgroups per CU on: two rank blocks per workgroup -- half the column-side traffic, one workgroup per CU; see the body)
+        if ((long)B * NB > (long)device_cu_count()) {
+            const size_t lds = 2 * (size_t)L.NC * 8 + 4 * 1024 * sizeof(int);
+            int rc = allow_lds(bitmask_boxes_kernel<4, 2, true>, lds);
+            if (rc) return rc;
+            bitmask_boxes_kernel<4, 2, true><<<dim3((NB + 1) / 2, 1, B), 1024, lds, st>>>(boxes, N, counts, thr, ws, L);
+        } else
         bitmask_boxes_kernel<4, 1, true><<<dim3(NB, 1, B), 1024, (size_t)L.NC * 8 + 4 * 1024 * sizeof(int), st>>>(boxes, N, counts, thr, ws, L);   // + the ranks' stash
     } else if (tiles4 >= 2048) {
         bitmask_boxes_kernel<4, 1><<<dim3(gnms_div_up(NB * ((N + 255) / 256), 4), 1, B), 256, 0, st>>>(boxes, N, counts, thr, ws, L);

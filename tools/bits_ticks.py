@@ -26,3 +26,13 @@ for kind in ("uniform", "clustered"):
     for w, base in (("wave 0", 0), ("wave 15", 8)):
         print(kind, w, " | ".join("%s %.0f" % (names[q], t[base + q]) for q in range(1, 6)))
 
+    # (round 6) the launch's timeline: start / end of every workgroup (last call), 10-ns ticks of the constant-rate clock
+    per = nbytes // B
+    nwg = 32                                                   # workgroups per image (two rank blocks each since round 6)
+    tl = np.stack([ws[b_ * per + off + 256: b_ * per + off + 256 + 16 * nwg].cpu().numpy().view(np.int64).reshape(nwg, 2) for b_ in range(B)])
+    t0 = tl[:, :, 0].min()
+    st, en = (tl[:, :, 0] - t0) / 100.0, (tl[:, :, 1] - t0) / 100.0
+    print(kind, "timeline, us from the first workgroup's start: starts min / median / max %.2f / %.2f / %.2f, ends min / median / max %.2f / %.2f / %.2f, "
+          "a workgroup's own time median / max %.2f / %.2f" % (st.min(), np.median(st), st.max(), en.min(), np.median(en), en.max(), np.median(en - st), (en - st).max()))
+    for b_ in (0, 7):
+        print(kind, "image %d: start by rank block (us):" % b_, " ".join("%.1f" % v for v in st[b_, ::2]), "| end:", " ".join("%.1f" % v for v in en[b_, ::2]))
