@@ -80,6 +80,8 @@ _SIGNATURES = {
                                                c_vp, c_vp, ctypes.c_size_t, c_vp, ctypes.c_size_t, c_vp]),
     "gnms_sgemm": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                   ctypes.c_int64, c_vp]),
+    "gnms_profile_sgemm": (ctypes.c_int, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_int, c_vp]),
     "_nms": (None, [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]),
     "gnms_nms_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "gnms_nms_sorted": (ctypes.c_int, [c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]),

@@ -29,18 +29,29 @@ __device__ __forceinline__ float bcastf(float v, int lane) {
 // keep_le: 0 = suppress when IoU > thresh (nms_kernel.cu:71); 1 = keep only IoU <= thresh (nms_others.py:146: a NaN overlap suppresses)
 // what the leader scan expects of a sort that never ran: boxes arrive sorted, rank == index.  The workgroups of the first row block do it on the side
 // (COLS columns each) -- the mask kernels read none of it, the scan runs a launch later
+// the counters, the call counter and the hand-off granules of the leader scan (what the sort kernels do for the layer), by ONE workgroup
+__device__ __forceinline__ void classic_init_counters(const ImgPtrs& I) {
+    if (threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;
+    if (threadIdx.x == 8) I.misc[8] = gnms_next_epoch(I.misc[8]);
+    for (int i = threadIdx.x; i < 17 * 32; i += blockDim.x) I.gran[i] = 0ull;
+}
 template <int COLS>
 __device__ __forceinline__ void classic_init_part(int n, char* ws, const gnms_ws_layout& L) {
     ImgPtrs I = img_ptrs(ws, L, 0);
     const int base = blockIdx.x * COLS, end = min(n, base + COLS);
     for (int k = base + (int)threadIdx.x; k < end; k += 256) { I.order[k] = k; I.rankof[k] = k; }
-    if (blockIdx.x == 0 && threadIdx.x < 8) I.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;
+    if (blockIdx.x == 0) classic_init_counters(I);
 }
 
 // J columns per lane: a wave's tile is 64 rows x 64 J columns, ~25 VALU instructions per pair (one IEEE division) all on ONE SIMD -- 11 us for
 // J = 4.  Up to ~8000 boxes such tiles are fewer than the machine's SIMDs (n = 500: 16 busy waves, 21 us; n = 4096: 24 us), and J = 1 gives
 // four times the waves a quarter of the work each (n = 500: 22.5 -> 8.8 us; n = 4096: 24 -> 20 with the 1D grid below); above, J = 4 keeps the box loads amortised.
-template <int J>
+// UPPER (round 6, n <= GNMS_MAX_BOXES): the tiles whose COLUMN block is not in front of the row block -- W[kb][c] for c >= 64 kb: whom a box of
+// block kb suppresses among the later boxes -- instead of those a suppressor can reach.  The overlap is symmetric bit for bit (sums, minima and
+// maxima commute), so the two triangles hold the same decisions; this one is what the layer's leader scan on ONE WORKGROUP PER SUPER-BLOCK
+// reads (leaders_sb_body: a super-block's table and its pulls from the earlier super-blocks), which replaces the one-workgroup general scan
+// -- 23.6 us at n = 4096, ~450 at 16384 -- behind `_nms`.
+template <int J, bool UPPER = false>
 __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restrict__ boxes, int n, int dim, float thresh, float shift, int keep_le,
                                                            char* ws, gnms_ws_layout L, int init) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -52,21 +63,24 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
         if (init) {
             ImgPtrs I0 = img_ptrs(ws, L, 0);
             for (int k = blockIdx.x * 256 + (int)threadIdx.x; k < n; k += gridDim.x * 256) { I0.order[k] = k; I0.rankof[k] = k; }
-            if (blockIdx.x == 0 && threadIdx.x < 8) I0.misc[threadIdx.x] = (threadIdx.x == 2) ? 1 : 0;
+            if (blockIdx.x == 0) classic_init_counters(I0);
         }
         const int w = blockIdx.x * 4 + wave, nbk = (n + 63) >> 6;
         if (w >= nbk * (nbk + 1) / 2) return;
-        kb = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
-        while (kb * (kb + 1) / 2 > w) --kb;
-        while ((kb + 1) * (kb + 2) / 2 <= w) ++kb;
-        c0 = (w - kb * (kb + 1) / 2) * 64;
+        int big = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+        while (big * (big + 1) / 2 > w) --big;
+        while ((big + 1) * (big + 2) / 2 <= w) ++big;
+        const int small = w - big * (big + 1) / 2;                   // small <= big: the pair of blocks of this tile
+        kb = UPPER ? small : big;
+        c0 = (UPPER ? big : small) * 64;
     } else {
         if (init && blockIdx.y == 0) classic_init_part<256 * J>(n, ws, L);
         kb = blockIdx.y;
         c0 = (blockIdx.x * 4 + wave) * (64 * J);
     }
     const int k0 = kb * 64;
-    if (k0 >= n || c0 >= n || c0 >= k0 + 64) return;      // suppressors come from ranks < k0 + 64
+    if (k0 >= n || c0 >= n) return;
+    if (UPPER ? (c0 + 64 * J <= k0) : (c0 >= k0 + 64)) return;      // lower: suppressors come from ranks < k0 + 64; upper: the suppressed from ranks >= k0
     ImgPtrs I = img_ptrs(ws, L, 0);
     float bx1[J], by1[J], bx2[J], by2[J], bs[J];
     int col[J];
@@ -85,19 +99,39 @@ __global__ __launch_bounds__(256) void classic_mask_kernel(const float* __restri
     unsigned lo[J], hi[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) lo[j] = hi[j] = 0u;
+    // (round 6) the decision without the division where that is safe, as bitmask_boxes_body takes it: with d = fma(-thresh, uni, inter) (one
+    // rounding, sign exact) and uni > 0, |d| > guard * uni puts the exact quotient more than 8 ulp of the threshold's magnitude away from it, so
+    // its fp32 rounding lies on the same side and `ov > thresh` is `d > 0`; a row with a pair inside the band (or uni <= 0, NaN, inf) divides.
+    const float guard = fmaxf(fabsf(thresh), 1.0f) * 9.6e-7f;
 #pragma unroll 8
     for (int r = 0; r < 64; ++r) {
         const float ax1 = bcastf(rx1, r), ay1 = bcastf(ry1, r), ax2 = bcastf(rx2, r), ay2 = bcastf(ry2, r), as = bcastf(rs, r);
+        float inter[J], uni[J], d[J];
+        bool unsure = false;
 #pragma unroll
         for (int j = 0; j < J; ++j) {
             // (v_max / v_min issued directly, the row coordinate from its SGPR: no canonicalising moves; iou3d_pair.h)
             const float left = gnms_iou3d::vmax_s(ax1, bx1[j]), right = gnms_iou3d::vmin_s(ax2, bx2[j]);   // :25
             const float top = gnms_iou3d::vmax_s(ay1, by1[j]), bottom = gnms_iou3d::vmin_s(ay2, by2[j]);   // :26
             const float width = fmaxf(right - left + shift, 0.f), height = fmaxf(bottom - top + shift, 0.f);   // :27
-            const float inter = width * height;                                  // :28
-            const float ov = inter / (as + bs[j] - inter);                       // :31
-            const bool sup = keep_le ? !(ov <= thresh) : (ov > thresh);           // :71 / nms_others.py:146
-            if (r < 32) lo[j] |= sup ? (1u << r) : 0u; else hi[j] |= sup ? (1u << (r - 32)) : 0u;
+            inter[j] = width * height;                                            // :28
+            uni[j] = as + bs[j] - inter[j];                                       // :31's denominator
+            d[j] = __builtin_fmaf(-thresh, uni[j], inter[j]);
+            unsure |= !(uni[j] > 0.0f) || !(uni[j] < INFINITY) || !(fabsf(d[j]) > guard * uni[j]);   // (also true for NaN)
+        }
+        if (__any(unsure)) {                                                      // (wave-uniform; rare)
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const float ov = inter[j] / uni[j];                               // :31
+                const bool sup = keep_le ? !(ov <= thresh) : (ov > thresh);       // :71 / nms_others.py:146
+                if (r < 32) lo[j] |= sup ? (1u << r) : 0u; else hi[j] |= sup ? (1u << (r - 32)) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const bool sup = d[j] > 0.0f;
+                if (r < 32) lo[j] |= sup ? (1u << r) : 0u; else hi[j] |= sup ? (1u << (r - 32)) : 0u;
+            }
         }
     }
     const unsigned long long rowmask = (nrows >= 64) ? ~0ull : ((1ull << nrows) - 1ull);
@@ -244,13 +278,19 @@ int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double
     char* ws = (char*)workspace;
     GNMS_CHECK_ARG(L.NB <= 65535, "gnms_nms_sorted: too many row blocks");
     // (init: the identity order and the counters the leader scan reads -- written by the first row block's workgroups, three launches instead of four)
+    // upper: the triangle the super-block scan reads (fp32, n <= GNMS_MAX_BOXES); else the one a suppressor can reach (general scan, block scan)
+    const bool upper = !is_fp64 && n <= GNMS_MAX_BOXES;
     auto mask = [&](int init) {
+        const dim3 g1(gnms_div_up(((n + 63) / 64) * (((n + 63) / 64) + 1) / 2, 4)), g4(gnms_div_up(n, 1024), L.NB);
         if (is_fp64)
             classic_mask_f64_kernel<<<dim3(gnms_div_up(n, 256), L.NB), 256, 0, st>>>((const double*)boxes, n, boxes_dim, thresh, shift, keep_le, ws, L, init);
-        else if ((long)L.NB * gnms_div_up(n, 256) / 2 < 4096)      // fewer 64 x 256 tiles than four per SIMD: 64 x 64 tiles
-            classic_mask_kernel<1><<<dim3(gnms_div_up(((n + 63) / 64) * (((n + 63) / 64) + 1) / 2, 4)), 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
-        else
-            classic_mask_kernel<4><<<dim3(gnms_div_up(n, 1024), L.NB), 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
+        else if ((long)L.NB * gnms_div_up(n, 256) / 2 < 4096) {     // fewer 64 x 256 tiles than four per SIMD: 64 x 64 tiles
+            if (upper) classic_mask_kernel<1, true><<<g1, 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
+            else classic_mask_kernel<1><<<g1, 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
+        } else {
+            if (upper) classic_mask_kernel<4, true><<<g4, 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
+            else classic_mask_kernel<4><<<g4, 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
+        }
     };
     if (n > GNMS_MAX_BOXES) {                                     // the reference's scan on the device (classic_scan_large_kernel)
         mask(0);
@@ -266,7 +306,8 @@ int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double
         const int rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(leaders_kernel), lds);       // (remembered per device and kernel)
         if (rc) return rc;
     }
-    leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L, 0, 1, 1);
+    if (upper) { const int spw = leaders_chain_wgs(n, 1); leaders_kernel<<<spw, 1024, lds, st>>>(n, nullptr, ws, L, 1, 1, spw); }   // one workgroup per super-block
+    else leaders_kernel<<<1, 1024, lds, st>>>(n, nullptr, ws, L, 0, 1, 1);
     GNMS_CHECK_LAUNCH();
     if (tag_ptr) classic_export_tag_kernel<<<1, 1024, 0, st>>>(ws, L, keep, num_out, tag_ptr, tag);
     else classic_export_kernel<<<gnms_div_up(n, 256), 256, 0, st>>>(n, ws, L, keep, num_out);

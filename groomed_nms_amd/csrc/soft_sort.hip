@@ -9,6 +9,11 @@
 // The C @ iou product is the one dense GEMM on the whole GrooMeD path (2 N^3 flop): it runs on the
 // matrix cores with v_mfma_f32_32x32x2_f32 (exact fp32, = an fmaf chain), 128x128x16 LDS tiles,
 // one wave per 64x64 quadrant (2x2 MFMA tiles, 64 accumulator registers).
+#include <dlfcn.h>
+#include <array>
+#include <map>
+#include <mutex>
+#include <hipblaslt/hipblaslt.h>   // (types and enumerators only: the entry points are resolved with dlsym, below)
 #include <type_traits>
 #include "nms_kernels.h"
 
@@ -189,7 +194,10 @@ constexpr int GM = 256, GN = 128, GK = 16, GLA = 20, GLB = 132;      // LDS row 
 // Split K (round 4b): slice z = blockIdx.z multiplies the k range [z K, (z + 1) K) into its own panel D + z slice_stride (launch_sgemm's
 // scratch, summed in slice order by sgemm_reduce_kernel) -- for the sizes whose tiles alone leave the machine empty (1024^3: 32 tiles).
 __global__ __launch_bounds__(256, 2) void sgemm_mfma_big_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ D,
-                                                                int K, long lda, long ldb, long ldd, int accumulate, long slice_stride) {
+                                                                int K, long lda, long ldb, long ldd, int accumulate, long slice_stride, int dephase = 0) {
+    // (round 6 experiment, gnms_profile_sgemm variant 3: the second half of the grid -- the CUs' second workgroups -- starts half a K tile late, so
+    // that the two workgroups of a CU do not sit in their barriers at the same time)
+    if (dephase && ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 >= (long)gridDim.x * gridDim.y) __builtin_amdgcn_s_sleep(32);
     A += (long)blockIdx.z * K;                                        // (K = the slice's length: a multiple of 32)
     Bm += (long)blockIdx.z * K * ldb;
     D += (long)blockIdx.z * slice_stride;
@@ -434,14 +442,169 @@ __global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The PLAIN product on the vendor libraries (round 6).  C @ iou of the soft sort is a plain fp32 GEMM with nothing to fuse into it, and the
+// libraries' tuned assembly kernels for gfx950 stay ahead of the kernels above at most sizes (profiles/r06_sgemm_variants.txt, TF, same box:
+// 512^3 own 12.5 / rocBLAS 33.8 / torch.matmul 14.4; 1024^3 54.6 / 106.0 / 99.2; 2048^3 104 / 119 / 139; 4096^3 140 / 139 / 149; 8192^3
+// 143 / 140 / 153 -- torch.matmul is hipBLASLt; all of them the same v_mfma_f32_32x32x2_f32, exact fp32 products).  So from 512^3 on the
+// product goes to rocBLAS, from 2048^3 on to hipBLASLt, when the library can be found; the hand-written kernels stay for everything else
+// (small or odd shapes, a stream that is being captured, a process without the libraries) and behind gnms_profile_sgemm for comparison.
+// Resolved with dlopen / dlsym at first use -- libgroomed_nms_hip.so has no link-time dependency on it; inside a PyTorch process the name
+// resolves to the copy PyTorch has already mapped.  One handle per device, created once; atomics off (deterministic sums).
+// ------------------------------------------------------------------------------------------------
+struct RocblasApi {
+    typedef int (*create_t)(void**);
+    typedef int (*set_stream_t)(void*, hipStream_t);
+    typedef int (*set_atomics_t)(void*, int);
+    typedef int (*sgemm_t)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
+    create_t create = nullptr;
+    set_stream_t set_stream = nullptr;
+    set_atomics_t set_atomics = nullptr;
+    sgemm_t sgemm = nullptr;
+    void* handle[64] = {};
+    std::mutex mu;
+    bool tried = false, ok = false;
+};
+RocblasApi g_rocblas;
+// true when the product was enqueued on the library
+bool rocblas_sgemm_rowmajor(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd, int accumulate,
+                            hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;   // (the library may allocate a workspace)
+    if (lda > 0x7fffffff || ldb > 0x7fffffff || ldd > 0x7fffffff) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    RocblasApi& R = g_rocblas;
+    std::lock_guard<std::mutex> lock(R.mu);
+    if (!R.tried) {
+        R.tried = true;
+        void* h = nullptr;
+        for (const char* name : {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"}) {
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        }
+        if (h) {
+            R.create = (RocblasApi::create_t)dlsym(h, "rocblas_create_handle");
+            R.set_stream = (RocblasApi::set_stream_t)dlsym(h, "rocblas_set_stream");
+            R.set_atomics = (RocblasApi::set_atomics_t)dlsym(h, "rocblas_set_atomics_mode");
+            R.sgemm = (RocblasApi::sgemm_t)dlsym(h, "rocblas_sgemm");
+            R.ok = R.create && R.set_stream && R.sgemm;
+        }
+    }
+    if (!R.ok) return false;
+    if (!R.handle[dev]) {
+        void* hd = nullptr;
+        if (R.create(&hd) != 0 || !hd) { R.ok = false; return false; }
+        if (R.set_atomics) (void)R.set_atomics(hd, 0);               // rocblas_atomics_not_allowed
+        R.handle[dev] = hd;
+    }
+    if (R.set_stream(R.handle[dev], st) != 0) return false;
+    // row-major D = A B  ==  column-major D^T = B^T A^T: (N x M) = (N x K)(K x M), operands swapped, no transposes
+    const float alpha = 1.0f, beta = accumulate ? 1.0f : 0.0f;
+    return R.sgemm(R.handle[dev], 111, 111, N, M, K, &alpha, B, (int)ldb, A, (int)lda, &beta, D, (int)ldd) == 0;   // 111 = rocblas_operation_none
+}
+
+// hipBLASLt, the library behind torch.matmul on this platform: ahead of rocBLAS's own sgemm and of the kernels here from 2048^3 on
+// (r06_sgemm_variants.txt).  The copy that matches the headers this file was compiled against is loaded by its path (PyTorch maps an older one
+// under the bare name; the two live side by side), one handle and one 32-MiB workspace per device, the heuristic's first algorithm per shape
+// remembered.  Row-major D = A B as the column-major product D^T = B^T A^T.
+struct LtApi {
+    decltype(&hipblasLtCreate) create = nullptr;
+    decltype(&hipblasLtMatrixLayoutCreate) layout_create = nullptr;
+    decltype(&hipblasLtMatmulDescCreate) desc_create = nullptr;
+    decltype(&hipblasLtMatmulPreferenceCreate) pref_create = nullptr;
+    decltype(&hipblasLtMatmulPreferenceSetAttribute) pref_set = nullptr;
+    decltype(&hipblasLtMatmulAlgoGetHeuristic) heuristic = nullptr;
+    decltype(&hipblasLtMatmul) matmul = nullptr;
+    struct Plan { hipblasLtMatmulDesc_t desc; hipblasLtMatrixLayout_t a, b, d; hipblasLtMatmulAlgo_t algo; size_t ws; };
+    hipblasLtHandle_t handle[64] = {};
+    void* wsp[64] = {};
+    hipblasLtMatmulPreference_t pref = nullptr;
+    std::map<std::array<int64_t, 7>, Plan> plans;
+    std::mutex mu;
+    bool tried = false, ok = false;
+};
+LtApi g_lt;
+constexpr size_t kLtWorkspace = (size_t)32 << 20;
+bool hipblaslt_sgemm_rowmajor(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd, int accumulate,
+                              hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    LtApi& R = g_lt;
+    std::lock_guard<std::mutex> lock(R.mu);
+    if (!R.tried) {
+        R.tried = true;
+        void* h = nullptr;
+        for (const char* name : {"/opt/rocm/lib/libhipblaslt.so.1", "libhipblaslt.so.1"}) {
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        }
+        if (h) {
+            R.create = (decltype(R.create))dlsym(h, "hipblasLtCreate");
+            R.layout_create = (decltype(R.layout_create))dlsym(h, "hipblasLtMatrixLayoutCreate");
+            R.desc_create = (decltype(R.desc_create))dlsym(h, "hipblasLtMatmulDescCreate");
+            R.pref_create = (decltype(R.pref_create))dlsym(h, "hipblasLtMatmulPreferenceCreate");
+            R.pref_set = (decltype(R.pref_set))dlsym(h, "hipblasLtMatmulPreferenceSetAttribute");
+            R.heuristic = (decltype(R.heuristic))dlsym(h, "hipblasLtMatmulAlgoGetHeuristic");
+            R.matmul = (decltype(R.matmul))dlsym(h, "hipblasLtMatmul");
+            R.ok = R.create && R.layout_create && R.desc_create && R.pref_create && R.pref_set && R.heuristic && R.matmul;
+            if (R.ok) {
+                const uint64_t wsz = kLtWorkspace;
+                R.ok = R.pref_create(&R.pref) == HIPBLAS_STATUS_SUCCESS &&
+                       R.pref_set(R.pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)) == HIPBLAS_STATUS_SUCCESS;
+            }
+        }
+    }
+    if (!R.ok) return false;
+    if (!R.handle[dev]) {
+        hipblasLtHandle_t hd = nullptr;
+        void* w = nullptr;
+        if (R.create(&hd) != HIPBLAS_STATUS_SUCCESS || !hd) { R.ok = false; return false; }
+        if (hipMalloc(&w, kLtWorkspace) != hipSuccess) { R.ok = false; return false; }
+        R.handle[dev] = hd;
+        R.wsp[dev] = w;
+    }
+    const std::array<int64_t, 7> key = {(int64_t)dev, M, N, K, lda, ldb, ldd};
+    auto it = R.plans.find(key);
+    if (it == R.plans.end()) {
+        LtApi::Plan P{};
+        // column-major: "A" = B^T as stored (N x K, ld ldb), "B" = A^T as stored (K x M, ld lda), C = D = D^T as stored (N x M, ld ldd)
+        if (R.desc_create(&P.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS ||
+            R.layout_create(&P.a, HIP_R_32F, (uint64_t)N, (uint64_t)K, ldb) != HIPBLAS_STATUS_SUCCESS ||
+            R.layout_create(&P.b, HIP_R_32F, (uint64_t)K, (uint64_t)M, lda) != HIPBLAS_STATUS_SUCCESS ||
+            R.layout_create(&P.d, HIP_R_32F, (uint64_t)N, (uint64_t)M, ldd) != HIPBLAS_STATUS_SUCCESS) return false;
+        hipblasLtMatmulHeuristicResult_t res[1];
+        int got = 0;
+        if (R.heuristic(R.handle[dev], P.desc, P.a, P.b, P.d, P.d, R.pref, 1, res, &got) != HIPBLAS_STATUS_SUCCESS || got < 1 ||
+            res[0].state != HIPBLAS_STATUS_SUCCESS || res[0].workspaceSize > kLtWorkspace) return false;
+        P.algo = res[0].algo;
+        P.ws = res[0].workspaceSize;
+        it = R.plans.emplace(key, P).first;
+    }
+    const LtApi::Plan& P = it->second;
+    const float alpha = 1.0f, beta = accumulate ? 1.0f : 0.0f;
+    return R.matmul(R.handle[dev], P.desc, &alpha, B, P.a, A, P.b, &beta, D, P.d, D, P.d, &P.algo, R.wsp[dev], kLtWorkspace, st) == HIPBLAS_STATUS_SUCCESS;
+}
+
+// variant: 0 = the product path (hipBLASLt from 2048^3 on, rocBLAS from 512^3 on, else -- and whenever a library is missing -- the kernels
+// here); 1 = the kernels here only; 2 = rocBLAS only, 4 = hipBLASLt only (an error if it is not there); 3 = the kernels here, the large one
+// de-phased (an experiment, see sgemm_mfma_big_kernel)
 int launch_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd, int accumulate,
-                 hipStream_t st) {
+                 hipStream_t st, int variant = 0) {
     if (M == 0 || N == 0) return GNMS_OK;
+    if (variant == 4 || (variant == 0 && M >= 2048 && N >= 2048 && K >= 2048)) {
+        if (hipblaslt_sgemm_rowmajor(A, B, D, M, N, K, lda, ldb, ldd, accumulate, st)) return GNMS_OK;
+        if (variant == 4) { gnms_set_error("gnms_profile_sgemm: hipBLASLt is not available"); return GNMS_ERR_UNSUPPORTED; }
+    }
+    if (variant == 2 || (variant == 0 && M >= 512 && N >= 512 && K >= 512)) {
+        if (rocblas_sgemm_rowmajor(A, B, D, M, N, K, lda, ldb, ldd, accumulate, st)) return GNMS_OK;
+        if (variant == 2) { gnms_set_error("gnms_profile_sgemm: rocBLAS is not available"); return GNMS_ERR_UNSUPPORTED; }
+    }
     const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
     if (aligned && M % GM == 0 && N % GN == 0 && K % (2 * GK) == 0 && K >= 2 * GK) {
         const long big_tiles = (long)(M / GM) * (N / GN);
         if (big_tiles >= 256) {
-            sgemm_mfma_big_kernel<<<dim3(N / GN, M / GM), 256, 0, st>>>(A, B, D, K, (long)lda, (long)ldb, (long)ldd, accumulate, 0L);
+            sgemm_mfma_big_kernel<<<dim3(N / GN, M / GM), 256, 0, st>>>(A, B, D, K, (long)lda, (long)ldb, (long)ldd, accumulate, 0L, variant == 3 ? 1 : 0);
             GNMS_CHECK_LAUNCH();
             return GNMS_OK;
         }
@@ -499,6 +662,14 @@ extern "C" int gnms_sgemm(const float* A, const float* B, float* D, int M, int N
     if (M == 0 || N == 0) return GNMS_OK;
     GNMS_CHECK_ARG(A && B && D, "gnms_sgemm: null pointer");
     return launch_sgemm(A, B, D, M, N, K, lda, ldb, ldd, 0, (hipStream_t)stream);
+}
+
+extern "C" int gnms_profile_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd,
+                                  int variant, void* stream) {
+    GNMS_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && variant >= 0 && variant <= 4, "gnms_profile_sgemm: bad argument");
+    if (M == 0 || N == 0) return GNMS_OK;
+    GNMS_CHECK_ARG(A && B && D, "gnms_profile_sgemm: null pointer");
+    return launch_sgemm(A, B, D, M, N, K, lda, ldb, ldd, 0, (hipStream_t)stream, variant);
 }
 
 extern "C" size_t gnms_soft_sort_backward_scratch_bytes(int N, int K) {

@@ -280,6 +280,12 @@ int gnms_soft_sort_backward(const float* scores, const float* matrix, int N, int
  * summed in order (deterministic; a different association of the same sum). */
 int gnms_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd,
                void* stream);
+/* Round 6: from 512 x 512 x 512 on the PLAIN product runs on rocBLAS, from 2048^3 on on hipBLASLt, when the library can be found (dlopen at
+ * first use; a stream that is being captured keeps the kernels of this library), see csrc/soft_sort.hip.  gnms_profile_sgemm picks the path
+ * for comparisons: variant 0 = what gnms_sgemm does, 1 = this library's MFMA kernels only, 2 = rocBLAS only, 4 = hipBLASLt only
+ * (GNMS_ERR_UNSUPPORTED when it is missing), 3 = variant 1 with the large kernel's workgroups de-phased (a measured experiment). */
+int gnms_profile_sgemm(const float* A, const float* B, float* D, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldd,
+                       int variant, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classical hard NMS (lib/nms)

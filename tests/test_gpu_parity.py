@@ -248,6 +248,35 @@ def test_sgemm_mfma(G):
         np.testing.assert_allclose(got, ref, atol=1e-6 * K + 1e-5, rtol=1e-5)
 
 
+@pytest.mark.gpu
+def test_sgemm_every_path_against_float64(G):
+    """Round 6: the plain product behind the soft sort goes to rocBLAS from 512^3 on and to hipBLASLt from 2048^3 on (dlopen at first use),
+    the library's own MFMA kernels serve everything else; gnms_profile_sgemm selects a path.  Every path against the float64 product on
+    asymmetric operands, row-major with padded leading dimensions (the column-major trick D^T = B^T A^T must not transpose anything), shapes on
+    both sides of the dispatch's thresholds; a path whose library is missing may refuse (GNMS_ERR_UNSUPPORTED), never return a wrong product."""
+    import ctypes
+    from groomed_nms_amd import _lib
+    from groomed_nms_amd._lib import ptr, stream_ptr
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(5)
+    for M, N, K, pad in ((300, 500, 700, 0), (512, 512, 512, 4), (640, 2048, 1024, 8), (2048, 2304, 2048, 0), (2560, 2048, 2176, 16)):
+        a = rng.uniform(-1, 1, size=(M, K + pad)).astype(np.float32)
+        b = rng.uniform(-1, 1, size=(K, N + pad)).astype(np.float32)
+        ref = a[:, :K].astype(np.float64) @ b[:, :N].astype(np.float64)
+        at, bt = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        for variant in (0, 1, 2, 3, 4):
+            d = torch.full((M, N + pad), -7.0, device=dev)
+            rc = lib.gnms_profile_sgemm(ptr(at), ptr(bt), ptr(d), M, N, K, K + pad, N + pad, N + pad, variant, stream_ptr(dev))
+            if rc == -2 and variant in (2, 4):            # GNMS_ERR_UNSUPPORTED: the vendor library is not in this process / image
+                continue
+            assert rc == 0, (M, N, K, variant, lib.gnms_last_error())
+            got = d.cpu().numpy()
+            np.testing.assert_allclose(got[:, :N], ref, atol=1e-6 * K + 1e-5, rtol=1e-5, err_msg=str((M, N, K, variant)))
+            if pad:
+                assert np.all(got[:, N:] == -7.0), (M, N, K, variant)     # the padding columns of D stay untouched
+
+
 def test_classic_nms(G, O, golden_misc):
     from groomed_nms_amd.nms import gpu_nms
     g = golden_misc
