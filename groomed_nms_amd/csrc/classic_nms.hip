@@ -202,6 +202,81 @@ __global__ __launch_bounds__(1024) void classic_export_tag_kernel(char* ws, gnms
     if (threadIdx.x == 0) __hip_atomic_store(tag_ptr, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LARGE inputs in CHUNKS (round 6; fp32, n > GNMS_MAX_BOXES: the reference's `use_nms and synced` inference path hands gpu_nms every anchor of
+// an image, > 100 k boxes, lib/rpn_util.py:1268).  Greedy NMS never needs the whole n x n matrix -- only (kept box, candidate) pairs:
+//   for every chunk of GNMS_MAX_BOXES boxes, in score order:
+//     classic_ext_kernel     which boxes of the chunk does a box KEPT SO FAR suppress?  (m x kept pair decisions straight from the boxes: the
+//                            kept list is a couple of thousand boxes where the matrix row would be the 126 720 of every anchor)
+//     classic_mask_kernel    the chunk's own upper block triangle, as for a small input
+//     leaders_kernel         the layer's scan, one workgroup per super-block, with those boxes removed from the start (ext0)
+//     classic_append_kernel  the chunk's kept boxes -> keep[] (global indices), their boxes -> the kept list, the count
+// The same keep list as the reference's scan (a box is suppressed iff some EARLIER KEPT box overlaps it by more than the threshold), with
+// n^2 / (2 chunks) + n kept pair decisions instead of n^2 / 2 and 33 MB of workspace instead of n^2 / 8 bytes: n = 126 720 took 5.0 ms of mask
+// kernel + 6.8 ms of one-workgroup block scan (classic_scan_large_kernel below, still the float64 path).
+// ------------------------------------------------------------------------------------------------
+// (one workgroup per 64 candidates, its sixteen waves each take every sixteenth kept box of a staged tile: 256 workgroups at m = 16 384 where
+// one thread per candidate and 256 per workgroup left three quarters of the machine idle -- 248 -> ~30 us per chunk)
+__global__ __launch_bounds__(1024) void classic_ext_kernel(const float* __restrict__ boxes, int base, int m, int dim, float thresh, float shift, int keep_le,
+                                                           const float4* __restrict__ kbox, const int* __restrict__ nkept_p, u64* __restrict__ extw) {
+    __shared__ float4 tile[1024];
+    __shared__ unsigned long long s_bits;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = blockIdx.x * 64 + lane;                              // chunk-local index of this lane's candidate (the same in all sixteen waves)
+    const int nk = *nkept_p;
+    const float* q = boxes + (size_t)(base + (k < m ? k : m - 1)) * dim;
+    const float bx1 = q[0], by1 = q[1], bx2 = q[2], by2 = q[3];
+    const float bs = (bx2 - bx1 + shift) * (by2 - by1 + shift);
+    const float guard = fmaxf(fabsf(thresh), 1.0f) * 9.6e-7f;          // (classic_mask_kernel's band: the two kernels take the same decisions)
+    if (tid == 0) s_bits = 0ull;
+    bool sup = false;
+    for (int t0 = 0; t0 < nk; t0 += 1024) {
+        __syncthreads();
+        if (t0 + tid < nk) tile[tid] = kbox[t0 + tid];
+        __syncthreads();
+        const int cnt = min(1024, nk - t0);
+        for (int j = wave; j < cnt; j += 16) {
+            const float4 a = tile[j];                                  // the kept box: the ROW of the matrix entry (nms_kernel.cu:24-32)
+            const float as = (a.z - a.x + shift) * (a.w - a.y + shift);
+            const float left = fmaxf(a.x, bx1), right = fminf(a.z, bx2), top = fmaxf(a.y, by1), bottom = fminf(a.w, by2);
+            const float width = fmaxf(right - left + shift, 0.f), height = fmaxf(bottom - top + shift, 0.f);
+            const float inter = width * height;
+            const float uni = as + bs - inter;
+            const float d = __builtin_fmaf(-thresh, uni, inter);
+            bool s1;
+            if (!(uni > 0.0f) || !(uni < INFINITY) || !(fabsf(d) > guard * uni)) { const float ov = inter / uni; s1 = keep_le ? !(ov <= thresh) : (ov > thresh); }
+            else s1 = d > 0.0f;
+            sup |= s1;
+        }
+    }
+    const u64 bits = __ballot(sup && k < m);
+    if (lane == 0 && bits) atomicOr(&s_bits, bits);
+    __syncthreads();
+    if (tid == 0 && blockIdx.x * 64 < m) extw[blockIdx.x] = s_bits;
+}
+
+__global__ __launch_bounds__(1024) void classic_append_kernel(char* ws, gnms_ws_layout L, const float* __restrict__ boxes, int base, int dim,
+                                                              int* __restrict__ keep, float4* __restrict__ kbox, int* __restrict__ nkept_p,
+                                                              int* __restrict__ num_out, int* __restrict__ tag_ptr, int tag, int last) {
+    ImgPtrs I = img_ptrs(ws, L, 0);
+    const int nl = I.misc[0], at = *nkept_p;
+    for (int t = threadIdx.x; t < nl; t += 1024) {
+        const int g = base + I.leadr[t];
+        keep[at + t] = g;
+        const float* q = boxes + (size_t)g * dim;
+        kbox[at + t] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();                                                   // (every thread has read the old count)
+    if (threadIdx.x == 0) {
+        *nkept_p = at + nl;
+        if (last) {
+            *num_out = at + nl;
+            if (tag_ptr) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); __hip_atomic_store(tag_ptr, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        }
+    }
+}
+
 // LARGE inputs (n > GNMS_MAX_BOXES; the reference's `use_nms and synced` inference path hands gpu_nms every anchor, > 100k boxes,
 // lib/rpn_util.py:1268): the leader machinery of the layer keeps per-image state for <= 16384 boxes, so these take the reference's own
 // scan (nms_kernel.cu:118-135) on the device instead -- one workgroup, `remv` (one word per 64 boxes) in LDS:
@@ -263,6 +338,16 @@ __global__ __launch_bounds__(1024) void classic_scan_large_kernel(int n, const u
 extern "C" size_t gnms_nms_workspace_bytes(int n) { return n > 0 ? gnms_make_layout(n).per_image : 0; }
 
 namespace {
+// what nms_sorted_impl really needs: the image's layout up to GNMS_MAX_BOXES (and for float64 boxes above: the whole bit matrix); fp32 above it
+// works in chunks -- one chunk's layout, the kept boxes, the chunk's pre-removed words, a counter (always <= gnms_nms_workspace_bytes(n))
+size_t nms_workspace_needed(int n, int is_fp64) {
+    if (n <= 0) return 0;
+    if (n <= GNMS_MAX_BOXES || is_fp64) return gnms_make_layout(n).per_image;
+    return gnms_make_layout(GNMS_MAX_BOXES).per_image + (((size_t)n * 16 + 255) & ~(size_t)255) + (size_t)(GNMS_MAX_BOXES / 64) * 8 + 256;
+}
+}  // namespace
+
+namespace {
 // boxes: float [n][dim] (is_fp64 = 0) or double [n][dim] (is_fp64 = 1)
 // tag_ptr: a word of fine-grained pinned memory that receives `tag` behind the last store to keep / num_out (`_nms`), or null
 int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double thresh, double shift, int keep_le, int32_t* keep,
@@ -274,7 +359,7 @@ int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double
     if (n > kClassicLargeMax) { gnms_set_error("gnms_nms_sorted: n=%d exceeds %d", n, kClassicLargeMax); return GNMS_ERR_UNSUPPORTED; }
     GNMS_CHECK_ARG(boxes && keep && workspace, "gnms_nms_sorted: null pointer");
     const gnms_ws_layout L = gnms_make_layout(n);
-    if (workspace_bytes < L.per_image) { gnms_set_error("gnms_nms_sorted: workspace too small"); return GNMS_ERR_WORKSPACE; }
+    if (workspace_bytes < nms_workspace_needed(n, is_fp64)) { gnms_set_error("gnms_nms_sorted: workspace too small"); return GNMS_ERR_WORKSPACE; }
     char* ws = (char*)workspace;
     GNMS_CHECK_ARG(L.NB <= 65535, "gnms_nms_sorted: too many row blocks");
     // (init: the identity order and the counters the leader scan reads -- written by the first row block's workgroups, three launches instead of four)
@@ -292,7 +377,40 @@ int nms_sorted_impl(const void* boxes, int is_fp64, int n, int boxes_dim, double
             else classic_mask_kernel<4><<<g4, 256, 0, st>>>((const float*)boxes, n, boxes_dim, (float)thresh, (float)shift, keep_le, ws, L, init);
         }
     };
-    if (n > GNMS_MAX_BOXES) {                                     // the reference's scan on the device (classic_scan_large_kernel)
+    if (n > GNMS_MAX_BOXES && !is_fp64) {                         // in chunks of GNMS_MAX_BOXES (see classic_ext_kernel)
+        const int C = GNMS_MAX_BOXES;
+        const gnms_ws_layout Lc = gnms_make_layout(C);
+        float4* kbox = reinterpret_cast<float4*>(ws + Lc.per_image);                          // [n] the kept boxes, in keep order
+        u64* extw = reinterpret_cast<u64*>(ws + Lc.per_image + (((size_t)n * 16 + 255) & ~(size_t)255));   // [C / 64]
+        int* nkept = reinterpret_cast<int*>(extw + C / 64);
+        GNMS_CHECK_HIP(hipMemsetAsync(nkept, 0, sizeof(int), st));
+        const float* bf = (const float*)boxes;
+        for (int base = 0; base < n; base += C) {
+            const int m = std::min(C, n - base);
+            if (base > 0) {
+                classic_ext_kernel<<<gnms_div_up(m, 64), 1024, 0, st>>>(bf, base, m, boxes_dim, (float)thresh, (float)shift, keep_le, kbox, nkept, extw);
+                GNMS_CHECK_LAUNCH();
+            }
+            const int nbm = (m + 63) / 64;
+            if ((long)nbm * gnms_div_up(m, 256) / 2 < 4096)
+                classic_mask_kernel<1, true><<<dim3(gnms_div_up(nbm * (nbm + 1) / 2, 4)), 256, 0, st>>>(bf + (size_t)base * boxes_dim, m, boxes_dim, (float)thresh, (float)shift, keep_le, ws, Lc, 1);
+            else
+                classic_mask_kernel<4, true><<<dim3(gnms_div_up(m, 1024), nbm), 256, 0, st>>>(bf + (size_t)base * boxes_dim, m, boxes_dim, (float)thresh, (float)shift, keep_le, ws, Lc, 1);
+            GNMS_CHECK_LAUNCH();
+            const size_t lds = leaders_lds_size(Lc.NB);
+            if (lds > 64 * 1024) {
+                const int rc = gnms_allow_lds_raw(reinterpret_cast<const void*>(leaders_kernel), lds);
+                if (rc) return rc;
+            }
+            const int spw = leaders_chain_wgs(m, 1);
+            leaders_kernel<<<spw, 1024, lds, st>>>(m, nullptr, ws, Lc, 1, 1, spw, base > 0 ? extw : nullptr);
+            GNMS_CHECK_LAUNCH();
+            classic_append_kernel<<<1, 1024, 0, st>>>(ws, Lc, bf, base, boxes_dim, keep, kbox, nkept, num_out, tag_ptr, tag, base + C >= n ? 1 : 0);
+            GNMS_CHECK_LAUNCH();
+        }
+        return GNMS_OK;
+    }
+    if (n > GNMS_MAX_BOXES) {                                     // float64: the reference's scan on the device (classic_scan_large_kernel)
         mask(0);
         GNMS_CHECK_LAUNCH();
         classic_scan_large_kernel<<<1, 1024, (size_t)L.NB * 8, st>>>(n, img_ptrs(ws, L, 0).W, (long)L.NC, keep, num_out, tag_ptr, tag);
@@ -378,7 +496,7 @@ extern "C" void _nms(int* keep_out, int* num_out, const float* boxes_host, int b
     if (hipGetDevice(&cur) != hipSuccess) { gnms_set_error("_nms: hipGetDevice failed"); return; }
     if (cur != device_id && hipSetDevice(device_id) != hipSuccess) { gnms_set_error("_nms: hipSetDevice(%d) failed", device_id); return; }   // :80-89
     const size_t bbytes = (size_t)boxes_num * boxes_dim * sizeof(float);
-    const size_t wbytes = gnms_nms_workspace_bytes(boxes_num);
+    const size_t wbytes = nms_workspace_needed(boxes_num, 0);
     const size_t off_ws = (bbytes + 255) / 256 * 256;
     // the pinned block: tag | keep[] + count | boxes
     const size_t st_keep = 256, st_boxes = st_keep + ((size_t)(boxes_num + 1) * 4 + 255) / 256 * 256, st_need = st_boxes + bbytes;

@@ -1572,7 +1572,8 @@ template <int STAGE = kNoStage, bool FUSED = false>
 __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int b, const int j0,
                                                const int j1, const int me, const float* __restrict__ stage_src = nullptr, long stage_ld = 0,
                                                const float stage_thr = 0.0f, const float stage_temp = 0.0f, const int stage_prune = 0,
-                                               const int Ppow2 = 0, const unsigned tag = 0u, const int nflags = 0, const size_t lds_side = 0) {
+                                               const int Ppow2 = 0, const unsigned tag = 0u, const int nflags = 0, const size_t lds_side = 0,
+                                               const u64* __restrict__ ext0 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t oa, ol, oc, op;
     leaders_lds_layout(L.NB, &oa, &ol, &oc, &op);
@@ -1785,7 +1786,8 @@ __device__ __forceinline__ int leaders_sb_body(int N, const int* __restrict__ co
         if (cl < 0) cl = c;
     }
     if (j + 1 > have) have = j + 1;                                // (every super-block up to j is in lmask from here on: polled above, or this workgroup's own)
-    const u64 ext = __ballot(cl >= 0);                             // removed-word of the wave's block (earlier super-blocks' leaders)
+    // (ext0, classical NMS in chunks -- classic_nms.hip: word kb of it = ranks of block kb that something OUTSIDE this scan has removed already)
+    const u64 ext = __ballot(cl >= 0) | ((ext0 != nullptr && live) ? ext0[kb0 + tbc] : 0ull);   // removed-word of the wave's block (earlier super-blocks' leaders)
     GNMS_TACC_IF(b == 0 && last_sb, 1);
     if constexpr (FUSED) {
         // A single super-block with nobody to hand masks to: ONE wave walks the blocks in order -- lane = rank of the block, the table words of
@@ -2082,7 +2084,7 @@ template <int STAGE = kNoStage>
 __device__ __forceinline__ int leaders_chain(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, const int B, const int spw,
                                              const int c, const int sym_arg, int* image, const float* __restrict__ stage_src = nullptr,
                                              long stage_ld = 0, const float stage_thr = 0.0f, const float stage_temp = 0.0f,
-                                             const int stage_prune = 0, const int Ppow2 = 0) {
+                                             const int stage_prune = 0, const int Ppow2 = 0, const u64* __restrict__ ext0 = nullptr) {
     const int jw = c / B, b = c - jw * B;
     *image = b;
     // sym_arg: 0 general, 1 symmetric, 2 as wsym_check_kernel found, 3 symmetric on trust (the check runs in this launch: wsym_check_in_launch)
@@ -2098,12 +2100,13 @@ __device__ __forceinline__ int leaders_chain(int N, const int* __restrict__ coun
     const int q = (nsb + spw - 1) / spw;
     const int j0 = jw * q, j1 = min(nsb, j0 + q);
     if (j0 >= j1) return 0;                                        // (workgroup-uniform)
-    return leaders_sb_body<STAGE>(N, counts, ws, L, b, j0, j1, jw, stage_src, stage_ld, stage_thr, stage_temp, stage_prune, Ppow2);
+    return leaders_sb_body<STAGE>(N, counts, ws, L, b, j0, j1, jw, stage_src, stage_ld, stage_thr, stage_temp, stage_prune, Ppow2, 0u, 0, 0, ext0);
 }
 
-__global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, int sym, int B, int spw) {
+__global__ __launch_bounds__(1024) void leaders_kernel(int N, const int* __restrict__ counts, char* ws, gnms_ws_layout L, int sym, int B, int spw,
+                                                       const u64* __restrict__ ext0 = nullptr) {
     int b;
-    leaders_chain(N, counts, ws, L, B, spw, (int)blockIdx.x, sym, &b);
+    leaders_chain(N, counts, ws, L, B, spw, (int)blockIdx.x, sym, &b, nullptr, 0, 0.0f, 0.0f, 0, 0, ext0);
 }
 
 // ------------------------------------------------------------------------------------------------

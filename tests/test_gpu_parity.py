@@ -2008,15 +2008,21 @@ def test_one_call_matrix_with_a_sliver_of_a_last_column_tile(G, O):
 
 def test_classic_nms_beyond_the_layer_limit(G, O):
     """`_nms` on more boxes than the layer's 16384 (the reference's inference path hands gpu_nms every anchor, lib/rpn_util.py:1268):
-    the reference's block scan on the device (classic_scan_large_kernel), kept indices identical to the oracle's; sizes around the
-    64-box block edge; beyond 262144 boxes it refuses."""
-    from groomed_nms_amd import synthetic, _lib
+    round 6 works in chunks of 16384 -- what the boxes kept so far suppress in the chunk (classic_ext_kernel), the chunk's own bit matrix, the
+    layer's scan with those boxes removed from the start, the kept boxes appended -- kept indices identical to the oracle's; sizes around the
+    64-box block edge and the chunk edge, one / two / three chunks, few clusters (every later chunk almost wholly suppressed by the first
+    chunk's boxes: the kept list stays tiny) and many (it grows to thousands); the +1-pixel rule and the <= rule of girshick_nms; beyond
+    262144 boxes it refuses."""
+    from groomed_nms_amd import synthetic, _lib, nms_others
     from groomed_nms_amd.nms import gpu_nms
     rng = np.random.default_rng(17)
-    for n, per in ((16385, 8), (20000, 24), (33000, 3)):
+    for n, per in ((16385, 8), (20000, 24), (33000, 3), (32768, 4000), (32769, 40), (49153, 16), (40000, 20000)):
         dets = np.concatenate([synthetic.clustered_boxes_2d(rng, n, per), synthetic.tie_free_scores(rng, n)[:, None]], 1).astype(np.float32)
         got = [int(i) for i in gpu_nms(dets, 0.5)]
         assert got == O.classic_nms(dets, 0.5, rule="gpu"), n
+    dets = np.concatenate([synthetic.clustered_boxes_2d(rng, 20000, 12), synthetic.tie_free_scores(rng, 20000)[:, None]], 1).astype(np.float32)
+    from oracle import nms_others_oracle as NO
+    assert [int(i) for i in nms_others.girshick_nms(dets, 0.45)] == [int(i) for i in NO.girshick_nms(dets, 0.45)], "girshick_nms (<= rule), float32 boxes in chunks"
     with pytest.raises(_lib.GnmsError):
         gpu_nms(np.zeros((262145, 5), np.float32), 0.5)
 
