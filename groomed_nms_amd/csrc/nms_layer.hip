@@ -774,15 +774,24 @@ int claim_slot_for(hipStream_t st, int** slot) {
         if (e != hipSuccess) { (void)hipFree(p); GNMS_CHECK_HIP(e); }
         R.base = p;
     }
+    // (the pool is finite: a slot per stream that ever called, one per captured launch, none reclaimed.  When it runs out the callers fall
+    // back to their slower forms -- said once on stderr, so that the cliff is visible: ADVICE r5)
+    auto exhausted = [] {
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            fprintf(stderr, "[groomed_nms_hip] all %d claim slots of this device are taken (one per stream that called, one per captured launch): "
+                            "gnms_iou2d and the one-call entry on small images fall back to their slower kernels from here on\n", kClaimSlots);
+        return kNoClaimSlot;
+    };
     int idx;
     if (capturing) {
-        if (R.capture_next < R.eager_next) return kNoClaimSlot;
+        if (R.capture_next < R.eager_next) return exhausted();
         idx = R.capture_next--;
     } else {
         auto it = R.by_stream.find(st);
         if (it != R.by_stream.end()) idx = it->second;
         else {
-            if (R.eager_next > R.capture_next) return kNoClaimSlot;
+            if (R.eager_next > R.capture_next) return exhausted();
             idx = R.by_stream[st] = R.eager_next++;
         }
     }

@@ -2020,6 +2020,11 @@ def test_classic_nms_beyond_the_layer_limit(G, O):
         dets = np.concatenate([synthetic.clustered_boxes_2d(rng, n, per), synthetic.tie_free_scores(rng, n)[:, None]], 1).astype(np.float32)
         got = [int(i) for i in gpu_nms(dets, 0.5)]
         assert got == O.classic_nms(dets, 0.5, rule="gpu"), n
+        if n <= 20000:                                     # boxes that arrive sorted (both call sites of the reference): the wrapper skips sort + gather
+            sd = dets[np.argsort(-dets[:, 4], kind="stable")]
+            assert [int(i) for i in gpu_nms(sd, 0.5)] == O.classic_nms(sd, 0.5, rule="gpu"), ("sorted", n)
+            sd[7, 4] = sd[6, 4]                            # ... and a tie takes the reference's argsort()[::-1] again
+            assert [int(i) for i in gpu_nms(sd, 0.5)] == O.classic_nms(sd, 0.5, rule="gpu"), ("tie", n)
     dets = np.concatenate([synthetic.clustered_boxes_2d(rng, 20000, 12), synthetic.tie_free_scores(rng, 20000)[:, None]], 1).astype(np.float32)
     from oracle import nms_others_oracle as NO
     assert [int(i) for i in nms_others.girshick_nms(dets, 0.45)] == [int(i) for i in NO.girshick_nms(dets, 0.45)], "girshick_nms (<= rule), float32 boxes in chunks"

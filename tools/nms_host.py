@@ -27,4 +27,13 @@ for n in (500, 2000, 4096, 16384, 126720):
         for _ in range(reps):
             keep = gpu_nms(dets, 0.4)
         best = min(best, (time.perf_counter() - t0) / reps * 1e6)
-    print(json.dumps({"what": "gpu_nms(dets, 0.4): _nms, host pointers, blocking", "n": n, "kept": int(len(keep)), "us_per_call": round(best, 1)}))
+    # the same boxes in random order: the wrapper's argsort + gather as the reference's gpu_nms.pyx has them (sorted input skips both, round 6)
+    sh = dets[np.random.default_rng(1).permutation(n)]
+    for _ in range(3):
+        gpu_nms(sh, 0.4)
+    t0 = time.perf_counter()
+    for _ in range(max(reps // 4, 3)):
+        gpu_nms(sh, 0.4)
+    unsorted = (time.perf_counter() - t0) / max(reps // 4, 3) * 1e6
+    print(json.dumps({"what": "gpu_nms(dets, 0.4): _nms, host pointers, blocking", "n": n, "kept": int(len(keep)), "us_per_call": round(best, 1),
+                      "us_per_call_unsorted_input": round(unsorted, 1)}))
