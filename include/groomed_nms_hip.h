@@ -294,10 +294,11 @@ int gnms_profile_sgemm(const float* A, const float* B, float* D, int M, int N, i
 /* EXACT reference symbol and contract (lib/nms/gpu_nms.hpp:1-2, lib/nms/nms_kernel.cu:91-144):
  * host pointers, boxes_host is boxes_num x boxes_dim fp32 pre-sorted by descending score,
  * keep_out holds boxes_num ints, blocking.  +1-pixel IoU (:24-32), strict '>' (:71).
- * boxes_num <= GNMS_MAX_BOXES runs the layer's leader scan; larger inputs -- the reference's `use_nms and synced` inference branch
- * (lib/rpn_util.py:1268) feeds every anchor, > 100 k -- run the reference's own block scan on the device (one workgroup; the n^2/8-byte
- * mask stays in HBM, 2 GB at 126 720 boxes as in the reference).  Limit: boxes_num <= 262144; above it *num_out = 0 and
- * gnms_last_error() says so (the Python wrapper gpu_nms raises). */
+ * boxes_num <= GNMS_MAX_BOXES runs the layer's leader scan (one workgroup per super-block); larger inputs -- the reference's `use_nms and
+ * synced` inference branch (lib/rpn_util.py:1268) feeds every anchor, > 100 k -- are processed in chunks of GNMS_MAX_BOXES (round 6): what the
+ * boxes kept so far suppress in the chunk straight from the boxes, the chunk's own bit matrix, the same scan, the kept boxes appended -- the
+ * reference's keep list with n^2 / (2 chunks) + n * kept pair decisions and 33 MB of device memory where the n x n mask is 2 GB at 126 720
+ * boxes.  Limit: boxes_num <= 262144; above it *num_out = 0 and gnms_last_error() says so (the Python wrapper gpu_nms raises). */
 void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
           float nms_overlap_thresh, int device_id);
 
