@@ -1277,6 +1277,58 @@ def test_host_threads_share_the_side_stream(G):
     assert not errors, errors[:5]
 
 
+@pytest.mark.gpu
+def test_one_launch_under_threads_and_streams(G):
+    """Round 6: six host threads, each on its own torch stream, call both small-image entries at once -- the matrix-in layer (one_launch_kernel)
+    and the one-call entry (one_launch_boxes_kernel: its matrix writers claim their tiles from a per-stream slot of the library's claim ring) --
+    on images of different sizes, each call with a workspace of its own: flags, call counters and claim slots of concurrent launches must not
+    meet.  Every result equals the single-threaded one bit for bit."""
+    import threading
+    from groomed_nms_amd import synthetic, overlaps
+    cases = []
+    for seed, B, N in ((1, 1, 500), (2, 2, 300), (3, 8, 256), (4, 1, 1024), (5, 3, 65), (6, 2, 512)):
+        b, s = synthetic.batch_2d(seed, B, N, "clustered", per=20)
+        cases.append((torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()))
+    refs = []
+    for b, s in cases:
+        sg = s.clone().requires_grad_(True)
+        one = G.differentiable_nms_with_iou2d_batched(sg, b)
+        one[0].sum().backward()
+        g1 = sg.grad.clone()
+        sg2 = s.clone().requires_grad_(True)
+        two = G.differentiable_nms_batched(sg2, overlaps.iou_batched(b))
+        two[0].sum().backward()
+        refs.append(([o.clone() for o in one[:7]], g1, [o.clone() for o in two[:6]], sg2.grad.clone()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for it in range(40):
+                k = (tid + it) % len(cases)
+                b, s = cases[k]
+                sg = s.clone().requires_grad_(True)
+                if (tid + it) % 2:
+                    out = G.differentiable_nms_with_iou2d_batched(sg, b)
+                    want, wg = refs[k][0], refs[k][1]
+                else:
+                    out = G.differentiable_nms_batched(sg, overlaps.iou_batched(b))
+                    want, wg = refs[k][2], refs[k][3]
+                out[0].sum().backward()
+                st.synchronize()
+                if not all(torch.equal(a, r) for a, r in zip(out, want)) or not torch.equal(sg.grad, wg):
+                    errors.append((tid, it, k))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:5]
+
+
 def test_api_edges(G):
     """What callers actually hand over: strided views, float64, a padded leading dimension, a matrix that requires grad, NumPy
     float64 in / CPU tensors out (lib/rpn_util.py:1319-1320), empty inputs, an unknown pruning method, impossible shapes."""
