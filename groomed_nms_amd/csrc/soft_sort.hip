@@ -515,6 +515,8 @@ struct LtApi {
     decltype(&hipblasLtMatmulPreferenceSetAttribute) pref_set = nullptr;
     decltype(&hipblasLtMatmulAlgoGetHeuristic) heuristic = nullptr;
     decltype(&hipblasLtMatmul) matmul = nullptr;
+    decltype(&hipblasLtMatmulDescDestroy) desc_destroy = nullptr;
+    decltype(&hipblasLtMatrixLayoutDestroy) layout_destroy = nullptr;
     struct Plan { hipblasLtMatmulDesc_t desc; hipblasLtMatrixLayout_t a, b, d; hipblasLtMatmulAlgo_t algo; size_t ws; };
     hipblasLtHandle_t handle[64] = {};
     void* wsp[64] = {};
@@ -547,6 +549,8 @@ bool hipblaslt_sgemm_rowmajor(const float* A, const float* B, float* D, int M, i
             R.pref_set = (decltype(R.pref_set))dlsym(h, "hipblasLtMatmulPreferenceSetAttribute");
             R.heuristic = (decltype(R.heuristic))dlsym(h, "hipblasLtMatmulAlgoGetHeuristic");
             R.matmul = (decltype(R.matmul))dlsym(h, "hipblasLtMatmul");
+            R.desc_destroy = (decltype(R.desc_destroy))dlsym(h, "hipblasLtMatmulDescDestroy");
+            R.layout_destroy = (decltype(R.layout_destroy))dlsym(h, "hipblasLtMatrixLayoutDestroy");
             R.ok = R.create && R.layout_create && R.desc_create && R.pref_create && R.pref_set && R.heuristic && R.matmul;
             if (R.ok) {
                 const uint64_t wsz = kLtWorkspace;
@@ -567,6 +571,13 @@ bool hipblaslt_sgemm_rowmajor(const float* A, const float* B, float* D, int M, i
     const std::array<int64_t, 7> key = {(int64_t)dev, M, N, K, lda, ldb, ldd};
     auto it = R.plans.find(key);
     if (it == R.plans.end()) {
+        if (R.plans.size() >= 256) {                                  // (a caller that walks through many shapes: the cache starts over instead of growing)
+            for (auto& kv : R.plans) {
+                if (R.desc_destroy) (void)R.desc_destroy(kv.second.desc);
+                if (R.layout_destroy) { (void)R.layout_destroy(kv.second.a); (void)R.layout_destroy(kv.second.b); (void)R.layout_destroy(kv.second.d); }
+            }
+            R.plans.clear();
+        }
         LtApi::Plan P{};
         // column-major: "A" = B^T as stored (N x K, ld ldb), "B" = A^T as stored (K x M, ld lda), C = D = D^T as stored (N x M, ld ldd)
         if (R.desc_create(&P.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS ||
