@@ -27,6 +27,8 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Extra objects:
   parity              max |d prob| and max |d grad_scores| of the timed entry against that oracle on every image of rank 0's batch,
                       and whether the valid-index sets agree -- the "max-|dscore| vs ref" half of BASELINE.json's metric
   other_kind          the same step on the other box generator (uniform <-> clustered), 1 GPU only
+  box_counts          N > 1 only: the other box counts north_star names (256, 1024, 16384 per image) at this world size -- whole-job boxes/s,
+                      timed like the headline (barrier + sync on both sides, MAX over ranks); at N = 1 the keys N256 / N1024 / N16384 hold them
   hip_graph_replay    the same step as a replayed HIP graph of the C-ABI calls (no host cost per step), 1 GPU only
   two_calls, dim3_*, N*, B*_N4096   the other shapes of the path (default line only), each with ms_per_step (eager, host included; the median of
                       three windows of its `steps`, all three in windows_ms), its own
@@ -294,6 +296,46 @@ def main():
         for _ in range(4):
             windows.append(gdist.timed_steps(step, args.steps, 0, torch.cuda.synchronize, heartbeat))
 
+    # N > 1: the other box counts north_star names (256, 1024, 16384 per image), every rank its own images, timed like the headline --
+    # barrier + device sync on both sides, the MAX over ranks -- so that the scaling run carries the whole grid at every world size (at
+    # N = 1 the keys N256 / N1024 / N16384 below are the same shapes with their roofline briefs).  A rank that cannot set a shape up says so
+    # BEFORE the timed region's collectives: either every rank times it or none does.
+    box_counts = None
+    if world > 1 and not args.no_extras and not args.graph and not args.two_calls and args.dim == 2 and not args.sorted_scores:
+        box_counts = {}
+        for n_, k_ in ((256, 60), (1024, 60), (16384, 6)):
+            if n_ == N:
+                continue
+            one_, err_ = None, ""
+            try:
+                bx_np, sc_np = synthetic.batch_2d(1000 + rank, B, n_, args.kind)
+                bx_ = torch.from_numpy(np.ascontiguousarray(bx_np)).to(dev)
+                sc_ = torch.from_numpy(np.ascontiguousarray(sc_np)).to(dev).requires_grad_(True)
+                ww_ = torch.from_numpy(np.tile(np.linspace(-1.0, 2.0, n_).astype(np.float32), (B, 1))).to(dev).contiguous()
+                nb_ = int(min(max(2, -(-(768 << 20) // max(4 * B * n_ * n_, 1))), 16))
+                bufs_ = [torch.empty((B, n_, n_), dtype=torch.float32, device=dev) for _ in range(nb_)]
+                st_ = {"i": 0}
+
+                def one_(bx_=bx_, sc_=sc_, ww_=ww_, bufs_=bufs_, st_=st_, nb_=nb_):
+                    st_["i"] = (st_["i"] + 1) % nb_
+                    prob = G.differentiable_nms_with_iou2d_batched(sc_, bx_, iou_out=bufs_[st_["i"]])[0]
+                    sc_.grad = None
+                    torch.autograd.backward(prob, ww_)
+                for _ in range(6):
+                    one_()
+                torch.cuda.synchronize()
+            except Exception as e:                                  # (e.g. out of memory beside another tenant)
+                one_, err_ = None, str(e)[:200]
+            if int(round(gdist.sum_over_ranks(1.0 if one_ is not None else 0.0))) == world:
+                dt_ = gdist.timed_steps(one_, k_, 2, torch.cuda.synchronize)
+                box_counts["N%d" % n_] = {"value": round(world * B * n_ * k_ / dt_, 1), "unit": "boxes/s", "ms_per_step": round(dt_ / k_ * 1e3, 4), "steps": k_,
+                                          "workload": "%d images/GPU x %d %s 2D boxes, %d GPUs" % (B, n_, args.kind, world)}
+            else:
+                box_counts["N%d" % n_] = {"error": err_ or "another rank could not set this shape up"}
+            one_ = None
+            bx_ = sc_ = ww_ = bufs_ = None
+            torch.cuda.empty_cache()
+
     out = None
     if rank == 0:
         one_call = not args.two_calls
@@ -420,6 +462,8 @@ def main():
             out["spread"] = {"windows": len(wm), "steps_per_window": args.steps, "min_ms": round(wm[0], 4), "median_ms": round(wm[len(wm) // 2], 4),
                              "max_ms": round(wm[-1], 4), "first_window_ms": round(dt / args.steps * 1e3, 4),
                              "what": "ms per step of %d consecutive windows of --steps steps in this run; `value` is the first" % len(wm)}
+        if box_counts:
+            out["box_counts"] = box_counts
         if gdist.share_gpu() and world > 1:
             out["debug_shared_gpu"] = "GNMS_SHARE_GPU=1: %d ranks share %d GPU(s), gloo collectives -- launcher-path check, not a scaling number" % (
                 world, torch.cuda.device_count())

@@ -1806,6 +1806,8 @@ def test_n_rank_launcher_end_to_end():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and "debug_shared_gpu" in d
     assert "asynchronous" in d["config"]["collective"] and d["config"]["parallelism"].endswith("dp2") and d["roofline"]["frac"] > 0
     assert "cpu_baseline" not in d                                           # rank 0 at N = 1 only
+    # the other box counts of north_star at this world size, every one timed by both ranks (bench.py `box_counts`)
+    assert set(d["box_counts"]) == {"N256", "N1024", "N16384"} and all(v.get("value", 0) > 0 for v in d["box_counts"].values()), d["box_counts"]
     # C5's shape exactly as the driver's 8-GPU run would start it: 8 ranks x 8 images x 16384 cuboids, folded onto this GPU
     r5 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dim", "3", "--boxes", "16384", "--batch", "8", "--steps", "2",
                          "--warmup", "1"], env=dict(env, GNMS_BENCH_PREWARM="2"), capture_output=True, text=True, timeout=1500)
