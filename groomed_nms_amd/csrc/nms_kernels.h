@@ -497,6 +497,13 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
     const u64 mine = all[r * 1024 + t];
     int same = 1;
     if (mine != ~0ull) {
+        // what leaves with the key -- its score, its box -- is fetched by INPUT index, known before the searches: requested here, the round
+        // trip runs under them (round 6: behind the rank it was one more exposed memory latency at the end of every workgroup)
+        const int idx = (int)((unsigned)mine & (role == 0 ? 0xffffffffu : kColIdxMask));
+        float sv = 0.0f;
+        float4 bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (role == 0) sv = scores[(size_t)b * N + idx];
+        if (boxes) bv = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];
         int pos[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) pos[q] = 0;
@@ -508,18 +515,16 @@ __device__ __forceinline__ void sort_merge_body(const float* __restrict__ scores
         int rank = 0;
 #pragma unroll
         for (int q = 0; q < R; ++q) rank += (q == r) ? t : pos[q] + ((all[q * 1024 + pos[q]] < mine) ? 1 : 0);
-        const int idx = (int)((unsigned)mine & (role == 0 ? 0xffffffffu : kColIdxMask));
         if (role == 0) {
             same = (idx == rank);
             I.order[rank] = idx;
             I.rankof[idx] = rank;
-            I.sscore[rank] = scores[(size_t)b * N + idx];
-            if (boxes) I.rbox[rank] = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];   // (the from-boxes layer: row boxes of the bit matrix)
+            I.sscore[rank] = sv;
+            if (boxes) I.rbox[rank] = bv;                             // (the from-boxes layer: row boxes of the bit matrix)
             if (order_out) order_out[(size_t)b * N + rank] = idx;
         } else {
-            const float4 v = reinterpret_cast<const float4*>(boxes)[(size_t)b * N + idx];
-            column_store(I, rank, idx, v, mode3d);
-            same = box_orders_plainly(v);                             // (role 1: "every box of this run is plain")
+            column_store(I, rank, idx, bv, mode3d);
+            same = box_orders_plainly(bv);                            // (role 1: "every box of this run is plain")
         }
     }
     if (role == 1 && !__syncthreads_and(same) && t == 0) I.misc[6] = 1;   // (zeroed by sort_runs_body, a launch earlier; every writer stores 1)
@@ -573,10 +578,33 @@ __device__ __forceinline__ void sort_count_body(const float* __restrict__ scores
     const float* bx = boxes ? boxes + (size_t)b * N * 4 : nullptr;
     float zlo = 0.0f, zscale = 0.0f;
     if (role == 1 && mode3d > 1) block_z_bands(reinterpret_cast<const float4*>(bx), n, mode3d, &zlo, &zscale);
-    for (int i = t; i < NP; i += 1024) keys[i] = (i < n) ? sort_key_of(role, s, bx, i, mode3d, zlo, zscale) : ~0ull;
+    const int k = blk * KPW + lane;                                    // (k < NP)
+    // key k is input index k: what leaves with it -- its score, its box -- needs no index from the sorted keys and is requested here, in front
+    // of everything (round 6: fetched by `idx` behind the count it was one more exposed memory round trip at the end of every workgroup)
+    float pre_s = 0.0f;
+    float4 pre_b = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (seg == 0 && k < n) {
+        if (role == 0) pre_s = s[k];
+        if (bx) pre_b = reinterpret_cast<const float4*>(bx)[k];
+    }
+    int flag = 1;                                                      // role 1: "every box is plain" (workgroup 0 decides, below)
+    if (role == 0) {
+        for (int i = t; i < NP; i += 1024) keys[i] = (i < n) ? sort_key_of(0, s, bx, i, mode3d, zlo, zscale) : ~0ull;
+    } else {
+        // (the plain test on the box the key is made of: as a pass of its own over the boxes it was a second memory round trip of workgroup 0,
+        // the one every launch of this kernel ends with)
+        for (int i = t; i < NP; i += 1024) {
+            u64 key = ~0ull;
+            if (i < n) {
+                const float4 v = reinterpret_cast<const float4*>(bx)[i];
+                key = column_key(v, i, mode3d, zlo, zscale);
+                flag &= box_orders_plainly(v) ? 1 : 0;
+            }
+            keys[i] = key;
+        }
+    }
     if (t < 64) rk[t] = 0;
     __syncthreads();
-    const int k = blk * KPW + lane;                                    // (k < NP)
     const u64 mine = keys[k];
     {
         const int per = NP / (1024 / KPW);                             // a multiple of 4 (KPW = 32: the launcher asks for NP % 128 == 0)
@@ -587,13 +615,8 @@ __device__ __forceinline__ void sort_count_body(const float* __restrict__ scores
     }
     // what only one workgroup per image and role does: the "already sorted" / "every box is plain" flags (every workgroup holds every key,
     // so the first one decides alone), the counters, the call counter, the hand-off granules
-    int flag = 1;
-    if (blk == 0) {
-        if (role == 0) {
-            for (int i = t; i + 1 < n; i += 1024) flag &= keys[i] < keys[i + 1];      // ascending keys in index order = the scores came in sorted
-        } else {
-            for (int i = t; i < n; i += 1024) flag &= box_orders_plainly(reinterpret_cast<const float4*>(bx)[i]) ? 1 : 0;
-        }
+    if (blk == 0 && role == 0) {
+        for (int i = t; i + 1 < n; i += 1024) flag &= keys[i] < keys[i + 1];          // ascending keys in index order = the scores came in sorted
     }
     const int all = __syncthreads_and(flag);                           // (also: every count has landed in rk)
     if (blk == 0) {
@@ -617,21 +640,21 @@ __device__ __forceinline__ void sort_count_body(const float* __restrict__ scores
                 if constexpr (FUSED) {
                     coh_store(I.order + rank, idx);
                     coh_store(I.rankof + idx, rank);
-                    coh_store(I.sscore + rank, s[idx]);
-                    if (boxes) coh_store_f4(I.rbox + rank, reinterpret_cast<const float4*>(bx)[idx]);
+                    coh_store(I.sscore + rank, pre_s);
+                    if (boxes) coh_store_f4(I.rbox + rank, pre_b);
                 } else {
                     I.order[rank] = idx;
                     I.rankof[idx] = rank;
-                    I.sscore[rank] = s[idx];
-                    if (boxes) I.rbox[rank] = reinterpret_cast<const float4*>(bx)[idx];
+                    I.sscore[rank] = pre_s;
+                    if (boxes) I.rbox[rank] = pre_b;
                 }
                 if (order_out) order_out[(size_t)b * N + rank] = idx;
             } else {
                 if constexpr (FUSED) {
                     coh_store(I.xidx + rank, idx);
-                    coh_store_f4(I.xbox + rank, reinterpret_cast<const float4*>(bx)[idx]);
+                    coh_store_f4(I.xbox + rank, pre_b);
                 } else {
-                    column_store(I, rank, idx, reinterpret_cast<const float4*>(bx)[idx], mode3d);
+                    column_store(I, rank, idx, pre_b, mode3d);
                 }
             }
         } else if (k < N && role == 0) {                               // padding ranks map to themselves (order is a permutation of [0, N))
