@@ -904,18 +904,43 @@ __global__ __launch_bounds__(1024) void one_launch_boxes_kernel(const float* __r
                                                                 int B, int kpw, int tpw, float* __restrict__ out, long ld, int* __restrict__ claims,
                                                                 int nwriters) {
     GNMS_TINIT();
-    const int NP = (N + 63) & ~63, nsort = NP / kpw, nbits = (L.NB * (L.NB + 1) / 2 + tpw - 1) / tpw;
+    // tpw == 0: the table with its sources in x order (one_launch_bits_from_boxes_x) -- [sort] [x sort] [table: NB a image] [chain] [CSR] [writers]:
+    // two sort roles of B * nsort workgroups are a round of the machine by themselves, so the writers come LAST and start as the sorts retire
+    const bool xt = tpw == 0;
+    const int NP = (N + 63) & ~63, nsort = NP / kpw, nbits = xt ? L.NB : (L.NB * (L.NB + 1) / 2 + tpw - 1) / tpw;
+    const int front = xt ? B * (2 * nsort + nbits + 2) : 0;
     int bx = (int)blockIdx.x, b;
-    if (bx < nwriters) {
-        // the writers FIRST in the grid: they wait for nobody and are the longest role at N = 1024 (every workgroup of the launch holds a CU
+    if (xt ? bx >= front : bx < nwriters) {
+        // (rank-space table) the writers FIRST in the grid: they wait for nobody and are the longest role at N = 1024 (every workgroup of the launch holds a CU
         // to itself -- the chain's LDS -- so behind the sort and table workgroups they would only start when those retire: 36 us against 20)
-        writers_staged_2d<true>(boxes, N, out, ld, B, claims, 64, 0);
+        writers_staged_2d<true>(boxes, N, out, ld, B, claims, 64, front);
         if (threadIdx.x == 0) {                                             // (thread 0 issued every claim of this workgroup and has consumed them all)
             int* done = claims + (size_t)B * 64;
             if (atomicAdd(done, 1) == nwriters - 1) {
                 for (int i = 0; i <= B; ++i) atomicExch(claims + (size_t)i * 64, 0);
             }
         }
+        return;
+    }
+    if (xt) {
+        if (bx < 2 * B * nsort) {
+            const int role = bx >= B * nsort ? 1 : 0;
+            bx -= role * B * nsort;
+            b = bx / nsort;
+            const unsigned tag = (unsigned)gnms_next_epoch(coh_load(img_ptrs(ws, L, b).misc + 8));
+            if (kpw == 32) sort_count_body<32, true>(scores, boxes, N, counts, ws, L, order_out, 0, bx - b * nsort, b, role, tag);
+            else sort_count_body<64, true>(scores, boxes, N, counts, ws, L, order_out, 0, bx - b * nsort, b, role, tag);
+            return;
+        }
+        bx -= 2 * B * nsort;
+        if (bx < B * nbits) {
+            b = bx / nbits;
+            const unsigned tag = (unsigned)gnms_next_epoch(coh_load(img_ptrs(ws, L, b).misc + 8));
+            one_launch_bits_from_boxes_x(N, counts, P.nms_threshold, ws, L, b, bx - b * nbits, tag, nsort);
+            return;
+        }
+        bx -= B * nbits;
+        one_launch_chain_or_csr<kFromBoxes>(boxes, N, (long)N, counts, P, ws, L, prob, valid, invalid, nvalid, ninvalid, B, bx, nsort, nbits);
         return;
     }
     bx -= nwriters;
@@ -1171,6 +1196,16 @@ int launch_one_matrix(const float* scores, const float* iou, int B, int N, int64
     return GNMS_OK;
 }
 
+// which table the one-call entry's one launch builds: 0 none (three launches), 1 rank space (one 64 x 64 task per workgroup, while all tasks
+// are at most one round of the machine), 2 sources in x order (beyond that, while the launch's front is at most two rounds)
+int one_launch_boxes_mode(int B, int N) {
+    const int cus = device_cu_count();
+    const int NP = (N + 63) & ~63, NB = NP / 64, nbp = NB * (NB + 1) / 2;
+    const int kpw = (NP % 128 == 0 && (long)B * (NP / 32) <= (long)cus / 2) ? 32 : 64;
+    if ((long)B * nbp <= (long)cus && nbp <= 13 * 32) return (long)B * (NP / kpw + nbp + 2) <= 3L * cus ? 1 : 0;
+    return (long)B * (2 * (NP / kpw) + NB + 2) <= 2L * cus ? 2 : 0;
+}
+
 // the one-call entry (gnms_forward_with_iou2d, masked groups): the same with the table from the boxes and the matrix writers behind the chain
 int launch_one_boxes(const float* scores, const float* boxes, int B, int N, const int32_t* counts, const gnms_params& P, char* ws,
                      const gnms_ws_layout& L, float* prob, int64_t* order, int64_t* valid, int64_t* invalid, int32_t* nvalid, int32_t* ninvalid,
@@ -1186,11 +1221,18 @@ int launch_one_boxes(const float* scores, const float* boxes, int B, int N, cons
     // Kernel time of the launch against sort + bits + tail_write_kernel, us (profiles/r06g_*): B = 8 N = 256 18.3 / 25.0, B = 16 N = 256
     // 17.5 / 24.9, B = 1 / 2 N = 500 18.1 / 20.5 and 18.2 / 21.9, B = 8 N = 512 22.8 / 23.4, B = 1 N = 1024 23.4 / 25.1 -- and with 2 / 4 / 8
     // tasks per workgroup B = 2 / 4 / 8 at N = 1024: 28.0 / 25.9, 31.2 / 26.7, 37.9 / 33.5 (the one launch loses).
-    const int tpw = 1;
-    const int ntab = gnms_div_up(nbp, tpw);
-    if ((long)B * ntab > (long)cus * 5 / 4 || ntab > 13 * 32) return GNMS_OK;
-    const long front = (long)B * (NP / kpw + ntab + 2);
-    if (front > 3L * cus) return GNMS_OK;
+    // Beyond one round: the table with its SOURCES IN X ORDER (one_launch_bits_from_boxes_x, tpw = 0) -- NB culled workgroups a image instead of
+    // NB (NB + 1) / 2 unculled ones, for a second sort role (the boxes by x centre) in the launch and the writers behind everything.  Kernel
+    // time, x-order table / rank-space table or the three launches, us, same box (profiles/r06x_*): B = 8 N = 1024 31.3 / 35.2 (three launches),
+    // B = 4 N = 1024 29.8 / 32.0, B = 16 N = 512 24.1 / 29.0, B = 8 N = 768 27.6 / 32.5, B = 4 N = 768 25.8 / 27.3, B = 2 N = 1024 28.9 / 31.1,
+    // B = 8 N = 512 24.4 / 25.9 -- and below a round of tasks the rank-space table wins: B = 1 N = 1024 27.1 / 25.0, B = 4 N = 512 23.2 / 20.2,
+    // B = 16 N = 256 21.9 / 18.8, B = 8 N = 256 22.0 / 18.3, B = 1, 2 N = 500 21.8 / 19.4, 22.5 / 19.6.
+    const int mode = one_launch_boxes_mode(B, N);
+    if (mode == 0) return GNMS_OK;
+    const bool xt = mode == 2;
+    const int tpw = xt ? 0 : 1;
+    const int ntab = nbp;
+    const long front = xt ? (long)B * (2 * (NP / kpw) + NB + 2) : (long)B * (NP / kpw + ntab + 2);
     int* claims = nullptr;
     int rc = claim_slot_for(st, &claims);
     if (rc == kNoClaimSlot) return GNMS_OK;
@@ -1199,7 +1241,7 @@ int launch_one_boxes(const float* scores, const float* boxes, int B, int N, cons
     long writers = (long)B * ((ncc * nrt + 15) >> 4);
     // (3/8 of the CUs write: at ~29 GB/s per writer workgroup the 32 MB of B = 8, N = 1024 then take as long as sort -> table -> chain
     // beside them on the other 5/8)
-    const long cap = (long)cus * 3 / 8;
+    const long cap = xt ? (long)cus / 2 : (long)cus * 3 / 8;                 // (x-order table: the writers are last in the grid and start as the sorts retire)
     if (writers > cap) writers = cap;
     if (writers < 1) writers = 1;
     size_t lds = one_launch_lds_size(N, true);
@@ -1389,8 +1431,7 @@ extern "C" const char* gnms_profile_write_kernel_name(int dim, int B, int N) {
     if (B <= 0 || N <= 0) return "";
     if (dim == 3 && chain_rides_in_write_launch(B, N) && sym_writers_in_tail_launch(N, N, nullptr)) return "tail_write_kernel";
     if (use_side_stream(B, N, N)) return dim == 3 ? "iou3d_nms_fast_kernel" : (N % 4 == 0 ? "write_staged_kernel" : "iou2d_kernel");
-    if (dim == 2 && N <= kOneLaunchMaxN && one_launch_enabled() && fast_tail_enabled() &&
-        (long)B * (((N + 63) / 64) * ((N + 63) / 64 + 1) / 2) <= (long)device_cu_count() * 5 / 4) return "one_launch_boxes_kernel";   // (launch_one_boxes' rule)
+    if (dim == 2 && N <= kOneLaunchMaxN && one_launch_enabled() && fast_tail_enabled() && one_launch_boxes_mode(B, N) != 0) return "one_launch_boxes_kernel";
     if (chain_rides_in_write_launch(B, N) && (dim == 2 || N <= 2048)) return "tail_write_kernel";
     if (dim == 3) return "iou3d_nms_fast_kernel";
     return "iou2d_kernel";

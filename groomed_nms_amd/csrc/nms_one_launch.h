@@ -5,6 +5,7 @@
 // and ~12 us of host enqueue.  Here the three are ROLES of one grid, handing over through flags in the workspace:
 //
 //   [B * nsort sort workgroups] [B * NB * split table workgroups] [B chain workgroups] [B CSR workgroups]
+//   (one-call entry, table in x order: [sort] [x sort] [B * NB table workgroups] [chain] [CSR] [matrix writers])
 //
 //   sort    sort_count_body<KPW, FUSED>: the score sort by counting, exactly the workgroup of sort_count_kernel; outputs through agent-scope
 //           stores, then its flag.
@@ -183,6 +184,76 @@ __device__ __forceinline__ void one_launch_bits_from_boxes(int N, const int* __r
     __builtin_amdgcn_s_waitcnt(0x0f70);                                          // vmcnt(0)
     __syncthreads();
     if (tid == 0) coh_store(I.gran + (size_t)3 * 32 + w, strong_gran(tag, kSlotBits + (unsigned)w));
+}
+
+// The table from the boxes with the SOURCES in x order (larger batches of larger images: B = 8, N = 1024).  In rank space a table task cannot be
+// culled -- 136 tasks of 64 x 64 pairs per image at N = 1024, every one a workgroup with a CU to itself -- where bitmask_boxes_body's x-sorted
+// columns keep 15-20 % of the rows.  Here workgroup tb of an image holds the 64 TARGET boxes of rank block tb as rows, wave v the 64 sources
+// x-rank 64 v .. 64 v + 63 as its lanes (N <= 1024: sixteen waves cover every source), rows that do not reach into the wave's hull are skipped,
+// and a set pair -- a few per row -- goes to bit (source rank & 63) of word (target row, source rank >> 6) of an LDS table by one LDS atomic;
+// the words of source blocks <= tb then leave as the table image's (tb, bb) entries.  Needs the x sort as a second sort role of the launch
+// (sort_count_body role 1: xidx, xbox).  The decision is bitmask_boxes_body's general row, operation for operation.
+__device__ __forceinline__ void one_launch_bits_from_boxes_x(int N, const int* __restrict__ counts, const float thr, char* ws, gnms_ws_layout L,
+                                                             const int b, const int tb, const unsigned tag, const int nsort) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64* tab = reinterpret_cast<u64*>(smem);                                     // [64 target rows][kSB source blocks]
+    const int n = gnms_count(counts, b, N);
+    ImgPtrs I = img_ptrs(ws, L, b);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = (n + 63) >> 6;
+    const bool live = tb < nb;                                                   // (workgroup-uniform)
+    for (int i = tid; i < 64 * kSB; i += 1024) tab[i] = 0ull;
+    if (wave == 0) one_launch_wait(I.gran + 32, nsort, tag, kSlotSort);          // the score sort: rbox, rankof
+    if (wave == 1) one_launch_wait(I.gran + 64, nsort, tag, kSlotSort + 32u);    // the x sort: xidx, xbox
+    __syncthreads();
+    const int k0 = tb * 64;
+    if (live && wave * 64 < n) {                                                 // (wave-uniform)
+        const int nrows = min(64, n - k0);
+        const float4 rb = coh_load_f4(I.rbox + min(k0 + lane, n - 1));
+        const int p = wave * 64 + lane, pp = p < n ? p : n - 1;                  // clamped duplicates: harmless in the hull, never set
+        const float4 cb = coh_load_f4(I.xbox + pp);
+        const int crank = coh_load(I.rankof + coh_load(I.xidx + pp));
+        const float carea = (cb.z - cb.x) * (cb.w - cb.y);
+        const bool cols_ok = __all((carea > 0.0f) && (carea < INFINITY));
+        const float hx0 = wave_min_f(cb.x), hy0 = wave_min_f(cb.y), hx1 = wave_max_f(cb.z), hy1 = wave_max_f(cb.w);
+        const bool cull = cols_ok && (thr >= 0.0f);
+        const float rarea = (rb.z - rb.x) * (rb.w - rb.y);
+        const bool row_fine = (rarea > 0.0f) && (rarea < INFINITY);
+        const u64 rows_ok = __ballot(row_fine);
+        const bool reaches = (rb.z > hx0) && (rb.x < hx1) && (rb.w > hy0) && (rb.y < hy1);
+        u64 todo = __ballot((lane < nrows) && (!(cull && row_fine) || reaches));
+        const float guard = fmaxf(fabsf(thr), 1.0f) * 9.6e-7f;                   // 8 ulp at the threshold's magnitude (bitmask_boxes_body)
+        const bool mine = (p < n) && ((crank >> 6) <= tb);                       // a source the table holds for this target block
+        while (todo) {                                                           // wave-uniform loop over the surviving rows
+            const int r = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const float ax1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.x), r));
+            const float ay1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.y), r));
+            const float ax2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.z), r));
+            const float ay2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rb.w), r));
+            const float aa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rarea), r));
+            const float w = fmaxf(gnms_iou3d::vmin_s(ax2, cb.z) - gnms_iou3d::vmax_s(ax1, cb.x), 0.0f);
+            const float h = fmaxf(gnms_iou3d::vmin_s(ay2, cb.w) - gnms_iou3d::vmax_s(ay1, cb.y), 0.0f);
+            const float inter = w * h;
+            const float uni = (aa + carea) - inter;
+            const float d = __builtin_fmaf(-thr, uni, inter);
+            const bool unsure = !(fabsf(d) > guard * uni);                       // also true for NaN
+            bool bit;
+            if (!(cols_ok && ((rows_ok >> r) & 1ull)) || __any(unsure)) bit = !(inter / uni <= thr);
+            else bit = d > 0.0f;
+            if (bit && mine) atomicOr(&tab[r * kSB + (crank >> 6)], 1ull << (crank & 63));
+        }
+    }
+    __syncthreads();
+    if (live) {
+        for (int i = tid; i < 64 * kSB; i += 1024) {
+            const int r = i / kSB, bb = i - r * kSB;
+            if (bb <= tb) coh_store(I.W + (size_t)(tb * (tb + 1) / 2 + bb) * 64 + r, (k0 + r < n) ? tab[i] : 0ull);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);                                          // vmcnt(0)
+    __syncthreads();
+    if (tid == 0) coh_store(I.gran + (size_t)3 * 32 + tb, strong_gran(tag, kSlotBits + (unsigned)tb));
 }
 
 // the chain's side region (the image's order / scores / boxes by rank, leaders_sb_body<.., FUSED>) lies behind everything else of the chain

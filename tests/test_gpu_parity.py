@@ -3008,6 +3008,8 @@ def test_counts_slot_ownership_under_threads(G):
 def test_one_launch_against_three_launches(O):
     """Round 6: up to N = 1024 the matrix-in layer is ONE launch (one_launch_kernel: sort, the scan's table straight from the matrix, chain;
     nms_one_launch.h); GNMS_ONE_LAUNCH=0 keeps the three launches (sort_count_kernel, bitmask_small_kernel, tail_kernel with the symmetry check).
+    The one-call entry's launch builds its table in rank space up to one round of tasks and with the sources in x order beyond (B = 8, N = 1024;
+    ragged B = 16, N = 512; B = 4, N = 768; pixel-grid boxes).
     Probabilities, order, lists, counts and gradients of the two are the same bit for bit -- sizes around the 64-row and 256-column edges,
     batches (ragged, with an empty image), already sorted scores, the presorted mode (never the one launch), an asymmetric matrix (the one
     launch reads the reference's own triangle, the three launches find the asymmetry and take the general scan), NaN entries (:250 removes
@@ -3107,6 +3109,14 @@ b, s = synthetic.batch_2d(15, 8, 1024, "uniform")
 run_boxes("box_b8_n1024", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda())
 b, s = synthetic.batch_2d(16, 8, 256, "clustered")
 run_boxes("box_b8_n256", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda())
+# (more than a round of rank-space table tasks: the table with its sources in x order, one_launch_bits_from_boxes_x)
+b, s = synthetic.batch_2d(18, 16, 512, "clustered", per=30)
+run_boxes("box_b16_n512", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(),
+          counts=torch.tensor([512, 511, 65, 64, 63, 1, 0, 500, 512, 300, 129, 128, 127, 2, 448, 449], dtype=torch.int32, device="cuda"))
+b, s = synthetic.batch_2d(19, 4, 768, "uniform")
+run_boxes("box_b4_n768", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), nms_threshold=0.25)
+b, s = synthetic.batch_2d(20, 3, 1000, "clustered", per=6)
+run_boxes("box_b3_n1000_pixel", torch.from_numpy(np.round(b / 8) * 8).cuda(), torch.from_numpy(s).cuda())      # pixel-grid boxes: overlaps AT the threshold's neighbours, exact ties
 b, s = synthetic.batch_2d(17, 5, 700, "clustered")
 run_boxes("box_ragged", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), counts=torch.tensor([700, 0, 1, 333, 65], dtype=torch.int32, device="cuda"))
 for gs in (2, 30):
