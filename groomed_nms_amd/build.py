@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgroomed_nms_hip.so")
 SOURCES = ["iou_kernels.hip", "nms_layer.hip", "soft_sort.hip", "classic_nms.hip", "nms_others.hip", "aploss.hip", "proposals.hip", "host_mailbox.hip"]
-HEADERS = ["gnms_common.h", "gnms_prof.h", "iou_tile.h", "iou3d_pair.h", "iou3d_tile.h", "iou3d_sym.h", "nms_kernels.h", "nms_backward_kernels.h", "nms_solve_kernels.h",
+HEADERS = ["gnms_common.h", "gnms_prof.h", "iou_tile.h", "iou3d_pair.h", "iou3d_tile.h", "iou3d_sym.h", "nms_kernels.h", "nms_one_launch.h", "nms_backward_kernels.h", "nms_solve_kernels.h",
            os.path.join("..", "..", "include", "groomed_nms_hip.h")]
 # -ffp-contract=off: products and sums round separately, like the reference's torch CPU kernels
 # (lib/core.py:499-508) -- this is what makes the overlap matrices bit-identical.
