@@ -3124,6 +3124,8 @@ for gs in (2, 30):
 bd = b.copy(); bd[:, 5] = bd[:, 4]; bd[:, 9, 2] = bd[:, 9, 0]; bd[:, 11, 3] = np.float32("nan"); bd[:, 13] = np.float32(0.0)   # duplicates, an empty box, a NaN coordinate, an all-zero box
 run_boxes("box_degenerate", torch.from_numpy(bd).cuda(), torch.from_numpy(s).cuda())
 run_boxes("box_thr0", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), nms_threshold=0.0)
+run_boxes("box_negthr", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), nms_threshold=-0.5)      # every pair set: a dense table, no cull
+run_boxes("box_thr1", torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), nms_threshold=1.0)         # nothing but NaN overlaps set
 for rep in range(3):
     run_boxes("box_rep%d" % rep, torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda())
 # one image through the reference's own signature (index tensors through the pinned counts slot), twenty calls of alternating sizes
