@@ -1196,6 +1196,10 @@ int launch_one_matrix(const float* scores, const float* iou, int B, int N, int64
     return GNMS_OK;
 }
 
+// keys per sort workgroup with the x-order table: 64.  (Measured: 128 keys a workgroup -- two sort roles + the tables then fit one round of the
+// machine, so every table workgroup is resident from the start -- loses to the longer count: B = 8 N = 1024 31.0 against 29.7 us, B = 8 N = 768
+// 27.4 / 26.6, B = 4 N = 1024 30.3 / 29.1; 32 keys where that fits half the machine: B = 2 N = 1024 28.0 / 28.2 -- no difference.)
+constexpr int kXtKpw = 64;
 // which table the one-call entry's one launch builds: 0 none (three launches), 1 rank space (one 64 x 64 task per workgroup, while all tasks
 // are at most one round of the machine), 2 sources in x order (beyond that, while the launch's front is at most two rounds)
 int one_launch_boxes_mode(int B, int N) {
@@ -1203,7 +1207,7 @@ int one_launch_boxes_mode(int B, int N) {
     const int NP = (N + 63) & ~63, NB = NP / 64, nbp = NB * (NB + 1) / 2;
     const int kpw = (NP % 128 == 0 && (long)B * (NP / 32) <= (long)cus / 2) ? 32 : 64;
     if ((long)B * nbp <= (long)cus && nbp <= 13 * 32) return (long)B * (NP / kpw + nbp + 2) <= 3L * cus ? 1 : 0;
-    return (long)B * (2 * (NP / kpw) + NB + 2) <= 2L * cus ? 2 : 0;
+    return (long)B * (2 * (NP / kXtKpw) + NB + 2) <= 2L * cus ? 2 : 0;
 }
 
 // the one-call entry (gnms_forward_with_iou2d, masked groups): the same with the table from the boxes and the matrix writers behind the chain
@@ -1215,7 +1219,7 @@ int launch_one_boxes(const float* scores, const float* boxes, int B, int N, cons
     if (!((ld % 4 == 0) && ((uintptr_t)out % 16 == 0))) return GNMS_OK;
     const int cus = device_cu_count();
     const int NP = (N + 63) & ~63, NB = NP / 64, nbp = NB * (NB + 1) / 2;
-    const int kpw = (NP % 128 == 0 && (long)B * (NP / 32) <= (long)cus / 2) ? 32 : 64;
+    int kpw = (NP % 128 == 0 && (long)B * (NP / 32) <= (long)cus / 2) ? 32 : 64;
     // One task (a 64 x 64 block of pair decisions on 16 waves) per table workgroup, and only while all of them are about one round of the
     // machine: in rank space nothing can be culled, and where the tasks queue the three launches (x-sorted, culled bit matrix: 5-7 us) win.
     // Kernel time of the launch against sort + bits + tail_write_kernel, us (profiles/r06g_*): B = 8 N = 256 18.3 / 25.0, B = 16 N = 256
@@ -1230,6 +1234,7 @@ int launch_one_boxes(const float* scores, const float* boxes, int B, int N, cons
     const int mode = one_launch_boxes_mode(B, N);
     if (mode == 0) return GNMS_OK;
     const bool xt = mode == 2;
+    if (xt) kpw = kXtKpw;
     const int tpw = xt ? 0 : 1;
     const int ntab = nbp;
     const long front = xt ? (long)B * (2 * (NP / kpw) + NB + 2) : (long)B * (NP / kpw + ntab + 2);
